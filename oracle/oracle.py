@@ -1,0 +1,301 @@
+"""ctypes front-end of the CPU oracle (oracle/icp_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by anything under cupoch_amd/.
+
+All matrices cross this API as numpy row-major (what a user writes); the C
+side uses Eigen's column-major layout, so 4x4 transforms are transposed here.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+
+EST_P2P, EST_PT2PL, EST_SYM, EST_GICP = 1, 2, 3, 5
+
+
+def build(force=False):
+    """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
+    src = os.path.join(_HERE, "icp_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    ref = os.environ.get("CUPOCH_REFERENCE", "/root/reference")
+    if os.path.isdir(os.path.join(ref, "src", "tests", "test_utility")):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "_ref", "REF=" + ref])
+
+
+class _Result(C.Structure):
+    _fields_ = [("transformation", C.c_float * 16),
+                ("fitness", C.c_float),
+                ("inlier_rmse", C.c_float),
+                ("n_corres", C.c_int64),
+                ("iterations", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+        _lib.oracle_search_knn.restype = C.c_int64
+        _lib.oracle_search_radius.restype = C.c_int64
+        _lib.oracle_search_bruteforce.restype = C.c_int64
+        _lib.oracle_voxel_downsample.restype = C.c_int64
+        _lib.oracle_compute_rmse.restype = C.c_float
+    return _lib
+
+
+def _f32(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _T_in(T):
+    """row-major numpy 4x4 -> column-major float[16]"""
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float32).reshape(4, 4).T)
+
+
+def _T_out(buf):
+    return np.array(buf, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+def num_threads():
+    return int(lib().oracle_num_threads())
+
+
+def transform_points(T, pts):
+    out = _f32(pts, (-1, 3)).copy()
+    lib().oracle_transform_points(_p(_T_in(T)), _p(out), C.c_int64(len(out)))
+    return out
+
+
+def transform_normals(T, nrm):
+    out = _f32(nrm, (-1, 3)).copy()
+    lib().oracle_transform_normals(_p(_T_in(T)), _p(out), C.c_int64(len(out)))
+    return out
+
+
+def rotate_covariances(T, covs):
+    """covs: (n,3,3) row-major symmetric or general; returns R C R^T."""
+    c = _f32(covs, (-1, 3, 3))
+    cm = np.ascontiguousarray(c.transpose(0, 2, 1))  # column-major per matrix
+    lib().oracle_rotate_covariances(_p(_T_in(T)), _p(cm), C.c_int64(len(cm)))
+    return np.ascontiguousarray(cm.transpose(0, 2, 1))
+
+
+def search_knn(tgt, qry, k):
+    tgt, qry = _f32(tgt, (-1, 3)), _f32(qry, (-1, 3))
+    idx = np.empty((len(qry), max(k, 1)), np.int32)
+    d2 = np.empty((len(qry), max(k, 1)), np.float32)
+    r = lib().oracle_search_knn(_p(tgt), C.c_int64(len(tgt)), _p(qry), C.c_int64(len(qry)),
+                                C.c_int(k), _p(idx), _p(d2))
+    return int(r), idx, d2
+
+
+def search_radius(tgt, qry, radius, max_nn):
+    tgt, qry = _f32(tgt, (-1, 3)), _f32(qry, (-1, 3))
+    idx = np.empty((len(qry), max(max_nn, 1)), np.int32)
+    d2 = np.empty((len(qry), max(max_nn, 1)), np.float32)
+    r = lib().oracle_search_radius(_p(tgt), C.c_int64(len(tgt)), _p(qry), C.c_int64(len(qry)),
+                                   C.c_float(radius), C.c_int(max_nn), _p(idx), _p(d2))
+    return int(r), idx, d2
+
+
+def search_bruteforce(tgt, qry, k, radius=-1.0):
+    tgt, qry = _f32(tgt, (-1, 3)), _f32(qry, (-1, 3))
+    idx = np.empty((len(qry), k), np.int32)
+    d2 = np.empty((len(qry), k), np.float32)
+    r = lib().oracle_search_bruteforce(_p(tgt), C.c_int64(len(tgt)), _p(qry),
+                                       C.c_int64(len(qry)), C.c_int(k), C.c_float(radius),
+                                       _p(idx), _p(d2))
+    return int(r), idx, d2
+
+
+def _cov_cm(covs):
+    if covs is None:
+        return None
+    c = _f32(covs, (-1, 3, 3))
+    return np.ascontiguousarray(c.transpose(0, 2, 1))
+
+
+def compute_system(est, src, tgt, corres, src_nrm=None, tgt_nrm=None, src_cov=None,
+                   tgt_cov=None):
+    """The accumulated 32-double system (layout documented in icp_oracle.c)."""
+    src, tgt = _f32(src, (-1, 3)), _f32(tgt, (-1, 3))
+    sn, tn = _f32(src_nrm, (-1, 3)), _f32(tgt_nrm, (-1, 3))
+    sc, tc = _cov_cm(src_cov), _cov_cm(tgt_cov)
+    cor = np.ascontiguousarray(corres, dtype=np.int32).reshape(-1, 2)
+    sys = np.zeros(32, np.float64)
+    lib().oracle_compute_system(C.c_int(est), _p(src), _p(sn), _p(sc), _p(tgt), _p(tn), _p(tc),
+                                _p(cor), C.c_int64(len(cor)), _p(sys))
+    return sys
+
+
+def solve_system(sys, det_thresh):
+    T = np.zeros(16, np.float32)
+    sys = np.ascontiguousarray(sys, np.float64)
+    ok = lib().oracle_solve_system(_p(sys), C.c_float(det_thresh), _p(T))
+    return bool(ok), T.reshape(4, 4).T.copy()
+
+
+def kabsch_from_sums(sys, n_model):
+    T = np.zeros(16, np.float32)
+    sys = np.ascontiguousarray(sys, np.float64)
+    lib().oracle_kabsch_from_sums(_p(sys), C.c_int64(n_model), _p(T))
+    return T.reshape(4, 4).T.copy()
+
+
+def kabsch(model, target):
+    model, target = _f32(model, (-1, 3)), _f32(target, (-1, 3))
+    T = np.zeros(16, np.float32)
+    lib().oracle_kabsch(_p(model), _p(target), C.c_int64(len(model)), _p(T))
+    return T.reshape(4, 4).T.copy()
+
+
+def vector6_to_matrix4(x):
+    x = _f32(x, (6,))
+    T = np.zeros(16, np.float32)
+    lib().oracle_vector6_to_matrix4(_p(x), _p(T))
+    return T.reshape(4, 4).T.copy()
+
+
+def compute_rmse(est, src, tgt, corres, src_nrm=None, tgt_nrm=None, src_cov=None, tgt_cov=None):
+    src, tgt = _f32(src, (-1, 3)), _f32(tgt, (-1, 3))
+    sn, tn = _f32(src_nrm, (-1, 3)), _f32(tgt_nrm, (-1, 3))
+    sc, tc = _cov_cm(src_cov), _cov_cm(tgt_cov)
+    cor = np.ascontiguousarray(corres, dtype=np.int32).reshape(-1, 2)
+    return float(lib().oracle_compute_rmse(C.c_int(est), _p(src), _p(sn), _p(sc), _p(tgt),
+                                           _p(tn), _p(tc), _p(cor), C.c_int64(len(cor))))
+
+
+def covariances_from_normals(nrm, eps=1e-3):
+    nrm = _f32(nrm, (-1, 3))
+    cm = np.empty((len(nrm), 3, 3), np.float32)
+    lib().oracle_covariances_from_normals(_p(nrm), C.c_int64(len(nrm)), C.c_float(eps), _p(cm))
+    return np.ascontiguousarray(cm.transpose(0, 2, 1))
+
+
+def gicp_weight(Cs, Ct):
+    W = np.zeros(9, np.float32)
+    cs = np.ascontiguousarray(np.asarray(Cs, np.float32).reshape(3, 3).T)
+    ct = np.ascontiguousarray(np.asarray(Ct, np.float32).reshape(3, 3).T)
+    lib().oracle_gicp_weight(_p(cs), _p(ct), _p(W))
+    return W.reshape(3, 3)
+
+
+class RegistrationResult:
+    def __init__(self, res, corres):
+        self.transformation = _T_out(res.transformation)
+        self.fitness = float(res.fitness)
+        self.inlier_rmse = float(res.inlier_rmse)
+        self.correspondence_set = corres[: int(res.n_corres)].copy()
+        self.iterations = int(res.iterations)
+
+
+def evaluate_registration(src, tgt, max_dist, T=None):
+    src, tgt = _f32(src, (-1, 3)), _f32(tgt, (-1, 3))
+    T = np.eye(4, dtype=np.float32) if T is None else T
+    cor = np.empty((max(len(src), 1), 2), np.int32)
+    res = _Result()
+    lib().oracle_evaluate_registration(_p(src), C.c_int64(len(src)), _p(tgt),
+                                       C.c_int64(len(tgt)), C.c_float(max_dist),
+                                       _p(_T_in(T)), _p(cor), C.byref(res))
+    return RegistrationResult(res, cor)
+
+
+def registration_icp(src, tgt, max_dist, init=None, est=EST_P2P, det_thresh=None,
+                     relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=30,
+                     src_nrm=None, tgt_nrm=None, src_cov=None, tgt_cov=None):
+    """Restatement of registration::RegistrationICP (registration.cu:121-172)."""
+    src, tgt = _f32(src, (-1, 3)), _f32(tgt, (-1, 3))
+    sn, tn = _f32(src_nrm, (-1, 3)), _f32(tgt_nrm, (-1, 3))
+    sc, tc = _cov_cm(src_cov), _cov_cm(tgt_cov)
+    init = np.eye(4, dtype=np.float32) if init is None else init
+    if det_thresh is None:
+        det_thresh = 1e-6 if est in (EST_PT2PL, EST_SYM) else -1.0
+    cor = np.empty((max(len(src), 1), 2), np.int32)
+    res = _Result()
+    lib().oracle_registration_icp(
+        _p(src), _p(sn), _p(sc), C.c_int64(len(src)), _p(tgt), _p(tn), _p(tc),
+        C.c_int64(len(tgt)), C.c_float(max_dist), _p(_T_in(init)), C.c_int(est),
+        C.c_float(det_thresh), C.c_float(relative_fitness), C.c_float(relative_rmse),
+        C.c_int(max_iteration), _p(cor), C.byref(res))
+    return RegistrationResult(res, cor)
+
+
+def voxel_downsample(pts, voxel, normals=None, colors=None):
+    pts = _f32(pts, (-1, 3))
+    nrm, col = _f32(normals, (-1, 3)), _f32(colors, (-1, 3))
+    op = np.empty_like(pts)
+    on = np.empty_like(pts) if nrm is not None else None
+    oc = np.empty_like(pts) if col is not None else None
+    m = lib().oracle_voxel_downsample(_p(pts), _p(nrm), _p(col), C.c_int64(len(pts)),
+                                      C.c_float(voxel), _p(op), _p(on), _p(oc))
+    m = int(m)
+    return op[:m].copy(), (None if on is None else on[:m].copy()), \
+        (None if oc is None else oc[:m].copy())
+
+
+def estimate_normals_knn(pts, k=30):
+    pts = _f32(pts, (-1, 3))
+    out = np.empty_like(pts)
+    lib().oracle_estimate_normals_knn(_p(pts), C.c_int64(len(pts)), C.c_int(k), _p(out))
+    return out
+
+
+# ---------------------------------------------------------------------------
+# oracle/_ref : the reference's own code compiled where it lies (optional)
+# ---------------------------------------------------------------------------
+def _ref_lib(name):
+    path = os.path.join(_HERE, "_ref", name)
+    return C.CDLL(path) if os.path.exists(path) else None
+
+
+def ref_rand_vec3f(n, vmin, vmax, seed):
+    """unit_test::Rand(Vector3f) driven by the reference's Raw generator."""
+    L = _ref_lib("libref_raw.so")
+    if L is None:
+        raise FileNotFoundError("oracle/_ref/libref_raw.so not built (needs /root/reference)")
+    out = np.empty((n, 3), np.float32)
+    vmin, vmax = _f32(vmin, (3,)), _f32(vmax, (3,))
+    L.ref_rand_vec3f(_p(out), C.c_int(n), _p(vmin), _p(vmax), C.c_int(seed))
+    return out
+
+
+def ref_flann_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_flann.so"))
+
+
+def ref_flann_knn(tgt, qry, k):
+    L = _ref_lib("libref_flann.so")
+    tgt, qry = _f32(tgt, (-1, 3)), _f32(qry, (-1, 3))
+    idx = np.empty((len(qry), k), np.int32)
+    d2 = np.empty((len(qry), k), np.float32)
+    L.ref_flann_knn(_p(tgt), C.c_int(len(tgt)), _p(qry), C.c_int(len(qry)), C.c_int(k),
+                    _p(idx), _p(d2))
+    return idx, d2
+
+
+def ref_flann_radius(tgt, qry, radius, max_nn):
+    L = _ref_lib("libref_flann.so")
+    tgt, qry = _f32(tgt, (-1, 3)), _f32(qry, (-1, 3))
+    idx = np.empty((len(qry), max_nn), np.int32)
+    d2 = np.empty((len(qry), max_nn), np.float32)
+    r = L.ref_flann_radius(_p(tgt), C.c_int(len(tgt)), _p(qry), C.c_int(len(qry)),
+                           C.c_float(radius), C.c_int(max_nn), _p(idx), _p(d2))
+    return int(r), idx, d2

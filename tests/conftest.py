@@ -1,0 +1,67 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this process")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "reference_tests.json")) as f:
+        return json.load(f)
+
+
+def make_pair(n, seed=42, rot_scale=0.2, noise=0.0, permute=True):
+    """BASELINE.md section 3 synthetic pair: target U[0,1)^3, unit normals,
+    source = T_gt^-1 * target (permuted).  Returns dict of float32 arrays."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tgt = rng.random((n, 3), dtype=np.float32)
+    nrm = np.random.Generator(np.random.PCG64(seed + 1)).standard_normal((n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    s = float(n) ** (-1.0 / 3.0)
+    ang = rot_scale * s
+    ax = np.array([1.0, 2.0, 3.0]) / np.sqrt(14.0)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+    t = rot_scale * s * np.array([1.0, -1.0, 1.0]) / np.sqrt(3.0)
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = t
+    Tinv = np.linalg.inv(T)
+    src = (tgt.astype(np.float64) @ Tinv[:3, :3].T + Tinv[:3, 3]).astype(np.float32)
+    src_nrm = (nrm.astype(np.float64) @ Tinv[:3, :3].T).astype(np.float32)
+    if noise > 0:
+        src += (np.random.Generator(np.random.PCG64(seed + 3)).standard_normal((n, 3)) *
+                noise * s).astype(np.float32)
+    if permute:
+        perm = np.random.Generator(np.random.PCG64(seed + 2)).permutation(n)
+        src, src_nrm = src[perm], src_nrm[perm]
+    return dict(src=np.ascontiguousarray(src), tgt=tgt, tgt_nrm=nrm,
+                src_nrm=np.ascontiguousarray(src_nrm), T_gt=T.astype(np.float32),
+                spacing=s, max_dist=2.0 * s)
