@@ -1,0 +1,131 @@
+"""Loader for libmi_icp.so (the HIP engine behind this package).
+
+There is no CPU fallback: if the shared library is missing or cannot be
+loaded, importing a compute entry point raises.  `build()` compiles it in-tree
+with hipcc for gfx950 (it cross-compiles on a box without a GPU).
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libmi_icp.so")
+INCLUDE = os.path.join(ROOT, "include")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+               "-shared", "-I/opt/rocm/include"]
+
+MI_ICP_HOST, MI_ICP_DEVICE = 0, 1
+EST_POINT_TO_POINT, EST_POINT_TO_PLANE, EST_SYMMETRIC, EST_GENERALIZED = 1, 2, 3, 5
+
+
+class MiIcpError(RuntimeError):
+    pass
+
+
+def _sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
+                  if f.endswith((".hip", ".h"))) + [os.path.join(INCLUDE, "mi_icp.h"),
+                                                 os.path.join(INCLUDE, "mi_icp_debug.h")]
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(s) > t for s in _sources())
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 ... -o cupoch_amd/lib/libmi_icp.so"""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise MiIcpError("hipcc not found; cannot build libmi_icp.so")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, "mi_icp.hip"), "-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+class Params(C.Structure):
+    _fields_ = [("relative_fitness", C.c_float), ("relative_rmse", C.c_float),
+                ("max_iteration", C.c_int32), ("det_thresh", C.c_float)]
+
+
+class Result(C.Structure):
+    _fields_ = [("transformation", C.c_float * 16), ("fitness", C.c_float),
+                ("inlier_rmse", C.c_float), ("n_correspondences", C.c_int64),
+                ("iterations", C.c_int32), ("nn_passes", C.c_int32)]
+
+
+# name -> (restype, argtypes); must list every MI_ICP_API symbol of include/mi_icp.h
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SIGNATURES = {
+    "mi_icp_create": (_I, [_I, C.POINTER(_P)]),
+    "mi_icp_destroy": (None, [_P]),
+    "mi_icp_last_error": (C.c_char_p, [_P]),
+    "mi_icp_version": (C.c_char_p, []),
+    "mi_icp_set_stream": (_I, [_P, _P]),
+    "mi_icp_synchronize": (_I, [_P]),
+    "mi_icp_set_target": (_I, [_P, _P, _P, _P, _L, _I]),
+    "mi_icp_set_source": (_I, [_P, _P, _P, _P, _L, _I]),
+    "mi_icp_search_radius_1nn": (_I, [_P, _P, _F, _P, _P, _I, _P]),
+    "mi_icp_get_correspondences": (_I, [_P, _P, _L, C.POINTER(_L), _I]),
+    "mi_icp_set_correspondences": (_I, [_P, _P, _L, _I]),
+    "mi_icp_compute_system": (_I, [_P, _I, _P, _P]),
+    "mi_icp_compute_transformation": (_I, [_P, _I, _P, _F, _P]),
+    "mi_icp_compute_rmse": (_I, [_P, _I, _P, C.POINTER(_F)]),
+    "mi_icp_solve_system": (_I, [_P, _F, _P]),
+    "mi_icp_kabsch_from_sums": (_I, [_P, _L, _P]),
+    "mi_icp_vector6_to_matrix4": (None, [_P, _P]),
+    "mi_icp_evaluate_registration": (_I, [_P, _F, _P, C.POINTER(Result)]),
+    "mi_icp_registration_icp": (_I, [_P, _I, _F, _P, C.POINTER(Params), C.POINTER(Result)]),
+    "mi_icp_icp_begin": (_I, [_P, _I, _F, _P, _F, C.POINTER(Result)]),
+    "mi_icp_icp_iterate": (_I, [_P, _I, C.POINTER(Result)]),
+    "mi_icp_transform": (_I, [_P, _P, _P, _P, _P, _L, _I]),
+    "mi_icp_voxel_downsample": (_I, [_P, _P, _P, _P, _L, _F, _P, _P, _P, C.POINTER(_L), _I]),
+    "mi_icp_covariances_from_normals": (_I, [_P, _P, _L, _F, _P, _I]),
+    "mi_icp_estimate_normals_knn": (_I, [_P, _P, _L, _I, _P, _I]),
+    "mi_icp_comm_unique_id": (_I, [_P]),
+    "mi_icp_comm_init": (_I, [_P, _P, _I, _I]),
+    "mi_icp_comm_destroy": (_I, [_P]),
+    "mi_icp_set_global_source_count": (_I, [_P, _L]),
+    "mi_icp_set_profiling": (_I, [_P, _I]),
+    "mi_icp_get_profile": (_I, [_P, _P]),
+    # include/mi_icp_debug.h (test-only)
+    "mi_icp_debug_sort_pairs": (_I, [_P, _P, _P, _L, _I]),
+    "mi_icp_debug_exclusive_scan": (_I, [_P, _P, _P, _L, _P]),
+    "mi_icp_debug_morton_order": (_I, [_P, _P, _L, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmi_icp.so and bind every entry point; raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MiIcpError(
+            "libmi_icp.so is not built (%s). Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or cupoch_amd._lib.build(); there is no CPU fallback." % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise MiIcpError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

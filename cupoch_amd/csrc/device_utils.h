@@ -1,0 +1,90 @@
+// device_utils.h -- shared device helpers for the gfx950 ICP kernels.
+//
+// Everything here assumes wave64 (CDNA4).  Compiled with -ffp-contract=off:
+// fused multiply-adds appear only where written explicitly, so the per-point
+// fp32 expressions are exactly the ones DESIGN.md documents (and the CPU
+// oracle evaluates):  d2 = fma(dz,dz, fma(dy,dy, dx*dx)),
+//                     R*p+t = fma(R02,z, fma(R01,y, R00*x)) + t.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi {
+
+constexpr int kWave = 64;
+constexpr int kLeaf = 8;          // points per LBVH leaf
+constexpr int kLeafFloats = 32;   // x[8] y[8] z[8] orig_idx[8] = one 128-B line
+
+// Row-major 3x4 rigid transform passed by value as a kernel argument (SGPRs).
+struct Xform {
+    float r00, r01, r02, t0;
+    float r10, r11, r12, t1;
+    float r20, r21, r22, t2;
+};
+
+// LBVH node, 32 B = one s_load_dwordx8.  `skip` is the node to visit when this
+// subtree is culled or finished (0 = traversal ends); `down` is the first
+// child, or 0x80000000 | leaf_index for a leaf.
+struct __attribute__((aligned(32))) Node {
+    float bmin[3];
+    float bmax[3];
+    uint32_t skip;
+    uint32_t down;
+};
+constexpr uint32_t kLeafFlag = 0x80000000u;
+
+// Pointers in the constant address space: a wave-uniform load through one of
+// these is selected as a scalar (s_load_*) instruction.
+typedef const __attribute__((address_space(4))) float* cfloat_p;
+typedef const __attribute__((address_space(4))) uint32_t* cuint_p;
+
+__device__ __forceinline__ float sq3(float dx, float dy, float dz) {
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+
+__device__ __forceinline__ void rotate(const Xform& T, float x, float y, float z, float& ox,
+                                       float& oy, float& oz) {
+    ox = __builtin_fmaf(T.r02, z, __builtin_fmaf(T.r01, y, T.r00 * x));
+    oy = __builtin_fmaf(T.r12, z, __builtin_fmaf(T.r11, y, T.r10 * x));
+    oz = __builtin_fmaf(T.r22, z, __builtin_fmaf(T.r21, y, T.r20 * x));
+}
+
+__device__ __forceinline__ void xform_point(const Xform& T, float x, float y, float z,
+                                            float& ox, float& oy, float& oz) {
+    rotate(T, x, y, z, ox, oy, oz);
+    ox += T.t0;
+    oy += T.t1;
+    oz += T.t2;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;  // valid in lane 0
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+// Workgroups are dealt to XCDs round-robin (block b -> XCD b % 8).  Remap so
+// that each XCD walks one contiguous eighth of the (Morton-ordered) work list
+// and neighbouring packets share that XCD's L2.  Speed only; any placement is
+// correct.  Returns false when the logical index is past the end.
+__device__ __forceinline__ bool xcd_remap(uint32_t nblocks, uint32_t& logical) {
+    const uint32_t b = blockIdx.x;
+    const uint32_t chunk = (nblocks + 7u) >> 3;  // grid = chunk * 8
+    logical = (b & 7u) * chunk + (b >> 3);
+    return logical < nblocks;
+}
+
+}  // namespace mi

@@ -1,0 +1,191 @@
+// geometry_kernels.h -- PointCloud-side kernels of the ICP path:
+//   Transform            geometry/pointcloud.cu:293-299, geometry_utils.cu:34-52,257-265
+//   VoxelDownSample      geometry/down_sample.cu:64-90,170-273
+//   covariances<-normals registration/generalized_icp.cu:18-30,52-59
+#pragma once
+#include "device_utils.h"
+
+namespace mi {
+
+// ---- Transform (in place on the caller's AoS arrays) --------------------------
+__global__ __launch_bounds__(256) void transform_cloud(Xform T, float* __restrict__ pts,
+                                                       float* __restrict__ nrm,
+                                                       float* __restrict__ cov, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (pts) {
+        float x, y, z;
+        xform_point(T, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], x, y, z);
+        pts[i * 3] = x;
+        pts[i * 3 + 1] = y;
+        pts[i * 3 + 2] = z;
+    }
+    if (nrm) {
+        float x, y, z;
+        rotate(T, nrm[i * 3], nrm[i * 3 + 1], nrm[i * 3 + 2], x, y, z);
+        nrm[i * 3] = x;
+        nrm[i * 3 + 1] = y;
+        nrm[i * 3 + 2] = z;
+    }
+    if (cov) {
+        const float R[3][3] = {{T.r00, T.r01, T.r02}, {T.r10, T.r11, T.r12}, {T.r20, T.r21, T.r22}};
+        float C[9], RC[3][3];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) C[e] = cov[i * 9 + e];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                RC[r][c] = __builtin_fmaf(R[r][2], C[c * 3 + 2],
+                                          __builtin_fmaf(R[r][1], C[c * 3 + 1], R[r][0] * C[c * 3]));
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                cov[i * 9 + c * 3 + r] = __builtin_fmaf(
+                        RC[r][2], R[c][2], __builtin_fmaf(RC[r][1], R[c][1], RC[r][0] * R[c][0]));
+    }
+}
+
+// ---- GICP: covariance from a normal, C = Rx diag(eps,1,1) Rx^T ----------------
+__global__ __launch_bounds__(256) void cov_from_normals(const float* __restrict__ nrm, int64_t n,
+                                                        float eps, float* __restrict__ cov) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x0 = nrm[i * 3], x1 = nrm[i * 3 + 1], x2 = nrm[i * 3 + 2];
+    float Rx[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    const float v[3] = {0.0f, -x2, x1};  // e1 x x
+    const float c = x0;                  // e1 . x
+    if (!(c < -0.99f)) {
+        const float sv[3][3] = {{0, -v[2], v[1]}, {v[2], 0, -v[0]}, {-v[1], v[0], 0}};
+        const float factor = 1.0f / (1.0f + c);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const float sv2 = sv[r][0] * sv[0][cc] + sv[r][1] * sv[1][cc] + sv[r][2] * sv[2][cc];
+                Rx[r][cc] = ((r == cc) ? 1.0f : 0.0f) + sv[r][cc] + sv2 * factor;
+            }
+    }
+    const float D[3] = {eps, 1.0f, 1.0f};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+            cov[i * 9 + cc * 3 + r] = Rx[r][0] * D[0] * Rx[cc][0] + Rx[r][1] * D[1] * Rx[cc][1] +
+                                      Rx[r][2] * D[2] * Rx[cc][2];
+}
+
+// ---- VoxelDownSample ----------------------------------------------------------
+struct VoxelGrid {
+    float ox, oy, oz;  // min_bound - voxel/2
+    float voxel;
+    int bits_y, bits_z;  // packed key = kx << (by+bz) | ky << bz | kz
+};
+
+__device__ __forceinline__ void voxel_key3(const VoxelGrid& g, const float* p, int32_t* k) {
+    // down_sample.cu:69-73: floor((pt - voxel_min_bound) / voxel_size)
+    k[0] = (int32_t)floorf((p[0] - g.ox) / g.voxel);
+    k[1] = (int32_t)floorf((p[1] - g.oy) / g.voxel);
+    k[2] = (int32_t)floorf((p[2] - g.oz) / g.voxel);
+}
+
+// axis < 0: packed lexicographic key of element i; axis 0..2: that axis' cell
+// index of element order[i] (one pass of the three-sort fallback)
+__global__ __launch_bounds__(256) void voxel_keys(const float* __restrict__ pts, int64_t n,
+                                                  VoxelGrid g, int axis,
+                                                  const uint32_t* __restrict__ order,
+                                                  uint64_t* __restrict__ keys,
+                                                  uint32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t o = order ? order[i] : i;
+    int32_t k[3];
+    voxel_key3(g, pts + o * 3, k);
+    if (axis < 0) {
+        keys[i] = ((uint64_t)(uint32_t)k[0] << (g.bits_y + g.bits_z)) |
+                  ((uint64_t)(uint32_t)k[1] << g.bits_z) | (uint64_t)(uint32_t)k[2];
+    } else {
+        keys[i] = (uint64_t)(uint32_t)k[axis];
+    }
+    vals[i] = (uint32_t)o;
+}
+
+// head[i] = 1 when sorted element i opens a new voxel
+__global__ __launch_bounds__(256) void voxel_heads(const float* __restrict__ pts, int64_t n,
+                                                   VoxelGrid g,
+                                                   const uint32_t* __restrict__ order,
+                                                   uint32_t* __restrict__ head) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t h = 1u;
+    if (i > 0) {
+        int32_t a[3], b[3];
+        voxel_key3(g, pts + (int64_t)order[i] * 3, a);
+        voxel_key3(g, pts + (int64_t)order[i - 1] * 3, b);
+        h = (a[0] != b[0] || a[1] != b[1] || a[2] != b[2]) ? 1u : 0u;
+    }
+    head[i] = h;
+}
+
+// seg_start[rank of head i] = i ; seg_start[m] = n is written by the host side
+__global__ __launch_bounds__(256) void voxel_seg_starts(const uint32_t* __restrict__ head,
+                                                        const uint32_t* __restrict__ pos,
+                                                        int64_t n,
+                                                        uint32_t* __restrict__ seg_start) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (head[i]) seg_start[pos[i]] = (uint32_t)i;
+}
+
+// 8 lanes per voxel: fp64 sums of points / normals / colors over the run, mean,
+// normals normalised after averaging (down_sample.cu:77-90)
+__global__ __launch_bounds__(256) void voxel_means(
+        const float* __restrict__ pts, const float* __restrict__ nrm,
+        const float* __restrict__ col, const uint32_t* __restrict__ order,
+        const uint32_t* __restrict__ seg_start, int64_t m, int64_t n,
+        float* __restrict__ out_pts, float* __restrict__ out_nrm, float* __restrict__ out_col) {
+    const int64_t seg = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int sub = (int)(threadIdx.x & 7u);
+    double ap[3] = {0, 0, 0}, an[3] = {0, 0, 0}, ac[3] = {0, 0, 0};
+    int64_t s = 0, e = 0;
+    if (seg < m) {
+        s = seg_start[seg];
+        e = (seg + 1 < m) ? (int64_t)seg_start[seg + 1] : n;
+    }
+    for (int64_t t = s + sub; t < e; t += 8) {
+        const int64_t o = order[t];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            ap[d] += (double)pts[o * 3 + d];
+            if (nrm) an[d] += (double)nrm[o * 3 + d];
+            if (col) ac[d] += (double)col[o * 3 + d];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) {
+            ap[d] += __shfl_down(ap[d], off, 8);
+            an[d] += __shfl_down(an[d], off, 8);
+            ac[d] += __shfl_down(ac[d], off, 8);
+        }
+    }
+    if (seg < m && sub == 0) {
+        const double cnt = (double)(e - s);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) out_pts[seg * 3 + d] = (float)(ap[d] / cnt);
+        if (nrm) {
+            const float v[3] = {(float)(an[0] / cnt), (float)(an[1] / cnt), (float)(an[2] / cnt)};
+            const float l = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) out_nrm[seg * 3 + d] = v[d] / l;
+        }
+        if (col) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) out_col[seg * 3 + d] = (float)(ac[d] / cnt);
+        }
+    }
+}
+
+}  // namespace mi

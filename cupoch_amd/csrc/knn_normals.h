@@ -1,0 +1,188 @@
+// knn_normals.h -- PointCloud::EstimateNormals(KDTreeSearchParamKNN(k)) on the
+// LBVH (geometry/estimate_normals.cu:38-127, geometry_functor.h:35-55).
+//
+// The reference runs FLANN's k-NN with the per-query heap in global memory
+// (N*k indices + distances written out), then a reduce_by_key over N*k
+// cumulant tuples.  Here a wave owns the 64 points of 8 consecutive leaves
+// (queries are the cloud's own points, already in Morton order), keeps each
+// lane's k candidates in LDS ([slot][lane], conflict-free for any slot), and
+// never materialises the neighbour lists:
+//   A. seed every lane's candidate set from the leaves around its own leaf in
+//      Morton order (spatially close, so the k-th distance is already tight);
+//   B. wave-uniform tree traversal as in nn_search.h with the lane's current
+//      k-th distance as its bound (seed leaves are skipped);
+//   C. fp32 cumulants over the lane's k neighbours, closed-form eigenvector
+//      (FastEigen3x3MinMaxVec), written to the point's ORIGINAL index.
+// Neighbours include the point itself; fewer than 3 neighbours or a zero
+// normal give (0,0,1), as the reference.
+#pragma once
+#include "device_utils.h"
+#include "eigen3.h"
+
+namespace mi {
+
+constexpr int kMaxKnn = 32;
+constexpr int kKnnThreads = 128;
+constexpr int kKnnWaves = kKnnThreads / 64;
+constexpr int kKnnLeavesPerBlock = kKnnWaves * 8;
+constexpr int kKnnSeedBefore = 4, kKnnSeedAfter = 12;  // leaves around the packet's first leaf
+
+struct KnnState {
+    float worst;  // current bound: +inf until k candidates are held
+    int count;
+    int worst_pos;
+};
+
+__device__ __forceinline__ void knn_offer(float* kd2, int32_t* kidx, int lane, int k, KnnState& s,
+                                          float d2, int32_t j) {
+    if (d2 < s.worst) {
+        kd2[s.worst_pos * 64 + lane] = d2;
+        kidx[s.worst_pos * 64 + lane] = j;
+        if (s.count < k) {
+            ++s.count;
+            s.worst_pos = s.count;
+        }
+        if (s.count >= k) {  // buffer full: find the new k-th (largest) distance
+            float w = -1.0f;
+            int wp = 0;
+            for (int t = 0; t < k; ++t) {
+                const float v = kd2[t * 64 + lane];
+                if (v > w) {
+                    w = v;
+                    wp = t;
+                }
+            }
+            s.worst = w;
+            s.worst_pos = wp;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
+        const Node* __restrict__ nodes_g, const float* __restrict__ tblk_g, int n, int nleaf, int k,
+        uint32_t nblocks, uint32_t max_steps, float* __restrict__ normals_out) {
+    __shared__ float s_d2[kKnnWaves][kMaxKnn * 64];
+    __shared__ int32_t s_idx[kKnnWaves][kMaxKnn * 64];
+    uint32_t logical;
+    if (!xcd_remap(nblocks, logical)) return;
+    const cuint_p nodes = (cuint_p)(uintptr_t)nodes_g;
+    const cfloat_p tblk = (cfloat_p)(uintptr_t)tblk_g;
+    const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
+    float* kd2 = s_d2[wid];
+    int32_t* kidx = s_idx[wid];
+
+    const int pkt = (int)logical * kKnnWaves + wid;
+    const int leaf0 = pkt * 8;
+    if (leaf0 >= nleaf) return;  // whole wave out of range (no block barriers below)
+    const int64_t i = (int64_t)pkt * 64 + lane;
+    const bool valid = i < n;
+    float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+    int32_t orig = -1;
+    if (valid) {
+        const float* line = tblk_g + (i >> 3) * kLeafFloats + (i & 7);
+        qx = line[0];
+        qy = line[8];
+        qz = line[16];
+        orig = __float_as_int(line[24]);
+    }
+    KnnState st;
+    st.worst = (valid && k > 0) ? INFINITY : -1.0f;
+    st.count = 0;
+    st.worst_pos = 0;
+
+    // ---- A: seed from the Morton neighbourhood ---------------------------------
+    const int seed_lo = max(0, leaf0 - kKnnSeedBefore);
+    const int seed_hi = min(nleaf, leaf0 + kKnnSeedAfter);
+    for (int L = seed_lo; L < seed_hi; ++L) {
+        const cfloat_p line = tblk + (size_t)L * kLeafFloats;
+#pragma unroll
+        for (int t = 0; t < kLeaf; ++t) {
+            const float d2 = sq3(qx - line[t], qy - line[8 + t], qz - line[16 + t]);
+            knn_offer(kd2, kidx, lane, k, st, d2, L * kLeaf + t);  // padding points have d2 = +inf
+        }
+    }
+
+    // ---- B: traversal -------------------------------------------------------------
+    uint32_t nd_i = 1u, steps = 0u;
+    while (nd_i != 0u && steps++ < max_steps) {
+        nd_i = __builtin_amdgcn_readfirstlane(nd_i);
+        const cuint_p nd = nodes + (size_t)nd_i * 8u;
+        const float bx0 = __uint_as_float(nd[0]), by0 = __uint_as_float(nd[1]),
+                    bz0 = __uint_as_float(nd[2]);
+        const float bx1 = __uint_as_float(nd[3]), by1 = __uint_as_float(nd[4]),
+                    bz1 = __uint_as_float(nd[5]);
+        const uint32_t skip = nd[6], down = nd[7];
+        const float dx = fmaxf(fmaxf(bx0 - qx, qx - bx1), 0.0f);
+        const float dy = fmaxf(fmaxf(by0 - qy, qy - by1), 0.0f);
+        const float dz = fmaxf(fmaxf(bz0 - qz, qz - bz1), 0.0f);
+        const float dbox = sq3(dx, dy, dz);
+        if (__ballot(dbox < st.worst) == 0ull) {
+            nd_i = skip;
+            continue;
+        }
+        if (down & kLeafFlag) {
+            const int L = (int)(down & ~kLeafFlag);
+            if (L < seed_lo || L >= seed_hi) {
+                const cfloat_p line = tblk + (size_t)L * kLeafFloats;
+#pragma unroll
+                for (int t = 0; t < kLeaf; ++t) {
+                    const float d2 = sq3(qx - line[t], qy - line[8 + t], qz - line[16 + t]);
+                    knn_offer(kd2, kidx, lane, k, st, d2, L * kLeaf + t);
+                }
+            }
+            nd_i = skip;
+        } else {
+            nd_i = down;
+        }
+    }
+
+    // ---- C: covariance of the neighbours -> normal ------------------------------------
+    if (!valid) return;
+    float nx = 0.0f, ny = 0.0f, nz = 1.0f;
+    if (k > 0 && st.count >= 3) {
+        float cum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < st.count; ++t) {
+            const int32_t j = kidx[t * 64 + lane];
+            const float* line = tblk_g + (int64_t)(j >> 3) * kLeafFloats + (j & 7);
+            const float px = line[0], py = line[8], pz = line[16];
+            cum[0] += px;
+            cum[1] += py;
+            cum[2] += pz;
+            cum[3] += px * px;
+            cum[4] += px * py;
+            cum[5] += px * pz;
+            cum[6] += py * py;
+            cum[7] += py * pz;
+            cum[8] += pz * pz;
+        }
+        const float cnt = (float)st.count;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) cum[e] = cum[e] / cnt;
+        M3 A;
+        A.m[0][0] = cum[3] - cum[0] * cum[0];
+        A.m[1][1] = cum[6] - cum[1] * cum[1];
+        A.m[2][2] = cum[8] - cum[2] * cum[2];
+        A.m[0][1] = A.m[1][0] = cum[4] - cum[0] * cum[1];
+        A.m[0][2] = A.m[2][0] = cum[5] - cum[0] * cum[2];
+        A.m[1][2] = A.m[2][1] = cum[7] - cum[1] * cum[2];
+        float eval[3], e[3][3];
+        fast_eigen3x3(A, eval, e);
+        int mi_ = 0;
+        if (eval[1] < eval[mi_]) mi_ = 1;
+        if (eval[2] < eval[mi_]) mi_ = 2;
+        const float vx = (mi_ == 0) ? e[0][0] : ((mi_ == 1) ? e[1][0] : e[2][0]);
+        const float vy = (mi_ == 0) ? e[0][1] : ((mi_ == 1) ? e[1][1] : e[2][1]);
+        const float vz = (mi_ == 0) ? e[0][2] : ((mi_ == 1) ? e[1][2] : e[2][2]);
+        const float l = sqrtf(vx * vx + vy * vy + vz * vz);
+        if (l != 0.0f && !isnan(l)) {
+            nx = vx;
+            ny = vy;
+            nz = vz;
+        }
+    }
+    normals_out[(int64_t)orig * 3] = nx;
+    normals_out[(int64_t)orig * 3 + 1] = ny;
+    normals_out[(int64_t)orig * 3 + 2] = nz;
+}
+
+}  // namespace mi

@@ -1,0 +1,213 @@
+// lbvh.h -- Morton ordering and LBVH construction for the target cloud, and
+// Morton-ordered SoA staging of the source cloud.
+//
+// Replaces knn::KDTreeFlann::SetRawData + flann::CudaKdTreeBuilder::buildTree
+// (knn/kdtree_flann.inl:124-144; third_party/flann/algorithms/
+// kdtree_cuda_builder.h:401-700), i.e. three thrust sorts plus ~10 thrust
+// passes per tree level with a host round trip per level, by:
+//   bounds -> 3*B-bit Morton keys -> one LSD radix sort -> leaves of 8
+//   consecutive points (one 128-B line each) -> implicit complete binary tree
+//   refitted bottom-up, one tiny launch per level, no host sync.
+// Topology is implicit (heap order, root = 1) but every node stores explicit
+// `skip`/`down` links, so the traversal kernel is layout-agnostic.
+#pragma once
+#include "device_utils.h"
+
+namespace mi {
+
+// ---- bounds ---------------------------------------------------------------
+constexpr int kBoundsBlocks = 512;
+
+__global__ __launch_bounds__(256) void bounds_partial(const float* __restrict__ pts, int n,
+                                                      float* __restrict__ partial /*[blocks][6]*/) {
+    __shared__ float red[4][6];
+    float mn[3] = {INFINITY, INFINITY, INFINITY};
+    float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = pts[i * 3 + d];
+            mn[d] = fminf(mn[d], v);
+            mx[d] = fmaxf(mx[d], v);
+        }
+    }
+    const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float a = wave_min(mn[d]), b = wave_max(mx[d]);
+        if (lane == 0) {
+            red[wid][d] = a;
+            red[wid][3 + d] = b;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int d = (int)threadIdx.x;
+        float v = red[0][d];
+        for (int w = 1; w < 4; ++w) v = (d < 3) ? fminf(v, red[w][d]) : fmaxf(v, red[w][d]);
+        partial[blockIdx.x * 6 + d] = v;
+    }
+}
+
+// one block of 64 threads: out[0..2] = min, out[3..5] = max, out[6] = max extent
+__global__ void bounds_final(const float* __restrict__ partial, int nblocks,
+                             float* __restrict__ out) {
+    const int lane = lane_id();
+    float mn[3] = {INFINITY, INFINITY, INFINITY};
+    float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int b = lane; b < nblocks; b += 64) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            mn[d] = fminf(mn[d], partial[b * 6 + d]);
+            mx[d] = fmaxf(mx[d], partial[b * 6 + 3 + d]);
+        }
+    }
+    float ext = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        mn[d] = wave_min(mn[d]);
+        mx[d] = wave_max(mx[d]);
+        ext = fmaxf(ext, mx[d] - mn[d]);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            out[d] = mn[d];
+            out[3 + d] = mx[d];
+        }
+        out[6] = ext;
+        out[7] = 0.0f;
+    }
+}
+
+// ---- Morton keys ------------------------------------------------------------
+__device__ __forceinline__ uint64_t spread3(uint32_t v) {  // 21 bits -> every third bit
+    uint64_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+// key = interleave(qx,qy,qz), q = cell of a cubic 2^bits grid over the bounds
+__global__ __launch_bounds__(256) void morton_keys(const float* __restrict__ pts, int n,
+                                                   const float* __restrict__ bounds, int bits,
+                                                   uint64_t* __restrict__ keys,
+                                                   uint32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float ext = bounds[6];
+    const float cells = (float)(1u << bits);
+    const float scale = (ext > 0.0f) ? cells / ext : 0.0f;
+    const float top = cells - 1.0f;
+    uint32_t q[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float f = (pts[i * 3 + d] - bounds[d]) * scale;
+        f = fminf(fmaxf(f, 0.0f), top);  // NaN -> 0
+        q[d] = (uint32_t)f;
+    }
+    keys[i] = (spread3(q[0]) << 2) | (spread3(q[1]) << 1) | spread3(q[2]);
+    vals[i] = (uint32_t)i;
+}
+
+// ---- target: leaves + implicit tree ----------------------------------------
+__device__ __forceinline__ uint32_t heap_skip(uint32_t n) {
+    uint32_t m = n + 1u;
+    m >>= __builtin_ctz(m);
+    return (m == 1u) ? 0u : m;
+}
+
+// one thread per leaf slot L in [0, P): gathers the leaf's <=8 points into the
+// 128-B leaf line, sorted normals / covariances next to them, and the leaf box
+__global__ __launch_bounds__(256) void build_leaves(
+        const uint32_t* __restrict__ order, const float* __restrict__ pts,
+        const float* __restrict__ nrm, const float* __restrict__ cov, int n, int nleaf, int P,
+        float* __restrict__ tblk, float4* __restrict__ tnrm, float* __restrict__ tcov,
+        Node* __restrict__ nodes) {
+    const int L = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (L >= P) return;
+    float mn[3] = {INFINITY, INFINITY, INFINITY};
+    float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (L < nleaf) {
+        float* line = tblk + (int64_t)L * kLeafFloats;
+#pragma unroll
+        for (int k = 0; k < kLeaf; ++k) {
+            const int64_t s = (int64_t)L * kLeaf + k;
+            float p[3] = {INFINITY, INFINITY, INFINITY};
+            int o = -1;
+            if (s < n) {
+                o = (int)order[s];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    p[d] = pts[(int64_t)o * 3 + d];
+                    mn[d] = fminf(mn[d], p[d]);
+                    mx[d] = fmaxf(mx[d], p[d]);
+                }
+                if (nrm)
+                    tnrm[s] = make_float4(nrm[(int64_t)o * 3], nrm[(int64_t)o * 3 + 1],
+                                          nrm[(int64_t)o * 3 + 2], 0.0f);
+                if (cov) {
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) tcov[s * 9 + e] = cov[(int64_t)o * 9 + e];
+                }
+            }
+            line[k] = p[0];
+            line[8 + k] = p[1];
+            line[16 + k] = p[2];
+            line[24 + k] = __int_as_float(o);
+        }
+    }
+    Node nd;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        nd.bmin[d] = mn[d];
+        nd.bmax[d] = mx[d];
+    }
+    const uint32_t id = (uint32_t)(P + L);
+    nd.skip = heap_skip(id);
+    nd.down = kLeafFlag | (uint32_t)L;
+    nodes[id] = nd;
+}
+
+// nodes [first, first+count): box = union of the two children
+__global__ __launch_bounds__(256) void build_level(Node* __restrict__ nodes, uint32_t first,
+                                                   uint32_t count) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= count) return;
+    const uint32_t id = first + t;
+    const Node a = nodes[2 * id], b = nodes[2 * id + 1];
+    Node nd;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        nd.bmin[d] = fminf(a.bmin[d], b.bmin[d]);
+        nd.bmax[d] = fmaxf(a.bmax[d], b.bmax[d]);
+    }
+    nd.skip = heap_skip(id);
+    nd.down = 2 * id;
+    nodes[id] = nd;
+}
+
+// ---- source: Morton-ordered SoA copy ---------------------------------------
+__global__ __launch_bounds__(256) void gather_source(
+        const uint32_t* __restrict__ order, const float* __restrict__ pts,
+        const float* __restrict__ nrm, const float* __restrict__ cov, int n,
+        float* __restrict__ sx, float* __restrict__ sy, float* __restrict__ sz,
+        int32_t* __restrict__ sperm, float4* __restrict__ snrm, float* __restrict__ scov) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const int64_t o = order[s];
+    sx[s] = pts[o * 3];
+    sy[s] = pts[o * 3 + 1];
+    sz[s] = pts[o * 3 + 2];
+    sperm[s] = (int32_t)o;
+    if (nrm) snrm[s] = make_float4(nrm[o * 3], nrm[o * 3 + 1], nrm[o * 3 + 2], 0.0f);
+    if (cov) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) scov[s * 9 + e] = cov[o * 9 + e];
+    }
+}
+
+}  // namespace mi

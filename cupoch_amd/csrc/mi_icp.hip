@@ -1,0 +1,1198 @@
+// mi_icp.hip -- libmi_icp.so: context, host orchestration and the C ABI
+// declared in include/mi_icp.h.  gfx950 only.
+//
+// The host loop mirrors registration::RegistrationICP
+// (registration/registration.cu:121-172) but keeps everything device-resident:
+// one nearest-neighbour launch + one reduction launch (+ its 1-block finish)
+// per iteration, one 256-byte D2H copy, the 6x6 solve on the host, and the new
+// 4x4 passed back as a kernel argument.  Nothing is allocated inside the loop.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mi_icp.h"
+#include "../../include/mi_icp_debug.h"
+#include "device_utils.h"
+#include "geometry_kernels.h"
+#include "host_solver.h"
+#include "knn_normals.h"
+#include "lbvh.h"
+#include "nn_search.h"
+#include "primitives.h"
+#include "reduce.h"
+
+using namespace mi;
+using host::Mat4;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                              hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+};
+
+bool load_rccl(Rccl& r) {
+    if (r.handle) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) return false;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+    return r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy;
+}
+
+Rccl g_rccl;
+
+}  // namespace
+
+struct mi_icp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // ---- target (Morton order) ----
+    int64_t nt = 0;
+    int nleaf = 0, P = 0;
+    bool t_has_nrm = false, t_has_cov = false;
+    DevBuf tblk, tnrm, tcov, nodes, inv_t;
+    bool inv_t_valid = false;
+
+    // ---- source (Morton order) ----
+    int64_t ns = 0, ns_global = 0;
+    bool s_has_nrm = false, s_has_cov = false;
+    DevBuf sx, sy, sz, sperm, snrm, scov, nn_idx, nn_d2, inv_s;
+    bool inv_s_valid = false;
+    bool nn_valid = false;  // nn_idx holds a search result (usable as seed / correspondences)
+
+    // ---- explicit correspondence set ----
+    DevBuf user_pairs;
+    int64_t n_user_pairs = -1;  // < 0: use the nearest-neighbour result
+
+    // ---- scratch ----
+    DevBuf keys0, keys1, vals0, vals1, hist, scan_tmp, bounds_part, bounds;
+    DevBuf partial, sys_dev, dense_idx, flags, pairs_out, seg_start;
+    DevBuf stage[6];
+    double* sys_host = nullptr;  // pinned, 32 doubles + spare
+    float* f_host = nullptr;     // pinned, 16 floats
+    uint32_t* u_host = nullptr;  // pinned, 4 words
+
+    // ---- registration loop state (mi_icp_icp_begin / mi_icp_icp_iterate) ----
+    struct Loop {
+        bool active = false;
+        int est = 0;
+        float r2 = 0.0f, det_thresh = -1.0f;
+        Mat4 T, A;             // reported transformation / what the points have seen
+        double sys[32] = {};
+        float fitness = 0.0f, rmse = 0.0f;
+        int iterations = 0, passes = 0;
+    } loop;
+
+    // ---- multi-GPU ----
+    ncclComm_t comm = nullptr;
+    int nranks = 1;
+
+    // ---- instrumentation ----
+    bool profiling = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_pending_nn = false, ev_pending_red = false;
+    double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+int fail(mi_icp_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail((c), MI_ICP_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                  \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                           \
+    } while (0)
+
+#define KCHK(c) HIPCHK(c, hipGetLastError())
+
+#define TRY(expr)                \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != MI_ICP_OK) return rc_; \
+    } while (0)
+
+template <class T>
+int ensure(mi_icp_ctx* c, DevBuf& b, size_t count, T** out) {
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+    if (b.bytes < bytes) {
+        if (b.p) {
+            // buffers may still be in use by enqueued work
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipFree(b.p));
+            b.p = nullptr;
+            b.bytes = 0;
+        }
+        HIPCHK(c, hipMalloc(&b.p, bytes));
+        b.bytes = bytes;
+    }
+    *out = (T*)b.p;
+    return MI_ICP_OK;
+}
+
+void release(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+// device view of a caller buffer (copied through a context-owned staging buffer
+// when it lives in host memory)
+template <class T>
+int to_device(mi_icp_ctx* c, const T* src, size_t count, int mem_kind, DevBuf& stage,
+              const T** out) {
+    if (!src || count == 0) {
+        *out = nullptr;
+        return MI_ICP_OK;
+    }
+    if (mem_kind == MI_ICP_DEVICE) {
+        *out = src;
+        return MI_ICP_OK;
+    }
+    T* d;
+    TRY(ensure(c, stage, count, &d));
+    HIPCHK(c, hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *out = d;
+    return MI_ICP_OK;
+}
+
+template <class T>
+int from_device(mi_icp_ctx* c, const T* dev, T* dst, size_t count, int mem_kind) {
+    if (!dst || count == 0) return MI_ICP_OK;
+    HIPCHK(c, hipMemcpyAsync(dst, dev, count * sizeof(T),
+                             mem_kind == MI_ICP_DEVICE ? hipMemcpyDeviceToDevice
+                                                       : hipMemcpyDeviceToHost,
+                             c->stream));
+    return MI_ICP_OK;
+}
+
+inline int blocks_for(int64_t n, int per = 256) { return (int)std::max<int64_t>(1, (n + per - 1) / per); }
+
+Xform make_xform(const Mat4& T) {
+    Xform x;
+    x.r00 = host::at(T, 0, 0); x.r01 = host::at(T, 0, 1); x.r02 = host::at(T, 0, 2); x.t0 = host::at(T, 0, 3);
+    x.r10 = host::at(T, 1, 0); x.r11 = host::at(T, 1, 1); x.r12 = host::at(T, 1, 2); x.t1 = host::at(T, 1, 3);
+    x.r20 = host::at(T, 2, 0); x.r21 = host::at(T, 2, 1); x.r22 = host::at(T, 2, 2); x.t2 = host::at(T, 2, 3);
+    return x;
+}
+
+Mat4 load_T(const float* T) {
+    if (!T) return host::identity4();
+    Mat4 m;
+    std::memcpy(m.data(), T, sizeof(float) * 16);
+    return m;
+}
+
+int morton_bits_for(int64_t n) {
+    int lg = 0;
+    while ((1ll << lg) < n) ++lg;
+    return std::min(21, std::max(6, (lg + 2) / 3 + 5));
+}
+
+// bounds (min/max/extent) of an AoS cloud into c->bounds (8 floats, device)
+int compute_bounds(mi_icp_ctx* c, const float* pts, int64_t n, float** bounds_out) {
+    float *part, *bnd;
+    TRY(ensure(c, c->bounds_part, (size_t)kBoundsBlocks * 6, &part));
+    TRY(ensure(c, c->bounds, 8, &bnd));
+    const int nb = std::min<int64_t>(kBoundsBlocks, blocks_for(n));
+    bounds_partial<<<nb, 256, 0, c->stream>>>(pts, (int)n, part);
+    KCHK(c);
+    bounds_final<<<1, 64, 0, c->stream>>>(part, nb, bnd);
+    KCHK(c);
+    *bounds_out = bnd;
+    return MI_ICP_OK;
+}
+
+int sort_buffers(mi_icp_ctx* c, int64_t n, SortBuffers* sb) {
+    const int nseg = sort_num_segments(n);
+    TRY(ensure(c, c->keys0, (size_t)n, &sb->keys[0]));
+    TRY(ensure(c, c->keys1, (size_t)n, &sb->keys[1]));
+    TRY(ensure(c, c->vals0, (size_t)n, &sb->vals[0]));
+    TRY(ensure(c, c->vals1, (size_t)n, &sb->vals[1]));
+    TRY(ensure(c, c->hist, (size_t)256 * nseg, &sb->hist));
+    TRY(ensure(c, c->scan_tmp, (size_t)std::max(scan_num_tiles((int64_t)256 * nseg), scan_num_tiles(n)) + 2,
+               &sb->scan_tmp));
+    return MI_ICP_OK;
+}
+
+// Morton order of an AoS cloud: returns the device array order[sorted] = original
+int morton_order(mi_icp_ctx* c, const float* pts, int64_t n, const uint32_t** order) {
+    float* bnd;
+    TRY(compute_bounds(c, pts, n, &bnd));
+    SortBuffers sb;
+    TRY(sort_buffers(c, n, &sb));
+    const int bits = morton_bits_for(n);
+    morton_keys<<<blocks_for(n), 256, 0, c->stream>>>(pts, (int)n, bnd, bits, sb.keys[0], sb.vals[0]);
+    KCHK(c);
+    const int cur = radix_sort_pairs(c->stream, sb, n, 3 * bits);
+    KCHK(c);
+    *order = sb.vals[cur];
+    return MI_ICP_OK;
+}
+
+struct EvTimer {
+    mi_icp_ctx* c;
+    int slot;  // 0: nn, 1: reduce
+    EvTimer(mi_icp_ctx* ctx, int s) : c(ctx), slot(s) {
+        if (c->profiling) (void)hipEventRecord(c->ev[slot * 2], c->stream);
+    }
+    ~EvTimer() {
+        if (c->profiling) {
+            (void)hipEventRecord(c->ev[slot * 2 + 1], c->stream);
+            (slot == 0 ? c->ev_pending_nn : c->ev_pending_red) = true;
+        }
+    }
+};
+
+void collect_events(mi_icp_ctx* c) {  // call after the stream has been synchronised
+    float ms = 0.0f;
+    if (c->ev_pending_nn && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) {
+        c->prof[0] += ms;
+        c->prof[1] += 1;
+    }
+    if (c->ev_pending_red && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) {
+        c->prof[2] += ms;
+        c->prof[3] += 1;
+    }
+    c->ev_pending_nn = c->ev_pending_red = false;
+}
+
+// ---- nearest-neighbour pass --------------------------------------------------
+int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed) {
+    if (c->ns <= 0) return MI_ICP_OK;
+    int32_t* idx = (int32_t*)c->nn_idx.p;
+    float* d2 = (float*)c->nn_d2.p;
+    if (c->nt <= 0) {
+        fill_i32<<<blocks_for(c->ns), 256, 0, c->stream>>>(idx, c->ns, -1);
+        KCHK(c);
+        c->nn_valid = true;
+        return MI_ICP_OK;
+    }
+    const uint32_t npackets = (uint32_t)((c->ns + 63) / 64);
+    const uint32_t nblocks = (npackets + kNNPacketsPerBlock - 1) / kNNPacketsPerBlock;
+    const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
+    const uint32_t max_steps = 2u * (uint32_t)c->P + 8u;
+    const Xform X = make_xform(T);
+    EvTimer t(c, 0);
+    if (seed && c->nn_valid)
+        nn_packet_kernel<true><<<grid, kNNThreads, 0, c->stream>>>(
+                (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns,
+                (const Node*)c->nodes.p, (const float*)c->tblk.p, X, r2, nblocks, max_steps, idx, d2);
+    else
+        nn_packet_kernel<false><<<grid, kNNThreads, 0, c->stream>>>(
+                (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns,
+                (const Node*)c->nodes.p, (const float*)c->tblk.p, X, r2, nblocks, max_steps, idx, d2);
+    KCHK(c);
+    c->nn_valid = true;
+    c->n_user_pairs = -1;
+    return MI_ICP_OK;
+}
+
+int ensure_inverse_maps(mi_icp_ctx* c) {
+    if (!c->inv_s_valid && c->ns > 0) {
+        int32_t* inv;
+        TRY(ensure(c, c->inv_s, (size_t)c->ns, &inv));
+        invert_perm_source<<<blocks_for(c->ns), 256, 0, c->stream>>>((const int32_t*)c->sperm.p, (int)c->ns, inv);
+        KCHK(c);
+        c->inv_s_valid = true;
+    }
+    if (!c->inv_t_valid && c->nt > 0) {
+        int32_t* inv;
+        TRY(ensure(c, c->inv_t, (size_t)c->nt, &inv));
+        invert_perm_target<<<blocks_for(c->nt), 256, 0, c->stream>>>((const float*)c->tblk.p, (int)c->nt, inv);
+        KCHK(c);
+        c->inv_t_valid = true;
+    }
+    return MI_ICP_OK;
+}
+
+template <int EST, int MODE>
+void launch_reduce_t(mi_icp_ctx* c, const ReduceArgs& a, const Xform& X, int grid, double* partial) {
+    reduce_kernel<EST, MODE><<<grid, kReduceThreads, 0, c->stream>>>(a, X, partial);
+}
+
+bool estimator_ready(const mi_icp_ctx* c, int est) {
+    switch (est) {
+        case kEstP2P: return true;
+        case kEstPt2Pl: return c->t_has_nrm;                  // transformation_estimation.cu:199-200
+        case kEstSym: return c->t_has_nrm && c->s_has_nrm;    // :293-294
+        case kEstGICP: return c->t_has_cov && c->s_has_cov;   // generalized_icp.cu:156-159
+        default: return false;
+    }
+}
+
+// Accumulate sys[32] on the device for the current correspondences.  When the
+// estimator's inputs are missing only the statistics ([28], [29]) are formed.
+int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T) {
+    double *partial, *sys;
+    TRY(ensure(c, c->partial, (size_t)kReduceBlocks * kSysSize, &partial));
+    TRY(ensure(c, c->sys_dev, kSysSize, &sys));
+    ReduceArgs a;
+    a.sx = (const float*)c->sx.p;
+    a.sy = (const float*)c->sy.p;
+    a.sz = (const float*)c->sz.p;
+    a.snrm = (const float4*)c->snrm.p;
+    a.scov = (const float*)c->scov.p;
+    a.tblk = (const float*)c->tblk.p;
+    a.tnrm = (const float4*)c->tnrm.p;
+    a.tcov = (const float*)c->tcov.p;
+    a.nn_idx = (const int32_t*)c->nn_idx.p;
+    a.pairs = nullptr;
+    a.inv_s = a.inv_t = nullptr;
+    a.ns = (int)c->ns;
+    a.nt = (int)c->nt;
+    a.count = c->ns;
+    if (c->n_user_pairs >= 0) {
+        TRY(ensure_inverse_maps(c));
+        a.pairs = (const int32_t*)c->user_pairs.p;
+        a.inv_s = (const int32_t*)c->inv_s.p;
+        a.inv_t = (const int32_t*)c->inv_t.p;
+        a.count = c->n_user_pairs;
+    }
+    if (c->ns <= 0 || c->nt <= 0 || (!a.pairs && !c->nn_valid)) a.count = 0;
+    const int grid = (int)std::min<int64_t>(kReduceBlocks, blocks_for(a.count, kReduceThreads));
+    const Xform X = make_xform(T);
+    if (!estimator_ready(c, est)) {
+        est = kEstP2P;
+        mode = 1;
+    }
+    {
+        EvTimer t(c, 1);
+        switch (est * 2 + mode) {
+            case kEstP2P * 2 + 0: launch_reduce_t<kEstP2P, 0>(c, a, X, grid, partial); break;
+            case kEstP2P * 2 + 1: launch_reduce_t<kEstP2P, 1>(c, a, X, grid, partial); break;
+            case kEstPt2Pl * 2 + 0: launch_reduce_t<kEstPt2Pl, 0>(c, a, X, grid, partial); break;
+            case kEstPt2Pl * 2 + 1: launch_reduce_t<kEstPt2Pl, 1>(c, a, X, grid, partial); break;
+            case kEstSym * 2 + 0: launch_reduce_t<kEstSym, 0>(c, a, X, grid, partial); break;
+            case kEstSym * 2 + 1: launch_reduce_t<kEstSym, 1>(c, a, X, grid, partial); break;
+            case kEstGICP * 2 + 0: launch_reduce_t<kEstGICP, 0>(c, a, X, grid, partial); break;
+            case kEstGICP * 2 + 1: launch_reduce_t<kEstGICP, 1>(c, a, X, grid, partial); break;
+            default: return fail(c, MI_ICP_ERR_INVALID, "unknown estimation type %d", est);
+        }
+        KCHK(c);
+        reduce_final<<<1, 256, 0, c->stream>>>(partial, grid, sys);
+        KCHK(c);
+    }
+    return MI_ICP_OK;
+}
+
+// all-reduce across ranks (if any), copy to the host, synchronise
+int fetch_system(mi_icp_ctx* c, double* out) {
+    double* sys = (double*)c->sys_dev.p;
+    if (c->comm) {
+        ncclResult_t r = g_rccl.AllReduce(sys, sys, kSysSize, ncclDouble, ncclSum, c->comm, c->stream);
+        if (r != ncclSuccess) return fail(c, MI_ICP_ERR_COMM, "ncclAllReduce failed (%d)", (int)r);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->sys_host, sys, kSysSize * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    collect_events(c);
+    std::memcpy(out, c->sys_host, kSysSize * sizeof(double));
+    return MI_ICP_OK;
+}
+
+// host step of ComputeTransformation for the built-in estimators
+Mat4 solve_update(const mi_icp_ctx* c, int est, const double* sys, float det_thresh) {
+    Mat4 update = host::identity4();
+    if (!(sys[29] > 0.0) || !estimator_ready(c, est)) return update;
+    if (est == kEstP2P) {
+        const int64_t n_model = c->ns_global > 0 ? c->ns_global : c->ns;
+        return host::kabsch_from_sums(sys, (long long)n_model);
+    }
+    if (est == kEstPt2Pl) {
+        host::solve_system(sys, det_thresh, update);
+    } else if (est == kEstSym) {
+        Mat4 half;
+        if (host::solve_system(sys, det_thresh, half)) update = host::square_rotation(half);
+    } else if (est == kEstGICP) {
+        host::solve_system(sys, -1.0f, update);  // no det check (generalized_icp.cu:180)
+    }
+    return update;
+}
+
+void stats_from_system(const mi_icp_ctx* c, const double* sys, float* fitness, float* rmse) {
+    // registration.cu:71-78
+    const double count = sys[29];
+    const int64_t n_src = c->ns_global > 0 ? c->ns_global : c->ns;
+    if (!(count > 0.0) || n_src <= 0) {
+        *fitness = 0.0f;
+        *rmse = 0.0f;
+        return;
+    }
+    *fitness = (float)count / (float)n_src;
+    *rmse = std::sqrt((float)sys[28] / (float)count);
+}
+
+int check_ctx(mi_icp_ctx* c) {
+    if (!c) return MI_ICP_ERR_INVALID;
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return fail(c, MI_ICP_ERR_HIP, "hipSetDevice(%d): %s", c->device, hipGetErrorString(e));
+    return MI_ICP_OK;
+}
+
+}  // namespace
+
+// ============================================================================
+// C ABI
+// ============================================================================
+extern "C" {
+
+const char* mi_icp_version(void) { return "mi_icp 0.1 (gfx950)"; }
+
+int mi_icp_create(int device, mi_icp_ctx** out) {
+    if (!out) return MI_ICP_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+        return MI_ICP_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return MI_ICP_ERR_NO_DEVICE;
+    mi_icp_ctx* c = new mi_icp_ctx();
+    c->device = device;
+    bool ok = hipHostMalloc((void**)&c->sys_host, 64 * sizeof(double), hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void**)&c->f_host, 64 * sizeof(float), hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void**)&c->u_host, 16 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+    for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    if (!ok) {
+        mi_icp_destroy(c);
+        return MI_ICP_ERR_HIP;
+    }
+    *out = c;
+    return MI_ICP_OK;
+}
+
+void mi_icp_destroy(mi_icp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    DevBuf* all[] = {&c->tblk, &c->tnrm, &c->tcov, &c->nodes, &c->inv_t, &c->sx, &c->sy, &c->sz,
+                     &c->sperm, &c->snrm, &c->scov, &c->nn_idx, &c->nn_d2, &c->inv_s,
+                     &c->user_pairs, &c->keys0, &c->keys1, &c->vals0, &c->vals1, &c->hist,
+                     &c->scan_tmp, &c->bounds_part, &c->bounds, &c->partial, &c->sys_dev,
+                     &c->dense_idx, &c->flags, &c->pairs_out, &c->seg_start, &c->stage[0],
+                     &c->stage[1], &c->stage[2], &c->stage[3], &c->stage[4], &c->stage[5]};
+    for (DevBuf* b : all) release(*b);
+    if (c->sys_host) (void)hipHostFree(c->sys_host);
+    if (c->f_host) (void)hipHostFree(c->f_host);
+    if (c->u_host) (void)hipHostFree(c->u_host);
+    for (int i = 0; i < 4; ++i)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    delete c;
+}
+
+const char* mi_icp_last_error(const mi_icp_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int mi_icp_set_stream(mi_icp_ctx* c, void* hip_stream) {
+    TRY(check_ctx(c));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = (hipStream_t)hip_stream;
+    return MI_ICP_OK;
+}
+
+int mi_icp_synchronize(mi_icp_ctx* c) {
+    TRY(check_ctx(c));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    collect_events(c);
+    return MI_ICP_OK;
+}
+
+int mi_icp_set_profiling(mi_icp_ctx* c, int enable) {
+    TRY(check_ctx(c));
+    c->profiling = enable != 0;
+    for (double& v : c->prof) v = 0.0;
+    c->ev_pending_nn = c->ev_pending_red = false;
+    return MI_ICP_OK;
+}
+
+int mi_icp_get_profile(mi_icp_ctx* c, double* out8) {
+    if (!c || !out8) return MI_ICP_ERR_INVALID;
+    std::memcpy(out8, c->prof, sizeof(c->prof));
+    return MI_ICP_OK;
+}
+
+// ---------------------------------------------------------------------------
+int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, const float* covs,
+                      int64_t n, int mem_kind) {
+    TRY(check_ctx(c));
+    if (n < 0 || n > 0x7fffff00ll || (n > 0 && !xyz)) return fail(c, MI_ICP_ERR_INVALID, "set_target: bad size/pointer");
+    c->nt = 0;
+    c->inv_t_valid = false;
+    c->nn_valid = false;
+    c->n_user_pairs = -1;
+    c->t_has_nrm = normals != nullptr && n > 0;
+    c->t_has_cov = covs != nullptr && n > 0;
+    if (n == 0) return MI_ICP_OK;
+    hipEvent_t e0 = c->ev[2], e1 = c->ev[3];
+    if (c->profiling) {
+        (void)hipStreamSynchronize(c->stream);
+        collect_events(c);
+        (void)hipEventRecord(e0, c->stream);
+    }
+
+    const float *d_pts, *d_nrm, *d_cov;
+    TRY(to_device(c, xyz, (size_t)n * 3, mem_kind, c->stage[0], &d_pts));
+    TRY(to_device(c, normals, (size_t)n * 3, mem_kind, c->stage[1], &d_nrm));
+    TRY(to_device(c, covs, (size_t)n * 9, mem_kind, c->stage[2], &d_cov));
+
+    const uint32_t* order;
+    TRY(morton_order(c, d_pts, n, &order));
+
+    const int nleaf = (int)((n + kLeaf - 1) / kLeaf);
+    int P = 1;
+    while (P < nleaf) P <<= 1;
+    float* tblk;
+    float4* tnrm = nullptr;
+    float* tcov = nullptr;
+    Node* nodes;
+    TRY(ensure(c, c->tblk, (size_t)nleaf * kLeafFloats, &tblk));
+    TRY(ensure(c, c->nodes, (size_t)2 * P, &nodes));
+    if (d_nrm) TRY(ensure(c, c->tnrm, (size_t)n, &tnrm));
+    if (d_cov) TRY(ensure(c, c->tcov, (size_t)n * 9, &tcov));
+    build_leaves<<<blocks_for(P), 256, 0, c->stream>>>(order, d_pts, d_nrm, d_cov, (int)n, nleaf, P,
+                                                       tblk, tnrm, tcov, nodes);
+    KCHK(c);
+    for (uint32_t first = (uint32_t)P / 2; first >= 1; first /= 2) {
+        build_level<<<blocks_for(first), 256, 0, c->stream>>>(nodes, first, first);
+        KCHK(c);
+    }
+    c->nt = n;
+    c->nleaf = nleaf;
+    c->P = P;
+    if (c->profiling) {
+        (void)hipEventRecord(e1, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->prof[4] = ms;
+    }
+    return MI_ICP_OK;
+}
+
+int mi_icp_set_source(mi_icp_ctx* c, const float* xyz, const float* normals, const float* covs,
+                      int64_t n, int mem_kind) {
+    TRY(check_ctx(c));
+    if (n < 0 || n > 0x7fffff00ll || (n > 0 && !xyz)) return fail(c, MI_ICP_ERR_INVALID, "set_source: bad size/pointer");
+    c->ns = 0;
+    c->inv_s_valid = false;
+    c->nn_valid = false;
+    c->n_user_pairs = -1;
+    c->s_has_nrm = normals != nullptr && n > 0;
+    c->s_has_cov = covs != nullptr && n > 0;
+    if (c->nranks == 1) c->ns_global = 0;
+    if (n == 0) return MI_ICP_OK;
+    hipEvent_t e0 = c->ev[2], e1 = c->ev[3];
+    if (c->profiling) {
+        (void)hipStreamSynchronize(c->stream);
+        collect_events(c);
+        (void)hipEventRecord(e0, c->stream);
+    }
+
+    const float *d_pts, *d_nrm, *d_cov;
+    TRY(to_device(c, xyz, (size_t)n * 3, mem_kind, c->stage[3], &d_pts));
+    TRY(to_device(c, normals, (size_t)n * 3, mem_kind, c->stage[4], &d_nrm));
+    TRY(to_device(c, covs, (size_t)n * 9, mem_kind, c->stage[5], &d_cov));
+
+    const uint32_t* order;
+    TRY(morton_order(c, d_pts, n, &order));
+
+    float *sx, *sy, *sz, *scov = nullptr, *d2;
+    int32_t *sperm, *idx;
+    float4* snrm = nullptr;
+    TRY(ensure(c, c->sx, (size_t)n, &sx));
+    TRY(ensure(c, c->sy, (size_t)n, &sy));
+    TRY(ensure(c, c->sz, (size_t)n, &sz));
+    TRY(ensure(c, c->sperm, (size_t)n, &sperm));
+    TRY(ensure(c, c->nn_idx, (size_t)n, &idx));
+    TRY(ensure(c, c->nn_d2, (size_t)n, &d2));
+    if (d_nrm) TRY(ensure(c, c->snrm, (size_t)n, &snrm));
+    if (d_cov) TRY(ensure(c, c->scov, (size_t)n * 9, &scov));
+    gather_source<<<blocks_for(n), 256, 0, c->stream>>>(order, d_pts, d_nrm, d_cov, (int)n, sx, sy, sz,
+                                                        sperm, snrm, scov);
+    KCHK(c);
+    c->ns = n;
+    if (c->profiling) {
+        (void)hipEventRecord(e1, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->prof[5] = ms;
+    }
+    return MI_ICP_OK;
+}
+
+int mi_icp_set_global_source_count(mi_icp_ctx* c, int64_t n_total) {
+    if (!c || n_total < 0) return MI_ICP_ERR_INVALID;
+    c->ns_global = n_total;
+    return MI_ICP_OK;
+}
+
+// ---------------------------------------------------------------------------
+static int export_dense_idx(mi_icp_ctx* c, int32_t** dense_out) {
+    int32_t* dense;
+    TRY(ensure(c, c->dense_idx, (size_t)std::max<int64_t>(c->ns, 1), &dense));
+    if (c->ns > 0) {
+        export_dense<<<blocks_for(c->ns), 256, 0, c->stream>>>(
+                (const int32_t*)c->nn_idx.p, (const float*)c->nn_d2.p, (const int32_t*)c->sperm.p,
+                (const float*)c->tblk.p, (int)c->ns, dense, nullptr);
+        KCHK(c);
+    }
+    *dense_out = dense;
+    return MI_ICP_OK;
+}
+
+int mi_icp_search_radius_1nn(mi_icp_ctx* c, const float* T, float radius, int32_t* idx_out,
+                             float* d2_out, int mem_kind, double* stats) {
+    TRY(check_ctx(c));
+    if (c->ns <= 0) return fail(c, MI_ICP_ERR_STATE, "search: no source set");
+    const Mat4 M = load_T(T);
+    const float r2 = radius * radius;  // kdtree_flann.inl:119-120
+    TRY(launch_nn(c, M, r2, false));
+    if (c->nt <= 0) {
+        float* d2 = (float*)c->nn_d2.p;
+        fill_i32<<<blocks_for(c->ns), 256, 0, c->stream>>>((int32_t*)d2, c->ns, 0x7f800000);
+        KCHK(c);
+    }
+    if (idx_out || d2_out) {
+        int32_t* dense;
+        float* dense_d2 = nullptr;
+        TRY(ensure(c, c->dense_idx, (size_t)c->ns, &dense));
+        if (d2_out) TRY(ensure(c, c->flags, (size_t)c->ns, (float**)&dense_d2));
+        export_dense<<<blocks_for(c->ns), 256, 0, c->stream>>>(
+                (const int32_t*)c->nn_idx.p, (const float*)c->nn_d2.p, (const int32_t*)c->sperm.p,
+                (const float*)c->tblk.p, (int)c->ns, dense, dense_d2);
+        KCHK(c);
+        TRY(from_device(c, dense, idx_out, (size_t)c->ns, mem_kind));
+        if (d2_out) TRY(from_device(c, dense_d2, d2_out, (size_t)c->ns, mem_kind));
+    }
+    if (stats) {
+        double sys[kSysSize];
+        TRY(launch_reduce(c, kEstP2P, 1, M));
+        TRY(fetch_system(c, sys));
+        stats[0] = sys[29];
+        stats[1] = sys[28];
+        stats[2] = (double)(c->ns_global > 0 ? c->ns_global : c->ns);
+    } else {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        collect_events(c);
+    }
+    return MI_ICP_OK;
+}
+
+int mi_icp_get_correspondences(mi_icp_ctx* c, int32_t* pairs, int64_t capacity, int64_t* count,
+                               int mem_kind) {
+    TRY(check_ctx(c));
+    if (!count) return fail(c, MI_ICP_ERR_INVALID, "get_correspondences: count is null");
+    *count = 0;
+    if (c->n_user_pairs >= 0) {
+        *count = c->n_user_pairs;
+        if (pairs && capacity >= c->n_user_pairs)
+            TRY(from_device(c, (const int32_t*)c->user_pairs.p, pairs, (size_t)c->n_user_pairs * 2, mem_kind));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return MI_ICP_OK;
+    }
+    if (!c->nn_valid || c->ns <= 0 || c->nt <= 0) return MI_ICP_OK;
+    int32_t* dense;
+    TRY(export_dense_idx(c, &dense));
+    uint32_t *flags, *tmp;
+    int32_t* out;
+    TRY(ensure(c, c->flags, (size_t)c->ns, &flags));
+    TRY(ensure(c, c->scan_tmp, (size_t)scan_num_tiles(c->ns) + 2, &tmp));
+    TRY(ensure(c, c->pairs_out, (size_t)c->ns * 2, &out));
+    corr_flags<<<blocks_for(c->ns), 256, 0, c->stream>>>(dense, (int)c->ns, flags);
+    KCHK(c);
+    exclusive_scan_u32(c->stream, flags, flags, c->ns, tmp);
+    KCHK(c);
+    corr_compact<<<blocks_for(c->ns), 256, 0, c->stream>>>(dense, flags, (int)c->ns, out);
+    KCHK(c);
+    HIPCHK(c, hipMemcpyAsync(c->u_host, tmp + scan_num_tiles(c->ns), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int64_t m = (int64_t)c->u_host[0];
+    *count = m;
+    if (pairs && capacity >= m && m > 0) {
+        TRY(from_device(c, out, pairs, (size_t)m * 2, mem_kind));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return MI_ICP_OK;
+}
+
+int mi_icp_set_correspondences(mi_icp_ctx* c, const int32_t* pairs, int64_t count, int mem_kind) {
+    TRY(check_ctx(c));
+    if (count < 0 || (count > 0 && !pairs)) return fail(c, MI_ICP_ERR_INVALID, "set_correspondences: bad arguments");
+    int32_t* d;
+    TRY(ensure(c, c->user_pairs, (size_t)std::max<int64_t>(count, 1) * 2, &d));
+    if (count > 0)
+        HIPCHK(c, hipMemcpyAsync(d, pairs, (size_t)count * 2 * sizeof(int32_t),
+                                 mem_kind == MI_ICP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                 c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller may free `pairs` on return
+    c->n_user_pairs = count;
+    return MI_ICP_OK;
+}
+
+// ---------------------------------------------------------------------------
+int mi_icp_compute_system(mi_icp_ctx* c, int est, const float* T, double* out32) {
+    TRY(check_ctx(c));
+    if (!out32) return fail(c, MI_ICP_ERR_INVALID, "compute_system: out is null");
+    if (est != kEstP2P && est != kEstPt2Pl && est != kEstSym && est != kEstGICP)
+        return fail(c, MI_ICP_ERR_INVALID, "unknown estimation type %d", est);
+    if (!estimator_ready(c, est))
+        return fail(c, MI_ICP_ERR_STATE, "estimation type %d needs normals/covariances that were not set", est);
+    const Mat4 M = load_T(T);
+    TRY(launch_reduce(c, est, 0, M));
+    return fetch_system(c, out32);
+}
+
+int mi_icp_compute_transformation(mi_icp_ctx* c, int est, const float* T, float det_thresh,
+                                  float* update16) {
+    TRY(check_ctx(c));
+    if (!update16) return fail(c, MI_ICP_ERR_INVALID, "compute_transformation: out is null");
+    if (est != kEstP2P && est != kEstPt2Pl && est != kEstSym && est != kEstGICP)
+        return fail(c, MI_ICP_ERR_INVALID, "unknown estimation type %d", est);
+    const Mat4 M = load_T(T);
+    double sys[kSysSize];
+    TRY(launch_reduce(c, est, 0, M));
+    TRY(fetch_system(c, sys));
+    const Mat4 u = solve_update(c, est, sys, det_thresh);
+    std::memcpy(update16, u.data(), sizeof(float) * 16);
+    return MI_ICP_OK;
+}
+
+int mi_icp_compute_rmse(mi_icp_ctx* c, int est, const float* T, float* rmse) {
+    TRY(check_ctx(c));
+    if (!rmse) return fail(c, MI_ICP_ERR_INVALID, "compute_rmse: out is null");
+    if (est != kEstP2P && est != kEstPt2Pl && est != kEstSym && est != kEstGICP)
+        return fail(c, MI_ICP_ERR_INVALID, "unknown estimation type %d", est);
+    *rmse = 0.0f;
+    if (!estimator_ready(c, est)) return MI_ICP_OK;  // the reference returns 0.0
+    const Mat4 M = load_T(T);
+    double sys[kSysSize];
+    TRY(launch_reduce(c, est, 1, M));
+    TRY(fetch_system(c, sys));
+    if (sys[29] > 0.0) *rmse = std::sqrt((float)sys[27] / (float)sys[29]);
+    return MI_ICP_OK;
+}
+
+int mi_icp_solve_system(const double* sys32, float det_thresh, float* T16) {
+    if (!sys32 || !T16) return MI_ICP_ERR_INVALID;
+    Mat4 T;
+    const bool ok = host::solve_system(sys32, det_thresh, T);
+    std::memcpy(T16, T.data(), sizeof(float) * 16);
+    return ok ? 1 : 0;
+}
+
+int mi_icp_kabsch_from_sums(const double* sys32, int64_t n_model, float* T16) {
+    if (!sys32 || !T16 || n_model <= 0) return MI_ICP_ERR_INVALID;
+    const Mat4 T = host::kabsch_from_sums(sys32, (long long)n_model);
+    std::memcpy(T16, T.data(), sizeof(float) * 16);
+    return MI_ICP_OK;
+}
+
+void mi_icp_vector6_to_matrix4(const float* x6, float* T16) {
+    const Mat4 T = host::vector6_to_matrix4(x6);
+    std::memcpy(T16, T.data(), sizeof(float) * 16);
+}
+
+// ---------------------------------------------------------------------------
+int mi_icp_evaluate_registration(mi_icp_ctx* c, float max_distance, const float* T,
+                                 mi_icp_result* out) {
+    TRY(check_ctx(c));
+    if (!out) return fail(c, MI_ICP_ERR_INVALID, "evaluate_registration: out is null");
+    const Mat4 M = load_T(T);
+    std::memset(out, 0, sizeof(*out));
+    std::memcpy(out->transformation, M.data(), sizeof(float) * 16);
+    if (max_distance <= 0.0f || c->ns <= 0) {  // registration.cu:40-42
+        c->nn_valid = false;
+        return MI_ICP_OK;
+    }
+    // registration.cu:114-116: the source is moved only when T is not (approximately) identity
+    const Mat4 apply = host::is_identity4(M) ? host::identity4() : M;
+    double sys[kSysSize];
+    TRY(launch_nn(c, apply, max_distance * max_distance, false));
+    TRY(launch_reduce(c, kEstP2P, 1, apply));
+    TRY(fetch_system(c, sys));
+    stats_from_system(c, sys, &out->fitness, &out->inlier_rmse);
+    out->n_correspondences = (int64_t)sys[29];
+    out->nn_passes = 1;
+    return MI_ICP_OK;
+}
+
+static void fill_result(const mi_icp_ctx* c, mi_icp_result* out) {
+    const auto& L = c->loop;
+    std::memcpy(out->transformation, L.T.data(), sizeof(float) * 16);
+    out->fitness = L.fitness;
+    out->inlier_rmse = L.rmse;
+    out->n_correspondences = (int64_t)L.sys[29];
+    out->iterations = L.iterations;
+    out->nn_passes = L.passes;
+}
+
+// one pass of GetRegistrationResultAndCorrespondences under the loop's current
+// transform + the reduction the next ComputeTransformation needs
+static int loop_evaluate(mi_icp_ctx* c, bool seed) {
+    auto& L = c->loop;
+    TRY(launch_nn(c, L.A, L.r2, seed));
+    TRY(launch_reduce(c, L.est, 0, L.A));
+    TRY(fetch_system(c, L.sys));
+    stats_from_system(c, L.sys, &L.fitness, &L.rmse);
+    ++L.passes;
+    return MI_ICP_OK;
+}
+
+// one iteration of the loop body (registration.cu:155-163)
+static int loop_step(mi_icp_ctx* c) {
+    auto& L = c->loop;
+    const Mat4 update = solve_update(c, L.est, L.sys, L.det_thresh);  // :157
+    L.T = host::mul4(update, L.T);                                     // :159
+    L.A = host::mul4(update, L.A);                                     // :160 (applied on load)
+    TRY(loop_evaluate(c, true));                                       // :162
+    ++L.iterations;
+    return MI_ICP_OK;
+}
+
+int mi_icp_icp_begin(mi_icp_ctx* c, int est, float max_distance, const float* init,
+                     float det_thresh, mi_icp_result* out) {
+    TRY(check_ctx(c));
+    if (est != kEstP2P && est != kEstPt2Pl && est != kEstSym && est != kEstGICP)
+        return fail(c, MI_ICP_ERR_INVALID, "unknown estimation type %d", est);
+    auto& L = c->loop;
+    L = mi_icp_ctx::Loop();
+    L.est = est;
+    L.det_thresh = det_thresh;
+    L.T = load_T(init);
+    L.A = host::is_identity4(L.T) ? host::identity4() : L.T;  // registration.cu:148-150
+    L.r2 = max_distance * max_distance;
+    if (max_distance <= 0.0f || c->ns <= 0) {
+        // the reference logs an error and keeps going; every pass then yields an
+        // empty result and identity updates, so the answer is `init` unchanged
+        c->nn_valid = false;
+        if (out) {
+            std::memset(out, 0, sizeof(*out));
+            fill_result(c, out);
+        }
+        return MI_ICP_OK;
+    }
+    L.active = true;
+    TRY(loop_evaluate(c, false));
+    if (out) fill_result(c, out);
+    return MI_ICP_OK;
+}
+
+int mi_icp_icp_iterate(mi_icp_ctx* c, int n_iterations, mi_icp_result* out) {
+    TRY(check_ctx(c));
+    if (n_iterations < 0) return fail(c, MI_ICP_ERR_INVALID, "icp_iterate: negative count");
+    if (c->loop.active)
+        for (int i = 0; i < n_iterations; ++i) TRY(loop_step(c));
+    if (out) fill_result(c, out);
+    return MI_ICP_OK;
+}
+
+int mi_icp_registration_icp(mi_icp_ctx* c, int est, float max_distance, const float* init,
+                            const mi_icp_params* params, mi_icp_result* out) {
+    TRY(check_ctx(c));
+    if (!out) return fail(c, MI_ICP_ERR_INVALID, "registration_icp: out is null");
+    mi_icp_params p = {1e-6f, 1e-6f, 30, 1e-6f};
+    if (params) p = *params;
+    TRY(mi_icp_icp_begin(c, est, max_distance, init, p.det_thresh, out));
+    auto& L = c->loop;
+    if (!L.active) return MI_ICP_OK;
+    for (int it = 0; it < p.max_iteration; ++it) {
+        const float b_fit = L.fitness, b_rmse = L.rmse;                   // :161
+        TRY(loop_step(c));
+        if (std::fabs(b_fit - L.fitness) < p.relative_fitness &&
+            std::fabs(b_rmse - L.rmse) < p.relative_rmse)                 // :165-170
+            break;
+    }
+    fill_result(c, out);
+    return MI_ICP_OK;
+}
+
+// ---------------------------------------------------------------------------
+int mi_icp_transform(mi_icp_ctx* c, const float* T, float* xyz, float* normals, float* covs,
+                     int64_t n, int mem_kind) {
+    TRY(check_ctx(c));
+    if (n < 0) return fail(c, MI_ICP_ERR_INVALID, "transform: negative size");
+    if (n == 0 || (!xyz && !normals && !covs)) return MI_ICP_OK;
+    const Xform X = make_xform(load_T(T));
+    const float *dp, *dn, *dc;
+    TRY(to_device(c, (const float*)xyz, (size_t)n * 3, mem_kind, c->stage[0], &dp));
+    TRY(to_device(c, (const float*)normals, (size_t)n * 3, mem_kind, c->stage[1], &dn));
+    TRY(to_device(c, (const float*)covs, (size_t)n * 9, mem_kind, c->stage[2], &dc));
+    transform_cloud<<<blocks_for(n), 256, 0, c->stream>>>(X, (float*)dp, (float*)dn, (float*)dc, n);
+    KCHK(c);
+    if (mem_kind == MI_ICP_HOST) {
+        TRY(from_device(c, dp, xyz, xyz ? (size_t)n * 3 : 0, mem_kind));
+        TRY(from_device(c, dn, normals, normals ? (size_t)n * 3 : 0, mem_kind));
+        TRY(from_device(c, dc, covs, covs ? (size_t)n * 9 : 0, mem_kind));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // pointcloud.cu:297 cudaDeviceSynchronize
+    return MI_ICP_OK;
+}
+
+int mi_icp_covariances_from_normals(mi_icp_ctx* c, const float* normals, int64_t n, float epsilon,
+                                    float* covs, int mem_kind) {
+    TRY(check_ctx(c));
+    if (n < 0 || (n > 0 && (!normals || !covs))) return fail(c, MI_ICP_ERR_INVALID, "covariances_from_normals: bad arguments");
+    if (n == 0) return MI_ICP_OK;
+    const float* dn;
+    TRY(to_device(c, normals, (size_t)n * 3, mem_kind, c->stage[1], &dn));
+    float* dc = covs;
+    if (mem_kind == MI_ICP_HOST) TRY(ensure(c, c->stage[2], (size_t)n * 9, &dc));
+    cov_from_normals<<<blocks_for(n), 256, 0, c->stream>>>(dn, n, epsilon, dc);
+    KCHK(c);
+    if (mem_kind == MI_ICP_HOST) TRY(from_device(c, (const float*)dc, covs, (size_t)n * 9, mem_kind));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MI_ICP_OK;
+}
+
+int mi_icp_voxel_downsample(mi_icp_ctx* c, const float* xyz, const float* normals,
+                            const float* colors, int64_t n, float voxel, float* out_xyz,
+                            float* out_normals, float* out_colors, int64_t* m, int mem_kind) {
+    TRY(check_ctx(c));
+    if (!m) return fail(c, MI_ICP_ERR_INVALID, "voxel_downsample: m is null");
+    *m = 0;
+    if (n < 0 || n > 0x7fffff00ll) return fail(c, MI_ICP_ERR_INVALID, "voxel_downsample: bad size");
+    if (n == 0 || !(voxel > 0.0f)) return MI_ICP_OK;  // down_sample.cu:173-176
+    if (!xyz || !out_xyz || (normals && !out_normals) || (colors && !out_colors))
+        return fail(c, MI_ICP_ERR_INVALID, "voxel_downsample: null buffer");
+
+    const float *dp, *dn, *dcol;
+    TRY(to_device(c, xyz, (size_t)n * 3, mem_kind, c->stage[0], &dp));
+    TRY(to_device(c, normals, (size_t)n * 3, mem_kind, c->stage[1], &dn));
+    TRY(to_device(c, colors, (size_t)n * 3, mem_kind, c->stage[2], &dcol));
+
+    float* bnd;
+    TRY(compute_bounds(c, dp, n, &bnd));
+    HIPCHK(c, hipMemcpyAsync(c->f_host, bnd, 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    VoxelGrid g;
+    float ext = 0.0f;
+    int bits[3];
+    {
+        const float* b = c->f_host;
+        const float origin[3] = {b[0] - voxel * 0.5f, b[1] - voxel * 0.5f, b[2] - voxel * 0.5f};
+        for (int d = 0; d < 3; ++d) ext = std::fmax(ext, (b[3 + d] + voxel * 0.5f) - origin[d]);
+        if (voxel * (float)INT32_MAX < ext) return MI_ICP_OK;  // down_sample.cu:186-189
+        g.ox = origin[0];
+        g.oy = origin[1];
+        g.oz = origin[2];
+        g.voxel = voxel;
+        for (int d = 0; d < 3; ++d) {
+            const double cells = std::floor(((double)b[3 + d] - (double)origin[d]) / (double)voxel) + 2.0;
+            int nb = 1;
+            while (nb < 32 && (double)(1ull << nb) < cells) ++nb;
+            bits[d] = nb;
+        }
+        g.bits_y = bits[1];
+        g.bits_z = bits[2];
+    }
+
+    SortBuffers sb;
+    TRY(sort_buffers(c, n, &sb));
+    const uint32_t* order;
+    const int nb = blocks_for(n);
+    if (bits[0] + bits[1] + bits[2] <= 64) {
+        voxel_keys<<<nb, 256, 0, c->stream>>>(dp, n, g, -1, nullptr, sb.keys[0], sb.vals[0]);
+        KCHK(c);
+        order = sb.vals[radix_sort_pairs(c->stream, sb, n, bits[0] + bits[1] + bits[2])];
+    } else {
+        // three stable sorts, least significant axis first
+        const uint32_t* prev = nullptr;
+        for (int axis = 2; axis >= 0; --axis) {
+            uint32_t* tmp_order = nullptr;
+            if (prev) {  // keys are rebuilt from the current order; keep it out of the sort's way
+                TRY(ensure(c, c->seg_start, (size_t)n + 1, &tmp_order));
+                HIPCHK(c, hipMemcpyAsync(tmp_order, prev, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+            }
+            voxel_keys<<<nb, 256, 0, c->stream>>>(dp, n, g, axis, tmp_order, sb.keys[0], sb.vals[0]);
+            KCHK(c);
+            prev = sb.vals[radix_sort_pairs(c->stream, sb, n, bits[axis])];
+            if (prev != sb.vals[0] && axis > 0) {
+                // next round writes keys[0]/vals[0]; the result already sits in the other pair
+            }
+        }
+        order = prev;
+    }
+    KCHK(c);
+
+    uint32_t *head, *pos, *seg_start, *tmp;
+    TRY(ensure(c, c->flags, (size_t)n, &head));
+    TRY(ensure(c, c->dense_idx, (size_t)n, (uint32_t**)&pos));
+    // `order` may live in seg_start's buffer only in the fallback's intermediate rounds, never at the end
+    TRY(ensure(c, c->scan_tmp, (size_t)scan_num_tiles(n) + 2, &tmp));
+    voxel_heads<<<nb, 256, 0, c->stream>>>(dp, n, g, order, head);
+    KCHK(c);
+    exclusive_scan_u32(c->stream, head, pos, n, tmp);
+    KCHK(c);
+    HIPCHK(c, hipMemcpyAsync(c->u_host, tmp + scan_num_tiles(n), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int64_t nvox = (int64_t)c->u_host[0];
+    TRY(ensure(c, c->seg_start, (size_t)n + 1, &seg_start));
+    voxel_seg_starts<<<nb, 256, 0, c->stream>>>(head, pos, n, seg_start);
+    KCHK(c);
+
+    float *op = out_xyz, *on = out_normals, *oc = out_colors;
+    if (mem_kind == MI_ICP_HOST) {
+        TRY(ensure(c, c->stage[3], (size_t)nvox * 3, &op));
+        if (dn) TRY(ensure(c, c->stage[4], (size_t)nvox * 3, &on));
+        if (dcol) TRY(ensure(c, c->stage[5], (size_t)nvox * 3, &oc));
+    }
+    voxel_means<<<blocks_for(nvox * 8), 256, 0, c->stream>>>(dp, dn, dcol, order, seg_start, nvox, n, op,
+                                                            dn ? on : nullptr, dcol ? oc : nullptr);
+    KCHK(c);
+    if (mem_kind == MI_ICP_HOST) {
+        TRY(from_device(c, (const float*)op, out_xyz, (size_t)nvox * 3, mem_kind));
+        if (dn) TRY(from_device(c, (const float*)on, out_normals, (size_t)nvox * 3, mem_kind));
+        if (dcol) TRY(from_device(c, (const float*)oc, out_colors, (size_t)nvox * 3, mem_kind));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *m = nvox;
+    return MI_ICP_OK;
+}
+
+int mi_icp_estimate_normals_knn(mi_icp_ctx* c, const float* xyz, int64_t n, int knn, float* normals,
+                                int mem_kind) {
+    TRY(check_ctx(c));
+    if (n < 0 || (n > 0 && (!xyz || !normals))) return fail(c, MI_ICP_ERR_INVALID, "estimate_normals: bad arguments");
+    if (knn > kMaxKnn) return fail(c, MI_ICP_ERR_INVALID, "estimate_normals: knn > %d not supported", kMaxKnn);
+    if (n == 0) return MI_ICP_OK;
+    // builds its own LBVH over the cloud: target slot is reused and invalidated afterwards
+    TRY(mi_icp_set_target(c, xyz, nullptr, nullptr, n, mem_kind));
+    float* dn = normals;
+    if (mem_kind == MI_ICP_HOST) TRY(ensure(c, c->stage[1], (size_t)n * 3, &dn));
+    const uint32_t nblocks = (uint32_t)((c->nleaf + kKnnLeavesPerBlock - 1) / kKnnLeavesPerBlock);
+    const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
+    knn_normals_kernel<<<grid, kKnnThreads, 0, c->stream>>>((const Node*)c->nodes.p, (const float*)c->tblk.p,
+                                                            (int)n, c->nleaf, knn, nblocks, 2u * (uint32_t)c->P + 8u, dn);
+    KCHK(c);
+    if (mem_kind == MI_ICP_HOST) TRY(from_device(c, (const float*)dn, normals, (size_t)n * 3, mem_kind));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->nt = 0;  // the tree belonged to this call
+    c->t_has_nrm = c->t_has_cov = false;
+    return MI_ICP_OK;
+}
+
+// ---------------------------------------------------------------------------
+int mi_icp_comm_unique_id(char* id128) {
+    if (!id128) return MI_ICP_ERR_INVALID;
+    if (!load_rccl(g_rccl)) return MI_ICP_ERR_COMM;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return MI_ICP_ERR_COMM;
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id128, &id, 128);
+    return MI_ICP_OK;
+}
+
+int mi_icp_comm_init(mi_icp_ctx* c, const char* id128, int nranks, int rank) {
+    TRY(check_ctx(c));
+    if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, MI_ICP_ERR_INVALID, "comm_init: bad arguments");
+    if (!load_rccl(g_rccl)) return fail(c, MI_ICP_ERR_COMM, "librccl could not be loaded: %s", dlerror());
+    ncclUniqueId id;
+    std::memcpy(&id, id128, 128);
+    if (c->comm) {
+        g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+        c->comm = nullptr;
+        return fail(c, MI_ICP_ERR_COMM, "ncclCommInitRank failed (%d)", (int)r);
+    }
+    c->nranks = nranks;
+    return MI_ICP_OK;
+}
+
+int mi_icp_comm_destroy(mi_icp_ctx* c) {
+    TRY(check_ctx(c));
+    if (c->comm) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    c->nranks = 1;
+    return MI_ICP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// test-only entry points (include/mi_icp_debug.h)
+int mi_icp_debug_sort_pairs(mi_icp_ctx* c, uint64_t* keys, uint32_t* vals, int64_t n, int key_bits) {
+    TRY(check_ctx(c));
+    if (n < 0 || key_bits < 1 || key_bits > 64 || (n > 0 && (!keys || !vals)))
+        return fail(c, MI_ICP_ERR_INVALID, "debug_sort_pairs: bad arguments");
+    if (n == 0) return MI_ICP_OK;
+    SortBuffers sb;
+    TRY(sort_buffers(c, n, &sb));
+    HIPCHK(c, hipMemcpyAsync(sb.keys[0], keys, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(sb.vals[0], vals, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    const int cur = radix_sort_pairs(c->stream, sb, n, key_bits);
+    KCHK(c);
+    HIPCHK(c, hipMemcpyAsync(keys, sb.keys[cur], (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(vals, sb.vals[cur], (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MI_ICP_OK;
+}
+
+int mi_icp_debug_exclusive_scan(mi_icp_ctx* c, const uint32_t* in, uint32_t* out, int64_t n,
+                                uint64_t* total) {
+    TRY(check_ctx(c));
+    if (n < 0 || (n > 0 && (!in || !out))) return fail(c, MI_ICP_ERR_INVALID, "debug_exclusive_scan: bad arguments");
+    if (total) *total = 0;
+    if (n == 0) return MI_ICP_OK;
+    uint32_t *d, *tmp;
+    TRY(ensure(c, c->flags, (size_t)n, &d));
+    TRY(ensure(c, c->scan_tmp, (size_t)scan_num_tiles(n) + 2, &tmp));
+    HIPCHK(c, hipMemcpyAsync(d, in, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    exclusive_scan_u32(c->stream, d, d, n, tmp);
+    KCHK(c);
+    HIPCHK(c, hipMemcpyAsync(out, d, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->u_host, tmp + scan_num_tiles(n), 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (total) *total = c->u_host[0];
+    return MI_ICP_OK;
+}
+
+int mi_icp_debug_morton_order(mi_icp_ctx* c, const float* xyz, int64_t n, uint32_t* order_out) {
+    TRY(check_ctx(c));
+    if (n <= 0 || !xyz || !order_out) return fail(c, MI_ICP_ERR_INVALID, "debug_morton_order: bad arguments");
+    const float* d_pts;
+    TRY(to_device(c, xyz, (size_t)n * 3, MI_ICP_HOST, c->stage[0], &d_pts));
+    const uint32_t* order;
+    TRY(morton_order(c, d_pts, n, &order));
+    HIPCHK(c, hipMemcpyAsync(order_out, order, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MI_ICP_OK;
+}
+
+}  // extern "C"

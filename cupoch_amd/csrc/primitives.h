@@ -1,0 +1,234 @@
+// primitives.h -- device-wide exclusive scan and LSD radix sort, hand-written
+// for wave64 (no rocPRIM / hipCUB).  They replace the thrust::exclusive_scan /
+// sort_by_key / remove_if calls of the reference's kd-tree builder
+// (third_party/flann/algorithms/kdtree_cuda_builder.h:484-668), of
+// VoxelDownSample (geometry/down_sample.cu:200-203) and of the correspondence
+// compaction (registration/registration.cu:62-69).
+#pragma once
+#include "device_utils.h"
+
+namespace mi {
+
+// ---------------------------------------------------------------------------
+// exclusive scan of uint32 (n < 2^31), three launches:
+//   tile sums -> scan of tile sums (one block) -> per-tile scan + offset
+// ---------------------------------------------------------------------------
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+// exclusive prefix of v over the 256 threads of a block; *total = block sum
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total,
+                                                         uint32_t* lds4) {
+    const int lane = lane_id();
+    const int wid = (int)(threadIdx.x >> 6);
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) lds4[wid] = x;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; ++w) {
+        const uint32_t s = lds4[w];
+        if (w < wid) woff += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return woff + x - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_tile_sums(const uint32_t* __restrict__ in,
+                                                               uint32_t* __restrict__ tile_sums,
+                                                               int n) {
+    __shared__ uint32_t lds4[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+        if (base + k < n) s += in[base + k];
+    uint32_t tot;
+    block_exclusive_scan(s, &tot, lds4);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+// one block; in-place exclusive scan of tile_sums[0..ntiles), total -> [ntiles]
+__global__ __launch_bounds__(kScanThreads) void scan_tile_offsets(uint32_t* __restrict__ tile_sums,
+                                                                  int ntiles) {
+    __shared__ uint32_t lds4[4];
+    uint32_t carry = 0;
+    for (int start = 0; start < ntiles; start += kScanTile) {
+        const int base = start + (int)threadIdx.x * kScanItems;
+        uint32_t v[kScanItems];
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            v[k] = (base + k < ntiles) ? tile_sums[base + k] : 0u;
+            s += v[k];
+        }
+        uint32_t tot;
+        uint32_t off = carry + block_exclusive_scan(s, &tot, lds4);
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            if (base + k < ntiles) tile_sums[base + k] = off;
+            off += v[k];
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) tile_sums[ntiles] = carry;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_apply(const uint32_t* in, uint32_t* out,
+                                                           const uint32_t* __restrict__ tile_offs,
+                                                           int n) {
+    __shared__ uint32_t lds4[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        s += v[k];
+    }
+    uint32_t tot;
+    uint32_t off = tile_offs[blockIdx.x] + block_exclusive_scan(s, &tot, lds4);
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (base + k < n) out[base + k] = off;
+        off += v[k];
+    }
+}
+
+static inline int scan_num_tiles(int64_t n) { return (int)((n + kScanTile - 1) / kScanTile); }
+
+// out may alias in.  tmp holds scan_num_tiles(n)+1 words; the grand total ends
+// up in tmp[scan_num_tiles(n)] (device memory).
+static inline void exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32_t* out, int64_t n,
+                                      uint32_t* tmp) {
+    if (n <= 0) return;
+    const int nt = scan_num_tiles(n);
+    scan_tile_sums<<<nt, kScanThreads, 0, st>>>(in, tmp, (int)n);
+    scan_tile_offsets<<<1, kScanThreads, 0, st>>>(tmp, nt);
+    scan_apply<<<nt, kScanThreads, 0, st>>>(in, out, tmp, (int)n);
+}
+
+// ---------------------------------------------------------------------------
+// LSD radix sort, 8 bits per pass, 64-bit keys + 32-bit payload, stable.
+// Work decomposition: each wave owns one contiguous segment of kSortSeg
+// elements and walks it in 64-element chunks, so the order inside a digit bin
+// is: segment, then chunk, then lane -- i.e. the input order.
+// Per pass: histogram [256][nseg]  ->  exclusive scan  ->  ranked scatter.
+// The in-chunk rank comes from wave ballots (8 ballots give each lane the mask
+// of its digit peers), not from atomics, which is what keeps the sort stable.
+// ---------------------------------------------------------------------------
+constexpr int kSortChunks = 16;
+constexpr int kSortSeg = 64 * kSortChunks;
+constexpr int kSortThreads = 256;
+constexpr int kSortWaves = kSortThreads / 64;
+
+static inline int sort_num_segments(int64_t n) { return (int)((n + kSortSeg - 1) / kSortSeg); }
+
+__global__ __launch_bounds__(kSortThreads) void rs_histogram(const uint64_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ hist, int n,
+                                                             int nseg, int shift) {
+    __shared__ uint32_t cnt[kSortWaves][256];
+    const int lane = lane_id();
+    const int wid = (int)(threadIdx.x >> 6);
+    const int seg = (int)blockIdx.x * kSortWaves + wid;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cnt[wid][lane + 64 * k] = 0;
+    __syncthreads();
+    if (seg < nseg) {
+        const int64_t base = (int64_t)seg * kSortSeg;
+        for (int c = 0; c < kSortChunks; ++c) {
+            const int64_t i = base + c * 64 + lane;
+            if (i < n) atomicAdd(&cnt[wid][(uint32_t)(keys[i] >> shift) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    if (seg < nseg) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int d = lane + 64 * k;
+            hist[(int64_t)d * nseg + seg] = cnt[wid][d];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kSortThreads) void rs_scatter(const uint64_t* __restrict__ keys_in,
+                                                           const uint32_t* __restrict__ vals_in,
+                                                           uint64_t* __restrict__ keys_out,
+                                                           uint32_t* __restrict__ vals_out,
+                                                           const uint32_t* __restrict__ offs, int n,
+                                                           int nseg, int shift) {
+    __shared__ uint32_t base[kSortWaves][256];
+    const int lane = lane_id();
+    const int wid = (int)(threadIdx.x >> 6);
+    const int seg = (int)blockIdx.x * kSortWaves + wid;
+    if (seg >= nseg) return;  // no block-level barrier below: waves are independent
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int d = lane + 64 * k;
+        base[wid][d] = offs[(int64_t)d * nseg + seg];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int64_t sbase = (int64_t)seg * kSortSeg;
+    for (int c = 0; c < kSortChunks; ++c) {
+        const int64_t i = sbase + c * 64 + lane;
+        const bool valid = i < n;
+        const uint64_t key = valid ? keys_in[i] : 0ull;
+        const uint32_t val = valid ? vals_in[i] : 0u;
+        const uint32_t digit = (uint32_t)(key >> shift) & 255u;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (digit >> b) & 1u;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+        const uint32_t cnt = (uint32_t)__popcll(peers);
+        uint32_t pos = 0;
+        if (valid) pos = base[wid][digit] + rank;
+        __builtin_amdgcn_wave_barrier();  // every lane has read its bin base ...
+        if (valid && rank == 0) base[wid][digit] = pos + cnt;  // ... before the bin leader advances it
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            keys_out[pos] = key;
+            vals_out[pos] = val;
+        }
+    }
+}
+
+struct SortBuffers {
+    uint64_t* keys[2];
+    uint32_t* vals[2];
+    uint32_t* hist;      // 256 * nseg words
+    uint32_t* scan_tmp;  // scan_num_tiles(256*nseg) + 1 words
+};
+
+// Sorts keys[0]/vals[0] by the low `key_bits` bits; returns the index (0 or 1)
+// of the buffer pair that holds the result.
+static inline int radix_sort_pairs(hipStream_t st, const SortBuffers& b, int64_t n, int key_bits) {
+    if (n <= 0) return 0;
+    const int nseg = sort_num_segments(n);
+    const int nblk = (nseg + kSortWaves - 1) / kSortWaves;
+    const int passes = (key_bits + 7) / 8;
+    int cur = 0;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * 8;
+        rs_histogram<<<nblk, kSortThreads, 0, st>>>(b.keys[cur], b.hist, (int)n, nseg, shift);
+        exclusive_scan_u32(st, b.hist, b.hist, (int64_t)256 * nseg, b.scan_tmp);
+        rs_scatter<<<nblk, kSortThreads, 0, st>>>(b.keys[cur], b.vals[cur], b.keys[cur ^ 1],
+                                                  b.vals[cur ^ 1], b.hist, (int)n, nseg, shift);
+        cur ^= 1;
+    }
+    return cur;
+}
+
+}  // namespace mi

@@ -1,0 +1,223 @@
+// reduce.h -- per-correspondence residual/Jacobian evaluation and the
+// reduction into the 6x6 normal equations (or the Kabsch sums).
+//
+// Replaces utility::ComputeJTJandJTr (utility/eigen.inl:84-145), i.e.
+// thrust::transform_reduce over a 172-byte tuple<Matrix6f,Vector6f,float>
+// (full 6x6, fp32 tree sum), by one pass that keeps the 21 upper-triangle
+// entries + 6 + 3 scalars per lane in fp64 registers, reduces across the wave
+// with shuffles, across the block through LDS, and across blocks with a
+// second single-block launch in a fixed order (bitwise reproducible, no
+// atomics).  The estimator functors are restated from
+//   point-to-plane  registration/transformation_estimation.cu:34-56
+//   symmetric       registration/transformation_estimation.cu:58-90
+//   GICP            registration/generalized_icp.cu:63-105 (+ eigenvalue.inl)
+//   point-to-point  registration/kabsch.cu:42-104 (three thrust reductions)
+// The source point is transformed on load (no materialised
+// PointCloud::Transform), normals by R, covariances by R*C*R^T.
+#pragma once
+#include "device_utils.h"
+#include "eigen3.h"
+
+namespace mi {
+
+constexpr int kEstP2P = 1, kEstPt2Pl = 2, kEstSym = 3, kEstGICP = 5;
+constexpr int kSysSize = 32;
+constexpr int kReduceThreads = 256;
+constexpr int kReduceBlocks = 1024;
+
+// R * C * R^T for a column-major 3x3 read from memory (geometry_utils.cu:257-265)
+__device__ __forceinline__ void rotate_cov(const Xform& T, const float* C, M3& out) {
+    const float R[3][3] = {{T.r00, T.r01, T.r02}, {T.r10, T.r11, T.r12}, {T.r20, T.r21, T.r22}};
+    float RC[3][3];  // [r][c]
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            RC[r][c] = __builtin_fmaf(R[r][2], C[c * 3 + 2],
+                                      __builtin_fmaf(R[r][1], C[c * 3 + 1], R[r][0] * C[c * 3 + 0]));
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            out.m[r][c] = __builtin_fmaf(RC[r][2], R[c][2],
+                                         __builtin_fmaf(RC[r][1], R[c][1], RC[r][0] * R[c][0]));
+}
+
+// ---- accumulation -------------------------------------------------------------
+__device__ __forceinline__ void accum_row(double* acc, const float* J, float r) {
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b, ++k) acc[k] = __builtin_fma((double)J[a], (double)J[b], acc[k]);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] = __builtin_fma((double)J[a], (double)r, acc[21 + a]);
+    acc[27] = __builtin_fma((double)r, (double)r, acc[27]);
+}
+
+struct ReduceArgs {
+    const float* sx;
+    const float* sy;
+    const float* sz;
+    const float4* snrm;   // sorted source normals (symmetric)
+    const float* scov;    // sorted source covariances (GICP)
+    const float* tblk;    // target leaf lines
+    const float4* tnrm;   // sorted target normals
+    const float* tcov;    // sorted target covariances
+    const int32_t* nn_idx;  // per sorted source position: sorted target position or -1
+    const int32_t* pairs;   // explicit pairs (original indices) or nullptr
+    const int32_t* inv_s;   // original -> sorted maps (pairs mode)
+    const int32_t* inv_t;
+    int ns, nt;
+    int64_t count;          // ns, or number of pairs
+};
+
+// MODE 0: accumulate the linear system; MODE 1: accumulate only the
+// estimator's ComputeRMSE error into acc[27] (+ [28],[29]).
+template <int EST, int MODE>
+__global__ __launch_bounds__(kReduceThreads) void reduce_kernel(ReduceArgs a, Xform T,
+                                                                double* __restrict__ partial) {
+    double acc[30];
+#pragma unroll
+    for (int k = 0; k < 30; ++k) acc[k] = 0.0;
+
+    const int64_t stride = (int64_t)gridDim.x * kReduceThreads;
+    for (int64_t k = (int64_t)blockIdx.x * kReduceThreads + threadIdx.x; k < a.count; k += stride) {
+        int64_t i;
+        int32_t j;
+        if (a.pairs) {
+            const int32_t pi = a.pairs[2 * k], pj = a.pairs[2 * k + 1];
+            if ((uint32_t)pi >= (uint32_t)a.ns || (uint32_t)pj >= (uint32_t)a.nt) continue;
+            i = a.inv_s[pi];
+            j = a.inv_t[pj];
+        } else {
+            i = k;
+            j = a.nn_idx[k];
+        }
+        if (j < 0) continue;
+        float vs[3], vt[3];
+        xform_point(T, a.sx[i], a.sy[i], a.sz[i], vs[0], vs[1], vs[2]);
+        const float* line = a.tblk + (int64_t)(j >> 3) * kLeafFloats + (j & 7);
+        vt[0] = line[0];
+        vt[1] = line[8];
+        vt[2] = line[16];
+        const float d[3] = {vs[0] - vt[0], vs[1] - vt[1], vs[2] - vt[2]};
+        acc[28] += (double)sq3(d[0], d[1], d[2]);
+        acc[29] += 1.0;
+
+        if (EST == kEstPt2Pl) {
+            const float4 n4 = a.tnrm[j];
+            const float nt[3] = {n4.x, n4.y, n4.z};
+            const float r = dot3(d, nt);
+            if (MODE == 0) {
+                float J[6];
+                cross3(vs, nt, J);
+                J[3] = nt[0];
+                J[4] = nt[1];
+                J[5] = nt[2];
+                accum_row(acc, J, r);
+            } else {
+                acc[27] += (double)(r * r);
+            }
+        } else if (EST == kEstSym) {
+            const float4 t4 = a.tnrm[j];
+            const float4 s4 = a.snrm[i];
+            float ns[3];
+            rotate(T, s4.x, s4.y, s4.z, ns[0], ns[1], ns[2]);
+            const float n[3] = {ns[0] + t4.x, ns[1] + t4.y, ns[2] + t4.z};
+            const float r = dot3(d, n);
+            if (MODE == 0) {
+                const float s[3] = {vs[0] + vt[0], vs[1] + vt[1], vs[2] + vt[2]};
+                float J[6];
+                cross3(s, n, J);
+                J[3] = n[0];
+                J[4] = n[1];
+                J[5] = n[2];
+                accum_row(acc, J, r);
+            } else {
+                const float e2 = r * r;  // transformation_estimation.cu:92-104 squares twice
+                acc[27] += (double)(e2 * e2);
+            }
+        } else if (EST == kEstGICP) {
+            M3 Cs, M, Mi, W;
+            rotate_cov(T, a.scov + i * 9, Cs);
+            const float* Ct = a.tcov + (int64_t)j * 9;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) M.m[r][c] = Ct[c * 3 + r] + Cs.m[r][c];
+            inverse3(M, Mi);
+            sqrt_matrix3x3(Mi, W);
+            if (MODE == 0) {
+                const float A[3][3] = {{0.0f, vs[2], -vs[1]}, {-vs[2], 0.0f, vs[0]}, {vs[1], -vs[0], 0.0f}};
+#pragma unroll
+                for (int row = 0; row < 3; ++row) {
+                    float J[6];
+#pragma unroll
+                    for (int col = 0; col < 3; ++col) {
+                        J[col] = W.m[row][0] * A[0][col] + W.m[row][1] * A[1][col] +
+                                 W.m[row][2] * A[2][col];
+                        J[3 + col] = W.m[row][col];
+                    }
+                    const float r = W.m[row][0] * d[0] + W.m[row][1] * d[1] + W.m[row][2] * d[2];
+                    accum_row(acc, J, r);
+                }
+            } else {
+                float Wd[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) Wd[r] = W.m[r][0] * d[0] + W.m[r][1] * d[1] + W.m[r][2] * d[2];
+                acc[27] += (double)dot3(d, Wd);
+            }
+        } else {  // point-to-point: Kabsch sums / squared distance
+            if (MODE == 0) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    acc[p] += (double)vs[p];
+                    acc[3 + p] += (double)vt[p];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        acc[6 + p * 3 + q] = __builtin_fma((double)vs[p], (double)vt[q], acc[6 + p * 3 + q]);
+                }
+                acc[27] += (double)sq3(d[0], d[1], d[2]);
+            } else {
+                acc[27] += (double)dot3(d, d);
+            }
+        }
+    }
+
+    __shared__ double red[kReduceThreads / 64][kSysSize];
+    const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
+#pragma unroll
+    for (int k = 0; k < 30; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) red[wid][k] = v;
+    }
+    if (lane == 0) {
+        red[wid][30] = 0.0;
+        red[wid][31] = 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x < kSysSize) {
+        const int k = (int)threadIdx.x;
+        partial[(int64_t)blockIdx.x * kSysSize + k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    }
+}
+
+// fixed-order sum of the per-block partials -> out[32]
+__global__ __launch_bounds__(256) void reduce_final(const double* __restrict__ partial, int nblocks,
+                                                    double* __restrict__ out) {
+    __shared__ double red[8][kSysSize];
+    const int k = (int)(threadIdx.x & 31u), part = (int)(threadIdx.x >> 5);
+    double s = 0.0;
+    for (int b = part; b < nblocks; b += 8) s += partial[(int64_t)b * kSysSize + k];
+    red[part][k] = s;
+    __syncthreads();
+    if (threadIdx.x < kSysSize) {
+        double t = 0.0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) t += red[p][k];
+        out[k] = t;
+    }
+}
+
+}  // namespace mi

@@ -1,0 +1,87 @@
+"""Multi-GPU ICP: one process per GPU (torch.distributed for rendezvous, RCCL for
+the per-iteration all-reduce, issued natively by libmi_icp.so on its own stream).
+
+The reference is single-GPU; this is the partitioning BASELINE.json asks for:
+every rank holds the full target (+ LBVH) and a spatially contiguous shard of
+the source; each iteration all-reduces the 32 fp64 values of the reduced system
+(256 bytes) and every rank solves the same 6x6 on its host, so no broadcast is
+needed and all ranks take identical steps.
+"""
+import numpy as np
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous [lo, hi) of rank's share of n items (sizes differ by at most 1)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _spread3(v):
+    v = v.astype(np.uint64) & np.uint64(0x1fffff)
+    v = (v | (v << np.uint64(32))) & np.uint64(0x1f00000000ffff)
+    v = (v | (v << np.uint64(16))) & np.uint64(0x1f0000ff0000ff)
+    v = (v | (v << np.uint64(8))) & np.uint64(0x100f00f00f00f00f)
+    v = (v | (v << np.uint64(4))) & np.uint64(0x10c30c30c30c30c3)
+    v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+    return v
+
+
+def morton_order(points, bits=10):
+    """Host-side Morton order of an (n,3) cloud (stable): the order in which the
+    source is cut into per-rank shards, so that each GPU walks one compact region
+    of the target tree."""
+    p = np.asarray(points, np.float32).reshape(-1, 3)
+    if len(p) == 0:
+        return np.zeros(0, np.int64)
+    mn = p.min(0)
+    ext = float((p.max(0) - mn).max())
+    scale = (float(1 << bits) / ext) if ext > 0 else 0.0
+    q = np.clip((p - mn) * np.float32(scale), 0, (1 << bits) - 1).astype(np.uint32)
+    key = (_spread3(q[:, 0]) << np.uint64(2)) | (_spread3(q[:, 1]) << np.uint64(1)) | _spread3(q[:, 2])
+    return np.argsort(key, kind="stable")
+
+
+def shard_source(points, rank, world, order=None):
+    """Indices (into the original source) of rank's spatial shard."""
+    order = morton_order(points) if order is None else order
+    lo, hi = shard_bounds(len(order), rank, world)
+    return np.sort(order[lo:hi])
+
+
+def exchange_unique_id(make_id, rank, device=None):
+    """Rank 0 creates the 128-byte RCCL unique id, everyone receives it through
+    the already-initialised torch.distributed group (gloo or nccl)."""
+    import torch
+    import torch.distributed as dist
+    buf = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        buf = torch.frombuffer(bytearray(make_id()), dtype=torch.uint8).clone()
+    if dist.get_backend() == "nccl":
+        buf = buf.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    dist.broadcast(buf, src=0)
+    return bytes(buf.cpu().numpy().tobytes())
+
+
+def init_engine_comm(engine, n_source_total):
+    """Attach an Engine to the job's ranks: RCCL communicator + global source size
+    (the fitness denominator, registration.cu:76)."""
+    import torch.distributed as dist
+    from .engine import comm_unique_id
+    rank, world = dist.get_rank(), dist.get_world_size()
+    uid = exchange_unique_id(comm_unique_id, rank)
+    engine.comm_init(uid, world, rank)
+    engine.set_global_source_count(n_source_total)
+    return rank, world
+
+
+def allreduce_system(sys32):
+    """Host-side equivalent of the in-library all-reduce, for any backend
+    (used by the CPU/gloo tests and by Python-level estimators)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(sys32, np.float64).copy())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.numpy()

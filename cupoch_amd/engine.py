@@ -1,0 +1,345 @@
+"""Thin object wrapper over the C ABI (include/mi_icp.h).
+
+Inputs may be numpy arrays (host memory, copied by the engine) or torch CUDA
+tensors (read in place on the device).  4x4 transforms are row-major numpy at
+this level (what a user writes); the C ABI takes Eigen's column-major layout,
+so they are transposed on the way in and out.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MI_ICP_DEVICE, MI_ICP_HOST, MiIcpError, Params, Result
+
+try:  # torch is plumbing (device memory, streams), not a hard requirement of the host path
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_tensor(a):
+    return torch is not None and isinstance(a, torch.Tensor)
+
+
+class _Buf:
+    """A float32/int32 array argument: keeps the backing object alive and exposes
+    (pointer, mem_kind)."""
+
+    def __init__(self, a, dtype, cols, device_index):
+        self.keep = None
+        self.ptr = None
+        self.kind = MI_ICP_HOST
+        self.n = 0
+        if a is None:
+            return
+        if _is_tensor(a):
+            tdt = {np.float32: torch.float32, np.int32: torch.int32}[dtype]
+            t = a
+            if t.dtype != tdt:
+                t = t.to(tdt)
+            t = t.reshape(-1, cols).contiguous()
+            if t.is_cuda:
+                if t.device.index != device_index:
+                    raise MiIcpError("tensor on cuda:%s passed to an engine on cuda:%s"
+                                     % (t.device.index, device_index))
+                self.kind = MI_ICP_DEVICE
+                self.ptr = C.c_void_p(t.data_ptr())
+            else:
+                t = t.numpy()
+                self.ptr = t.ctypes.data_as(C.c_void_p)
+            self.keep = t
+            self.n = int(t.shape[0])
+        else:
+            arr = np.ascontiguousarray(np.asarray(a, dtype=dtype).reshape(-1, cols))
+            self.keep = arr
+            self.ptr = arr.ctypes.data_as(C.c_void_p)
+            self.n = int(arr.shape[0])
+
+
+def _T_in(T):
+    if T is None:
+        return None, None
+    if _is_tensor(T):
+        T = T.detach().cpu().numpy()
+    a = np.ascontiguousarray(np.asarray(T, dtype=np.float32).reshape(4, 4).T)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def _T_out(buf16):
+    return np.array(buf16, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+class Engine:
+    """One mi_icp context = one GPU."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        self._L = _lib.load()
+        self._ctx = C.c_void_p()
+        rc = self._L.mi_icp_create(int(device), C.byref(self._ctx))
+        if rc != 0:
+            self._ctx = None
+            raise MiIcpError("mi_icp_create(device=%d) failed with status %d "
+                             "(no MI355X visible?)" % (device, rc))
+        self.device = int(device)
+        self.n_source = 0
+        self.n_target = 0
+        if use_torch_stream and torch is not None and torch.cuda.is_available():
+            with torch.cuda.device(self.device):
+                self.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # -- plumbing --------------------------------------------------------------
+    def _chk(self, rc):
+        if rc < 0:
+            msg = self._L.mi_icp_last_error(self._ctx)
+            raise MiIcpError("mi_icp error %d: %s" % (rc, (msg or b"").decode()))
+        return rc
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.mi_icp_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        self._chk(self._L.mi_icp_set_stream(self._ctx, C.c_void_p(int(hip_stream))))
+
+    def synchronize(self):
+        self._chk(self._L.mi_icp_synchronize(self._ctx))
+
+    def _same_kind(self, *bufs):
+        kinds = {b.kind for b in bufs if b.ptr is not None}
+        if len(kinds) > 1:
+            raise MiIcpError("all arrays of one call must live on the same side (host or device)")
+        return kinds.pop() if kinds else MI_ICP_HOST
+
+    # -- clouds ------------------------------------------------------------------
+    def set_target(self, points, normals=None, covariances=None):
+        p = _Buf(points, np.float32, 3, self.device)
+        n = _Buf(normals, np.float32, 3, self.device)
+        c = _Buf(_cov_in(covariances), np.float32, 9, self.device)
+        kind = self._same_kind(p, n, c)
+        self._chk(self._L.mi_icp_set_target(self._ctx, p.ptr, n.ptr, c.ptr, p.n, kind))
+        self.synchronize()  # the staging copies above may be freed by the caller now
+        self.n_target = p.n
+
+    def set_source(self, points, normals=None, covariances=None):
+        p = _Buf(points, np.float32, 3, self.device)
+        n = _Buf(normals, np.float32, 3, self.device)
+        c = _Buf(_cov_in(covariances), np.float32, 9, self.device)
+        kind = self._same_kind(p, n, c)
+        self._chk(self._L.mi_icp_set_source(self._ctx, p.ptr, n.ptr, c.ptr, p.n, kind))
+        self.synchronize()
+        self.n_source = p.n
+
+    def set_global_source_count(self, n_total):
+        self._chk(self._L.mi_icp_set_global_source_count(self._ctx, int(n_total)))
+
+    # -- search ---------------------------------------------------------------------
+    def search_radius_1nn(self, radius, T=None, want_d2=True):
+        """(indices[int32 n], d2[float32 n], stats) in original source order;
+        -1 / +inf where no target point lies within `radius` (strict)."""
+        idx = np.empty(self.n_source, np.int32)
+        d2 = np.empty(self.n_source, np.float32) if want_d2 else None
+        stats = np.zeros(3, np.float64)
+        _, tp = _T_in(T)
+        self._chk(self._L.mi_icp_search_radius_1nn(
+            self._ctx, tp, float(radius), idx.ctypes.data_as(C.c_void_p),
+            None if d2 is None else d2.ctypes.data_as(C.c_void_p), MI_ICP_HOST,
+            stats.ctypes.data_as(C.c_void_p)))
+        return idx, d2, stats
+
+    def get_correspondences(self):
+        cnt = C.c_int64(0)
+        self._chk(self._L.mi_icp_get_correspondences(self._ctx, None, 0, C.byref(cnt), MI_ICP_HOST))
+        out = np.empty((max(cnt.value, 0), 2), np.int32)
+        if cnt.value > 0:
+            self._chk(self._L.mi_icp_get_correspondences(
+                self._ctx, out.ctypes.data_as(C.c_void_p), cnt.value, C.byref(cnt), MI_ICP_HOST))
+        return out
+
+    def set_correspondences(self, pairs):
+        b = _Buf(pairs, np.int32, 2, self.device)
+        self._chk(self._L.mi_icp_set_correspondences(self._ctx, b.ptr, b.n, b.kind))
+
+    # -- estimation -------------------------------------------------------------------
+    def compute_system(self, est, T=None):
+        out = np.zeros(32, np.float64)
+        _, tp = _T_in(T)
+        self._chk(self._L.mi_icp_compute_system(self._ctx, int(est), tp,
+                                                out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def compute_transformation(self, est, T=None, det_thresh=1e-6):
+        out = (C.c_float * 16)()
+        _, tp = _T_in(T)
+        self._chk(self._L.mi_icp_compute_transformation(self._ctx, int(est), tp,
+                                                        float(det_thresh), out))
+        return _T_out(out)
+
+    def compute_rmse(self, est, T=None):
+        out = C.c_float(0)
+        _, tp = _T_in(T)
+        self._chk(self._L.mi_icp_compute_rmse(self._ctx, int(est), tp, C.byref(out)))
+        return float(out.value)
+
+    # -- registration --------------------------------------------------------------------
+    def evaluate_registration(self, max_distance, T=None):
+        res = Result()
+        _, tp = _T_in(T)
+        self._chk(self._L.mi_icp_evaluate_registration(self._ctx, float(max_distance), tp,
+                                                       C.byref(res)))
+        return res
+
+    def registration_icp(self, est, max_distance, init=None, relative_fitness=1e-6,
+                         relative_rmse=1e-6, max_iteration=30, det_thresh=1e-6):
+        res = Result()
+        prm = Params(float(relative_fitness), float(relative_rmse), int(max_iteration),
+                     float(det_thresh))
+        _, tp = _T_in(init)
+        self._chk(self._L.mi_icp_registration_icp(self._ctx, int(est), float(max_distance), tp,
+                                                  C.byref(prm), C.byref(res)))
+        return res
+
+    def icp_begin(self, est, max_distance, init=None, det_thresh=1e-6):
+        res = Result()
+        _, tp = _T_in(init)
+        self._chk(self._L.mi_icp_icp_begin(self._ctx, int(est), float(max_distance), tp,
+                                           float(det_thresh), C.byref(res)))
+        return res
+
+    def icp_iterate(self, n_iterations=1):
+        res = Result()
+        self._chk(self._L.mi_icp_icp_iterate(self._ctx, int(n_iterations), C.byref(res)))
+        return res
+
+    # -- geometry ---------------------------------------------------------------------------
+    def transform(self, T, points=None, normals=None, covariances=None):
+        """In place on torch CUDA tensors; numpy inputs are returned transformed."""
+        p = _Buf(points, np.float32, 3, self.device)
+        n = _Buf(normals, np.float32, 3, self.device)
+        c = _Buf(_cov_in(covariances), np.float32, 9, self.device)
+        kind = self._same_kind(p, n, c)
+        cnt = max(p.n, n.n, c.n)
+        _, tp = _T_in(T)
+        self._chk(self._L.mi_icp_transform(self._ctx, tp, p.ptr, n.ptr, c.ptr, cnt, kind))
+        return p.keep, n.keep, _cov_out(c.keep)
+
+    def voxel_downsample(self, points, voxel_size, normals=None, colors=None):
+        p = _Buf(points, np.float32, 3, self.device)
+        n = _Buf(normals, np.float32, 3, self.device)
+        c = _Buf(colors, np.float32, 3, self.device)
+        kind = self._same_kind(p, n, c)
+        m = C.c_int64(0)
+        if kind == MI_ICP_DEVICE:
+            dev = p.keep.device
+            mk = lambda b: torch.empty((p.n, 3), dtype=torch.float32, device=dev) if b.ptr is not None else None
+            ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        else:
+            mk = lambda b: np.empty((p.n, 3), np.float32) if b.ptr is not None else None
+            ptr = lambda t: None if t is None else t.ctypes.data_as(C.c_void_p)
+        op, on, oc = mk(p), mk(n), mk(c)
+        self._chk(self._L.mi_icp_voxel_downsample(self._ctx, p.ptr, n.ptr, c.ptr, p.n,
+                                                  float(voxel_size), ptr(op), ptr(on), ptr(oc),
+                                                  C.byref(m), kind))
+        k = int(m.value)
+        cut = lambda t: None if t is None else t[:k]
+        return cut(op) if op is not None else np.empty((0, 3), np.float32), cut(on), cut(oc)
+
+    def covariances_from_normals(self, normals, epsilon=1e-3):
+        n = _Buf(normals, np.float32, 3, self.device)
+        if n.kind == MI_ICP_DEVICE:
+            out = torch.empty((n.n, 9), dtype=torch.float32, device=n.keep.device)
+            optr = C.c_void_p(out.data_ptr())
+        else:
+            out = np.empty((n.n, 9), np.float32)
+            optr = out.ctypes.data_as(C.c_void_p)
+        self._chk(self._L.mi_icp_covariances_from_normals(self._ctx, n.ptr, n.n, float(epsilon),
+                                                          optr, n.kind))
+        return _cov_out(out)
+
+    def estimate_normals_knn(self, points, knn=30):
+        p = _Buf(points, np.float32, 3, self.device)
+        if p.kind == MI_ICP_DEVICE:
+            out = torch.empty((p.n, 3), dtype=torch.float32, device=p.keep.device)
+            optr = C.c_void_p(out.data_ptr())
+        else:
+            out = np.empty((p.n, 3), np.float32)
+            optr = out.ctypes.data_as(C.c_void_p)
+        self._chk(self._L.mi_icp_estimate_normals_knn(self._ctx, p.ptr, p.n, int(knn), optr, p.kind))
+        self.n_target = 0
+        return out
+
+    # -- multi-GPU / instrumentation -------------------------------------------------------------
+    def comm_init(self, unique_id, nranks, rank):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self._L.mi_icp_comm_init(self._ctx, buf, int(nranks), int(rank)))
+
+    def comm_destroy(self):
+        self._chk(self._L.mi_icp_comm_destroy(self._ctx))
+
+    def set_profiling(self, enable=True):
+        self._chk(self._L.mi_icp_set_profiling(self._ctx, 1 if enable else 0))
+
+    def get_profile(self):
+        out = np.zeros(8, np.float64)
+        self._chk(self._L.mi_icp_get_profile(self._ctx, out.ctypes.data_as(C.c_void_p)))
+        return dict(nn_ms=out[0], nn_launches=int(out[1]), reduce_ms=out[2],
+                    reduce_launches=int(out[3]), build_target_ms=out[4], build_source_ms=out[5])
+
+
+def comm_unique_id():
+    L = _lib.load()
+    buf = C.create_string_buffer(128)
+    rc = L.mi_icp_comm_unique_id(buf)
+    if rc != 0:
+        raise MiIcpError("mi_icp_comm_unique_id failed (%d): RCCL not loadable" % rc)
+    return bytes(buf.raw)
+
+
+def _cov_in(covs):
+    """(n,3,3) row-major user layout -> (n,9) column-major (Eigen::Matrix3f)."""
+    if covs is None:
+        return None
+    if _is_tensor(covs):
+        c = covs.reshape(-1, 3, 3)
+        return c.transpose(1, 2).contiguous().reshape(-1, 9)
+    c = np.asarray(covs, np.float32).reshape(-1, 3, 3)
+    return np.ascontiguousarray(c.transpose(0, 2, 1)).reshape(-1, 9)
+
+
+def _cov_out(c9):
+    if c9 is None:
+        return None
+    if _is_tensor(c9):
+        return c9.reshape(-1, 3, 3).transpose(1, 2).contiguous()
+    return np.ascontiguousarray(np.asarray(c9).reshape(-1, 3, 3).transpose(0, 2, 1))
+
+
+def solve_system(sys32, det_thresh=1e-6):
+    L = _lib.load()
+    sys32 = np.ascontiguousarray(sys32, np.float64)
+    out = (C.c_float * 16)()
+    ok = L.mi_icp_solve_system(sys32.ctypes.data_as(C.c_void_p), float(det_thresh), out)
+    return bool(ok > 0), _T_out(out)
+
+
+def kabsch_from_sums(sys32, n_model):
+    L = _lib.load()
+    sys32 = np.ascontiguousarray(sys32, np.float64)
+    out = (C.c_float * 16)()
+    L.mi_icp_kabsch_from_sums(sys32.ctypes.data_as(C.c_void_p), int(n_model), out)
+    return _T_out(out)
+
+
+def vector6_to_matrix4(x):
+    L = _lib.load()
+    x = np.ascontiguousarray(x, np.float32)
+    out = (C.c_float * 16)()
+    L.mi_icp_vector6_to_matrix4(x.ctypes.data_as(C.c_void_p), out)
+    return _T_out(out)

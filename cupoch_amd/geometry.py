@@ -1,0 +1,137 @@
+"""cupoch.geometry.PointCloud mirror (src/cupoch/geometry/pointcloud.h:43-263,
+python surface src/python/cupoch_pybind/geometry/pointcloud.cpp:33-200) --
+only the members the ICP path touches.  Arrays live on the GPU as torch
+tensors; every operation below runs a HIP kernel through the C ABI."""
+import numpy as np
+
+from . import utility
+from .engine import Engine
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+_engines = {}
+
+
+def get_engine(device=None):
+    """Process-wide engine per GPU (the reference's per-process allocator/streams)."""
+    d = utility.default_device() if device is None else int(device)
+    if d not in _engines:
+        _engines[d] = Engine(d)
+    return _engines[d]
+
+
+class KDTreeSearchParamKNN:
+    """knn::KDTreeSearchParamKNN (knn/kdtree_search_param.h:49-56)"""
+
+    def __init__(self, knn=30):
+        self.knn = int(knn)
+
+
+class PointCloud:
+    def __init__(self, points=None):
+        self._points = utility.Vector3fVector() if points is None else _v3(points)
+        self._normals = None
+        self._colors = None
+        self._covariances = None
+
+    # device-vector style properties ------------------------------------------------
+    @property
+    def points(self):
+        return self._points
+
+    @points.setter
+    def points(self, v):
+        self._points = _v3(v)
+
+    @property
+    def normals(self):
+        return self._normals if self._normals is not None else utility.Vector3fVector()
+
+    @normals.setter
+    def normals(self, v):
+        self._normals = _v3(v)
+
+    @property
+    def colors(self):
+        return self._colors if self._colors is not None else utility.Vector3fVector()
+
+    @colors.setter
+    def colors(self, v):
+        self._colors = _v3(v)
+
+    @property
+    def covariances(self):
+        return self._covariances if self._covariances is not None else utility.Matrix3fVector()
+
+    @covariances.setter
+    def covariances(self, v):
+        self._covariances = v if isinstance(v, utility.Matrix3fVector) else utility.Matrix3fVector(v)
+
+    # pointcloud.h:82-96 ------------------------------------------------------------------
+    def has_points(self):
+        return len(self._points) > 0
+
+    def has_normals(self):
+        return self.has_points() and self._normals is not None and len(self._normals) == len(self._points)
+
+    def has_colors(self):
+        return self.has_points() and self._colors is not None and len(self._colors) == len(self._points)
+
+    def has_covariances(self):
+        return (self.has_points() and self._covariances is not None
+                and len(self._covariances) == len(self._points))
+
+    def is_empty(self):
+        return not self.has_points()
+
+    def clone(self):
+        out = PointCloud()
+        out._points = utility.Vector3fVector(self._points.tensor.clone())
+        for name in ("_normals", "_colors"):
+            v = getattr(self, name)
+            if v is not None:
+                setattr(out, name, utility.Vector3fVector(v.tensor.clone()))
+        if self._covariances is not None:
+            out._covariances = utility.Matrix3fVector(self._covariances.tensor.clone())
+        return out
+
+    # PointCloud::Transform (pointcloud.cu:293-299) ------------------------------------------
+    def transform(self, transformation):
+        eng = get_engine(self._points.tensor.device.index)
+        n = self._normals.tensor if self._normals is not None and len(self._normals) else None
+        c = self._covariances.tensor if self._covariances is not None and len(self._covariances) else None
+        _, _, c_new = eng.transform(np.asarray(transformation, np.float32), self._points.tensor, n, c)
+        if c_new is not None:
+            self._covariances.tensor = c_new
+        return self
+
+    # PointCloud::VoxelDownSample (down_sample.cu:170-273) --------------------------------------
+    def voxel_down_sample(self, voxel_size):
+        out = PointCloud()
+        if not self.has_points():
+            return out
+        eng = get_engine(self._points.tensor.device.index)
+        n = self._normals.tensor if self.has_normals() else None
+        c = self._colors.tensor if self.has_colors() else None
+        p2, n2, c2 = eng.voxel_downsample(self._points.tensor, float(voxel_size), n, c)
+        out._points = utility.Vector3fVector(p2.clone())
+        if n2 is not None:
+            out._normals = utility.Vector3fVector(n2.clone())
+        if c2 is not None:
+            out._colors = utility.Vector3fVector(c2.clone())
+        return out
+
+    # PointCloud::EstimateNormals (estimate_normals.cu:82-127), KNN search only ----------------------
+    def estimate_normals(self, search_param=None):
+        k = 30 if search_param is None else int(getattr(search_param, "knn", 30))
+        eng = get_engine(self._points.tensor.device.index)
+        nrm = eng.estimate_normals_knn(self._points.tensor, k)
+        self._normals = utility.Vector3fVector(nrm)
+        return True
+
+
+def _v3(v):
+    return v if isinstance(v, utility.Vector3fVector) else utility.Vector3fVector(v)

@@ -1,0 +1,232 @@
+/*
+ * mi_icp.h -- C ABI of libmi_icp.so, the MI355X (gfx950) ICP registration
+ * engine that sits behind cupoch's registration / geometry C++ surface.
+ *
+ * Every entry point names the reference interface it replaces
+ * (paths relative to the cupoch tree, v0.2.11.0).  The reference-side
+ * bindings (C++ classes in namespace cupoch, Python ctypes) are shown in
+ * INTEGRATION.md; cupoch_amd/cpp and the Python modules under cupoch_amd implement them.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = MI_ICP_OK, negative = error;
+ *     nothing throws or exit()s across this boundary (the reference prints and
+ *     exit(0)s on device errors, utility/platform.cu:60-67);
+ *     mi_icp_last_error() returns the text of the last failure on a context.
+ *   - points / normals / colors are AoS float[n][3] with a 12-byte stride
+ *     (the memory layout of device_vector<Eigen::Vector3f>,
+ *     geometry/pointcloud.h:259-262); covariances are float[n][9],
+ *     column-major 3x3 (Eigen::Matrix3f); 4x4 transforms are float[16]
+ *     column-major, i.e. exactly Eigen::Matrix4f::data();
+ *     correspondences are int32 pairs (source_idx, target_idx) =
+ *     device_vector<Eigen::Vector2i> (registration/transformation_estimation.h:36).
+ *   - every buffer argument carries a mem_kind: MI_ICP_HOST (pageable or
+ *     pinned host memory, copied by the engine) or MI_ICP_DEVICE (a HIP device
+ *     pointer on the context's GPU, read in place).  The caller owns all
+ *     buffers it passes; the context owns its internal SoA copies, LBVH and
+ *     scratch arena.
+ *   - one context per GPU; a context is not thread-safe, independent contexts
+ *     may be driven from different host threads.
+ *   - all work is enqueued on the context's stream (mi_icp_set_stream; the
+ *     default is the null stream).  Functions that return scalars or host
+ *     buffers synchronise that stream before returning.
+ */
+#ifndef MI_ICP_H_
+#define MI_ICP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_ICP_API __attribute__((visibility("default")))
+
+enum {
+    MI_ICP_OK = 0,
+    MI_ICP_ERR_INVALID = -1,   /* bad argument (null, negative size, bad enum) */
+    MI_ICP_ERR_STATE = -2,     /* call order: no target / source / normals set */
+    MI_ICP_ERR_HIP = -3,       /* a HIP runtime call failed */
+    MI_ICP_ERR_COMM = -4,      /* RCCL unavailable or failed */
+    MI_ICP_ERR_NO_DEVICE = -5  /* no usable gfx950 device */
+};
+
+enum { MI_ICP_HOST = 0, MI_ICP_DEVICE = 1 };
+
+/* registration::TransformationEstimationType
+ * (registration/transformation_estimation.h:38-45), same values */
+enum {
+    MI_ICP_EST_POINT_TO_POINT = 1,
+    MI_ICP_EST_POINT_TO_PLANE = 2,
+    MI_ICP_EST_SYMMETRIC = 3,
+    MI_ICP_EST_GENERALIZED = 5
+};
+
+typedef struct mi_icp_ctx mi_icp_ctx;
+
+/* registration::ICPConvergenceCriteria (registration/registration.h:35-49)
+ * + the estimator's scalar parameter. */
+typedef struct {
+    float relative_fitness; /* default 1e-6; compared as an ABSOLUTE difference */
+    float relative_rmse;    /* default 1e-6; ditto (registration.cu:165-170) */
+    int32_t max_iteration;  /* default 30 */
+    float det_thresh;       /* PointToPlane / Symmetric det check, default 1e-6;
+                               <= 0 disables it (utility/eigen.cu:114) */
+} mi_icp_params;
+
+/* registration::RegistrationResult (registration/registration.h:51-67);
+ * the correspondence set itself is fetched with mi_icp_get_correspondences. */
+typedef struct {
+    float transformation[16]; /* column-major */
+    float fitness;
+    float inlier_rmse;
+    int64_t n_correspondences;
+    int32_t iterations;   /* solves executed */
+    int32_t nn_passes;    /* nearest-neighbour passes executed (iterations+1) */
+} mi_icp_result;
+
+/* ---- context / errors  (replaces utility::InitializeAllocator + GetStream,
+ *      utility/device_vector.h:78-106, utility/platform.cu:38-67) ---------- */
+MI_ICP_API int mi_icp_create(int device, mi_icp_ctx** out);
+MI_ICP_API void mi_icp_destroy(mi_icp_ctx* ctx);
+MI_ICP_API const char* mi_icp_last_error(const mi_icp_ctx* ctx);
+MI_ICP_API const char* mi_icp_version(void);
+/* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) */
+MI_ICP_API int mi_icp_set_stream(mi_icp_ctx* ctx, void* hip_stream);
+MI_ICP_API int mi_icp_synchronize(mi_icp_ctx* ctx);
+
+/* ---- clouds -----------------------------------------------------------
+ * mi_icp_set_target replaces knn::KDTreeFlann::KDTreeFlann(target.points_) /
+ * SetRawData (knn/kdtree_flann.inl:124-144) and FLANN's
+ * CudaKdTreeBuilder::buildTree (third_party/flann/algorithms/
+ * kdtree_cuda_builder.h:401-700): Morton-sorts the target and builds the LBVH.
+ * normals / covs may be NULL.
+ * mi_icp_set_source replaces `geometry::PointCloud pcd = source`
+ * (registration/registration.cu:147): the engine keeps a Morton-sorted SoA
+ * copy and never mutates the caller's cloud. */
+MI_ICP_API int mi_icp_set_target(mi_icp_ctx* ctx, const float* xyz, const float* normals,
+                                 const float* covs, int64_t n, int mem_kind);
+MI_ICP_API int mi_icp_set_source(mi_icp_ctx* ctx, const float* xyz, const float* normals,
+                                 const float* covs, int64_t n, int mem_kind);
+
+/* ---- nearest neighbours -------------------------------------------------
+ * knn::KDTreeFlann::SearchRadius(source.points_, r, max_nn = 1, indices,
+ * dists) as used by GetRegistrationResultAndCorrespondences
+ * (registration/registration.cu:33-80, knn/kdtree_flann.inl:96-122):
+ * for every source point transformed by T, the target point with the
+ * smallest d2 subject to the strict test d2 < float(r*r); no match ->
+ * idx -1, d2 +inf.  idx_out / d2_out are in ORIGINAL source order and hold
+ * ORIGINAL target indices; either may be NULL.  stats[3] (optional) receives
+ * {count, sum d2, n_source}.  T == NULL means identity.
+ * The result also becomes the context's current correspondence set. */
+MI_ICP_API int mi_icp_search_radius_1nn(mi_icp_ctx* ctx, const float* T, float radius,
+                                        int32_t* idx_out, float* d2_out, int mem_kind,
+                                        double* stats);
+
+/* ---- correspondences ----------------------------------------------------
+ * get: RegistrationResult::correspondence_set_ (registration.cu:54-69):
+ * pairs (i, j), ascending in source index i (stable compaction).
+ * `capacity` is in pairs; *count receives the number of pairs available.
+ * set: supplies an explicit CorrespondenceSet for the
+ * TransformationEstimation::ComputeTransformation / ComputeRMSE entry points
+ * below (registration/transformation_estimation.h:50-65). */
+MI_ICP_API int mi_icp_get_correspondences(mi_icp_ctx* ctx, int32_t* pairs, int64_t capacity,
+                                          int64_t* count, int mem_kind);
+MI_ICP_API int mi_icp_set_correspondences(mi_icp_ctx* ctx, const int32_t* pairs,
+                                          int64_t count, int mem_kind);
+
+/* ---- estimation ---------------------------------------------------------
+ * mi_icp_compute_system replaces utility::ComputeJTJandJTr
+ * (utility/eigen.inl:84-145) over the estimator's Jacobian functor
+ * (registration/transformation_estimation.cu:34-90,
+ *  registration/generalized_icp.cu:63-105) or, for point-to-point, the three
+ * reductions of registration/kabsch.cu:42-104.  The source is taken under T
+ * (points R*p+t, normals R*n, covariances R*C*R^T).  out[32] (fp64):
+ *   [0..20] upper triangle of JtJ row-major, [21..26] Jtr, [27] sum r^2,
+ *   [28] sum d2, [29] count;
+ *   point-to-point: [0..2] sum ps, [3..5] sum pt, [6..14] sum ps*pt^T
+ *   (row-major), [27] sum |ps-pt|^2, [28] sum d2, [29] count.
+ * mi_icp_compute_transformation = TransformationEstimation*::
+ * ComputeTransformation (transformation_estimation.cu:137-142,195-222,
+ * 289-350; generalized_icp.cu:152-183) incl. SolveJacobianSystemAndObtain-
+ * ExtrinsicMatrix (utility/eigen.cu:107-122) / Kabsch (kabsch.cu:105-118);
+ * solver failure -> identity.  mi_icp_compute_rmse = ::ComputeRMSE. */
+MI_ICP_API int mi_icp_compute_system(mi_icp_ctx* ctx, int est_type, const float* T,
+                                     double* out32);
+MI_ICP_API int mi_icp_compute_transformation(mi_icp_ctx* ctx, int est_type, const float* T,
+                                             float det_thresh, float* update16);
+MI_ICP_API int mi_icp_compute_rmse(mi_icp_ctx* ctx, int est_type, const float* T,
+                                   float* rmse);
+/* host-only helpers, exposed for parity tests:
+ * utility::SolveJacobianSystemAndObtainExtrinsicMatrix (utility/eigen.cu:107-122),
+ * utility::TransformVector6fToMatrix4f (utility/eigen.cu:28-50). */
+MI_ICP_API int mi_icp_solve_system(const double* sys32, float det_thresh, float* T16);
+MI_ICP_API int mi_icp_kabsch_from_sums(const double* sys32, int64_t n_model, float* T16);
+MI_ICP_API void mi_icp_vector6_to_matrix4(const float* x6, float* T16);
+
+/* ---- the registration loop ---------------------------------------------
+ * registration::EvaluateRegistration (registration.cu:106-119) and
+ * registration::RegistrationICP (registration.cu:121-172) with the built-in
+ * estimators.  init == NULL means identity.  GICP expects covariances on both
+ * clouds (RegistrationGeneralizedICP's InitializePointCloudForGeneralizedICP,
+ * generalized_icp.cu:37-61, is mi_icp_covariances_from_normals). */
+MI_ICP_API int mi_icp_evaluate_registration(mi_icp_ctx* ctx, float max_distance,
+                                            const float* T, mi_icp_result* out);
+MI_ICP_API int mi_icp_registration_icp(mi_icp_ctx* ctx, int est_type, float max_distance,
+                                       const float* init, const mi_icp_params* params,
+                                       mi_icp_result* out);
+
+/* Stepping form of the same loop (no reference counterpart: the reference only
+ * offers the whole call).  begin = the setup + first correspondence pass
+ * (registration.cu:144-152); iterate(n) = n executions of the loop body
+ * (registration.cu:155-163) without the convergence test.  Used by per-frame
+ * callers that budget iterations themselves and by bench.py, which times
+ * exactly K iterations. */
+MI_ICP_API int mi_icp_icp_begin(mi_icp_ctx* ctx, int est_type, float max_distance,
+                                const float* init, float det_thresh, mi_icp_result* out);
+MI_ICP_API int mi_icp_icp_iterate(mi_icp_ctx* ctx, int n_iterations, mi_icp_result* out);
+
+/* ---- geometry -----------------------------------------------------------
+ * PointCloud::Transform (geometry/pointcloud.cu:293-299): in place on the
+ * caller's arrays; any of the three may be NULL. */
+MI_ICP_API int mi_icp_transform(mi_icp_ctx* ctx, const float* T, float* xyz, float* normals,
+                                float* covs, int64_t n, int mem_kind);
+/* PointCloud::VoxelDownSample (geometry/down_sample.cu:170-273): outputs in
+ * lexicographic voxel order; out arrays must hold n entries; *m receives the
+ * voxel count (0 for voxel_size <= 0 or a too-small voxel, as the reference
+ * returns an empty cloud).  normals / colors and their outputs may be NULL. */
+MI_ICP_API int mi_icp_voxel_downsample(mi_icp_ctx* ctx, const float* xyz, const float* normals,
+                                       const float* colors, int64_t n, float voxel_size,
+                                       float* out_xyz, float* out_normals, float* out_colors,
+                                       int64_t* m, int mem_kind);
+/* InitializePointCloudForGeneralizedICP's normals -> covariances
+ * (registration/generalized_icp.cu:18-30,52-59). */
+MI_ICP_API int mi_icp_covariances_from_normals(mi_icp_ctx* ctx, const float* normals,
+                                               int64_t n, float epsilon, float* covs,
+                                               int mem_kind);
+/* PointCloud::EstimateNormals(KDTreeSearchParamKNN(knn))
+ * (geometry/estimate_normals.cu:82-127), knn <= 64. */
+MI_ICP_API int mi_icp_estimate_normals_knn(mi_icp_ctx* ctx, const float* xyz, int64_t n,
+                                           int knn, float* normals, int mem_kind);
+
+/* ---- multi-GPU (new: the reference is single-GPU) -------------------------
+ * One context per rank/GPU, each holding the full target and its own shard of
+ * the source.  After mi_icp_comm_init every accumulated system is summed
+ * across ranks with one ncclAllReduce(double, 32) on the context's stream
+ * before the host solve, so all ranks take identical steps. */
+MI_ICP_API int mi_icp_comm_unique_id(char* id128);
+MI_ICP_API int mi_icp_comm_init(mi_icp_ctx* ctx, const char* id128, int nranks, int rank);
+MI_ICP_API int mi_icp_comm_destroy(mi_icp_ctx* ctx);
+/* total source size over all ranks (fitness denominator, registration.cu:76) */
+MI_ICP_API int mi_icp_set_global_source_count(mi_icp_ctx* ctx, int64_t n_total);
+
+/* ---- instrumentation ----------------------------------------------------
+ * enable != 0: every nearest-neighbour and reduction launch is bracketed by
+ * hipEvents on the context's stream.  out[8] = {nn_ms_total, nn_launches,
+ * reduce_ms_total, reduce_launches, build_ms_target, build_ms_source, 0, 0}. */
+MI_ICP_API int mi_icp_set_profiling(mi_icp_ctx* ctx, int enable);
+MI_ICP_API int mi_icp_get_profile(mi_icp_ctx* ctx, double* out8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_ICP_H_ */

@@ -1,0 +1,26 @@
+/*
+ * mi_icp_debug.h -- test-only entry points of libmi_icp.so.  Not part of the
+ * drop-in boundary (nothing in the reference binds to these): they expose the
+ * hand-written device primitives (radix sort, exclusive scan) that replace
+ * thrust::sort_by_key / exclusive_scan inside the engine, so that the parity
+ * tests can pin them on their own.  Buffers are host memory.
+ */
+#ifndef MI_ICP_DEBUG_H_
+#define MI_ICP_DEBUG_H_
+#include "mi_icp.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* stable LSD radix sort of (key, value) pairs by the low key_bits bits, in place */
+MI_ICP_API int mi_icp_debug_sort_pairs(mi_icp_ctx* ctx, uint64_t* keys, uint32_t* vals,
+                                       int64_t n, int key_bits);
+/* out[i] = sum of in[0..i); *total = sum of all (out may alias in) */
+MI_ICP_API int mi_icp_debug_exclusive_scan(mi_icp_ctx* ctx, const uint32_t* in, uint32_t* out,
+                                           int64_t n, uint64_t* total);
+/* Morton order of a cloud as the engine computes it: order[sorted] = original */
+MI_ICP_API int mi_icp_debug_morton_order(mi_icp_ctx* ctx, const float* xyz, int64_t n,
+                                         uint32_t* order);
+#ifdef __cplusplus
+}
+#endif
+#endif

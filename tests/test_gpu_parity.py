@@ -1,0 +1,338 @@
+"""GPU parity tests: the HIP path through the C ABI against the CPU oracle on
+identical inputs, the reference's golden vectors, and edge cases.
+Integer / index results are bit-exact (up to equal-distance ties, which the
+reference resolves by traversal order); fp32 per-point values (d2) are
+bit-exact; fp64-accumulated sums agree to 1e-9 relative; final transforms to
+1e-5 Frobenius (the tolerance BASELINE.json's north_star states)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_pair
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+P2P, PT2PL, SYM, GICP = 1, 2, 3, 5
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from cupoch_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def cuda(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rigid(angle, axis, t):
+    axis = np.asarray(axis, np.float64)
+    axis /= np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    T = np.eye(4)
+    T[:3, :3] = np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
+    T[:3, 3] = t
+    return T.astype(np.float32)
+
+
+def check_nn(idx, d2, oi, od, src_t, tgt):
+    """bit-exact d2; index equal, or a genuine tie (same d2 to a different point)."""
+    oi, od = oi[:, 0], od[:, 0]
+    assert np.array_equal(np.isinf(d2), np.isinf(od)), "hit/miss pattern differs"
+    assert np.array_equal(idx < 0, oi < 0)
+    hit = oi >= 0
+    assert np.array_equal(d2[hit], od[hit]), "d2 not bit-exact: max diff %g" % np.abs(d2[hit] - od[hit]).max()
+    diff = np.flatnonzero(idx != oi)
+    if len(diff):
+        # ties only: the engine's pick must be at exactly the same distance
+        dd = src_t[diff] - tgt[idx[diff]]
+        d_alt = (dd[:, 2] * dd[:, 2] + (dd[:, 1] * dd[:, 1] + dd[:, 0] * dd[:, 0])).astype(np.float32)
+        assert np.allclose(d_alt, od[diff], rtol=1e-6), "index mismatch that is not a tie"
+        assert len(diff) <= max(2, len(idx) // 1000)
+
+
+# --------------------------------------------------------------------------- search
+@pytest.mark.parametrize("n", [1, 5, 8, 9, 63, 64, 65, 513, 4096, 100000])
+def test_radius_1nn_matches_oracle_bit_exact(eng, n):
+    rng = np.random.default_rng(n)
+    tgt = rng.random((n, 3), dtype=np.float32)
+    m = max(1, n // 2 + 3)
+    src = rng.random((m, 3), dtype=np.float32)
+    radius = 1.5 * n ** (-1 / 3)
+    eng.set_target(tgt)
+    eng.set_source(src)
+    idx, d2, stats = eng.search_radius_1nn(radius)
+    cnt, oi, od = orc.search_radius(tgt, src, radius, 1)
+    check_nn(idx, d2, oi, od, src, tgt)
+    assert stats[0] == cnt and stats[2] == m
+    np.testing.assert_allclose(stats[1], od[np.isfinite(od)].astype(np.float64).sum(), rtol=1e-12)
+
+
+def test_radius_1nn_with_transform_and_device_inputs(eng):
+    d = make_pair(300000, seed=5)
+    T = rigid(0.3, [1, -2, 0.5], [0.05, -0.02, 0.01])
+    eng.set_target(cuda(d["tgt"]))
+    eng.set_source(cuda(d["src"]))
+    idx, d2, stats = eng.search_radius_1nn(d["max_dist"], T)
+    src_t = orc.transform_points(T, d["src"])
+    cnt, oi, od = orc.search_radius(d["tgt"], src_t, d["max_dist"], 1)
+    check_nn(idx, d2, oi, od, src_t, d["tgt"])
+    assert 0 < cnt < len(src_t)                      # misses and hits both exercised
+    cor = eng.get_correspondences()
+    keep = oi[:, 0] >= 0
+    ref = np.stack([np.flatnonzero(keep), idx[keep]], 1).astype(np.int32)
+    np.testing.assert_array_equal(cor, ref)          # ascending in source index, stable
+
+
+def test_search_golden_vectors(eng, golden):
+    g = golden["lbvh_search_nn"]                     # src/tests/knn/lbvh_knn.cpp:47-86
+    eng.set_target(np.asarray(g["points"], np.float32))
+    eng.set_source(np.asarray([g["query"]], np.float32))
+    idx, d2, _ = eng.search_radius_1nn(1e3)
+    assert idx[0] == g["ref_index"] and abs(d2[0] - g["ref_distance2"]) <= 1e-9
+    g = golden["kdtree_search_radius"]               # src/tests/knn/kdtree_flann.cpp:93-135, max_nn -> 1
+    idx, d2, st = eng.search_radius_1nn(g["radius"])
+    assert idx[0] == g["ref_indices"][0] and abs(d2[0] - g["ref_distance2"][0]) <= g["tol"]
+    assert st[0] == 1
+
+
+def test_search_edge_cases(eng):
+    tgt = np.array([[1, 0, 0], [0, 1, 0], [1, 0, 0]], np.float32)
+    eng.set_target(tgt)
+    eng.set_source(np.zeros((1, 3), np.float32))
+    idx, d2, st = eng.search_radius_1nn(1.0)          # d2 == r2 is NOT a match (strict <)
+    assert idx[0] == -1 and np.isinf(d2[0]) and st[0] == 0
+    idx, d2, st = eng.search_radius_1nn(1.0001)
+    assert idx[0] in (0, 2) and d2[0] == 1.0          # exact duplicate: either is the reference's answer
+    # all-equal points, collinear points, a far outlier
+    pts = np.zeros((100, 3), np.float32)
+    eng.set_target(pts)
+    eng.set_source(pts[:10] + 0.5)
+    idx, d2, _ = eng.search_radius_1nn(1.0)
+    assert (idx >= 0).all() and np.allclose(d2, 0.75)
+    line = np.stack([np.linspace(0, 1, 1000), np.zeros(1000), np.zeros(1000)], 1).astype(np.float32)
+    line[-1] = [1e6, -1e6, 1e6]
+    eng.set_target(line)
+    q = np.array([[0.5004, 0.1, 0.0], [1e6, -1e6, 1e6 + 1], [-5, 0, 0]], np.float32)
+    eng.set_source(q)
+    idx, d2, _ = eng.search_radius_1nn(2.0)
+    _, oi, od = orc.search_radius(line, q, 2.0, 1)
+    check_nn(idx, d2, oi, od, q, line)
+    # empty target -> every query misses; empty source is a state error on search
+    eng.set_target(np.zeros((0, 3), np.float32))
+    idx, d2, st = eng.search_radius_1nn(1.0)
+    assert (idx == -1).all() and np.isinf(d2).all() and st[0] == 0
+    assert len(eng.get_correspondences()) == 0
+
+
+# --------------------------------------------------------------------------- systems
+def _systems_inputs(n=60000, seed=9):
+    d = make_pair(n, seed=seed, noise=0.05)
+    d["src_cov"] = orc.covariances_from_normals(d["src_nrm"])
+    d["tgt_cov"] = orc.covariances_from_normals(d["tgt_nrm"])
+    return d
+
+
+@pytest.mark.parametrize("est", [P2P, PT2PL, SYM, GICP])
+def test_compute_system_matches_oracle(eng, est):
+    d = _systems_inputs()
+    T = rigid(0.01, [0.3, 1, -0.2], [0.002, 0.001, -0.003])
+    eng.set_target(cuda(d["tgt"]), cuda(d["tgt_nrm"]), cuda(d["tgt_cov"]))
+    eng.set_source(cuda(d["src"]), cuda(d["src_nrm"]), cuda(d["src_cov"]))
+    idx, _, _ = eng.search_radius_1nn(d["max_dist"], T)
+    got = eng.compute_system(est, T)
+    cor = eng.get_correspondences()
+    src_t = orc.transform_points(T, d["src"])
+    nrm_t = orc.transform_normals(T, d["src_nrm"])
+    cov_t = orc.rotate_covariances(T, d["src_cov"])
+    ref = orc.compute_system(est, src_t, d["tgt"], cor, nrm_t, d["tgt_nrm"], cov_t, d["tgt_cov"])
+    scale = np.abs(ref).max()
+    tol = 1e-9 if est != GICP else 2e-5            # GICP goes through acosf/cosf: libm vs device ulps
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * scale)
+    rm = eng.compute_rmse(est, T)
+    rr = orc.compute_rmse(est, src_t, d["tgt"], cor, nrm_t, d["tgt_nrm"], cov_t, d["tgt_cov"])
+    assert rm == pytest.approx(rr, rel=1e-5)
+    # ComputeTransformation = system + host solve
+    U = eng.compute_transformation(est, T, det_thresh=-1.0)
+    if est == P2P:
+        Uref = orc.kabsch_from_sums(ref, len(d["src"]))
+    elif est == SYM:
+        ok, half = orc.solve_system(ref, -1.0)
+        Uref = np.eye(4, dtype=np.float32)
+        Uref[:3, :3] = (half[:3, :3].astype(np.float64) @ half[:3, :3].astype(np.float64)).astype(np.float32)
+        Uref[:3, 3] = half[:3, 3]
+    else:
+        _, Uref = orc.solve_system(ref, -1.0)
+    np.testing.assert_allclose(U, Uref, atol=3e-6)
+
+
+def test_explicit_correspondence_set(eng):
+    d = _systems_inputs(5000, seed=2)
+    eng.set_target(d["tgt"], d["tgt_nrm"])
+    eng.set_source(d["src"], d["src_nrm"])
+    rng = np.random.default_rng(0)
+    cor = np.stack([rng.integers(0, 5000, 3000), rng.integers(0, 5000, 3000)], 1).astype(np.int32)
+    eng.set_correspondences(cor)                     # arbitrary pairs, sources repeat
+    for est in (P2P, PT2PL, SYM):
+        got = eng.compute_system(est)
+        ref = orc.compute_system(est, d["src"], d["tgt"], cor, d["src_nrm"], d["tgt_nrm"])
+        np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-9 * np.abs(ref).max())
+    np.testing.assert_array_equal(eng.get_correspondences(), cor)
+    eng.set_correspondences(np.zeros((0, 2), np.int32))
+    np.testing.assert_array_equal(eng.compute_transformation(PT2PL), np.eye(4))   # empty -> identity
+
+
+# --------------------------------------------------------------------------- ICP
+@pytest.mark.parametrize("est", [P2P, PT2PL, SYM, GICP])
+@pytest.mark.parametrize("n", [2000, 100000])
+def test_icp_final_transform_matches_oracle(eng, est, n):
+    d = make_pair(n, seed=21 + est, noise=0.02)
+    kw, okw = {}, {}
+    if est in (PT2PL, SYM):
+        okw = dict(src_nrm=d["src_nrm"], tgt_nrm=d["tgt_nrm"])
+    if est == GICP:
+        sc, tc = orc.covariances_from_normals(d["src_nrm"]), orc.covariances_from_normals(d["tgt_nrm"])
+        okw = dict(src_cov=sc, tgt_cov=tc)
+    eng.set_target(d["tgt"], d["tgt_nrm"] if est != P2P else None, okw.get("tgt_cov"))
+    eng.set_source(d["src"], d["src_nrm"] if est == SYM else None, okw.get("src_cov"))
+    res = eng.registration_icp(est, d["max_dist"], None, 0.0, 0.0, 15, -1.0)
+    T = np.array(res.transformation, np.float32).reshape(4, 4).T
+    ref = orc.registration_icp(d["src"], d["tgt"], d["max_dist"], est=est, det_thresh=-1.0,
+                               relative_fitness=0.0, relative_rmse=0.0, max_iteration=15, **okw)
+    assert res.iterations == 15 and res.nn_passes == 16 and ref.iterations == 15
+    err = np.linalg.norm(T - ref.transformation)
+    assert err <= 1e-5, "||T - T_oracle||_F = %g" % err
+    assert res.fitness == pytest.approx(ref.fitness, abs=2e-5)
+    assert res.inlier_rmse == pytest.approx(ref.inlier_rmse, rel=1e-3, abs=1e-7)
+    cor = eng.get_correspondences()
+    assert (np.diff(cor[:, 0]) > 0).all()
+    # same sets up to the few points whose nearest neighbour flips on the last ulp of T
+    a = set(map(tuple, cor.tolist()))
+    b = set(map(tuple, ref.correspondence_set.tolist()))
+    assert len(a ^ b) <= max(4, len(b) // 500)
+
+
+def test_icp_default_criteria_init_and_convergence(eng):
+    d = make_pair(50000, seed=77)
+    init = rigid(0.01, [0, 0, 1], [0.001, 0.0, -0.001])
+    eng.set_target(d["tgt"], d["tgt_nrm"])
+    eng.set_source(d["src"])
+    res = eng.registration_icp(PT2PL, d["max_dist"], init, 1e-6, 1e-6, 30, -1.0)
+    ref = orc.registration_icp(d["src"], d["tgt"], d["max_dist"], init=init, est=orc.EST_PT2PL,
+                               tgt_nrm=d["tgt_nrm"], det_thresh=-1.0)
+    T = np.array(res.transformation, np.float32).reshape(4, 4).T
+    assert np.linalg.norm(T - ref.transformation) <= 1e-5
+    assert np.linalg.norm(T - d["T_gt"]) <= 2e-5
+    assert res.iterations < 30 and abs(res.iterations - ref.iterations) <= 1    # converged, same place
+    ev = eng.evaluate_registration(d["max_dist"], T)
+    oe = orc.evaluate_registration(d["src"], d["tgt"], d["max_dist"], T)
+    assert ev.fitness == pytest.approx(oe.fitness, abs=1e-5) and ev.fitness > 0.999
+
+
+def test_icp_reference_error_paths(eng):
+    d = make_pair(3000, seed=4)
+    eng.set_target(d["tgt"])                               # no normals
+    eng.set_source(d["src"])
+    res = eng.registration_icp(PT2PL, d["max_dist"], None, 1e-6, 1e-6, 5, 1e-6)
+    np.testing.assert_array_equal(np.array(res.transformation).reshape(4, 4), np.eye(4))  # identity updates
+    assert res.fitness > 0.9
+    res = eng.registration_icp(P2P, 0.0, None, 1e-6, 1e-6, 5, 1e-6)   # invalid distance: empty result
+    assert res.fitness == 0 and res.n_correspondences == 0
+    # det_thresh = 1e-6 with a big cloud: fp32 determinant overflows -> identity updates (quirk 6)
+    big = make_pair(400000, seed=8)
+    eng.set_target(cuda(big["tgt"]), cuda(big["tgt_nrm"]))
+    eng.set_source(cuda(big["src"]))
+    sys = eng.compute_system(PT2PL) if eng.search_radius_1nn(big["max_dist"])[2][0] else None
+    from cupoch_amd.engine import solve_system
+    ok_e, _ = solve_system(sys, 1e-6)
+    ok_o, _ = orc.solve_system(sys, 1e-6)
+    assert ok_e == ok_o
+
+
+# --------------------------------------------------------------------------- geometry
+def test_transform_roundtrip_golden_and_oracle(eng, golden):
+    g = golden["pointcloud_transform"]                # src/tests/geometry/pointcloud.cpp:143-174
+    T = np.asarray(g["transformation"], np.float32)
+    Tinv = np.eye(4, dtype=np.float32)
+    Tinv[:3, :3] = T[:3, :3].T
+    Tinv[:3, 3] = -T[:3, :3].T @ T[:3, 3]
+    p = np.asarray(g["points"], np.float32)
+    n = np.asarray(g["normals"], np.float32)
+    p1, n1, _ = eng.transform(T, p, n)
+    np.testing.assert_array_equal(p1, orc.transform_points(T, p))      # same fp32 expression: bit-exact
+    np.testing.assert_array_equal(n1, orc.transform_normals(T, n))
+    p2, n2, _ = eng.transform(Tinv, p1, n1)
+    np.testing.assert_allclose(p2, p, atol=g["tol"])
+    np.testing.assert_allclose(n2, n, atol=g["tol"])
+    rng = np.random.default_rng(1)
+    cov = rng.standard_normal((1000, 3, 3)).astype(np.float32)
+    pts = cuda(rng.standard_normal((1000, 3)).astype(np.float32))
+    ref_pts = orc.transform_points(T, pts.cpu().numpy())
+    _, _, c1 = eng.transform(T, pts, None, cuda(cov))                   # device tensors: in place
+    np.testing.assert_array_equal(pts.cpu().numpy(), ref_pts)
+    np.testing.assert_array_equal(c1.cpu().numpy(), orc.rotate_covariances(T, cov))
+
+
+def _rows(a):
+    a = np.asarray(a, np.float64)
+    return a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+
+
+def test_voxel_downsample_golden(eng, golden):
+    g = golden["voxel_down_sample"]                   # src/tests/geometry/pointcloud.cpp:371-469
+    p, n, c = eng.voxel_downsample(np.asarray(g["points"], np.float32), g["voxel_size"],
+                                   np.asarray(g["normals"], np.float32),
+                                   np.asarray(g["colors"], np.float32))
+    assert len(p) == len(g["ref_points"])
+    np.testing.assert_allclose(_rows(p), _rows(g["ref_points"]), atol=g["tol"])
+    np.testing.assert_allclose(_rows(n), _rows(g["ref_normals"]), atol=g["tol"])
+    np.testing.assert_allclose(_rows(c), _rows(g["ref_colors"]), atol=g["tol"])
+
+
+@pytest.mark.parametrize("n,voxel", [(1000, 0.1), (200000, 0.02), (200000, 1e-4), (5000, 10.0)])
+def test_voxel_downsample_matches_oracle(eng, n, voxel):
+    rng = np.random.default_rng(n)
+    pts = rng.random((n, 3), dtype=np.float32)
+    nrm = rng.standard_normal((n, 3)).astype(np.float32)
+    col = rng.random((n, 3), dtype=np.float32)
+    p, nn, c = eng.voxel_downsample(cuda(pts), voxel, cuda(nrm), cuda(col))
+    rp, rn, rc = orc.voxel_downsample(pts, voxel, nrm, col)
+    assert len(p) == len(rp)                                  # same voxels, same (lexicographic) order
+    np.testing.assert_allclose(p.cpu().numpy(), rp, atol=1e-6)
+    np.testing.assert_allclose(nn.cpu().numpy(), rn, atol=2e-5)
+    np.testing.assert_allclose(c.cpu().numpy(), rc, atol=1e-6)
+    p0, _, _ = eng.voxel_downsample(pts, 0.0)                 # down_sample.cu:173-176 -> empty cloud
+    assert len(p0) == 0
+    p1, n1, c1 = eng.voxel_downsample(pts, voxel)             # no normals / colors path
+    np.testing.assert_allclose(p1, rp, atol=1e-6)
+    assert n1 is None and c1 is None
+
+
+def test_covariances_from_normals_matches_oracle(eng):
+    rng = np.random.default_rng(0)
+    nrm = rng.standard_normal((10000, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm[0] = [-1, 0, 0]                                       # c < -0.99 shortcut (generalized_icp.cu:23-26)
+    nrm[1] = [1, 0, 0]
+    got = eng.covariances_from_normals(nrm, 1e-3)
+    np.testing.assert_allclose(got, orc.covariances_from_normals(nrm, 1e-3), atol=1e-7)
+
+
+def test_estimate_normals_golden_and_oracle(eng, golden):
+    g = golden["estimate_normals"]                    # src/tests/geometry/pointcloud.cpp:535-597
+    got = eng.estimate_normals_knn(np.asarray(g["points"], np.float32), g["knn"])
+    ref = np.asarray(g["ref_normals"], np.float32)
+    flip = np.sign(ref[:, 0]) * np.sign(got[:, 0]) < 0
+    got[flip] *= -1
+    np.testing.assert_allclose(got, ref, atol=g["tol"])
+    rng = np.random.default_rng(12)
+    pts = rng.random((30000, 3), dtype=np.float32)
+    pts[:, 2] = 0.2 * np.sin(3 * pts[:, 0]) + 0.01 * rng.standard_normal(30000).astype(np.float32)
+    for k in (20, 30):
+        got = eng.estimate_normals_knn(cuda(pts), k).cpu().numpy()
+        ref = orc.estimate_normals_knn(pts, k)
+        dots = np.abs((got * ref).sum(1))
+        assert (dots > 1 - 1e-4).mean() > 0.999, "normals differ: %g" % (dots > 1 - 1e-4).mean()
