@@ -105,6 +105,7 @@ SIGNATURES = {
     "mi_icp_debug_sort_pairs": (_I, [_P, _P, _P, _L, _I]),
     "mi_icp_debug_exclusive_scan": (_I, [_P, _P, _P, _L, _P]),
     "mi_icp_debug_morton_order": (_I, [_P, _P, _L, _P]),
+    "mi_icp_debug_nn_stats": (_I, [_P, _P, _F, _I, _P]),
 }
 
 _lib = None

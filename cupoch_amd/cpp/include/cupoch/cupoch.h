@@ -1,0 +1,9 @@
+// cupoch/cupoch.h -- aggregate header of the ICP path (reference: src/cupoch/cupoch.h)
+#pragma once
+#include "cupoch/geometry/pointcloud.h"
+#include "cupoch/knn/kdtree_search_param.h"
+#include "cupoch/registration/generalized_icp.h"
+#include "cupoch/registration/registration.h"
+#include "cupoch/registration/transformation_estimation.h"
+#include "cupoch/utility/device_vector.h"
+#include "cupoch/utility/eigen.h"

@@ -22,17 +22,6 @@ struct Xform {
     float r20, r21, r22, t2;
 };
 
-// LBVH node, 32 B = one s_load_dwordx8.  `skip` is the node to visit when this
-// subtree is culled or finished (0 = traversal ends); `down` is the first
-// child, or 0x80000000 | leaf_index for a leaf.
-struct __attribute__((aligned(32))) Node {
-    float bmin[3];
-    float bmax[3];
-    uint32_t skip;
-    uint32_t down;
-};
-constexpr uint32_t kLeafFlag = 0x80000000u;
-
 // Pointers in the constant address space: a wave-uniform load through one of
 // these is selected as a scalar (s_load_*) instruction.
 typedef const __attribute__((address_space(4))) float* cfloat_p;

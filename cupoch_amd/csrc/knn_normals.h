@@ -18,6 +18,7 @@
 #pragma once
 #include "device_utils.h"
 #include "eigen3.h"
+#include "traverse.h"
 
 namespace mi {
 
@@ -29,6 +30,7 @@ constexpr int kKnnSeedBefore = 4, kKnnSeedAfter = 12;  // leaves around the pack
 
 struct KnnState {
     float worst;  // current bound: +inf until k candidates are held
+    float rb;     // Linf search radius derived from it (traverse.h)
     int count;
     int worst_pos;
 };
@@ -54,18 +56,19 @@ __device__ __forceinline__ void knn_offer(float* kd2, int32_t* kidx, int lane, i
             }
             s.worst = w;
             s.worst_pos = wp;
+            s.rb = bound_radius(w);
         }
     }
 }
 
 __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
-        const Node* __restrict__ nodes_g, const float* __restrict__ tblk_g, int n, int nleaf, int k,
+        const float* __restrict__ pairs_g, const float* __restrict__ tblk_g, uint32_t P, int n, int nleaf,
+        int k,
         uint32_t nblocks, uint32_t max_steps, float* __restrict__ normals_out) {
     __shared__ float s_d2[kKnnWaves][kMaxKnn * 64];
     __shared__ int32_t s_idx[kKnnWaves][kMaxKnn * 64];
     uint32_t logical;
     if (!xcd_remap(nblocks, logical)) return;
-    const cuint_p nodes = (cuint_p)(uintptr_t)nodes_g;
     const cfloat_p tblk = (cfloat_p)(uintptr_t)tblk_g;
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
     float* kd2 = s_d2[wid];
@@ -87,6 +90,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
     }
     KnnState st;
     st.worst = (valid && k > 0) ? INFINITY : -1.0f;
+    st.rb = (valid && k > 0) ? INFINITY : -INFINITY;
     st.count = 0;
     st.worst_pos = 0;
 
@@ -103,38 +107,16 @@ __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
     }
 
     // ---- B: traversal -------------------------------------------------------------
-    uint32_t nd_i = 1u, steps = 0u;
-    while (nd_i != 0u && steps++ < max_steps) {
-        nd_i = __builtin_amdgcn_readfirstlane(nd_i);
-        const cuint_p nd = nodes + (size_t)nd_i * 8u;
-        const float bx0 = __uint_as_float(nd[0]), by0 = __uint_as_float(nd[1]),
-                    bz0 = __uint_as_float(nd[2]);
-        const float bx1 = __uint_as_float(nd[3]), by1 = __uint_as_float(nd[4]),
-                    bz1 = __uint_as_float(nd[5]);
-        const uint32_t skip = nd[6], down = nd[7];
-        const float dx = fmaxf(fmaxf(bx0 - qx, qx - bx1), 0.0f);
-        const float dy = fmaxf(fmaxf(by0 - qy, qy - by1), 0.0f);
-        const float dz = fmaxf(fmaxf(bz0 - qz, qz - bz1), 0.0f);
-        const float dbox = sq3(dx, dy, dz);
-        if (__ballot(dbox < st.worst) == 0ull) {
-            nd_i = skip;
-            continue;
-        }
-        if (down & kLeafFlag) {
-            const int L = (int)(down & ~kLeafFlag);
-            if (L < seed_lo || L >= seed_hi) {
-                const cfloat_p line = tblk + (size_t)L * kLeafFloats;
+    traverse_pairs(pairs_g, P, qx, qy, qz, st.rb, max_steps, [&](uint32_t Lu) {
+        const int L = (int)Lu;
+        if (L >= seed_lo && L < seed_hi) return;
+        const cfloat_p line = tblk + (size_t)L * kLeafFloats;
 #pragma unroll
-                for (int t = 0; t < kLeaf; ++t) {
-                    const float d2 = sq3(qx - line[t], qy - line[8 + t], qz - line[16 + t]);
-                    knn_offer(kd2, kidx, lane, k, st, d2, L * kLeaf + t);
-                }
-            }
-            nd_i = skip;
-        } else {
-            nd_i = down;
+        for (int t = 0; t < kLeaf; ++t) {
+            const float d2 = sq3(qx - line[t], qy - line[8 + t], qz - line[16 + t]);
+            knn_offer(kd2, kidx, lane, k, st, d2, L * kLeaf + t);
         }
-    }
+    });
 
     // ---- C: covariance of the neighbours -> normal ------------------------------------
     if (!valid) return;

@@ -8,10 +8,11 @@
 //   bounds -> 3*B-bit Morton keys -> one LSD radix sort -> leaves of 8
 //   consecutive points (one 128-B line each) -> implicit complete binary tree
 //   refitted bottom-up, one tiny launch per level, no host sync.
-// Topology is implicit (heap order, root = 1) but every node stores explicit
-// `skip`/`down` links, so the traversal kernel is layout-agnostic.
+// Topology is implicit (heap order, root = 1, children 2n / 2n+1, leaf L = node
+// P+L); boxes are stored per sibling pair (see traverse.h).
 #pragma once
 #include "device_utils.h"
+#include "traverse.h"
 
 namespace mi {
 
@@ -114,10 +115,15 @@ __global__ __launch_bounds__(256) void morton_keys(const float* __restrict__ pts
 }
 
 // ---- target: leaves + implicit tree ----------------------------------------
-__device__ __forceinline__ uint32_t heap_skip(uint32_t n) {
-    uint32_t m = n + 1u;
-    m >>= __builtin_ctz(m);
-    return (m == 1u) ? 0u : m;
+// box of node `id` lives in pair[id >> 1], slot id & 1
+__device__ __forceinline__ void store_box(float* __restrict__ pairs, uint32_t id, const float* mn,
+                                          const float* mx) {
+    float* pr = pairs + (size_t)(id >> 1) * kPairFloats + (id & 1u);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        pr[2 * d] = mn[d];
+        pr[6 + 2 * d] = mx[d];
+    }
 }
 
 // one thread per leaf slot L in [0, P): gathers the leaf's <=8 points into the
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(256) void build_leaves(
         const uint32_t* __restrict__ order, const float* __restrict__ pts,
         const float* __restrict__ nrm, const float* __restrict__ cov, int n, int nleaf, int P,
         float* __restrict__ tblk, float4* __restrict__ tnrm, float* __restrict__ tcov,
-        Node* __restrict__ nodes) {
+        float* __restrict__ pairs) {
     const int L = (int)(blockIdx.x * 256 + threadIdx.x);
     if (L >= P) return;
     float mn[3] = {INFINITY, INFINITY, INFINITY};
@@ -160,34 +166,23 @@ __global__ __launch_bounds__(256) void build_leaves(
             line[24 + k] = __int_as_float(o);
         }
     }
-    Node nd;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        nd.bmin[d] = mn[d];
-        nd.bmax[d] = mx[d];
-    }
-    const uint32_t id = (uint32_t)(P + L);
-    nd.skip = heap_skip(id);
-    nd.down = kLeafFlag | (uint32_t)L;
-    nodes[id] = nd;
+    store_box(pairs, (uint32_t)(P + L), mn, mx);  // empty slots keep the inverted (+inf,-inf) box
 }
 
-// nodes [first, first+count): box = union of the two children
-__global__ __launch_bounds__(256) void build_level(Node* __restrict__ nodes, uint32_t first,
+// nodes [first, first+count): box = union of the two children (= the two slots of pair[id])
+__global__ __launch_bounds__(256) void build_level(float* __restrict__ pairs, uint32_t first,
                                                    uint32_t count) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= count) return;
     const uint32_t id = first + t;
-    const Node a = nodes[2 * id], b = nodes[2 * id + 1];
-    Node nd;
+    const float* ch = pairs + (size_t)id * kPairFloats;
+    float mn[3], mx[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        nd.bmin[d] = fminf(a.bmin[d], b.bmin[d]);
-        nd.bmax[d] = fmaxf(a.bmax[d], b.bmax[d]);
+        mn[d] = fminf(ch[2 * d], ch[2 * d + 1]);
+        mx[d] = fmaxf(ch[6 + 2 * d], ch[6 + 2 * d + 1]);
     }
-    nd.skip = heap_skip(id);
-    nd.down = 2 * id;
-    nodes[id] = nd;
+    store_box(pairs, id, mn, mx);
 }
 
 // ---- source: Morton-ordered SoA copy ---------------------------------------

@@ -294,7 +294,7 @@ void collect_events(mi_icp_ctx* c) {  // call after the stream has been synchron
 }
 
 // ---- nearest-neighbour pass --------------------------------------------------
-int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed) {
+int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long long* stats = nullptr) {
     if (c->ns <= 0) return MI_ICP_OK;
     int32_t* idx = (int32_t*)c->nn_idx.p;
     float* d2 = (float*)c->nn_d2.p;
@@ -307,17 +307,20 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed) {
     const uint32_t npackets = (uint32_t)((c->ns + 63) / 64);
     const uint32_t nblocks = (npackets + kNNPacketsPerBlock - 1) / kNNPacketsPerBlock;
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
-    const uint32_t max_steps = 2u * (uint32_t)c->P + 8u;
+    const uint32_t max_steps = (uint32_t)c->P + 8u;  // one step per internal node at most
     const Xform X = make_xform(T);
     EvTimer t(c, 0);
-    if (seed && c->nn_valid)
-        nn_packet_kernel<true><<<grid, kNNThreads, 0, c->stream>>>(
-                (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns,
-                (const Node*)c->nodes.p, (const float*)c->tblk.p, X, r2, nblocks, max_steps, idx, d2);
-    else
-        nn_packet_kernel<false><<<grid, kNNThreads, 0, c->stream>>>(
-                (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns,
-                (const Node*)c->nodes.p, (const float*)c->tblk.p, X, r2, nblocks, max_steps, idx, d2);
+#define MI_NN_ARGS (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns, \
+                   (const float*)c->nodes.p, (const float*)c->tblk.p, (uint32_t)c->P, X, r2, nblocks, max_steps, idx, d2, stats
+    const bool use_seed = seed && c->nn_valid;
+    if (stats) {
+        if (use_seed) nn_packet_kernel<true, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
+        else nn_packet_kernel<false, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
+    } else {
+        if (use_seed) nn_packet_kernel<true, false><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
+        else nn_packet_kernel<false, false><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
+    }
+#undef MI_NN_ARGS
     KCHK(c);
     c->nn_valid = true;
     c->n_user_pairs = -1;
@@ -578,9 +581,9 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     float* tblk;
     float4* tnrm = nullptr;
     float* tcov = nullptr;
-    Node* nodes;
+    float* nodes;
     TRY(ensure(c, c->tblk, (size_t)nleaf * kLeafFloats, &tblk));
-    TRY(ensure(c, c->nodes, (size_t)2 * P, &nodes));
+    TRY(ensure(c, c->nodes, (size_t)P * kPairFloats, &nodes));
     if (d_nrm) TRY(ensure(c, c->tnrm, (size_t)n, &tnrm));
     if (d_cov) TRY(ensure(c, c->tcov, (size_t)n * 9, &tcov));
     build_leaves<<<blocks_for(P), 256, 0, c->stream>>>(order, d_pts, d_nrm, d_cov, (int)n, nleaf, P,
@@ -1094,8 +1097,8 @@ int mi_icp_estimate_normals_knn(mi_icp_ctx* c, const float* xyz, int64_t n, int 
     if (mem_kind == MI_ICP_HOST) TRY(ensure(c, c->stage[1], (size_t)n * 3, &dn));
     const uint32_t nblocks = (uint32_t)((c->nleaf + kKnnLeavesPerBlock - 1) / kKnnLeavesPerBlock);
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
-    knn_normals_kernel<<<grid, kKnnThreads, 0, c->stream>>>((const Node*)c->nodes.p, (const float*)c->tblk.p,
-                                                            (int)n, c->nleaf, knn, nblocks, 2u * (uint32_t)c->P + 8u, dn);
+    knn_normals_kernel<<<grid, kKnnThreads, 0, c->stream>>>((const float*)c->nodes.p, (const float*)c->tblk.p,
+                                                            (uint32_t)c->P, (int)n, c->nleaf, knn, nblocks, 2u * (uint32_t)c->P + 8u, dn);
     KCHK(c);
     if (mem_kind == MI_ICP_HOST) TRY(from_device(c, (const float*)dn, normals, (size_t)n * 3, mem_kind));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1192,6 +1195,20 @@ int mi_icp_debug_morton_order(mi_icp_ctx* c, const float* xyz, int64_t n, uint32
     TRY(morton_order(c, d_pts, n, &order));
     HIPCHK(c, hipMemcpyAsync(order_out, order, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MI_ICP_OK;
+}
+
+int mi_icp_debug_nn_stats(mi_icp_ctx* c, const float* T, float radius, int use_seed, uint64_t* out4) {
+    TRY(check_ctx(c));
+    if (!out4 || c->ns <= 0 || c->nt <= 0) return fail(c, MI_ICP_ERR_INVALID, "debug_nn_stats: bad state/arguments");
+    unsigned long long* d;
+    TRY(ensure(c, c->flags, 8, (unsigned long long**)&d));
+    HIPCHK(c, hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), c->stream));
+    TRY(launch_nn(c, load_T(T), radius * radius, use_seed != 0, d));
+    HIPCHK(c, hipMemcpyAsync(c->sys_host, d, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    collect_events(c);
+    std::memcpy(out4, c->sys_host, 4 * sizeof(uint64_t));
     return MI_ICP_OK;
 }
 

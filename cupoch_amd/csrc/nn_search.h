@@ -11,41 +11,68 @@
 // The reference runs one query per thread, each thread chasing its own pointers
 // through the tree.  Here a WAVE owns a packet of 64 Morton-consecutive source
 // points (a compact blob in space, whatever rigid transform is applied) and
-// traverses the tree ONCE for all of them:
-//   - the traversal state (node index) is wave-uniform and lives in SGPRs; a
-//     node is one s_load_dwordx8, a leaf three s_load_dwordx8 -- no divergent
-//     memory access at all in the hot loop;
-//   - each lane keeps only its query, best d2 and best index (11 VGPRs total,
-//     8 waves/SIMD) and tests the node box / the 8 leaf points against ITS
-//     query; a node is entered when a wave ballot says any lane still needs it;
-//   - links are explicit (`skip`, `down`), so no stack is needed.
+// traverses the tree ONCE for all of them (traverse.h): node data arrives by
+// scalar loads, both children are tested per step with packed fp32 math, and a
+// lane holds only its query, best d2 / index and search radius.
+// A leaf is one 128-B line of 8 points: the 8 squared distances are formed two
+// at a time (v_pk_fma_f32), reduced with v_min3, and the index is resolved only
+// when some lane actually improved (rare once the search is seeded).
 // Accept test is the reference's: strict d2 < r2 with r2 = float(r*r); no
 // match -> idx -1, d2 +inf.  Equal-distance ties keep the first-visited point
 // (as FLANN does; the visit order differs).
 #pragma once
 #include "device_utils.h"
+#include "traverse.h"
 
 namespace mi {
 
 constexpr int kNNThreads = 256;
 constexpr int kNNPacketsPerBlock = kNNThreads / 64;
 
-template <bool SEED>
+// 8 leaf points against the lane's query: exact fp32 d2 = fma(dz,dz,fma(dy,dy,dx*dx))
+__device__ __forceinline__ void nn_leaf(const float* tblk_g, uint32_t L, float qx, float qy, float qz,
+                                        float& best, int32_t& bidx, float& rb) {
+    const cf2_p line = (cf2_p)(uintptr_t)(tblk_g + (size_t)L * kLeafFloats);
+    const f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+    f2 d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f2 dx = qx2 - line[k], dy = qy2 - line[4 + k], dz = qz2 - line[8 + k];
+        d[k] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+    }
+    const float m = fminf(fminf(fminf(d[0].x, d[0].y), fminf(d[1].x, d[1].y)),
+                          fminf(fminf(d[2].x, d[2].y), fminf(d[3].x, d[3].y)));
+    if (__ballot(m < best) != 0ull) {
+        if (m < best) {  // first point of the line at distance m, as a sequential strict-< scan picks
+            int k = 7;
+            k = (d[3].x == m) ? 6 : k;
+            k = (d[2].y == m) ? 5 : k;
+            k = (d[2].x == m) ? 4 : k;
+            k = (d[1].y == m) ? 3 : k;
+            k = (d[1].x == m) ? 2 : k;
+            k = (d[0].y == m) ? 1 : k;
+            k = (d[0].x == m) ? 0 : k;
+            best = m;
+            bidx = (int32_t)(L * kLeaf) + k;
+            rb = bound_radius(m);
+        }
+    }
+}
+
+template <bool SEED, bool STATS>
 __global__ __launch_bounds__(kNNThreads) void nn_packet_kernel(
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
-        int ns, const Node* __restrict__ nodes_g, const float* __restrict__ tblk_g, Xform T,
-        float r2, uint32_t nblocks, uint32_t max_steps, int32_t* __restrict__ nn_idx,
-        float* __restrict__ nn_d2) {
+        int ns, const float* __restrict__ pairs_g, const float* __restrict__ tblk_g, uint32_t P,
+        Xform T, float r2, uint32_t nblocks, uint32_t max_steps, int32_t* __restrict__ nn_idx,
+        float* __restrict__ nn_d2, unsigned long long* __restrict__ stats) {
     uint32_t logical;
     if (!xcd_remap(nblocks, logical)) return;
-    const cuint_p nodes = (cuint_p)(uintptr_t)nodes_g;
-    const cfloat_p tblk = (cfloat_p)(uintptr_t)tblk_g;
 
     const int64_t i = ((int64_t)logical * kNNPacketsPerBlock + (threadIdx.x >> 6)) * 64 + lane_id();
     const bool valid = i < ns;
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
     if (valid) xform_point(T, sx[i], sy[i], sz[i], qx, qy, qz);
-    // invalid lanes carry best = -1: no d2 (>= 0) is ever below it
+    // invalid lanes: best = -1 is below every d2, rb = -inf is below every box distance
     float best = valid ? r2 : -1.0f;
     int32_t bidx = -1;
 
@@ -61,45 +88,22 @@ __global__ __launch_bounds__(kNNThreads) void nn_packet_kernel(
             }
         }
     }
+    float rb = valid ? bound_radius(best) : -INFINITY;
 
-    // every node is visited at most once, so max_steps = 2P bounds the walk; the
-    // cap only matters if the tree were corrupt (a hung GPU is worse than a wrong answer)
-    uint32_t n = 1u, steps = 0u;
-    while (n != 0u && steps++ < max_steps) {
-        n = __builtin_amdgcn_readfirstlane(n);
-        const cuint_p nd = nodes + (size_t)n * 8u;
-        const float bx0 = __uint_as_float(nd[0]), by0 = __uint_as_float(nd[1]),
-                    bz0 = __uint_as_float(nd[2]);
-        const float bx1 = __uint_as_float(nd[3]), by1 = __uint_as_float(nd[4]),
-                    bz1 = __uint_as_float(nd[5]);
-        const uint32_t skip = nd[6], down = nd[7];
-        const float dx = fmaxf(fmaxf(bx0 - qx, qx - bx1), 0.0f);
-        const float dy = fmaxf(fmaxf(by0 - qy, qy - by1), 0.0f);
-        const float dz = fmaxf(fmaxf(bz0 - qz, qz - bz1), 0.0f);
-        const float dbox = sq3(dx, dy, dz);
-        if (__ballot(dbox < best) == 0ull) {
-            n = skip;
-            continue;
-        }
-        if (down & kLeafFlag) {
-            const uint32_t L = down & ~kLeafFlag;
-            const cfloat_p line = tblk + (size_t)L * kLeafFloats;
-#pragma unroll
-            for (int k = 0; k < kLeaf; ++k) {
-                const float d2 = sq3(qx - line[k], qy - line[8 + k], qz - line[16 + k]);
-                if (d2 < best) {
-                    best = d2;
-                    bidx = (int32_t)(L * kLeaf + k);
-                }
-            }
-            n = skip;
-        } else {
-            n = down;
-        }
-    }
+    uint32_t leaves = 0u;
+    const uint32_t steps = traverse_pairs(pairs_g, P, qx, qy, qz, rb, max_steps, [&](uint32_t L) {
+        if (STATS) ++leaves;
+        nn_leaf(tblk_g, L, qx, qy, qz, best, bidx, rb);
+    });
+
     if (valid) {
         nn_idx[i] = bidx;
         nn_d2[i] = (bidx >= 0) ? best : INFINITY;
+    }
+    if (STATS && lane_id() == 0) {  // traversal census for tuning (mi_icp_debug_nn_stats)
+        atomicAdd(stats + 0, (unsigned long long)steps);
+        atomicAdd(stats + 1, (unsigned long long)leaves);
+        atomicAdd(stats + 2, 1ull);
     }
 }
 

@@ -26,7 +26,7 @@ class _Buf:
     """A float32/int32 array argument: keeps the backing object alive and exposes
     (pointer, mem_kind)."""
 
-    def __init__(self, a, dtype, cols, device_index):
+    def __init__(self, a, dtype, cols, device_index, copy=False):
         self.keep = None
         self.ptr = None
         self.kind = MI_ICP_HOST
@@ -52,6 +52,8 @@ class _Buf:
             self.n = int(t.shape[0])
         else:
             arr = np.ascontiguousarray(np.asarray(a, dtype=dtype).reshape(-1, cols))
+            if copy and np.shares_memory(arr, a):
+                arr = arr.copy()
             self.keep = arr
             self.ptr = arr.ctypes.data_as(C.c_void_p)
             self.n = int(arr.shape[0])
@@ -220,10 +222,11 @@ class Engine:
 
     # -- geometry ---------------------------------------------------------------------------
     def transform(self, T, points=None, normals=None, covariances=None):
-        """In place on torch CUDA tensors; numpy inputs are returned transformed."""
-        p = _Buf(points, np.float32, 3, self.device)
-        n = _Buf(normals, np.float32, 3, self.device)
-        c = _Buf(_cov_in(covariances), np.float32, 9, self.device)
+        """In place on torch CUDA tensors (as PointCloud::Transform); numpy inputs are
+        left untouched and transformed copies are returned."""
+        p = _Buf(points, np.float32, 3, self.device, copy=True)
+        n = _Buf(normals, np.float32, 3, self.device, copy=True)
+        c = _Buf(_cov_in(covariances), np.float32, 9, self.device, copy=True)
         kind = self._same_kind(p, n, c)
         cnt = max(p.n, n.n, c.n)
         _, tp = _T_in(T)

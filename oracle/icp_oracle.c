@@ -35,6 +35,7 @@
  * The HIP engine uses the same per-point expressions, so nearest-neighbour
  * indices and d2 are comparable bit for bit.
  */
+#define _POSIX_C_SOURCE 200809L
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
@@ -1382,6 +1383,52 @@ ORACLE_API void oracle_kabsch(const float *model, const float *target, int64_t n
     }
     sys[29] = (double)n;
     oracle_kabsch_from_sums(sys, n, T);
+}
+
+
+/* ------------------------------------------------------------------ */
+/* cpu_baseline leg of bench.py: wall-clock of ONE point-to-plane ICP   */
+/* iteration (radius 1-NN for every sampled source point, 6x6          */
+/* accumulation, solve) over the first n_sample source points against  */
+/* the full target; tree build timed separately.  OpenMP over queries. */
+/* ------------------------------------------------------------------ */
+#include <time.h>
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+ORACLE_API int oracle_bench_iteration(const float *src, int64_t ns, const float *tgt,
+                                      const float *tgt_nrm, int64_t nt, float max_dist,
+                                      int64_t n_sample, int repeats, double *build_s,
+                                      double *iter_s, double *fitness) {
+    if (n_sample > ns) n_sample = ns;
+    double t0 = now_s();
+    kd_tree *tree = kd_build(tgt, (int)nt);
+    *build_s = now_s() - t0;
+    int *ti = (int *)malloc(sizeof(int) * (size_t)n_sample);
+    float *td = (float *)malloc(sizeof(float) * (size_t)n_sample);
+    int32_t *cor = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)n_sample);
+    double best = 1e300;
+    oracle_result res;
+    for (int r = 0; r < repeats; ++r) {
+        t0 = now_s();
+        eval_correspondences(tree, src, n_sample, max_dist, cor, ti, td, &res);
+        double sys[32];
+        float T[16];
+        oracle_compute_system(EST_PT2PL, src, NULL, NULL, tgt, tgt_nrm, NULL, cor, res.n_corres, sys);
+        oracle_solve_system(sys, -1.0f, T);
+        const double dt = now_s() - t0;
+        if (dt < best) best = dt;
+    }
+    *iter_s = best;
+    *fitness = res.fitness;
+    kd_free(tree);
+    free(ti);
+    free(td);
+    free(cor);
+    return 0;
 }
 
 ORACLE_API int oracle_num_threads(void) {

@@ -299,3 +299,14 @@ def ref_flann_radius(tgt, qry, radius, max_nn):
     r = L.ref_flann_radius(_p(tgt), C.c_int(len(tgt)), _p(qry), C.c_int(len(qry)),
                            C.c_float(radius), C.c_int(max_nn), _p(idx), _p(d2))
     return int(r), idx, d2
+
+
+def bench_iteration(src, tgt, tgt_nrm, max_dist, n_sample, repeats=1):
+    """(build_s, iter_s, fitness): wall-clock of one point-to-plane iteration over the
+    first n_sample source points against the full target (bench.py cpu_baseline)."""
+    src, tgt, tn = _f32(src, (-1, 3)), _f32(tgt, (-1, 3)), _f32(tgt_nrm, (-1, 3))
+    b, t, f = C.c_double(0), C.c_double(0), C.c_double(0)
+    lib().oracle_bench_iteration(_p(src), C.c_int64(len(src)), _p(tgt), _p(tn),
+                                 C.c_int64(len(tgt)), C.c_float(max_dist), C.c_int64(n_sample),
+                                 C.c_int(repeats), C.byref(b), C.byref(t), C.byref(f))
+    return b.value, t.value, f.value
