@@ -115,6 +115,11 @@ def main():
     build_ms = (time.perf_counter() - t0) * 1e3
     if world > 1:
         D.init_engine_comm(eng, n)
+    elif os.environ.get("MI_ICP_FORCE_COMM") == "1":
+        # single-rank communicator: exercises the RCCL all-reduce path on a 1-GPU box
+        from cupoch_amd.engine import comm_unique_id
+        eng.comm_init(comm_unique_id(), 1, 0)
+        eng.set_global_source_count(n)
 
     # det_thresh <= 0: at this size the fp32 determinant of JtJ overflows and the
     # reference's default check would reject every solve

@@ -1,0 +1,353 @@
+// cupoch_amd.cpp -- the C++ surface of cupoch's ICP path
+// (namespace cupoch::{geometry,registration,utility}; headers under
+// cupoch_amd/cpp/include/cupoch) implemented over libmi_icp.so's C ABI.
+// Same names, defaults and error behaviour as the reference
+// (registration/registration.cu:106-172, transformation_estimation.cu,
+// generalized_icp.cu:37-61,185-198, geometry/pointcloud.cu:293-299,
+// down_sample.cu:170-273, estimate_normals.cu:82-127); no kernel lives here.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <stdexcept>
+
+#include "cupoch/cupoch.h"
+#include "mi_icp.h"
+
+namespace cupoch {
+
+// ---------------------------------------------------------------- utility
+namespace utility {
+
+static void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) {
+        // the reference prints and exit(0)s (utility/platform.cu:60-67); throwing is the
+        // closest well-behaved equivalent for a library
+        throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+    }
+}
+void* device_alloc(size_t bytes) {
+    if (bytes == 0) return nullptr;
+    void* p = nullptr;
+    hip_check(hipMalloc(&p, bytes), "hipMalloc");
+    return p;
+}
+void device_free(void* p) {
+    if (p) (void)hipFree(p);
+}
+void copy_h2d(void* d, const void* s, size_t n) { hip_check(hipMemcpy(d, s, n, hipMemcpyHostToDevice), "hipMemcpy H2D"); }
+void copy_d2h(void* d, const void* s, size_t n) { hip_check(hipMemcpy(d, s, n, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
+void copy_d2d(void* d, const void* s, size_t n) { hip_check(hipMemcpy(d, s, n, hipMemcpyDeviceToDevice), "hipMemcpy D2D"); }
+
+Eigen::Matrix4f TransformVector6fToMatrix4f(const Eigen::Vector6f& input) {
+    Eigen::Matrix4f out;
+    mi_icp_vector6_to_matrix4(input.data(), out.data());
+    return out;
+}
+
+Eigen::Matrix4f InverseTransform(const Eigen::Matrix4f& input) {
+    Eigen::Matrix4f inv = Eigen::Matrix4f::Identity();
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) inv(r, c) = input(c, r);
+    for (int r = 0; r < 3; ++r)
+        inv(r, 3) = -(inv(r, 0) * input(0, 3) + inv(r, 1) * input(1, 3) + inv(r, 2) * input(2, 3));
+    return inv;
+}
+
+std::pair<bool, Eigen::Matrix4f> SolveJacobianSystemAndObtainExtrinsicMatrix(
+        const Eigen::Matrix6f& JTJ, const Eigen::Vector6f& JTr, float det_thresh) {
+    double sys[32] = {0};
+    int k = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) sys[k++] = JTJ(i, j);
+    for (int i = 0; i < 6; ++i) sys[21 + i] = JTr(i);
+    Eigen::Matrix4f T;
+    const int ok = mi_icp_solve_system(sys, det_thresh, T.data());
+    return {ok > 0, T};
+}
+
+}  // namespace utility
+
+// ---------------------------------------------------------------- engine
+namespace {
+
+void LogError(const char* msg) { std::fprintf(stderr, "[cupoch_amd] Error: %s\n", msg); }    // console.h:54-56: logs, continues
+void LogWarning(const char* msg) { std::fprintf(stderr, "[cupoch_amd] Warning: %s\n", msg); }
+
+mi_icp_ctx* Engine() {
+    static mi_icp_ctx* ctx = nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (mi_icp_create(dev, &ctx) != MI_ICP_OK)
+            throw std::runtime_error("mi_icp_create failed: no MI355X device available (there is no CPU fallback)");
+    });
+    return ctx;
+}
+
+void Check(int rc) {
+    if (rc < 0) throw std::runtime_error(std::string("mi_icp: ") + mi_icp_last_error(Engine()));
+}
+
+const float* Ptr(const utility::device_vector<Eigen::Vector3f>& v) { return v.empty() ? nullptr : v.data()->data(); }
+const float* Ptr(const utility::device_vector<Eigen::Matrix3f>& v) { return v.empty() ? nullptr : v.data()->data(); }
+
+void LoadClouds(const geometry::PointCloud& source, const geometry::PointCloud& target) {
+    mi_icp_ctx* c = Engine();
+    Check(mi_icp_set_target(c, Ptr(target.points_), target.HasNormals() ? Ptr(target.normals_) : nullptr,
+                            target.HasCovariances() ? Ptr(target.covariances_) : nullptr,
+                            (int64_t)target.points_.size(), MI_ICP_DEVICE));
+    Check(mi_icp_set_source(c, Ptr(source.points_), source.HasNormals() ? Ptr(source.normals_) : nullptr,
+                            source.HasCovariances() ? Ptr(source.covariances_) : nullptr,
+                            (int64_t)source.points_.size(), MI_ICP_DEVICE));
+}
+
+registration::RegistrationResult MakeResult(const mi_icp_result& r) {
+    registration::RegistrationResult out;
+    std::memcpy(out.transformation_.data(), r.transformation, sizeof(float) * 16);
+    out.fitness_ = r.fitness;
+    out.inlier_rmse_ = r.inlier_rmse;
+    int64_t count = 0;
+    Check(mi_icp_get_correspondences(Engine(), nullptr, 0, &count, MI_ICP_DEVICE));
+    out.correspondence_set_.resize((size_t)count);
+    if (count > 0)
+        Check(mi_icp_get_correspondences(Engine(), out.correspondence_set_.data()->data(), count, &count,
+                                         MI_ICP_DEVICE));
+    return out;
+}
+
+// estimator entry points on explicit correspondence sets
+int EstType(registration::TransformationEstimationType t) { return (int)t; }
+
+Eigen::Matrix4f ComputeWith(int est, float det_thresh, const geometry::PointCloud& source,
+                            const geometry::PointCloud& target, const registration::CorrespondenceSet& corres) {
+    if (corres.empty()) return Eigen::Matrix4f::Identity();
+    LoadClouds(source, target);
+    Check(mi_icp_set_correspondences(Engine(), corres.data()->data(), (int64_t)corres.size(), MI_ICP_DEVICE));
+    Eigen::Matrix4f T;
+    Check(mi_icp_compute_transformation(Engine(), est, nullptr, det_thresh, T.data()));
+    return T;
+}
+
+float RmseWith(int est, const geometry::PointCloud& source, const geometry::PointCloud& target,
+               const registration::CorrespondenceSet& corres) {
+    if (corres.empty()) return 0.0f;
+    LoadClouds(source, target);
+    Check(mi_icp_set_correspondences(Engine(), corres.data()->data(), (int64_t)corres.size(), MI_ICP_DEVICE));
+    float rmse = 0.0f;
+    Check(mi_icp_compute_rmse(Engine(), est, nullptr, &rmse));
+    return rmse;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- geometry
+namespace geometry {
+
+PointCloud& PointCloud::Transform(const Eigen::Matrix4f& transformation) {
+    const size_t n = points_.size();
+    Check(mi_icp_transform(Engine(), transformation.data(),
+                           points_.empty() ? nullptr : points_.data()->data(),
+                           normals_.size() == n && n ? normals_.data()->data() : nullptr,
+                           covariances_.size() == n && n ? covariances_.data()->data() : nullptr,
+                           (int64_t)n, MI_ICP_DEVICE));
+    return *this;
+}
+
+std::shared_ptr<PointCloud> PointCloud::VoxelDownSample(float voxel_size) const {
+    auto out = std::make_shared<PointCloud>();
+    if (voxel_size <= 0.0f) {
+        LogWarning("[VoxelDownSample] voxel_size <= 0.");  // down_sample.cu:173-176
+        return out;
+    }
+    const size_t n = points_.size();
+    if (n == 0) return out;
+    const bool hn = HasNormals(), hc = HasColors();
+    out->points_.resize(n);
+    if (hn) out->normals_.resize(n);
+    if (hc) out->colors_.resize(n);
+    int64_t m = 0;
+    Check(mi_icp_voxel_downsample(Engine(), Ptr(points_), hn ? Ptr(normals_) : nullptr,
+                                  hc ? Ptr(colors_) : nullptr, (int64_t)n, voxel_size,
+                                  out->points_.data()->data(), hn ? out->normals_.data()->data() : nullptr,
+                                  hc ? out->colors_.data()->data() : nullptr, &m, MI_ICP_DEVICE));
+    if (m == 0) LogWarning("[VoxelDownSample] voxel_size is too small.");
+    out->points_.resize((size_t)m);
+    if (hn) out->normals_.resize((size_t)m);
+    if (hc) out->colors_.resize((size_t)m);
+    return out;
+}
+
+bool PointCloud::EstimateNormals(const knn::KDTreeSearchParam& search_param) {
+    if (search_param.GetSearchType() != knn::KDTreeSearchParam::SearchType::Knn) {
+        LogError("EstimateNormals: only KDTreeSearchParamKNN is implemented by this engine.");
+        return false;
+    }
+    const int k = ((const knn::KDTreeSearchParamKNN&)search_param).knn_;
+    normals_.resize(points_.size());
+    if (points_.empty()) return true;
+    Check(mi_icp_estimate_normals_knn(Engine(), Ptr(points_), (int64_t)points_.size(), k,
+                                      normals_.data()->data(), MI_ICP_DEVICE));
+    return true;
+}
+
+static Eigen::Vector3f Bound(const utility::device_vector<Eigen::Vector3f>& pts, bool want_max) {
+    const auto h = pts.to_host();
+    if (h.empty()) return Eigen::Vector3f::Zero();
+    Eigen::Vector3f b = h[0];
+    for (const auto& p : h)
+        for (int d = 0; d < 3; ++d) b[d] = want_max ? std::fmax(b[d], p[d]) : std::fmin(b[d], p[d]);
+    return b;
+}
+Eigen::Vector3f PointCloud::GetMinBound() const { return Bound(points_, false); }
+Eigen::Vector3f PointCloud::GetMaxBound() const { return Bound(points_, true); }
+
+}  // namespace geometry
+
+// ---------------------------------------------------------------- registration
+namespace registration {
+
+float TransformationEstimationPointToPoint::ComputeRMSE(const geometry::PointCloud& s, const geometry::PointCloud& t,
+                                                        const CorrespondenceSet& c) const {
+    return RmseWith(MI_ICP_EST_POINT_TO_POINT, s, t, c);
+}
+Eigen::Matrix4f TransformationEstimationPointToPoint::ComputeTransformation(const geometry::PointCloud& s,
+                                                                            const geometry::PointCloud& t,
+                                                                            const CorrespondenceSet& c) const {
+    return ComputeWith(MI_ICP_EST_POINT_TO_POINT, -1.0f, s, t, c);
+}
+float TransformationEstimationPointToPlane::ComputeRMSE(const geometry::PointCloud& s, const geometry::PointCloud& t,
+                                                        const CorrespondenceSet& c) const {
+    if (!t.HasNormals()) return 0.0f;
+    return RmseWith(MI_ICP_EST_POINT_TO_PLANE, s, t, c);
+}
+Eigen::Matrix4f TransformationEstimationPointToPlane::ComputeTransformation(const geometry::PointCloud& s,
+                                                                            const geometry::PointCloud& t,
+                                                                            const CorrespondenceSet& c) const {
+    if (!t.HasNormals()) return Eigen::Matrix4f::Identity();
+    return ComputeWith(MI_ICP_EST_POINT_TO_PLANE, det_thresh_, s, t, c);
+}
+float TransformationEstimationSymmetricMethod::ComputeRMSE(const geometry::PointCloud& s, const geometry::PointCloud& t,
+                                                           const CorrespondenceSet& c) const {
+    if (!s.HasNormals() || !t.HasNormals()) return 0.0f;
+    return RmseWith(MI_ICP_EST_SYMMETRIC, s, t, c);
+}
+Eigen::Matrix4f TransformationEstimationSymmetricMethod::ComputeTransformation(const geometry::PointCloud& s,
+                                                                               const geometry::PointCloud& t,
+                                                                               const CorrespondenceSet& c) const {
+    if (!s.HasNormals() || !t.HasNormals()) return Eigen::Matrix4f::Identity();
+    return ComputeWith(MI_ICP_EST_SYMMETRIC, det_thresh_, s, t, c);
+}
+float TransformationEstimationForGeneralizedICP::ComputeRMSE(const geometry::PointCloud& s,
+                                                             const geometry::PointCloud& t,
+                                                             const CorrespondenceSet& c) const {
+    if (!s.HasCovariances() || !t.HasCovariances()) return 0.0f;
+    return RmseWith(MI_ICP_EST_GENERALIZED, s, t, c);
+}
+Eigen::Matrix4f TransformationEstimationForGeneralizedICP::ComputeTransformation(const geometry::PointCloud& s,
+                                                                                 const geometry::PointCloud& t,
+                                                                                 const CorrespondenceSet& c) const {
+    if (!s.HasCovariances() || !t.HasCovariances()) return Eigen::Matrix4f::Identity();
+    return ComputeWith(MI_ICP_EST_GENERALIZED, -1.0f, s, t, c);
+}
+
+RegistrationResult EvaluateRegistration(const geometry::PointCloud& source, const geometry::PointCloud& target,
+                                        float max_correspondence_distance, const Eigen::Matrix4f& transformation) {
+    LoadClouds(source, target);
+    mi_icp_result r;
+    Check(mi_icp_evaluate_registration(Engine(), max_correspondence_distance, transformation.data(), &r));
+    return MakeResult(r);
+}
+
+static bool IsBuiltin(const TransformationEstimation& e) {
+    return dynamic_cast<const TransformationEstimationPointToPoint*>(&e) ||
+           dynamic_cast<const TransformationEstimationPointToPlane*>(&e) ||
+           dynamic_cast<const TransformationEstimationSymmetricMethod*>(&e) ||
+           dynamic_cast<const TransformationEstimationForGeneralizedICP*>(&e);
+}
+
+RegistrationResult RegistrationICP(const geometry::PointCloud& source, const geometry::PointCloud& target,
+                                   float max_correspondence_distance, const Eigen::Matrix4f& init,
+                                   const TransformationEstimation& estimation,
+                                   const ICPConvergenceCriteria& criteria) {
+    if (max_correspondence_distance <= 0.0f) LogError("Invalid max_correspondence_distance.");  // registration.cu:130-132
+    const auto type = estimation.GetTransformationEstimationType();
+    if ((type == TransformationEstimationType::PointToPlane || type == TransformationEstimationType::ColoredICP) &&
+        !target.HasNormals())
+        LogError("TransformationEstimationPointToPlane and TransformationEstimationColoredICP require "
+                 "pre-computed target normal vectors.");  // registration.cu:134-143
+
+    if (IsBuiltin(estimation)) {  // fused device loop
+        float det = -1.0f;
+        if (auto* p = dynamic_cast<const TransformationEstimationPointToPlane*>(&estimation)) det = p->det_thresh_;
+        if (auto* p = dynamic_cast<const TransformationEstimationSymmetricMethod*>(&estimation)) det = p->det_thresh_;
+        LoadClouds(source, target);
+        mi_icp_params prm = {criteria.relative_fitness_, criteria.relative_rmse_, criteria.max_iteration_, det};
+        mi_icp_result r;
+        Check(mi_icp_registration_icp(Engine(), EstType(type), max_correspondence_distance, init.data(), &prm, &r));
+        return MakeResult(r);
+    }
+
+    // user-defined estimator: the reference loop verbatim (registration.cu:144-171)
+    Eigen::Matrix4f transformation = init;
+    geometry::PointCloud pcd = source;
+    if (!init.isIdentity()) pcd.Transform(init);
+    auto evaluate = [&](const Eigen::Matrix4f& T) {
+        LoadClouds(pcd, target);
+        mi_icp_result r;
+        Check(mi_icp_evaluate_registration(Engine(), max_correspondence_distance, nullptr, &r));
+        RegistrationResult res = MakeResult(r);
+        res.transformation_ = T;
+        return res;
+    };
+    RegistrationResult result = evaluate(transformation);
+    for (int i = 0; i < criteria.max_iteration_; ++i) {
+        const Eigen::Matrix4f update = estimation.ComputeTransformation(pcd, target, result.correspondence_set_);
+        transformation = update * transformation;
+        pcd.Transform(update);
+        RegistrationResult backup = result;
+        result = evaluate(transformation);
+        if (std::fabs(backup.fitness_ - result.fitness_) < criteria.relative_fitness_ &&
+            std::fabs(backup.inlier_rmse_ - result.inlier_rmse_) < criteria.relative_rmse_)
+            break;
+    }
+    return result;
+}
+
+// InitializePointCloudForGeneralizedICP (generalized_icp.cu:37-61)
+static std::shared_ptr<geometry::PointCloud> InitializeForGICP(const geometry::PointCloud& pcd, float epsilon) {
+    auto out = std::make_shared<geometry::PointCloud>(pcd);
+    if (out->HasCovariances()) return out;
+    if (!out->HasNormals()) out->EstimateNormals(knn::KDTreeSearchParamKNN(20));
+    out->covariances_.resize(out->points_.size());
+    if (!out->points_.empty())
+        Check(mi_icp_covariances_from_normals(Engine(), Ptr(out->normals_), (int64_t)out->points_.size(), epsilon,
+                                              out->covariances_.data()->data(), MI_ICP_DEVICE));
+    return out;
+}
+
+RegistrationResult RegistrationGeneralizedICP(const geometry::PointCloud& source, const geometry::PointCloud& target,
+                                              float max_correspondence_distance, const Eigen::Matrix4f& init,
+                                              const TransformationEstimationForGeneralizedICP& estimation,
+                                              const ICPConvergenceCriteria& criteria) {
+    return RegistrationICP(*InitializeForGICP(source, estimation.epsilon_), *InitializeForGICP(target, estimation.epsilon_),
+                           max_correspondence_distance, init, estimation, criteria);
+}
+
+Eigen::Matrix4f_u Kabsch(const utility::device_vector<Eigen::Vector3f>& model,
+                         const utility::device_vector<Eigen::Vector3f>& target) {
+    // all points paired by index (kabsch.cu:122-): an identity correspondence set
+    const size_t n = model.size();
+    std::vector<Eigen::Vector2i> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = Eigen::Vector2i((int)i, (int)i);
+    CorrespondenceSet corres(h);
+    geometry::PointCloud s, t;
+    s.points_ = model;
+    t.points_ = target;
+    return ComputeWith(MI_ICP_EST_POINT_TO_POINT, -1.0f, s, t, corres);
+}
+
+}  // namespace registration
+}  // namespace cupoch

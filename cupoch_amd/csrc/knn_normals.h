@@ -30,13 +30,13 @@ constexpr int kKnnSeedBefore = 4, kKnnSeedAfter = 12;  // leaves around the pack
 
 struct KnnState {
     float worst;  // current bound: +inf until k candidates are held
-    float rb;     // Linf search radius derived from it (traverse.h)
     int count;
     int worst_pos;
 };
 
-__device__ __forceinline__ void knn_offer(float* kd2, int32_t* kidx, int lane, int k, KnnState& s,
+__device__ __forceinline__ bool knn_offer(float* kd2, int32_t* kidx, int lane, int k, KnnState& s,
                                           float d2, int32_t j) {
+    bool shrunk = false;
     if (d2 < s.worst) {
         kd2[s.worst_pos * 64 + lane] = d2;
         kidx[s.worst_pos * 64 + lane] = j;
@@ -56,13 +56,15 @@ __device__ __forceinline__ void knn_offer(float* kd2, int32_t* kidx, int lane, i
             }
             s.worst = w;
             s.worst_pos = wp;
-            s.rb = bound_radius(w);
+            shrunk = true;
         }
     }
+    return shrunk;
 }
 
 __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
-        const float* __restrict__ pairs_g, const float* __restrict__ tblk_g, uint32_t P, int n, int nleaf,
+        const float* __restrict__ records_g, const float* __restrict__ tblk_g, uint32_t leaf_first, int n,
+        int nleaf,
         int k,
         uint32_t nblocks, uint32_t max_steps, float* __restrict__ normals_out) {
     __shared__ float s_d2[kKnnWaves][kMaxKnn * 64];
@@ -90,7 +92,6 @@ __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
     }
     KnnState st;
     st.worst = (valid && k > 0) ? INFINITY : -1.0f;
-    st.rb = (valid && k > 0) ? INFINITY : -INFINITY;
     st.count = 0;
     st.worst_pos = 0;
 
@@ -105,17 +106,21 @@ __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
             knn_offer(kd2, kidx, lane, k, st, d2, L * kLeaf + t);  // padding points have d2 = +inf
         }
     }
+    Cube cube;
+    set_cube(cube, qx, qy, qz, st.worst);
 
     // ---- B: traversal -------------------------------------------------------------
-    traverse_pairs(pairs_g, P, qx, qy, qz, st.rb, max_steps, [&](uint32_t Lu) {
+    traverse_wide(records_g, leaf_first, cube, max_steps, [&](uint32_t Lu) {
         const int L = (int)Lu;
         if (L >= seed_lo && L < seed_hi) return;
         const cfloat_p line = tblk + (size_t)L * kLeafFloats;
+        bool shrunk = false;
 #pragma unroll
         for (int t = 0; t < kLeaf; ++t) {
             const float d2 = sq3(qx - line[t], qy - line[8 + t], qz - line[16 + t]);
-            knn_offer(kd2, kidx, lane, k, st, d2, L * kLeaf + t);
+            shrunk |= knn_offer(kd2, kidx, lane, k, st, d2, L * kLeaf + t);
         }
+        if (shrunk) set_cube(cube, qx, qy, qz, st.worst);
     });
 
     // ---- C: covariance of the neighbours -> normal ------------------------------------

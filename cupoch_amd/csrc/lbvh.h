@@ -6,10 +6,10 @@
 // kdtree_cuda_builder.h:401-700), i.e. three thrust sorts plus ~10 thrust
 // passes per tree level with a host round trip per level, by:
 //   bounds -> 3*B-bit Morton keys -> one LSD radix sort -> leaves of 8
-//   consecutive points (one 128-B line each) -> implicit complete binary tree
-//   refitted bottom-up, one tiny launch per level, no host sync.
-// Topology is implicit (heap order, root = 1, children 2n / 2n+1, leaf L = node
-// P+L); boxes are stored per sibling pair (see traverse.h).
+//   consecutive points (one 128-B line each) -> implicit complete 8-ary tree
+//   refitted bottom-up, one small launch per level (7 at 10M points), no host sync.
+// Topology is implicit: a complete 8-ary tree over the leaves, one 256-B record of
+// 8 child boxes per node (see traverse.h).
 #pragma once
 #include "device_utils.h"
 #include "traverse.h"
@@ -114,11 +114,12 @@ __global__ __launch_bounds__(256) void morton_keys(const float* __restrict__ pts
     vals[i] = (uint32_t)i;
 }
 
-// ---- target: leaves + implicit tree ----------------------------------------
-// box of node `id` lives in pair[id >> 1], slot id & 1
-__device__ __forceinline__ void store_box(float* __restrict__ pairs, uint32_t id, const float* mn,
+// ---- target: leaves + implicit 8-ary tree ------------------------------------
+// box of child node `id` lives in the record of id >> 3, slot id & 7
+__device__ __forceinline__ void store_box(float* __restrict__ records, uint32_t id, const float* mn,
                                           const float* mx) {
-    float* pr = pairs + (size_t)(id >> 1) * kPairFloats + (id & 1u);
+    const uint32_t c = id & 7u;
+    float* pr = records + (size_t)record_index(id >> 3) * kRecordFloats + (c >> 1) * kPairStride + (c & 1u);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         pr[2 * d] = mn[d];
@@ -126,15 +127,17 @@ __device__ __forceinline__ void store_box(float* __restrict__ pairs, uint32_t id
     }
 }
 
-// one thread per leaf slot L in [0, P): gathers the leaf's <=8 points into the
-// 128-B leaf line, sorted normals / covariances next to them, and the leaf box
+// one thread per leaf slot L in [0, nslots), nslots = 8 * ceil(nleaf / 8): gathers the
+// leaf's <=8 points into the 128-B leaf line, sorted normals / covariances next
+// to them, and writes the leaf box into its parent's record.  Slots past nleaf
+// get the inverted box.
 __global__ __launch_bounds__(256) void build_leaves(
         const uint32_t* __restrict__ order, const float* __restrict__ pts,
-        const float* __restrict__ nrm, const float* __restrict__ cov, int n, int nleaf, int P,
-        float* __restrict__ tblk, float4* __restrict__ tnrm, float* __restrict__ tcov,
-        float* __restrict__ pairs) {
+        const float* __restrict__ nrm, const float* __restrict__ cov, int n, int nleaf, int nslots,
+        uint32_t leaf_first, float* __restrict__ tblk, float4* __restrict__ tnrm,
+        float* __restrict__ tcov, float* __restrict__ records) {
     const int L = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (L >= P) return;
+    if (L >= nslots) return;
     float mn[3] = {INFINITY, INFINITY, INFINITY};
     float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     if (L < nleaf) {
@@ -166,23 +169,31 @@ __global__ __launch_bounds__(256) void build_leaves(
             line[24 + k] = __int_as_float(o);
         }
     }
-    store_box(pairs, (uint32_t)(P + L), mn, mx);  // empty slots keep the inverted (+inf,-inf) box
+    // the leaf is child (L & 7) of last-level node leaf_first + (L >> 3)
+    store_box(records, (leaf_first + ((uint32_t)L >> 3)) * 8u + ((uint32_t)L & 7u), mn, mx);
 }
 
-// nodes [first, first+count): box = union of the two children (= the two slots of pair[id])
-__global__ __launch_bounds__(256) void build_level(float* __restrict__ pairs, uint32_t first,
-                                                   uint32_t count) {
+// level-k nodes first + t, t in [0, count): box = union of the node's 8 child slots,
+// written into the parent's record; t >= used (padding up to a multiple of 8)
+// writes the inverted box.
+__global__ __launch_bounds__(256) void build_level(float* __restrict__ records, uint32_t first,
+                                                   uint32_t used, uint32_t count) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= count) return;
     const uint32_t id = first + t;
-    const float* ch = pairs + (size_t)id * kPairFloats;
-    float mn[3], mx[3];
+    float mn[3] = {INFINITY, INFINITY, INFINITY};
+    float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (t < used) {
+        const float* rec = records + (size_t)record_index(id) * kRecordFloats;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        mn[d] = fminf(ch[2 * d], ch[2 * d + 1]);
-        mx[d] = fmaxf(ch[6 + 2 * d], ch[6 + 2 * d + 1]);
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                mn[d] = fminf(mn[d], fminf(rec[p * kPairStride + 2 * d], rec[p * kPairStride + 2 * d + 1]));
+                mx[d] = fmaxf(mx[d], fmaxf(rec[p * kPairStride + 6 + 2 * d], rec[p * kPairStride + 6 + 2 * d + 1]));
+            }
     }
-    store_box(pairs, id, mn, mx);
+    store_box(records, id, mn, mx);
 }
 
 // ---- source: Morton-ordered SoA copy ---------------------------------------

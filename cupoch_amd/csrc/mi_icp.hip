@@ -74,9 +74,11 @@ struct mi_icp_ctx {
 
     // ---- target (Morton order) ----
     int64_t nt = 0;
-    int nleaf = 0, P = 0;
+    int nleaf = 0;
+    uint32_t leaf_first = 1, nrecords = 0;  // 8-ary tree: first last-level node id, record count
     bool t_has_nrm = false, t_has_cov = false;
-    DevBuf tblk, tnrm, tcov, nodes, inv_t;
+    DevBuf tblk, tnrm, tcov, nodes, inv_t, tbounds;
+    int tbits = 0;  // Morton quantisation of the target (reused for the source, see set_source)
     bool inv_t_valid = false;
 
     // ---- source (Morton order) ----
@@ -251,13 +253,17 @@ int sort_buffers(mi_icp_ctx* c, int64_t n, SortBuffers* sb) {
     return MI_ICP_OK;
 }
 
-// Morton order of an AoS cloud: returns the device array order[sorted] = original
-int morton_order(mi_icp_ctx* c, const float* pts, int64_t n, const uint32_t** order) {
-    float* bnd;
-    TRY(compute_bounds(c, pts, n, &bnd));
+// Morton order of an AoS cloud: returns the device array order[sorted] = original.
+// grid_bounds/grid_bits: quantise on another cloud's grid instead of the cloud's own.
+int morton_order(mi_icp_ctx* c, const float* pts, int64_t n, const uint32_t** order,
+                 const float* grid_bounds = nullptr, int grid_bits = 0, float** own_bounds = nullptr) {
+    float* bnd = nullptr;
+    if (!grid_bounds || own_bounds) TRY(compute_bounds(c, pts, n, &bnd));
+    if (own_bounds) *own_bounds = bnd;
+    if (grid_bounds) bnd = const_cast<float*>(grid_bounds);
     SortBuffers sb;
     TRY(sort_buffers(c, n, &sb));
-    const int bits = morton_bits_for(n);
+    const int bits = grid_bounds ? grid_bits : morton_bits_for(n);
     morton_keys<<<blocks_for(n), 256, 0, c->stream>>>(pts, (int)n, bnd, bits, sb.keys[0], sb.vals[0]);
     KCHK(c);
     const int cur = radix_sort_pairs(c->stream, sb, n, 3 * bits);
@@ -307,11 +313,11 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
     const uint32_t npackets = (uint32_t)((c->ns + 63) / 64);
     const uint32_t nblocks = (npackets + kNNPacketsPerBlock - 1) / kNNPacketsPerBlock;
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
-    const uint32_t max_steps = (uint32_t)c->P + 8u;  // one step per internal node at most
+    const uint32_t max_steps = c->nrecords + 8u;  // every record is visited at most once
     const Xform X = make_xform(T);
     EvTimer t(c, 0);
 #define MI_NN_ARGS (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns, \
-                   (const float*)c->nodes.p, (const float*)c->tblk.p, (uint32_t)c->P, X, r2, nblocks, max_steps, idx, d2, stats
+                   (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, X, r2, nblocks, max_steps, idx, d2, stats
     const bool use_seed = seed && c->nn_valid;
     if (stats) {
         if (use_seed) nn_packet_kernel<true, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
@@ -409,7 +415,7 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T) {
             default: return fail(c, MI_ICP_ERR_INVALID, "unknown estimation type %d", est);
         }
         KCHK(c);
-        reduce_final<<<1, 256, 0, c->stream>>>(partial, grid, sys);
+        reduce_final<<<1, 1024, 0, c->stream>>>(partial, grid, sys);
         KCHK(c);
     }
     return MI_ICP_OK;
@@ -503,7 +509,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    DevBuf* all[] = {&c->tblk, &c->tnrm, &c->tcov, &c->nodes, &c->inv_t, &c->sx, &c->sy, &c->sz,
+    DevBuf* all[] = {&c->tblk, &c->tnrm, &c->tcov, &c->nodes, &c->inv_t, &c->tbounds, &c->sx, &c->sy, &c->sz,
                      &c->sperm, &c->snrm, &c->scov, &c->nn_idx, &c->nn_d2, &c->inv_s,
                      &c->user_pairs, &c->keys0, &c->keys1, &c->vals0, &c->vals1, &c->hist,
                      &c->scan_tmp, &c->bounds_part, &c->bounds, &c->partial, &c->sys_dev,
@@ -573,29 +579,47 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     TRY(to_device(c, covs, (size_t)n * 9, mem_kind, c->stage[2], &d_cov));
 
     const uint32_t* order;
-    TRY(morton_order(c, d_pts, n, &order));
+    float *own_bounds, *tb;
+    TRY(morton_order(c, d_pts, n, &order, nullptr, 0, &own_bounds));
+    TRY(ensure(c, c->tbounds, 8, &tb));
+    HIPCHK(c, hipMemcpyAsync(tb, own_bounds, 8 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    c->tbits = morton_bits_for(n);
 
     const int nleaf = (int)((n + kLeaf - 1) / kLeaf);
-    int P = 1;
-    while (P < nleaf) P <<= 1;
+    int levels = 1;  // 8-ary levels of records above the leaves
+    uint32_t leaf_first = 1u;
+    while ((uint64_t)leaf_first * 8u < (uint64_t)nleaf) {
+        leaf_first *= 8u;
+        ++levels;
+    }
+    if (levels > kMaxLevels) return fail(c, MI_ICP_ERR_INVALID, "set_target: cloud too large for the 64-bit traversal stack");
+    const uint32_t used_last = (uint32_t)((nleaf + 7) / 8);
+    const uint32_t nrecords = full_levels_below(leaf_first) + used_last;
     float* tblk;
     float4* tnrm = nullptr;
     float* tcov = nullptr;
     float* nodes;
     TRY(ensure(c, c->tblk, (size_t)nleaf * kLeafFloats, &tblk));
-    TRY(ensure(c, c->nodes, (size_t)P * kPairFloats, &nodes));
+    TRY(ensure(c, c->nodes, (size_t)nrecords * kRecordFloats, &nodes));
     if (d_nrm) TRY(ensure(c, c->tnrm, (size_t)n, &tnrm));
     if (d_cov) TRY(ensure(c, c->tcov, (size_t)n * 9, &tcov));
-    build_leaves<<<blocks_for(P), 256, 0, c->stream>>>(order, d_pts, d_nrm, d_cov, (int)n, nleaf, P,
-                                                       tblk, tnrm, tcov, nodes);
+    const int nslots = (int)used_last * 8;
+    build_leaves<<<blocks_for(nslots), 256, 0, c->stream>>>(order, d_pts, d_nrm, d_cov, (int)n, nleaf, nslots,
+                                                            leaf_first, tblk, tnrm, tcov, nodes);
     KCHK(c);
-    for (uint32_t first = (uint32_t)P / 2; first >= 1; first /= 2) {
-        build_level<<<blocks_for(first), 256, 0, c->stream>>>(nodes, first, first);
-        KCHK(c);
+    {
+        uint32_t used = used_last;
+        for (uint32_t first = leaf_first; first > 1u; first /= 8u) {
+            const uint32_t count = ((used + 7u) / 8u) * 8u;
+            build_level<<<blocks_for(count), 256, 0, c->stream>>>(nodes, first, used, count);
+            KCHK(c);
+            used = (used + 7u) / 8u;
+        }
     }
     c->nt = n;
     c->nleaf = nleaf;
-    c->P = P;
+    c->leaf_first = leaf_first;
+    c->nrecords = nrecords;
     if (c->profiling) {
         (void)hipEventRecord(e1, c->stream);
         (void)hipStreamSynchronize(c->stream);
@@ -629,6 +653,9 @@ int mi_icp_set_source(mi_icp_ctx* c, const float* xyz, const float* normals, con
     TRY(to_device(c, normals, (size_t)n * 3, mem_kind, c->stage[4], &d_nrm));
     TRY(to_device(c, covs, (size_t)n * 9, mem_kind, c->stage[5], &d_cov));
 
+    // Packets are 64 consecutive points of this order (measured: ordering the source on
+    // the target's Morton grid instead of its own does not reduce the records a packet
+    // visits -- the ~2x overlap of neighbouring leaf boxes dominates, not grid alignment).
     const uint32_t* order;
     TRY(morton_order(c, d_pts, n, &order));
 
@@ -1098,7 +1125,7 @@ int mi_icp_estimate_normals_knn(mi_icp_ctx* c, const float* xyz, int64_t n, int 
     const uint32_t nblocks = (uint32_t)((c->nleaf + kKnnLeavesPerBlock - 1) / kKnnLeavesPerBlock);
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
     knn_normals_kernel<<<grid, kKnnThreads, 0, c->stream>>>((const float*)c->nodes.p, (const float*)c->tblk.p,
-                                                            (uint32_t)c->P, (int)n, c->nleaf, knn, nblocks, 2u * (uint32_t)c->P + 8u, dn);
+                                                            c->leaf_first, (int)n, c->nleaf, knn, nblocks, c->nrecords + 8u, dn);
     KCHK(c);
     if (mem_kind == MI_ICP_HOST) TRY(from_device(c, (const float*)dn, normals, (size_t)n * 3, mem_kind));
     HIPCHK(c, hipStreamSynchronize(c->stream));

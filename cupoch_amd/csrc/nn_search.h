@@ -11,8 +11,8 @@
 // The reference runs one query per thread, each thread chasing its own pointers
 // through the tree.  Here a WAVE owns a packet of 64 Morton-consecutive source
 // points (a compact blob in space, whatever rigid transform is applied) and
-// traverses the tree ONCE for all of them (traverse.h): node data arrives by
-// scalar loads, both children are tested per step with packed fp32 math, and a
+// traverses the tree ONCE for all of them (traverse.h): node records arrive by
+// scalar loads, 8 children are tested per step with packed fp32 math, and a
 // lane holds only its query, best d2 / index and search radius.
 // A leaf is one 128-B line of 8 points: the 8 squared distances are formed two
 // at a time (v_pk_fma_f32), reduced with v_min3, and the index is resolved only
@@ -31,7 +31,7 @@ constexpr int kNNPacketsPerBlock = kNNThreads / 64;
 
 // 8 leaf points against the lane's query: exact fp32 d2 = fma(dz,dz,fma(dy,dy,dx*dx))
 __device__ __forceinline__ void nn_leaf(const float* tblk_g, uint32_t L, float qx, float qy, float qz,
-                                        float& best, int32_t& bidx, float& rb) {
+                                        float& best, int32_t& bidx, Cube& cube) {
     const cf2_p line = (cf2_p)(uintptr_t)(tblk_g + (size_t)L * kLeafFloats);
     const f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
     f2 d[4];
@@ -54,7 +54,7 @@ __device__ __forceinline__ void nn_leaf(const float* tblk_g, uint32_t L, float q
             k = (d[0].x == m) ? 0 : k;
             best = m;
             bidx = (int32_t)(L * kLeaf) + k;
-            rb = bound_radius(m);
+            set_cube(cube, qx, qy, qz, m);
         }
     }
 }
@@ -62,8 +62,8 @@ __device__ __forceinline__ void nn_leaf(const float* tblk_g, uint32_t L, float q
 template <bool SEED, bool STATS>
 __global__ __launch_bounds__(kNNThreads) void nn_packet_kernel(
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
-        int ns, const float* __restrict__ pairs_g, const float* __restrict__ tblk_g, uint32_t P,
-        Xform T, float r2, uint32_t nblocks, uint32_t max_steps, int32_t* __restrict__ nn_idx,
+        int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
+        uint32_t leaf_first, Xform T, float r2, uint32_t nblocks, uint32_t max_steps, int32_t* __restrict__ nn_idx,
         float* __restrict__ nn_d2, unsigned long long* __restrict__ stats) {
     uint32_t logical;
     if (!xcd_remap(nblocks, logical)) return;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kNNThreads) void nn_packet_kernel(
     const bool valid = i < ns;
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
     if (valid) xform_point(T, sx[i], sy[i], sz[i], qx, qy, qz);
-    // invalid lanes: best = -1 is below every d2, rb = -inf is below every box distance
+    // invalid lanes: best = -1 is below every d2 and yields an empty search cube
     float best = valid ? r2 : -1.0f;
     int32_t bidx = -1;
 
@@ -88,12 +88,13 @@ __global__ __launch_bounds__(kNNThreads) void nn_packet_kernel(
             }
         }
     }
-    float rb = valid ? bound_radius(best) : -INFINITY;
+    Cube cube;
+    set_cube(cube, qx, qy, qz, best);  // invalid lanes: best = -1 -> empty cube
 
     uint32_t leaves = 0u;
-    const uint32_t steps = traverse_pairs(pairs_g, P, qx, qy, qz, rb, max_steps, [&](uint32_t L) {
+    const uint32_t steps = traverse_wide(records_g, leaf_first, cube, max_steps, [&](uint32_t L) {
         if (STATS) ++leaves;
-        nn_leaf(tblk_g, L, qx, qy, qz, best, bidx, rb);
+        nn_leaf(tblk_g, L, qx, qy, qz, best, bidx, cube);
     });
 
     if (valid) {

@@ -1,0 +1,138 @@
+// C++ drop-in check: the same calls a cupoch user writes (examples/cpp/registration.cpp,
+// src/tests/registration/kabsch.cpp), against libcupoch_amd.so.  Prints one JSON
+// object; tests/test_gpu_cpp.py asserts on it.
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <vector>
+
+#include "cupoch/cupoch.h"
+
+using namespace cupoch;
+using Eigen::Matrix4f;
+using Eigen::Vector3f;
+
+static Matrix4f Rigid(float angle, float ax, float ay, float az, float tx, float ty, float tz) {
+    const float n = std::sqrt(ax * ax + ay * ay + az * az);
+    Eigen::Vector6f x;
+    x[0] = angle * ax / n; x[1] = angle * ay / n; x[2] = angle * az / n;
+    x[3] = tx; x[4] = ty; x[5] = tz;
+    return utility::TransformVector6fToMatrix4f(x);
+}
+
+static float Fro(const Matrix4f& a, const Matrix4f& b) { return (a - b).norm(); }
+
+// a user-defined estimator: exercises the virtual interface / generic loop
+class MyPointToPlane : public registration::TransformationEstimation {
+public:
+    registration::TransformationEstimationType GetTransformationEstimationType() const override {
+        return registration::TransformationEstimationType::Unspecified;
+    }
+    float ComputeRMSE(const geometry::PointCloud& s, const geometry::PointCloud& t,
+                      const registration::CorrespondenceSet& c) const override {
+        return inner.ComputeRMSE(s, t, c);
+    }
+    Matrix4f ComputeTransformation(const geometry::PointCloud& s, const geometry::PointCloud& t,
+                                   const registration::CorrespondenceSet& c) const override {
+        ++calls;
+        return inner.ComputeTransformation(s, t, c);
+    }
+    registration::TransformationEstimationPointToPlane inner{-1.0f};
+    mutable int calls = 0;
+};
+
+int main() {
+    const int n = 50000;
+    std::mt19937 rng(7);
+    std::uniform_real_distribution<float> U(0.0f, 1.0f);
+    std::normal_distribution<float> N(0.0f, 1.0f);
+    std::vector<Vector3f> tgt(n), nrm(n);
+    for (int i = 0; i < n; ++i) {
+        tgt[i] = Vector3f(U(rng), U(rng), U(rng));
+        Vector3f v(N(rng), N(rng), N(rng));
+        const float l = v.norm();
+        nrm[i] = Vector3f(v[0] / l, v[1] / l, v[2] / l);
+    }
+    const float s = std::pow((float)n, -1.0f / 3.0f);
+    const Matrix4f T_gt = Rigid(0.2f * s, 1, 2, 3, 0.1f * s, -0.1f * s, 0.1f * s);
+    const Matrix4f T_inv = utility::InverseTransform(T_gt);
+
+    geometry::PointCloud target(tgt);
+    target.SetNormals(nrm);
+    geometry::PointCloud source = target;       // deep copy
+    source.Transform(T_inv);                    // source = T_gt^-1 * target
+
+    std::printf("{");
+    // Transform round trip (src/tests/geometry/pointcloud.cpp:143-174)
+    {
+        geometry::PointCloud p = target;
+        p.Transform(T_gt);
+        p.Transform(T_inv);
+        auto a = p.GetPoints();
+        double worst = 0;
+        for (int i = 0; i < n; ++i) worst = std::fmax(worst, (a[i] - tgt[i]).norm());
+        std::printf("\"roundtrip_max\": %.3g, ", worst);
+    }
+    const float r = 2.0f * s;
+    registration::ICPConvergenceCriteria crit;  // defaults 1e-6, 1e-6, 30
+    {
+        auto res = registration::RegistrationICP(source, target, r);  // default: point-to-point, identity init
+        std::printf("\"p2p_err\": %.3g, \"p2p_fitness\": %.6f, \"p2p_ncorr\": %zu, ", Fro(res.transformation_, T_gt),
+                    res.fitness_, res.correspondence_set_.size());
+        auto cs = res.GetCorrespondenceSet();
+        bool asc = true;
+        for (size_t i = 1; i < cs.size(); ++i) asc = asc && cs[i][0] > cs[i - 1][0];
+        std::printf("\"p2p_corr_ascending\": %s, ", asc ? "true" : "false");
+    }
+    {
+        auto res = registration::RegistrationICP(source, target, r, Matrix4f::Identity(),
+                                                 registration::TransformationEstimationPointToPlane(-1.0f), crit);
+        std::printf("\"pt2pl_err\": %.3g, \"pt2pl_rmse\": %.3g, ", Fro(res.transformation_, T_gt), res.inlier_rmse_);
+        auto ev = registration::EvaluateRegistration(source, target, r, res.transformation_);
+        std::printf("\"eval_fitness\": %.6f, ", ev.fitness_);
+    }
+    {
+        auto res = registration::RegistrationICP(source, target, r, Matrix4f::Identity(),
+                                                 registration::TransformationEstimationSymmetricMethod(-1.0f), crit);
+        std::printf("\"sym_err\": %.3g, ", Fro(res.transformation_, T_gt));
+    }
+    {
+        auto res = registration::RegistrationGeneralizedICP(source, target, r);   // covariances from normals, eps 1e-3
+        std::printf("\"gicp_err\": %.3g, ", Fro(res.transformation_, T_gt));
+    }
+    {
+        MyPointToPlane mine;
+        auto res = registration::RegistrationICP(source, target, r, Matrix4f::Identity(), mine,
+                                                 registration::ICPConvergenceCriteria(1e-6, 1e-6, 8));
+        std::printf("\"custom_err\": %.3g, \"custom_calls\": %d, ", Fro(res.transformation_, T_gt), mine.calls);
+    }
+    {   // no target normals: logged error, identity updates (registration.cu:134-143, transformation_estimation.cu:199-200)
+        geometry::PointCloud bare(tgt);
+        auto res = registration::RegistrationICP(source, bare, r, Matrix4f::Identity(),
+                                                 registration::TransformationEstimationPointToPlane(), crit);
+        std::printf("\"no_normals_is_identity\": %s, ", res.transformation_.isIdentity() ? "true" : "false");
+    }
+    {   // Kabsch golden shape (src/tests/registration/kabsch.cpp:35-55)
+        std::vector<Vector3f> pts(20);
+        for (auto& p : pts) p = Vector3f(1000 * U(rng), 1000 * U(rng), 1000 * U(rng));
+        const Matrix4f ref = Rigid(30.0f / 180.0f * (float)M_PI, 0, 0, 1, 0, 0, 0);
+        geometry::PointCloud a(pts), b(pts);
+        b.Transform(ref);
+        const Matrix4f res = registration::Kabsch(a.points_, b.points_);
+        std::printf("\"kabsch_ok\": %s, ", res.isApprox(ref, 1e-3f) ? "true" : "false");
+    }
+    {   // VoxelDownSample + EstimateNormals on the path's callers side
+        auto down = target.VoxelDownSample(0.05f);
+        bool unit = true;
+        auto dn = down->GetNormals();
+        for (auto& v : dn) unit = unit && std::fabs(v.norm() - 1.0f) < 1e-4f;
+        std::printf("\"voxels\": %zu, \"voxel_normals_unit\": %s, ", down->points_.size(), unit ? "true" : "false");
+        auto empty = target.VoxelDownSample(0.0f);
+        std::printf("\"voxel_zero_empty\": %s, ", empty->IsEmpty() ? "true" : "false");
+        geometry::PointCloud q(tgt);
+        q.EstimateNormals(knn::KDTreeSearchParamKNN(20));
+        std::printf("\"has_normals\": %s", q.HasNormals() ? "true" : "false");
+    }
+    std::printf("}\n");
+    return 0;
+}

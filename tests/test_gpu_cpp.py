@@ -1,0 +1,36 @@
+"""GPU: the C++ drop-in surface (namespace cupoch, cupoch_amd/cpp) compiled with
+g++ against libcupoch_amd.so and run as a user program."""
+import json
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cpp_surface_end_to_end(tmp_path):
+    from cupoch_amd import _lib
+    _lib.build()
+    cpp = os.path.join(ROOT, "cupoch_amd", "cpp")
+    subprocess.check_call(["make", "-s", "-C", cpp])
+    exe = str(tmp_path / "test_registration")
+    libdir = os.path.join(ROOT, "cupoch_amd", "lib")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__",
+                           "-I" + os.path.join(cpp, "include"), "-I" + os.path.join(ROOT, "include"),
+                           "-I/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "test_registration.cpp"),
+                           "-o", exe, "-L" + libdir, "-lcupoch_amd", "-lmi_icp", "-L/opt/rocm/lib",
+                           "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["roundtrip_max"] < 1e-6
+    for k in ("p2p_err", "pt2pl_err", "sym_err", "gicp_err", "custom_err"):
+        assert r[k] < 2e-5, (k, r[k])
+    assert r["p2p_fitness"] > 0.999 and r["eval_fitness"] > 0.999 and r["p2p_ncorr"] > 49000
+    assert r["p2p_corr_ascending"] and r["kabsch_ok"] and r["no_normals_is_identity"]
+    assert r["custom_calls"] >= 1
+    assert 1000 < r["voxels"] <= 9261 and r["voxel_normals_unit"] and r["voxel_zero_empty"] and r["has_normals"]
+    assert "require pre-computed target normal vectors" in out.stderr      # LogError path
