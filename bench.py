@@ -98,7 +98,6 @@ def main():
     n = args.points
     src, tgt, nrm, T_gt, max_dist = synth(n)
     eng = Engine(local)
-    eng.set_profiling(True)
     if world > 1:
         mine = D.shard_source(src, rank, world)
         src_local = np.ascontiguousarray(src[mine])
@@ -123,6 +122,12 @@ def main():
 
     # det_thresh <= 0: at this size the fp32 determinant of JtJ overflows and the
     # reference's default check would reject every solve
+    # N == 1: per-kernel HIP events run INSIDE the timed region (they cost ~4 us per
+    # launch, 1.6 % at 10M).  N > 1: the timed region runs without them -- at 1/8 of the
+    # work they would be 10 % of a step -- and the kernel averages come from a second
+    # pass of the same K steps right after.
+    in_region_events = world == 1 and os.environ.get("MI_ICP_BENCH_NO_EVENTS") != "1"
+    eng.set_profiling(in_region_events)
     eng.icp_begin(_lib.EST_POINT_TO_PLANE, max_dist, None, -1.0)
     eng.icp_iterate(args.warmup)
     prof0 = eng.get_profile()
@@ -141,6 +146,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof1 = eng.get_profile()
+    if not in_region_events:
+        eng.set_profiling(True)
+        prof0 = eng.get_profile()
+        eng.icp_iterate(args.steps)
+        prof1 = eng.get_profile()
 
     T = np.array(res.transformation, np.float32).reshape(4, 4).T
     err = float(np.linalg.norm(T - T_gt))

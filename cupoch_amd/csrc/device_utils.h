@@ -48,10 +48,29 @@ __device__ __forceinline__ void xform_point(const Xform& T, float x, float y, fl
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+// One DPP hop of a 64-bit value (two v_mov_b32 with a DPP modifier); lanes without a
+// source -- or rows masked out by ROW_MASK -- receive 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_hop(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int kWaveSumLane = 63;  // wave_sum leaves the total in the LAST lane
+
+// fp64 wave reduction on the DPP network: row_shr 1,2,4,8 scan each row of 16 lanes,
+// row_bcast:15 / row_bcast:31 carry the row totals across; 18 VALU instructions and no
+// LDS traffic (the ds_bpermute form -- 12 LDS ops per value -- made the 30-value epilogue
+// of reduce_kernel cost ~19 us per CU).
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;  // valid in lane 0
+    v += dpp_hop<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_hop<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_hop<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_hop<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row sum
+    v += dpp_hop<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_hop<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;                     // valid in lane 63
 }
 
 __device__ __forceinline__ float wave_min(float v) {

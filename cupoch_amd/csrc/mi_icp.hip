@@ -25,6 +25,7 @@
 #include "host_solver.h"
 #include "knn_normals.h"
 #include "lbvh.h"
+#include "loop.h"
 #include "nn_search.h"
 #include "primitives.h"
 #include "reduce.h"
@@ -100,16 +101,12 @@ struct mi_icp_ctx {
     float* f_host = nullptr;     // pinned, 16 floats
     uint32_t* u_host = nullptr;  // pinned, 4 words
 
-    // ---- registration loop state (mi_icp_icp_begin / mi_icp_icp_iterate) ----
-    struct Loop {
-        bool active = false;
-        int est = 0;
-        float r2 = 0.0f, det_thresh = -1.0f;
-        Mat4 T, A;             // reported transformation / what the points have seen
-        double sys[32] = {};
-        float fitness = 0.0f, rmse = 0.0f;
-        int iterations = 0, passes = 0;
-    } loop;
+    // ---- registration loop (device-resident, loop.h) ----
+    DevBuf loop_dev, ticket;
+    DevLoop* loop_host = nullptr;  // pinned mirror of the device state
+    bool loop_active = false;
+    float loop_r2 = 0.0f;
+    int loop_est = 0;
 
     // ---- multi-GPU ----
     ncclComm_t comm = nullptr;
@@ -117,7 +114,10 @@ struct mi_icp_ctx {
 
     // ---- instrumentation ----
     bool profiling = false;
+    static constexpr int kEvPairs = 16;   // per kind: one pair per launch of a chunk
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t evp[2][kEvPairs][2] = {};
+    int evp_n[2] = {0, 0};
     bool ev_pending_nn = false, ev_pending_red = false;
     double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -206,13 +206,7 @@ int from_device(mi_icp_ctx* c, const T* dev, T* dst, size_t count, int mem_kind)
 
 inline int blocks_for(int64_t n, int per = 256) { return (int)std::max<int64_t>(1, (n + per - 1) / per); }
 
-Xform make_xform(const Mat4& T) {
-    Xform x;
-    x.r00 = host::at(T, 0, 0); x.r01 = host::at(T, 0, 1); x.r02 = host::at(T, 0, 2); x.t0 = host::at(T, 0, 3);
-    x.r10 = host::at(T, 1, 0); x.r11 = host::at(T, 1, 1); x.r12 = host::at(T, 1, 2); x.t1 = host::at(T, 1, 3);
-    x.r20 = host::at(T, 2, 0); x.r21 = host::at(T, 2, 1); x.r22 = host::at(T, 2, 2); x.t2 = host::at(T, 2, 3);
-    return x;
-}
+Xform make_xform(const Mat4& T) { return xform_from(T); }
 
 Mat4 load_T(const float* T) {
     if (!T) return host::identity4();
@@ -275,14 +269,24 @@ int morton_order(mi_icp_ctx* c, const float* pts, int64_t n, const uint32_t** or
 struct EvTimer {
     mi_icp_ctx* c;
     int slot;  // 0: nn, 1: reduce
-    EvTimer(mi_icp_ctx* ctx, int s) : c(ctx), slot(s) {
-        if (c->profiling) (void)hipEventRecord(c->ev[slot * 2], c->stream);
+    hipEvent_t stop = nullptr;
+    bool pooled;
+    EvTimer(mi_icp_ctx* ctx, int s, bool in_loop) : c(ctx), slot(s), pooled(in_loop) {
+        if (!c->profiling) return;
+        if (pooled) {
+            if (c->evp_n[slot] >= mi_icp_ctx::kEvPairs) return;
+            const int i = c->evp_n[slot]++;
+            (void)hipEventRecord(c->evp[slot][i][0], c->stream);
+            stop = c->evp[slot][i][1];
+        } else {
+            (void)hipEventRecord(c->ev[slot * 2], c->stream);
+            stop = c->ev[slot * 2 + 1];
+        }
     }
     ~EvTimer() {
-        if (c->profiling) {
-            (void)hipEventRecord(c->ev[slot * 2 + 1], c->stream);
-            (slot == 0 ? c->ev_pending_nn : c->ev_pending_red) = true;
-        }
+        if (!stop) return;
+        (void)hipEventRecord(stop, c->stream);
+        if (!pooled) (slot == 0 ? c->ev_pending_nn : c->ev_pending_red) = true;
     }
 };
 
@@ -299,8 +303,23 @@ void collect_events(mi_icp_ctx* c) {  // call after the stream has been synchron
     c->ev_pending_nn = c->ev_pending_red = false;
 }
 
+// pooled events of a loop chunk: only the first `executed` launches did real work
+void collect_pooled(mi_icp_ctx* c, int executed) {
+    for (int slot = 0; slot < 2; ++slot) {
+        for (int i = 0; i < c->evp_n[slot] && i < executed; ++i) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, c->evp[slot][i][0], c->evp[slot][i][1]) == hipSuccess) {
+                c->prof[slot * 2] += ms;
+                c->prof[slot * 2 + 1] += 1;
+            }
+        }
+        c->evp_n[slot] = 0;
+    }
+}
+
 // ---- nearest-neighbour pass --------------------------------------------------
-int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long long* stats = nullptr) {
+int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long long* stats = nullptr,
+              const DevLoop* loop = nullptr) {
     if (c->ns <= 0) return MI_ICP_OK;
     int32_t* idx = (int32_t*)c->nn_idx.p;
     float* d2 = (float*)c->nn_d2.p;
@@ -315,9 +334,9 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
     const uint32_t max_steps = c->nrecords + 8u;  // every record is visited at most once
     const Xform X = make_xform(T);
-    EvTimer t(c, 0);
+    EvTimer t(c, 0, loop != nullptr);
 #define MI_NN_ARGS (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns, \
-                   (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, X, r2, nblocks, max_steps, idx, d2, stats
+                   (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, X, loop, r2, nblocks, max_steps, idx, d2, stats
     const bool use_seed = seed && c->nn_valid;
     if (stats) {
         if (use_seed) nn_packet_kernel<true, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
@@ -352,8 +371,9 @@ int ensure_inverse_maps(mi_icp_ctx* c) {
 }
 
 template <int EST, int MODE>
-void launch_reduce_t(mi_icp_ctx* c, const ReduceArgs& a, const Xform& X, int grid, double* partial) {
-    reduce_kernel<EST, MODE><<<grid, kReduceThreads, 0, c->stream>>>(a, X, partial);
+void launch_reduce_t(mi_icp_ctx* c, const ReduceArgs& a, const Xform& X, const DevLoop* loop, int grid,
+                     double* partial, uint32_t* ticket, double* out) {
+    reduce_kernel<EST, MODE><<<grid, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, out);
 }
 
 bool estimator_ready(const mi_icp_ctx* c, int est) {
@@ -366,12 +386,18 @@ bool estimator_ready(const mi_icp_ctx* c, int est) {
     }
 }
 
-// Accumulate sys[32] on the device for the current correspondences.  When the
-// estimator's inputs are missing only the statistics ([28], [29]) are formed.
-int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T) {
+// Accumulate sys[32] on the device (into c->sys_dev) for the current correspondences.
+// When the estimator's inputs are missing only the statistics ([28], [29]) are formed.
+int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, const DevLoop* loop = nullptr) {
     double *partial, *sys;
+    uint32_t* ticket;
     TRY(ensure(c, c->partial, (size_t)kReduceBlocks * kSysSize, &partial));
     TRY(ensure(c, c->sys_dev, kSysSize, &sys));
+    if (!c->ticket.p) {
+        TRY(ensure(c, c->ticket, 64, &ticket));
+        HIPCHK(c, hipMemsetAsync(ticket, 0, 256, c->stream));
+    }
+    ticket = (uint32_t*)c->ticket.p;
     ReduceArgs a;
     a.sx = (const float*)c->sx.p;
     a.sy = (const float*)c->sy.p;
@@ -395,39 +421,44 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T) {
         a.count = c->n_user_pairs;
     }
     if (c->ns <= 0 || c->nt <= 0 || (!a.pairs && !c->nn_valid)) a.count = 0;
-    const int grid = (int)std::min<int64_t>(kReduceBlocks, blocks_for(a.count, kReduceThreads));
+    // ~4 elements per thread up to 1024 blocks: enough blocks to hide the gather latency,
+    // few enough partials for the finishing block
+    const int grid = (int)std::min<int64_t>(kReduceBlocks, blocks_for(a.count, kReduceThreads * 4));
     const Xform X = make_xform(T);
     if (!estimator_ready(c, est)) {
         est = kEstP2P;
         mode = 1;
     }
     {
-        EvTimer t(c, 1);
+        EvTimer t(c, 1, loop != nullptr);
         switch (est * 2 + mode) {
-            case kEstP2P * 2 + 0: launch_reduce_t<kEstP2P, 0>(c, a, X, grid, partial); break;
-            case kEstP2P * 2 + 1: launch_reduce_t<kEstP2P, 1>(c, a, X, grid, partial); break;
-            case kEstPt2Pl * 2 + 0: launch_reduce_t<kEstPt2Pl, 0>(c, a, X, grid, partial); break;
-            case kEstPt2Pl * 2 + 1: launch_reduce_t<kEstPt2Pl, 1>(c, a, X, grid, partial); break;
-            case kEstSym * 2 + 0: launch_reduce_t<kEstSym, 0>(c, a, X, grid, partial); break;
-            case kEstSym * 2 + 1: launch_reduce_t<kEstSym, 1>(c, a, X, grid, partial); break;
-            case kEstGICP * 2 + 0: launch_reduce_t<kEstGICP, 0>(c, a, X, grid, partial); break;
-            case kEstGICP * 2 + 1: launch_reduce_t<kEstGICP, 1>(c, a, X, grid, partial); break;
+            case kEstP2P * 2 + 0: launch_reduce_t<kEstP2P, 0>(c, a, X, loop, grid, partial, ticket, sys); break;
+            case kEstP2P * 2 + 1: launch_reduce_t<kEstP2P, 1>(c, a, X, loop, grid, partial, ticket, sys); break;
+            case kEstPt2Pl * 2 + 0: launch_reduce_t<kEstPt2Pl, 0>(c, a, X, loop, grid, partial, ticket, sys); break;
+            case kEstPt2Pl * 2 + 1: launch_reduce_t<kEstPt2Pl, 1>(c, a, X, loop, grid, partial, ticket, sys); break;
+            case kEstSym * 2 + 0: launch_reduce_t<kEstSym, 0>(c, a, X, loop, grid, partial, ticket, sys); break;
+            case kEstSym * 2 + 1: launch_reduce_t<kEstSym, 1>(c, a, X, loop, grid, partial, ticket, sys); break;
+            case kEstGICP * 2 + 0: launch_reduce_t<kEstGICP, 0>(c, a, X, loop, grid, partial, ticket, sys); break;
+            case kEstGICP * 2 + 1: launch_reduce_t<kEstGICP, 1>(c, a, X, loop, grid, partial, ticket, sys); break;
             default: return fail(c, MI_ICP_ERR_INVALID, "unknown estimation type %d", est);
         }
         KCHK(c);
-        reduce_final<<<1, 1024, 0, c->stream>>>(partial, grid, sys);
-        KCHK(c);
     }
+    return MI_ICP_OK;
+}
+
+int allreduce_system(mi_icp_ctx* c) {
+    if (!c->comm) return MI_ICP_OK;
+    double* sys = (double*)c->sys_dev.p;
+    ncclResult_t r = g_rccl.AllReduce(sys, sys, kSysSize, ncclDouble, ncclSum, c->comm, c->stream);
+    if (r != ncclSuccess) return fail(c, MI_ICP_ERR_COMM, "ncclAllReduce failed (%d)", (int)r);
     return MI_ICP_OK;
 }
 
 // all-reduce across ranks (if any), copy to the host, synchronise
 int fetch_system(mi_icp_ctx* c, double* out) {
     double* sys = (double*)c->sys_dev.p;
-    if (c->comm) {
-        ncclResult_t r = g_rccl.AllReduce(sys, sys, kSysSize, ncclDouble, ncclSum, c->comm, c->stream);
-        if (r != ncclSuccess) return fail(c, MI_ICP_ERR_COMM, "ncclAllReduce failed (%d)", (int)r);
-    }
+    TRY(allreduce_system(c));
     HIPCHK(c, hipMemcpyAsync(c->sys_host, sys, kSysSize * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     collect_events(c);
@@ -435,36 +466,14 @@ int fetch_system(mi_icp_ctx* c, double* out) {
     return MI_ICP_OK;
 }
 
-// host step of ComputeTransformation for the built-in estimators
+// host step of ComputeTransformation for the built-in estimators (one-shot entry points)
 Mat4 solve_update(const mi_icp_ctx* c, int est, const double* sys, float det_thresh) {
-    Mat4 update = host::identity4();
-    if (!(sys[29] > 0.0) || !estimator_ready(c, est)) return update;
-    if (est == kEstP2P) {
-        const int64_t n_model = c->ns_global > 0 ? c->ns_global : c->ns;
-        return host::kabsch_from_sums(sys, (long long)n_model);
-    }
-    if (est == kEstPt2Pl) {
-        host::solve_system(sys, det_thresh, update);
-    } else if (est == kEstSym) {
-        Mat4 half;
-        if (host::solve_system(sys, det_thresh, half)) update = host::square_rotation(half);
-    } else if (est == kEstGICP) {
-        host::solve_system(sys, -1.0f, update);  // no det check (generalized_icp.cu:180)
-    }
-    return update;
+    const int64_t n_model = c->ns_global > 0 ? c->ns_global : c->ns;
+    return mi::solve_update(est, estimator_ready(c, est), sys, det_thresh, n_model);
 }
 
 void stats_from_system(const mi_icp_ctx* c, const double* sys, float* fitness, float* rmse) {
-    // registration.cu:71-78
-    const double count = sys[29];
-    const int64_t n_src = c->ns_global > 0 ? c->ns_global : c->ns;
-    if (!(count > 0.0) || n_src <= 0) {
-        *fitness = 0.0f;
-        *rmse = 0.0f;
-        return;
-    }
-    *fitness = (float)count / (float)n_src;
-    *rmse = std::sqrt((float)sys[28] / (float)count);
+    mi::stats_from_system(sys, c->ns_global > 0 ? c->ns_global : c->ns, fitness, rmse);
 }
 
 int check_ctx(mi_icp_ctx* c) {
@@ -495,7 +504,11 @@ int mi_icp_create(int device, mi_icp_ctx** out) {
     bool ok = hipHostMalloc((void**)&c->sys_host, 64 * sizeof(double), hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void**)&c->f_host, 64 * sizeof(float), hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void**)&c->u_host, 16 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->loop_host, sizeof(DevLoop), hipHostMallocDefault) == hipSuccess;
     for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    for (int k = 0; k < 2 && ok; ++k)
+        for (int i = 0; i < mi_icp_ctx::kEvPairs && ok; ++i)
+            ok = hipEventCreate(&c->evp[k][i][0]) == hipSuccess && hipEventCreate(&c->evp[k][i][1]) == hipSuccess;
     if (!ok) {
         mi_icp_destroy(c);
         return MI_ICP_ERR_HIP;
@@ -513,12 +526,17 @@ void mi_icp_destroy(mi_icp_ctx* c) {
                      &c->sperm, &c->snrm, &c->scov, &c->nn_idx, &c->nn_d2, &c->inv_s,
                      &c->user_pairs, &c->keys0, &c->keys1, &c->vals0, &c->vals1, &c->hist,
                      &c->scan_tmp, &c->bounds_part, &c->bounds, &c->partial, &c->sys_dev,
-                     &c->dense_idx, &c->flags, &c->pairs_out, &c->seg_start, &c->stage[0],
+                     &c->dense_idx, &c->flags, &c->pairs_out, &c->seg_start, &c->loop_dev, &c->ticket, &c->stage[0],
                      &c->stage[1], &c->stage[2], &c->stage[3], &c->stage[4], &c->stage[5]};
     for (DevBuf* b : all) release(*b);
     if (c->sys_host) (void)hipHostFree(c->sys_host);
     if (c->f_host) (void)hipHostFree(c->f_host);
     if (c->u_host) (void)hipHostFree(c->u_host);
+    if (c->loop_host) (void)hipHostFree(c->loop_host);
+    for (int k = 0; k < 2; ++k)
+        for (int i = 0; i < mi_icp_ctx::kEvPairs; ++i)
+            for (int e = 0; e < 2; ++e)
+                if (c->evp[k][i][e]) (void)hipEventDestroy(c->evp[k][i][e]);
     for (int i = 0; i < 4; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
@@ -879,8 +897,9 @@ int mi_icp_evaluate_registration(mi_icp_ctx* c, float max_distance, const float*
     return MI_ICP_OK;
 }
 
+// ---- device-resident registration loop (loop.h) -------------------------------------------
 static void fill_result(const mi_icp_ctx* c, mi_icp_result* out) {
-    const auto& L = c->loop;
+    const DevLoop& L = *c->loop_host;
     std::memcpy(out->transformation, L.T.data(), sizeof(float) * 16);
     out->fitness = L.fitness;
     out->inlier_rmse = L.rmse;
@@ -889,63 +908,103 @@ static void fill_result(const mi_icp_ctx* c, mi_icp_result* out) {
     out->nn_passes = L.passes;
 }
 
-// one pass of GetRegistrationResultAndCorrespondences under the loop's current
-// transform + the reduction the next ComputeTransformation needs
-static int loop_evaluate(mi_icp_ctx* c, bool seed) {
-    auto& L = c->loop;
-    TRY(launch_nn(c, L.A, L.r2, seed));
-    TRY(launch_reduce(c, L.est, 0, L.A));
-    TRY(fetch_system(c, L.sys));
-    stats_from_system(c, L.sys, &L.fitness, &L.rmse);
-    ++L.passes;
+static int loop_pull(mi_icp_ctx* c) {  // device state -> pinned mirror, synchronises
+    HIPCHK(c, hipMemcpyAsync(c->loop_host, c->loop_dev.p, sizeof(DevLoop), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return MI_ICP_OK;
 }
 
-// one iteration of the loop body (registration.cu:155-163)
-static int loop_step(mi_icp_ctx* c) {
-    auto& L = c->loop;
-    const Mat4 update = solve_update(c, L.est, L.sys, L.det_thresh);  // :157
-    L.T = host::mul4(update, L.T);                                     // :159
-    L.A = host::mul4(update, L.A);                                     // :160 (applied on load)
-    TRY(loop_evaluate(c, true));                                       // :162
-    ++L.iterations;
+// one evaluation: search under the loop's transform, reduction, all-reduce, step kernel
+static int loop_enqueue_evaluation(mi_icp_ctx* c, bool seed) {
+    DevLoop* d = (DevLoop*)c->loop_dev.p;
+    const Mat4 I = host::identity4();
+    TRY(launch_nn(c, I, c->loop_r2, seed, nullptr, d));
+    TRY(launch_reduce(c, c->loop_est, 0, I, d));
+    TRY(allreduce_system(c));
+    loop_step_kernel<<<1, 64, 0, c->stream>>>(d, (const double*)c->sys_dev.p, 0);
+    KCHK(c);
+    return MI_ICP_OK;
+}
+
+// Enqueue up to `budget` iterations in chunks, looking at `done` between chunks.
+static int loop_run(mi_icp_ctx* c, int budget) {
+    constexpr int kChunk = 8;
+    while (budget > 0) {
+        const int n = std::min(budget, kChunk);
+        const int passes_before = c->loop_host->passes;
+        for (int i = 0; i < n; ++i) TRY(loop_enqueue_evaluation(c, true));
+        TRY(loop_pull(c));
+        collect_pooled(c, c->loop_host->passes - passes_before);
+        budget -= n;
+        if (c->loop_host->done) break;
+    }
+    return MI_ICP_OK;
+}
+
+static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* init, float det_thresh,
+                      int max_iterations, float rel_fitness, float rel_rmse) {
+    if (est != kEstP2P && est != kEstPt2Pl && est != kEstSym && est != kEstGICP)
+        return fail(c, MI_ICP_ERR_INVALID, "unknown estimation type %d", est);
+    DevLoop& L = *c->loop_host;
+    std::memset(&L, 0, sizeof(L));
+    L.est = est;
+    L.det_thresh = det_thresh;
+    L.T = load_T(init);
+    L.A = host::is_identity4(L.T) ? host::identity4() : L.T;  // registration.cu:148-150
+    L.X = xform_from(L.A);
+    L.max_iterations = max_iterations;
+    L.rel_fitness = rel_fitness;
+    L.rel_rmse = rel_rmse;
+    L.n_source_global = c->ns_global > 0 ? c->ns_global : c->ns;
+    L.ready = estimator_ready(c, est) ? 1 : 0;
+    c->loop_active = false;
+    c->loop_est = est;
+    c->loop_r2 = max_distance * max_distance;
+    if (max_distance <= 0.0f || c->ns <= 0) {
+        // the reference logs an error and keeps going; every pass then yields an
+        // empty result and identity updates, so the answer is `init` unchanged
+        c->nn_valid = false;
+        L.done = 1;
+        return MI_ICP_OK;
+    }
+    DevLoop* d;
+    TRY(ensure(c, c->loop_dev, 1, &d));
+    HIPCHK(c, hipMemcpyAsync(d, &L, sizeof(DevLoop), hipMemcpyHostToDevice, c->stream));
+    c->loop_active = true;
+    TRY(loop_enqueue_evaluation(c, false));
     return MI_ICP_OK;
 }
 
 int mi_icp_icp_begin(mi_icp_ctx* c, int est, float max_distance, const float* init,
                      float det_thresh, mi_icp_result* out) {
     TRY(check_ctx(c));
-    if (est != kEstP2P && est != kEstPt2Pl && est != kEstSym && est != kEstGICP)
-        return fail(c, MI_ICP_ERR_INVALID, "unknown estimation type %d", est);
-    auto& L = c->loop;
-    L = mi_icp_ctx::Loop();
-    L.est = est;
-    L.det_thresh = det_thresh;
-    L.T = load_T(init);
-    L.A = host::is_identity4(L.T) ? host::identity4() : L.T;  // registration.cu:148-150
-    L.r2 = max_distance * max_distance;
-    if (max_distance <= 0.0f || c->ns <= 0) {
-        // the reference logs an error and keeps going; every pass then yields an
-        // empty result and identity updates, so the answer is `init` unchanged
-        c->nn_valid = false;
-        if (out) {
-            std::memset(out, 0, sizeof(*out));
-            fill_result(c, out);
-        }
-        return MI_ICP_OK;
+    TRY(loop_begin(c, est, max_distance, init, det_thresh, 0, -1.0f, -1.0f));
+    if (c->loop_active) {
+        TRY(loop_pull(c));
+        collect_pooled(c, 1);
     }
-    L.active = true;
-    TRY(loop_evaluate(c, false));
-    if (out) fill_result(c, out);
+    if (out) {
+        std::memset(out, 0, sizeof(*out));
+        fill_result(c, out);
+    }
     return MI_ICP_OK;
 }
 
 int mi_icp_icp_iterate(mi_icp_ctx* c, int n_iterations, mi_icp_result* out) {
     TRY(check_ctx(c));
     if (n_iterations < 0) return fail(c, MI_ICP_ERR_INVALID, "icp_iterate: negative count");
-    if (c->loop.active)
-        for (int i = 0; i < n_iterations; ++i) TRY(loop_step(c));
-    if (out) fill_result(c, out);
+    if (c->loop_active && n_iterations > 0) {
+        // re-open the loop for n more updates: the update for the next iteration is formed
+        // from the system of the last evaluation (resume = step without stats/test)
+        DevLoop* d = (DevLoop*)c->loop_dev.p;
+        loop_step_kernel<<<1, 64, 0, c->stream>>>(d, (const double*)c->sys_dev.p, n_iterations);
+        KCHK(c);
+        TRY(loop_run(c, n_iterations));
+    }
+    if (out) {
+        std::memset(out, 0, sizeof(*out));
+        fill_result(c, out);
+    }
     return MI_ICP_OK;
 }
 
@@ -955,16 +1014,15 @@ int mi_icp_registration_icp(mi_icp_ctx* c, int est, float max_distance, const fl
     if (!out) return fail(c, MI_ICP_ERR_INVALID, "registration_icp: out is null");
     mi_icp_params p = {1e-6f, 1e-6f, 30, 1e-6f};
     if (params) p = *params;
-    TRY(mi_icp_icp_begin(c, est, max_distance, init, p.det_thresh, out));
-    auto& L = c->loop;
-    if (!L.active) return MI_ICP_OK;
-    for (int it = 0; it < p.max_iteration; ++it) {
-        const float b_fit = L.fitness, b_rmse = L.rmse;                   // :161
-        TRY(loop_step(c));
-        if (std::fabs(b_fit - L.fitness) < p.relative_fitness &&
-            std::fabs(b_rmse - L.rmse) < p.relative_rmse)                 // :165-170
-            break;
+    // a negative threshold can never be undercut by |difference|: same as "never converges"
+    TRY(loop_begin(c, est, max_distance, init, p.det_thresh, std::max(p.max_iteration, 0),
+                   std::max(p.relative_fitness, 0.0f), std::max(p.relative_rmse, 0.0f)));
+    if (c->loop_active) {
+        TRY(loop_pull(c));
+        collect_pooled(c, 1);
+        if (!c->loop_host->done) TRY(loop_run(c, std::max(p.max_iteration, 0)));
     }
+    std::memset(out, 0, sizeof(*out));
     fill_result(c, out);
     return MI_ICP_OK;
 }

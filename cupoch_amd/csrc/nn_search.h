@@ -22,6 +22,7 @@
 // (as FLANN does; the visit order differs).
 #pragma once
 #include "device_utils.h"
+#include "loop.h"
 #include "traverse.h"
 
 namespace mi {
@@ -59,14 +60,21 @@ __device__ __forceinline__ void nn_leaf(const float* tblk_g, uint32_t L, float q
     }
 }
 
+// `loop` != nullptr: the transform comes from the device-resident loop state and the
+// kernel is a no-op once that loop is done; otherwise Tv (by value) is used.
 template <bool SEED, bool STATS>
 __global__ __launch_bounds__(kNNThreads) void nn_packet_kernel(
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
         int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
-        uint32_t leaf_first, Xform T, float r2, uint32_t nblocks, uint32_t max_steps, int32_t* __restrict__ nn_idx,
+        uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, uint32_t nblocks, uint32_t max_steps, int32_t* __restrict__ nn_idx,
         float* __restrict__ nn_d2, unsigned long long* __restrict__ stats) {
     uint32_t logical;
     if (!xcd_remap(nblocks, logical)) return;
+    Xform T = Tv;
+    if (loop) {
+        if (loop->done) return;
+        T = loop->X;
+    }
 
     const int64_t i = ((int64_t)logical * kNNPacketsPerBlock + (threadIdx.x >> 6)) * 64 + lane_id();
     const bool valid = i < ns;

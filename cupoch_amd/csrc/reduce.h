@@ -6,8 +6,8 @@
 // (full 6x6, fp32 tree sum), by one pass that keeps the 21 upper-triangle
 // entries + 6 + 3 scalars per lane in fp64 registers, reduces across the wave
 // with shuffles, across the block through LDS, and across blocks with a
-// second single-block launch in a fixed order (bitwise reproducible, no
-// atomics).  The estimator functors are restated from
+// last-arriving block in a fixed order (bitwise reproducible; the only atomic is
+// the arrival ticket).  The estimator functors are restated from
 //   point-to-plane  registration/transformation_estimation.cu:34-56
 //   symmetric       registration/transformation_estimation.cu:58-90
 //   GICP            registration/generalized_icp.cu:63-105 (+ eigenvalue.inl)
@@ -17,6 +17,7 @@
 #pragma once
 #include "device_utils.h"
 #include "eigen3.h"
+#include "loop.h"
 
 namespace mi {
 
@@ -74,9 +75,20 @@ struct ReduceArgs {
 
 // MODE 0: accumulate the linear system; MODE 1: accumulate only the
 // estimator's ComputeRMSE error into acc[27] (+ [28],[29]).
+// partial: [gridDim.x][32] per-block sums; ticket: arrival counter (zero before the
+// first launch, reset by the finishing block); out32: the fixed-order total, written by
+// whichever block arrives last.  `loop` as in nn_packet_kernel.
 template <int EST, int MODE>
-__global__ __launch_bounds__(kReduceThreads) void reduce_kernel(ReduceArgs a, Xform T,
-                                                                double* __restrict__ partial) {
+__global__ __launch_bounds__(kReduceThreads) void reduce_kernel(ReduceArgs a, Xform Tv,
+                                                                const DevLoop* __restrict__ loop,
+                                                                double* __restrict__ partial,
+                                                                uint32_t* __restrict__ ticket,
+                                                                double* __restrict__ out32) {
+    Xform T = Tv;
+    if (loop) {
+        if (loop->done) return;
+        T = loop->X;
+    }
     double acc[30];
 #pragma unroll
     for (int k = 0; k < 30; ++k) acc[k] = 0.0;
@@ -185,14 +197,15 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_kernel(ReduceArgs a, Xf
         }
     }
 
-    __shared__ double red[kReduceThreads / 64][kSysSize];
+    __shared__ double red[kReduceThreads / 32][kSysSize];
+    __shared__ uint32_t s_last;
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
 #pragma unroll
     for (int k = 0; k < 30; ++k) {
         const double v = wave_sum(acc[k]);
-        if (lane == 0) red[wid][k] = v;
+        if (lane == kWaveSumLane) red[wid][k] = v;
     }
-    if (lane == 0) {
+    if (lane == kWaveSumLane) {
         red[wid][30] = 0.0;
         red[wid][31] = 0.0;
     }
@@ -201,22 +214,51 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_kernel(ReduceArgs a, Xf
         const int k = (int)threadIdx.x;
         partial[(int64_t)blockIdx.x * kSysSize + k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
     }
-}
-
-// fixed-order sum of the per-block partials -> out[32]
-__global__ __launch_bounds__(1024) void reduce_final(const double* __restrict__ partial, int nblocks,
-                                                     double* __restrict__ out) {
-    __shared__ double red[32][kSysSize];
-    const int k = (int)(threadIdx.x & 31u), part = (int)(threadIdx.x >> 5);
-    double s = 0.0;
-    for (int b = part; b < nblocks; b += 32) s += partial[(int64_t)b * kSysSize + k];
-    red[part][k] = s;
+    // ---- hand-off to the finishing block: agent-scope release -> ticket -> acquire
+    // (cdna_hip_programming.md section 6, Guideline 16)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x < kSysSize) {
-        double t = 0.0;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    {   // fixed-order total of the per-block partials (independent of which block finishes)
+        const int k = (int)(threadIdx.x & 31u), part = (int)(threadIdx.x >> 5);
+        constexpr int kParts = kReduceThreads / 32;
+        // 16 independent accumulators keep 16 loads in flight: the partials were written by
+        // other CUs / XCDs, every load is a ~1 us miss, and a single dependent chain made this
+        // phase cost 20 us.  The association order is fixed, so the sum is reproducible.
+        const int nb = (int)gridDim.x;
+        const double* pk = partial + k;
+        constexpr int kU = 16;
+        double acc16[kU];
 #pragma unroll
-        for (int p = 0; p < 32; ++p) t += red[p][k];
-        out[k] = t;
+        for (int u = 0; u < kU; ++u) acc16[u] = 0.0;
+        int b = part;
+        for (; b + (kU - 1) * kParts < nb; b += kU * kParts) {
+#pragma unroll
+            for (int u = 0; u < kU; ++u) acc16[u] += pk[(int64_t)(b + u * kParts) * kSysSize];
+        }
+        for (; b < nb; b += kParts) acc16[0] += pk[(int64_t)b * kSysSize];
+#pragma unroll
+        for (int w = kU / 2; w > 0; w >>= 1)
+#pragma unroll
+            for (int u = 0; u < w; ++u) acc16[u] += acc16[u + w];
+        red[part][k] = acc16[0];
+        __syncthreads();
+        if (threadIdx.x < kSysSize) {
+            double t = 0.0;
+#pragma unroll
+            for (int p = 0; p < kParts; ++p) t += red[p][k];
+            out32[k] = t;
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
