@@ -216,4 +216,49 @@ __global__ __launch_bounds__(256) void gather_source(
     }
 }
 
+// ---- source: re-ordering by the current match ---------------------------------
+// After the first correspondence pass every source point knows its target point.
+// Ordering the source by that target position makes a packet's 64 matches
+// CONSECUTIVE in the target's order -- the packet then needs ~8 target leaves under
+// one or two bottom records instead of the ~18 leaves a geometrically compact but
+// unaligned packet touches.  Any source order is correct; this one is just cheaper
+// to search for as long as the clouds stay roughly where they are (ICP iterations).
+__global__ __launch_bounds__(256) void match_order_keys(const int32_t* __restrict__ nn_idx, int ns,
+                                                        uint32_t unmatched_key,
+                                                        uint64_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ns) return;
+    const int32_t j = nn_idx[i];
+    keys[i] = (j < 0) ? (uint64_t)unmatched_key : (uint64_t)(uint32_t)j;  // unmatched points keep their order at the end
+    vals[i] = (uint32_t)i;
+}
+
+struct SourceArrays {
+    float *sx, *sy, *sz;
+    int32_t* sperm;
+    float4* snrm;  // may be null
+    float* scov;   // may be null
+    int32_t* nn_idx;
+    float* nn_d2;
+};
+
+__global__ __launch_bounds__(256) void permute_source(const uint32_t* __restrict__ ord, int ns,
+                                                      SourceArrays in, SourceArrays out) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= ns) return;
+    const int64_t o = ord[p];
+    out.sx[p] = in.sx[o];
+    out.sy[p] = in.sy[o];
+    out.sz[p] = in.sz[o];
+    out.sperm[p] = in.sperm[o];
+    out.nn_idx[p] = in.nn_idx[o];
+    out.nn_d2[p] = in.nn_d2[o];
+    if (in.snrm) out.snrm[p] = in.snrm[o];
+    if (in.scov) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) out.scov[p * 9 + e] = in.scov[o * 9 + e];
+    }
+}
+
 }  // namespace mi

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -23,6 +24,7 @@
 #include "device_utils.h"
 #include "geometry_kernels.h"
 #include "host_solver.h"
+#include "kd_refine.h"
 #include "knn_normals.h"
 #include "lbvh.h"
 #include "loop.h"
@@ -86,6 +88,7 @@ struct mi_icp_ctx {
     int64_t ns = 0, ns_global = 0;
     bool s_has_nrm = false, s_has_cov = false;
     DevBuf sx, sy, sz, sperm, snrm, scov, nn_idx, nn_d2, inv_s;
+    DevBuf alt[8];  // second set of the source arrays (match-order re-sort ping-pong)
     bool inv_s_valid = false;
     bool nn_valid = false;  // nn_idx holds a search result (usable as seed / correspondences)
 
@@ -262,7 +265,16 @@ int morton_order(mi_icp_ctx* c, const float* pts, int64_t n, const uint32_t** or
     KCHK(c);
     const int cur = radix_sort_pairs(c->stream, sb, n, 3 * bits);
     KCHK(c);
-    *order = sb.vals[cur];
+    static const bool no_kd = std::getenv("MI_ICP_NO_KD") != nullptr;  // A/B switch for tuning
+    if (no_kd) {
+        *order = sb.vals[cur];
+        return MI_ICP_OK;
+    }
+    // Morton runs -> kd cells inside every group of 4096 points (kd_refine.h)
+    const int ngroups = (int)((n + kKdGroup - 1) / kKdGroup);
+    kd_refine_groups<<<ngroups, kKdThreads, 0, c->stream>>>(pts, sb.vals[cur], sb.vals[cur ^ 1], (int)n);
+    KCHK(c);
+    *order = sb.vals[cur ^ 1];
     return MI_ICP_OK;
 }
 
@@ -526,7 +538,8 @@ void mi_icp_destroy(mi_icp_ctx* c) {
                      &c->sperm, &c->snrm, &c->scov, &c->nn_idx, &c->nn_d2, &c->inv_s,
                      &c->user_pairs, &c->keys0, &c->keys1, &c->vals0, &c->vals1, &c->hist,
                      &c->scan_tmp, &c->bounds_part, &c->bounds, &c->partial, &c->sys_dev,
-                     &c->dense_idx, &c->flags, &c->pairs_out, &c->seg_start, &c->loop_dev, &c->ticket, &c->stage[0],
+                     &c->dense_idx, &c->flags, &c->pairs_out, &c->seg_start, &c->loop_dev, &c->ticket, &c->alt[0],
+                     &c->alt[1], &c->alt[2], &c->alt[3], &c->alt[4], &c->alt[5], &c->alt[6], &c->alt[7], &c->stage[0],
                      &c->stage[1], &c->stage[2], &c->stage[3], &c->stage[4], &c->stage[5]};
     for (DevBuf* b : all) release(*b);
     if (c->sys_host) (void)hipHostFree(c->sys_host);
@@ -898,6 +911,50 @@ int mi_icp_evaluate_registration(mi_icp_ctx* c, float max_distance, const float*
 }
 
 // ---- device-resident registration loop (loop.h) -------------------------------------------
+// Re-order the staged source by its current matches (lbvh.h: match_order_keys).
+// Enqueue-only; the second set of source arrays becomes the live one.
+static int resort_source_by_match(mi_icp_ctx* c) {
+    const int64_t n = c->ns;
+    if (n <= 0 || c->nt <= 0 || !c->nn_valid) return MI_ICP_OK;
+    SortBuffers sb;
+    TRY(sort_buffers(c, n, &sb));
+    int bits = 1;
+    while (bits < 32 && (1ull << bits) <= (uint64_t)c->nt) ++bits;  // keys 0..nt (nt = unmatched)
+    match_order_keys<<<blocks_for(n), 256, 0, c->stream>>>((const int32_t*)c->nn_idx.p, (int)n, (uint32_t)c->nt,
+                                                           sb.keys[0], sb.vals[0]);
+    KCHK(c);
+    const uint32_t* ord = sb.vals[radix_sort_pairs(c->stream, sb, n, bits)];
+    KCHK(c);
+    SourceArrays in, out;
+    in.sx = (float*)c->sx.p; in.sy = (float*)c->sy.p; in.sz = (float*)c->sz.p;
+    in.sperm = (int32_t*)c->sperm.p;
+    in.snrm = c->s_has_nrm ? (float4*)c->snrm.p : nullptr;
+    in.scov = c->s_has_cov ? (float*)c->scov.p : nullptr;
+    in.nn_idx = (int32_t*)c->nn_idx.p; in.nn_d2 = (float*)c->nn_d2.p;
+    TRY(ensure(c, c->alt[0], (size_t)n, &out.sx));
+    TRY(ensure(c, c->alt[1], (size_t)n, &out.sy));
+    TRY(ensure(c, c->alt[2], (size_t)n, &out.sz));
+    TRY(ensure(c, c->alt[3], (size_t)n, &out.sperm));
+    TRY(ensure(c, c->alt[4], (size_t)n, &out.nn_idx));
+    TRY(ensure(c, c->alt[5], (size_t)n, &out.nn_d2));
+    out.snrm = nullptr;
+    out.scov = nullptr;
+    if (in.snrm) TRY(ensure(c, c->alt[6], (size_t)n, &out.snrm));
+    if (in.scov) TRY(ensure(c, c->alt[7], (size_t)n * 9, &out.scov));
+    permute_source<<<blocks_for(n), 256, 0, c->stream>>>(ord, (int)n, in, out);
+    KCHK(c);
+    std::swap(c->sx, c->alt[0]);
+    std::swap(c->sy, c->alt[1]);
+    std::swap(c->sz, c->alt[2]);
+    std::swap(c->sperm, c->alt[3]);
+    std::swap(c->nn_idx, c->alt[4]);
+    std::swap(c->nn_d2, c->alt[5]);
+    if (in.snrm) std::swap(c->snrm, c->alt[6]);
+    if (in.scov) std::swap(c->scov, c->alt[7]);
+    c->inv_s_valid = false;
+    return MI_ICP_OK;
+}
+
 static void fill_result(const mi_icp_ctx* c, mi_icp_result* out) {
     const DevLoop& L = *c->loop_host;
     std::memcpy(out->transformation, L.T.data(), sizeof(float) * 16);
@@ -972,6 +1029,10 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
     HIPCHK(c, hipMemcpyAsync(d, &L, sizeof(DevLoop), hipMemcpyHostToDevice, c->stream));
     c->loop_active = true;
     TRY(loop_enqueue_evaluation(c, false));
+    // from here on the packets follow the target's order (pays for itself in ~4 iterations)
+    static const bool no_resort = std::getenv("MI_ICP_NO_RESORT") != nullptr;  // A/B switch for tuning
+    if (!no_resort && c->ns >= 32768 && (max_iterations >= 4 || max_iterations == 0))
+        TRY(resort_source_by_match(c));
     return MI_ICP_OK;
 }
 

@@ -96,7 +96,6 @@ __device__ __forceinline__ void pair_hits(uint32_t& hit, const Cube& c, float am
             "v_cmpx_gt_f32_e32 %[bmxx], %[lox]\n\t"
             "v_cmpx_gt_f32_e32 %[bmxy], %[loy]\n\t"
             "v_cmpx_gt_f32_e32 %[bmxz], %[loz]\n\t"
-            "s_nop 0\n\t"
             "s_cmp_lg_u64 exec, 0\n\t"
             "s_mov_b64 exec, %[sv]\n\t"
             "s_addc_u32 %[hit], %[hit], %[hit]\n\t"
@@ -106,7 +105,6 @@ __device__ __forceinline__ void pair_hits(uint32_t& hit, const Cube& c, float am
             "v_cmpx_gt_f32_e32 %[amxx], %[lox]\n\t"
             "v_cmpx_gt_f32_e32 %[amxy], %[loy]\n\t"
             "v_cmpx_gt_f32_e32 %[amxz], %[loz]\n\t"
-            "s_nop 0\n\t"
             "s_cmp_lg_u64 exec, 0\n\t"
             "s_mov_b64 exec, %[sv]\n\t"
             "s_addc_u32 %[hit], %[hit], %[hit]\n\t"
