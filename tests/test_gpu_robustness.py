@@ -1,0 +1,127 @@
+"""GPU: the search/registration on inputs that are NOT a cloud against a moved copy of
+itself -- partial overlap, outliers, clusters, lopsided sizes, large initial transforms,
+context reuse -- always against the oracle on identical inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from test_gpu_parity import check_nn, rigid
+
+pytestmark = pytest.mark.gpu
+P2P, PT2PL = 1, 2
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from cupoch_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def T_of(res):
+    return np.array(res.transformation, np.float32).reshape(4, 4).T
+
+
+def clustered(n, seed):
+    rng = np.random.default_rng(seed)
+    centers = rng.random((12, 3)) * 4
+    scale = rng.uniform(0.01, 0.3, 12)
+    which = rng.integers(0, 12, n)
+    pts = centers[which] + rng.standard_normal((n, 3)) * scale[which, None]
+    pts[: n // 50] = pts[n // 50: 2 * (n // 50)]            # exact duplicates
+    pts[-5:] = rng.random((5, 3)) * 1000                     # far outliers
+    return pts.astype(np.float32)
+
+
+def unit(v):
+    return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+
+def test_search_on_clustered_data_with_duplicates_and_outliers(eng):
+    tgt = clustered(150000, 1)
+    src = clustered(90000, 2)
+    eng.set_target(tgt)
+    eng.set_source(src)
+    for radius in (0.005, 0.05, 5.0):
+        idx, d2, st = eng.search_radius_1nn(radius)
+        cnt, oi, od = orc.search_radius(tgt, src, radius, 1)
+        assert st[0] == cnt
+        check_nn(idx, d2, oi, od, src, tgt)
+
+
+def test_partial_overlap_and_lopsided_sizes(eng):
+    rng = np.random.default_rng(3)
+    tgt = rng.random((120000, 3), dtype=np.float32)
+    nrm = unit(rng.standard_normal((120000, 3)))
+    T = rigid(0.004, [1, 1, 0], [0.002, -0.001, 0.001])
+    # source: half of the target's volume moved by T^-1, plus 30 % points with no partner at all
+    keep = tgt[:, 0] < 0.5
+    inside = orc.transform_points(np.linalg.inv(T).astype(np.float32), tgt[keep])
+    lost = (rng.random((len(inside) * 3 // 10, 3), dtype=np.float32) + np.float32([2, 2, 2]))
+    src = np.concatenate([inside, lost])[rng.permutation(len(inside) + len(lost))]
+    eng.set_target(tgt, nrm)
+    eng.set_source(src)
+    res = eng.registration_icp(PT2PL, 0.02, None, 1e-6, 1e-6, 30, -1.0)
+    ref = orc.registration_icp(src, tgt, 0.02, est=orc.EST_PT2PL, tgt_nrm=nrm, det_thresh=-1.0)
+    assert np.linalg.norm(T_of(res) - ref.transformation) <= 1e-5
+    assert res.fitness == pytest.approx(ref.fitness, abs=1e-5) and 0.6 < res.fitness < 0.8
+    np.testing.assert_array_equal(eng.get_correspondences(), ref.correspondence_set)
+    # tiny target / big source and the other way round
+    for ns, nt in ((200000, 3000), (3000, 200000)):
+        a = rng.random((nt, 3), dtype=np.float32)
+        b = rng.random((ns, 3), dtype=np.float32)
+        eng.set_target(a)
+        eng.set_source(b)
+        r = 2.0 * nt ** (-1 / 3)
+        idx, d2, st = eng.search_radius_1nn(r)
+        cnt, oi, od = orc.search_radius(a, b, r, 1)
+        assert st[0] == cnt
+        check_nn(idx, d2, oi, od, b, a)
+
+
+def test_large_initial_transform_and_context_reuse(eng):
+    rng = np.random.default_rng(5)
+    tgt = rng.random((80000, 3), dtype=np.float32)
+    nrm = unit(rng.standard_normal((80000, 3)))
+    T_true = rigid(2.1, [0.2, -1, 0.4], [3.0, -2.0, 0.5])      # 120 degrees + a big shift
+    src = orc.transform_points(np.linalg.inv(T_true).astype(np.float32), tgt)[rng.permutation(80000)]
+    init = (rigid(0.003, [0, 0, 1], [0.001, 0.001, -0.001]) @ T_true).astype(np.float32)
+    eng.set_target(tgt, nrm)
+    eng.set_source(src)
+    for est, kw in ((PT2PL, dict(tgt_nrm=nrm, det_thresh=-1.0)), (P2P, {})):
+        res = eng.registration_icp(est, 0.03, init, 1e-6, 1e-6, 30, -1.0)     # same context, new call
+        ref = orc.registration_icp(src, tgt, 0.03, init=init, est=est, **kw)
+        assert np.linalg.norm(T_of(res) - ref.transformation) <= 1e-5
+        assert np.linalg.norm(T_of(res) - T_true) < 1e-4 and res.fitness > 0.999
+    # a second target on the same context, identity start that does NOT converge to anything useful
+    eng.set_target(tgt[:30000] + np.float32(10.0))
+    res = eng.registration_icp(P2P, 0.03, None, 1e-6, 1e-6, 5, -1.0)
+    ref = orc.registration_icp(src, tgt[:30000] + np.float32(10.0), 0.03, est=orc.EST_P2P, max_iteration=5)
+    assert res.fitness == ref.fitness == 0.0
+    np.testing.assert_array_equal(T_of(res), np.eye(4))
+
+
+def test_iteration_limits_and_immediate_convergence(eng):
+    rng = np.random.default_rng(7)
+    tgt = rng.random((40000, 3), dtype=np.float32)
+    nrm = unit(rng.standard_normal((40000, 3)))
+    T = rigid(0.004, [1, 0, 1], [0.001, 0.002, 0.0])
+    src = orc.transform_points(np.linalg.inv(T).astype(np.float32), tgt)
+    eng.set_target(tgt, nrm)
+    eng.set_source(src)
+    for max_it, rel in ((0, 1e-6), (1, 1e-6), (3, 0.0), (30, 10.0)):
+        res = eng.registration_icp(PT2PL, 0.04, None, rel, rel, max_it, -1.0)
+        ref = orc.registration_icp(src, tgt, 0.04, est=orc.EST_PT2PL, tgt_nrm=nrm, det_thresh=-1.0,
+                                   relative_fitness=rel, relative_rmse=rel, max_iteration=max_it)
+        assert res.iterations == ref.iterations, (max_it, rel)
+        assert res.nn_passes == ref.iterations + 1
+        assert np.linalg.norm(T_of(res) - ref.transformation) <= 1e-5
+    # stepping API == whole call
+    eng.icp_begin(PT2PL, 0.04, None, -1.0)
+    a = eng.icp_iterate(2)
+    b = eng.icp_iterate(3)
+    whole = eng.registration_icp(PT2PL, 0.04, None, 0.0, 0.0, 5, -1.0)
+    assert a.iterations == 2 and b.iterations == 5 and whole.iterations == 5
+    assert np.linalg.norm(T_of(b) - T_of(whole)) <= 1e-6
