@@ -95,6 +95,7 @@ SIGNATURES = {
     "mi_icp_voxel_downsample": (_I, [_P, _P, _P, _P, _L, _F, _P, _P, _P, C.POINTER(_L), _I]),
     "mi_icp_covariances_from_normals": (_I, [_P, _P, _L, _F, _P, _I]),
     "mi_icp_estimate_normals_knn": (_I, [_P, _P, _L, _I, _P, _I]),
+    "mi_icp_estimate_normals_radius": (_I, [_P, _P, _L, _F, _I, _P, _I]),
     "mi_icp_comm_unique_id": (_I, [_P]),
     "mi_icp_comm_init": (_I, [_P, _P, _I, _I]),
     "mi_icp_comm_destroy": (_I, [_P]),

@@ -181,16 +181,24 @@ std::shared_ptr<PointCloud> PointCloud::VoxelDownSample(float voxel_size) const 
 }
 
 bool PointCloud::EstimateNormals(const knn::KDTreeSearchParam& search_param) {
-    if (search_param.GetSearchType() != knn::KDTreeSearchParam::SearchType::Knn) {
-        LogError("EstimateNormals: only KDTreeSearchParamKNN is implemented by this engine.");
-        return false;
-    }
-    const int k = ((const knn::KDTreeSearchParamKNN&)search_param).knn_;
     normals_.resize(points_.size());
     if (points_.empty()) return true;
-    Check(mi_icp_estimate_normals_knn(Engine(), Ptr(points_), (int64_t)points_.size(), k,
-                                      normals_.data()->data(), MI_ICP_DEVICE));
-    return true;
+    switch (search_param.GetSearchType()) {
+        case knn::KDTreeSearchParam::SearchType::Knn:
+            Check(mi_icp_estimate_normals_knn(Engine(), Ptr(points_), (int64_t)points_.size(),
+                                              ((const knn::KDTreeSearchParamKNN&)search_param).knn_,
+                                              normals_.data()->data(), MI_ICP_DEVICE));
+            return true;
+        case knn::KDTreeSearchParam::SearchType::Radius: {
+            const auto& p = (const knn::KDTreeSearchParamRadius&)search_param;
+            Check(mi_icp_estimate_normals_radius(Engine(), Ptr(points_), (int64_t)points_.size(), p.radius_,
+                                                 p.max_nn_, normals_.data()->data(), MI_ICP_DEVICE));
+            return true;
+        }
+        default:
+            LogError("Unknown search param type.");  // estimate_normals.cu:102-104
+            return false;
+    }
 }
 
 static Eigen::Vector3f Bound(const utility::device_vector<Eigen::Vector3f>& pts, bool want_max) {

@@ -44,7 +44,7 @@ __device__ __forceinline__ bool knn_offer(float* kd2, int32_t* kidx, int lane, i
             ++s.count;
             s.worst_pos = s.count;
         }
-        if (s.count >= k) {  // buffer full: find the new k-th (largest) distance
+        if (s.count >= k) {  // buffer full: the bound becomes the k-th (largest) distance held
             float w = -1.0f;
             int wp = 0;
             for (int t = 0; t < k; ++t) {
@@ -65,8 +65,7 @@ __device__ __forceinline__ bool knn_offer(float* kd2, int32_t* kidx, int lane, i
 __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
         const float* __restrict__ records_g, const float* __restrict__ tblk_g, uint32_t leaf_first, int n,
         int nleaf,
-        int k,
-        uint32_t nblocks, uint32_t max_steps, float* __restrict__ normals_out) {
+        int k, float r2, uint32_t nblocks, uint32_t max_steps, float* __restrict__ normals_out) {
     __shared__ float s_d2[kKnnWaves][kMaxKnn * 64];
     __shared__ int32_t s_idx[kKnnWaves][kMaxKnn * 64];
     uint32_t logical;
@@ -91,7 +90,8 @@ __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
         orig = __float_as_int(line[24]);
     }
     KnnState st;
-    st.worst = (valid && k > 0) ? INFINITY : -1.0f;
+    // r2 = +inf: plain k-NN; finite: the k nearest with d2 < r2 (KDTreeSearchParamRadius)
+    st.worst = (valid && k > 0) ? r2 : -1.0f;
     st.count = 0;
     st.worst_pos = 0;
 

@@ -1231,11 +1231,11 @@ int mi_icp_voxel_downsample(mi_icp_ctx* c, const float* xyz, const float* normal
     return MI_ICP_OK;
 }
 
-int mi_icp_estimate_normals_knn(mi_icp_ctx* c, const float* xyz, int64_t n, int knn, float* normals,
-                                int mem_kind) {
+static int estimate_normals_impl(mi_icp_ctx* c, const float* xyz, int64_t n, int knn, float r2,
+                                 float* normals, int mem_kind) {
     TRY(check_ctx(c));
     if (n < 0 || (n > 0 && (!xyz || !normals))) return fail(c, MI_ICP_ERR_INVALID, "estimate_normals: bad arguments");
-    if (knn > kMaxKnn) return fail(c, MI_ICP_ERR_INVALID, "estimate_normals: knn > %d not supported", kMaxKnn);
+    if (knn > kMaxKnn) return fail(c, MI_ICP_ERR_INVALID, "estimate_normals: more than %d neighbours are not supported", kMaxKnn);
     if (n == 0) return MI_ICP_OK;
     // builds its own LBVH over the cloud: target slot is reused and invalidated afterwards
     TRY(mi_icp_set_target(c, xyz, nullptr, nullptr, n, mem_kind));
@@ -1244,13 +1244,24 @@ int mi_icp_estimate_normals_knn(mi_icp_ctx* c, const float* xyz, int64_t n, int 
     const uint32_t nblocks = (uint32_t)((c->nleaf + kKnnLeavesPerBlock - 1) / kKnnLeavesPerBlock);
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
     knn_normals_kernel<<<grid, kKnnThreads, 0, c->stream>>>((const float*)c->nodes.p, (const float*)c->tblk.p,
-                                                            c->leaf_first, (int)n, c->nleaf, knn, nblocks, c->nrecords + 8u, dn);
+                                                            c->leaf_first, (int)n, c->nleaf, knn, r2, nblocks,
+                                                            c->nrecords + 8u, dn);
     KCHK(c);
     if (mem_kind == MI_ICP_HOST) TRY(from_device(c, (const float*)dn, normals, (size_t)n * 3, mem_kind));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->nt = 0;  // the tree belonged to this call
     c->t_has_nrm = c->t_has_cov = false;
     return MI_ICP_OK;
+}
+
+int mi_icp_estimate_normals_knn(mi_icp_ctx* c, const float* xyz, int64_t n, int knn, float* normals,
+                                int mem_kind) {
+    return estimate_normals_impl(c, xyz, n, knn, INFINITY, normals, mem_kind);
+}
+
+int mi_icp_estimate_normals_radius(mi_icp_ctx* c, const float* xyz, int64_t n, float radius, int max_nn,
+                                   float* normals, int mem_kind) {
+    return estimate_normals_impl(c, xyz, n, max_nn, radius * radius, normals, mem_kind);
 }
 
 // ---------------------------------------------------------------------------

@@ -278,6 +278,19 @@ class Engine:
         self.n_target = 0
         return out
 
+    def estimate_normals_radius(self, points, radius, max_nn=30):
+        p = _Buf(points, np.float32, 3, self.device)
+        if p.kind == MI_ICP_DEVICE:
+            out = torch.empty((p.n, 3), dtype=torch.float32, device=p.keep.device)
+            optr = C.c_void_p(out.data_ptr())
+        else:
+            out = np.empty((p.n, 3), np.float32)
+            optr = out.ctypes.data_as(C.c_void_p)
+        self._chk(self._L.mi_icp_estimate_normals_radius(self._ctx, p.ptr, p.n, float(radius),
+                                                         int(max_nn), optr, p.kind))
+        self.n_target = 0
+        return out
+
     # -- multi-GPU / instrumentation -------------------------------------------------------------
     def comm_init(self, unique_id, nranks, rank):
         buf = C.create_string_buffer(bytes(unique_id), 128)

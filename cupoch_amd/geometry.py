@@ -30,6 +30,14 @@ class KDTreeSearchParamKNN:
         self.knn = int(knn)
 
 
+class KDTreeSearchParamRadius:
+    """knn::KDTreeSearchParamRadius (knn/kdtree_search_param.h:58-66)"""
+
+    def __init__(self, radius, max_nn=100):
+        self.radius = float(radius)
+        self.max_nn = int(max_nn)
+
+
 class PointCloud:
     def __init__(self, points=None):
         self._points = utility.Vector3fVector() if points is None else _v3(points)
@@ -124,11 +132,14 @@ class PointCloud:
             out._colors = utility.Vector3fVector(c2.clone())
         return out
 
-    # PointCloud::EstimateNormals (estimate_normals.cu:82-127), KNN search only ----------------------
+    # PointCloud::EstimateNormals (estimate_normals.cu:82-127): KNN or Radius search parameter ----------
     def estimate_normals(self, search_param=None):
-        k = 30 if search_param is None else int(getattr(search_param, "knn", 30))
         eng = get_engine(self._points.tensor.device.index)
-        nrm = eng.estimate_normals_knn(self._points.tensor, k)
+        if isinstance(search_param, KDTreeSearchParamRadius):
+            nrm = eng.estimate_normals_radius(self._points.tensor, search_param.radius, search_param.max_nn)
+        else:
+            k = 30 if search_param is None else int(getattr(search_param, "knn", 30))
+            nrm = eng.estimate_normals_knn(self._points.tensor, k)
         self._normals = utility.Vector3fVector(nrm)
         return True
 

@@ -207,6 +207,13 @@ MI_ICP_API int mi_icp_covariances_from_normals(mi_icp_ctx* ctx, const float* nor
  * (geometry/estimate_normals.cu:82-127), knn <= 64. */
 MI_ICP_API int mi_icp_estimate_normals_knn(mi_icp_ctx* ctx, const float* xyz, int64_t n,
                                            int knn, float* normals, int mem_kind);
+/* PointCloud::EstimateNormals(KDTreeSearchParamRadius(radius, max_nn)): the max_nn
+ * (<= 32) nearest points with d2 < radius^2, as KDTreeFlann::SearchRadius
+ * feeds it (geometry/estimate_normals.cu:93-101, knn/kdtree_flann.inl:96-122);
+ * fewer than 3 neighbours -> (0,0,1). */
+MI_ICP_API int mi_icp_estimate_normals_radius(mi_icp_ctx* ctx, const float* xyz, int64_t n,
+                                              float radius, int max_nn, float* normals,
+                                              int mem_kind);
 
 /* ---- multi-GPU (new: the reference is single-GPU) -------------------------
  * One context per rank/GPU, each holding the full target and its own shard of

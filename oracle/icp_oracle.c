@@ -1328,7 +1328,20 @@ static void normal_from_cumulants(const float *cum, int count, float *out) {
     memcpy(out, nrm, sizeof(nrm));
 }
 
+static int estimate_normals_impl(const float *pts, int64_t n, int k, float r2, float *out);
+
 ORACLE_API int oracle_estimate_normals_knn(const float *pts, int64_t n, int k, float *out) {
+    return estimate_normals_impl(pts, n, k, INFINITY, out);
+}
+
+/* KDTreeSearchParamRadius(radius, max_nn): the max_nn nearest with d2 < radius^2
+ * (estimate_normals.cu:93-101 over kdtree_flann.inl:96-122) */
+ORACLE_API int oracle_estimate_normals_radius(const float *pts, int64_t n, float radius, int max_nn,
+                                              float *out) {
+    return estimate_normals_impl(pts, n, max_nn, radius * radius, out);
+}
+
+static int estimate_normals_impl(const float *pts, int64_t n, int k, float r2, float *out) {
     if (k <= 0) {
         for (int64_t i = 0; i < n; ++i) {
             out[3 * i] = 0;
@@ -1344,7 +1357,7 @@ ORACLE_API int oracle_estimate_normals_knn(const float *pts, int64_t n, int k, f
         float *d2 = (float *)malloc(sizeof(float) * (size_t)k);
 #pragma omp for schedule(dynamic, 256)
         for (int64_t i = 0; i < n; ++i) {
-            kd_result r = {k, 0, INFINITY, d2, idx};
+            kd_result r = {k, 0, r2, d2, idx};
             kd_search_rec(t, 0, pts + 3 * i, &r);
             float cum[9] = {0};
             for (int s = 0; s < r.count; ++s) {

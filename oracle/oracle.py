@@ -258,6 +258,14 @@ def estimate_normals_knn(pts, k=30):
     return out
 
 
+def estimate_normals_radius(pts, radius, max_nn=30):
+    pts = _f32(pts, (-1, 3))
+    out = np.empty_like(pts)
+    lib().oracle_estimate_normals_radius(_p(pts), C.c_int64(len(pts)), C.c_float(radius),
+                                         C.c_int(max_nn), _p(out))
+    return out
+
+
 # ---------------------------------------------------------------------------
 # oracle/_ref : the reference's own code compiled where it lies (optional)
 # ---------------------------------------------------------------------------

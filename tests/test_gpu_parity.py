@@ -339,3 +339,14 @@ def test_estimate_normals_golden_and_oracle(eng, golden):
         # summation-order noise; a different k-th neighbour on an exact tie moves a few more
         assert (dots > 1 - 1e-4).mean() > 0.995, "normals differ: %g" % (dots > 1 - 1e-4).mean()
         assert np.median(1 - dots) < 1e-6
+    # KDTreeSearchParamRadius(radius, max_nn): sparse neighbourhoods fall back to (0,0,1)
+    # (with 3-6 neighbours the fp32 raw-moment covariance is nearly singular: its smallest
+    # eigenvector amplifies summation-order noise, so the sparse case is held to a looser bar)
+    for radius, max_nn, agree in ((0.02, 30, 0.99), (0.004, 16, 0.9)):
+        got = eng.estimate_normals_radius(cuda(pts), radius, max_nn).cpu().numpy()
+        ref = orc.estimate_normals_radius(pts, radius, max_nn)
+        fallback = (ref == np.float32([0, 0, 1])).all(1)
+        assert ((got == np.float32([0, 0, 1])).all(1) == fallback).mean() > 0.999
+        dots = np.abs((got * ref).sum(1))
+        assert (dots > 1 - 1e-3).mean() > agree, (radius, (dots > 1 - 1e-3).mean())
+    assert fallback.any() and not fallback.all()
