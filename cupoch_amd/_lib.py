@@ -21,6 +21,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 MI_ICP_HOST, MI_ICP_DEVICE = 0, 1
 EST_POINT_TO_POINT, EST_POINT_TO_PLANE, EST_SYMMETRIC, EST_GENERALIZED = 1, 2, 3, 5
+EST_COLORED = 4
 
 
 class MiIcpError(RuntimeError):
@@ -96,6 +97,11 @@ SIGNATURES = {
     "mi_icp_covariances_from_normals": (_I, [_P, _P, _L, _F, _P, _I]),
     "mi_icp_estimate_normals_knn": (_I, [_P, _P, _L, _I, _P, _I]),
     "mi_icp_estimate_normals_radius": (_I, [_P, _P, _L, _F, _I, _P, _I]),
+    "mi_icp_set_target_colors": (_I, [_P, _P, _I]),
+    "mi_icp_set_source_colors": (_I, [_P, _P, _I]),
+    "mi_icp_set_lambda_geometric": (_I, [_P, _F]),
+    "mi_icp_compute_color_gradients": (_I, [_P, _F, _I, _P, _I]),
+    "mi_icp_registration_colored_icp": (_I, [_P, _F, _P, C.POINTER(Params), _F, C.POINTER(Result)]),
     "mi_icp_comm_unique_id": (_I, [_P]),
     "mi_icp_comm_init": (_I, [_P, _P, _I, _I]),
     "mi_icp_comm_destroy": (_I, [_P]),

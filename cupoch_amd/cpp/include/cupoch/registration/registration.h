@@ -46,6 +46,13 @@ RegistrationResult RegistrationGeneralizedICP(
         const TransformationEstimationForGeneralizedICP& estimation = TransformationEstimationForGeneralizedICP(),
         const ICPConvergenceCriteria& criteria = ICPConvergenceCriteria());
 
+/// registration/colored_icp.h:40-48
+RegistrationResult RegistrationColoredICP(
+        const geometry::PointCloud& source, const geometry::PointCloud& target, float max_distance,
+        const Eigen::Matrix4f& init = Eigen::Matrix4f::Identity(),
+        const ICPConvergenceCriteria& criteria = ICPConvergenceCriteria(), float lambda_geometric = 0.968,
+        float det_thresh = 1.0e-6);
+
 /// registration/kabsch.h: all points paired by index
 Eigen::Matrix4f_u Kabsch(const utility::device_vector<Eigen::Vector3f>& model,
                          const utility::device_vector<Eigen::Vector3f>& target);

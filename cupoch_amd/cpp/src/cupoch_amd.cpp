@@ -344,6 +344,25 @@ RegistrationResult RegistrationGeneralizedICP(const geometry::PointCloud& source
                            max_correspondence_distance, init, estimation, criteria);
 }
 
+// registration::RegistrationColoredICP (colored_icp.cu:329-341)
+RegistrationResult RegistrationColoredICP(const geometry::PointCloud& source, const geometry::PointCloud& target,
+                                          float max_distance, const Eigen::Matrix4f& init,
+                                          const ICPConvergenceCriteria& criteria, float lambda_geometric,
+                                          float det_thresh) {
+    if (max_distance <= 0.0f) LogError("Invalid max_correspondence_distance.");
+    if (!target.HasNormals())
+        LogError("TransformationEstimationPointToPlane and TransformationEstimationColoredICP require "
+                 "pre-computed target normal vectors.");
+    LoadClouds(source, target);
+    if (target.HasNormals() && target.HasColors())
+        Check(mi_icp_set_target_colors(Engine(), Ptr(target.colors_), MI_ICP_DEVICE));
+    if (source.HasColors()) Check(mi_icp_set_source_colors(Engine(), Ptr(source.colors_), MI_ICP_DEVICE));
+    mi_icp_params prm = {criteria.relative_fitness_, criteria.relative_rmse_, criteria.max_iteration_, det_thresh};
+    mi_icp_result r;
+    Check(mi_icp_registration_colored_icp(Engine(), max_distance, init.data(), &prm, lambda_geometric, &r));
+    return MakeResult(r);
+}
+
 Eigen::Matrix4f_u Kabsch(const utility::device_vector<Eigen::Vector3f>& model,
                          const utility::device_vector<Eigen::Vector3f>& target) {
     // all points paired by index (kabsch.cu:122-): an identity correspondence set

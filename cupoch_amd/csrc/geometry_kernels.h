@@ -188,4 +188,28 @@ __global__ __launch_bounds__(256) void voxel_means(
     }
 }
 
+// ---- colored ICP: intensities in the staged orders --------------------------------------
+// (c0 + c1 + c2) / 3.0 exactly as colored_icp.cu:91,105-107,195-200 evaluate it
+// (fp32 sum, division in double, narrowed).
+__device__ __forceinline__ float intensity_of(const float* rgb) {
+    return (float)((double)((rgb[0] + rgb[1]) + rgb[2]) / 3.0);
+}
+
+__global__ __launch_bounds__(256) void target_intensity(const float* __restrict__ tblk,
+                                                        const float* __restrict__ rgb, int n,
+                                                        float4* __restrict__ tnrm) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const int32_t orig = __float_as_int(tblk[(s >> 3) * kLeafFloats + 24 + (s & 7)]);
+    tnrm[s].w = intensity_of(rgb + (int64_t)orig * 3);
+}
+
+__global__ __launch_bounds__(256) void source_intensity(const int32_t* __restrict__ sperm,
+                                                        const float* __restrict__ rgb, int n,
+                                                        float* __restrict__ sint) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    sint[s] = intensity_of(rgb + (int64_t)sperm[s] * 3);
+}
+
 }  // namespace mi

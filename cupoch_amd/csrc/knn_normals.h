@@ -15,6 +15,12 @@
 //      (FastEigen3x3MinMaxVec), written to the point's ORIGINAL index.
 // Neighbours include the point itself; fewer than 3 neighbours or a zero
 // normal give (0,0,1), as the reference.
+//
+// OUT = 1 reuses phases A/B for InitializePointCloudForColoredICP
+// (registration/colored_icp.cu:72-148): phase C then fits the intensity gradient
+// in the tangent plane over the lane's neighbours (nearest one -- the point
+// itself -- skipped) and writes it in the tree's order for the colored-ICP
+// reduction.
 #pragma once
 #include "device_utils.h"
 #include "eigen3.h"
@@ -62,10 +68,15 @@ __device__ __forceinline__ bool knn_offer(float* kd2, int32_t* kidx, int lane, i
     return shrunk;
 }
 
+// OUT 0: normals_out[orig] (3 floats).  OUT 1: tgrad[sorted] (float4, w = 0) and, when
+// not null, normals_out[orig] receives the gradient for inspection; tnrm = sorted target
+// normals with the intensity in .w.
+template <int OUT>
 __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
         const float* __restrict__ records_g, const float* __restrict__ tblk_g, uint32_t leaf_first, int n,
         int nleaf,
-        int k, float r2, uint32_t nblocks, uint32_t max_steps, float* __restrict__ normals_out) {
+        int k, float r2, uint32_t nblocks, uint32_t max_steps, float* __restrict__ normals_out,
+        const float4* __restrict__ tnrm, float4* __restrict__ tgrad) {
     __shared__ float s_d2[kKnnWaves][kMaxKnn * 64];
     __shared__ int32_t s_idx[kKnnWaves][kMaxKnn * 64];
     uint32_t logical;
@@ -123,8 +134,68 @@ __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
         if (shrunk) set_cube(cube, qx, qy, qz, st.worst);
     });
 
-    // ---- C: covariance of the neighbours -> normal ------------------------------------
     if (!valid) return;
+    if (OUT == 1) {
+        // ---- C': colour gradient (colored_icp.cu:88-120) ------------------------------------
+        float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+        if (k > 0 && st.count >= 5) {  // nn = count - 1 >= 4
+            int skip = 0;  // the reference drops the first (nearest) entry of the sorted list
+            float dmin = kd2[lane];
+            for (int t = 1; t < st.count; ++t) {
+                const float v = kd2[t * 64 + lane];
+                if (v < dmin) {
+                    dmin = v;
+                    skip = t;
+                }
+            }
+            const float4 n4 = tnrm[i];
+            const float nt[3] = {n4.x, n4.y, n4.z};
+            const float it = n4.w;
+            M3 A;
+            float b[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c2 = 0; c2 < 3; ++c2) A.m[r][c2] = 0.0f;
+            for (int t = 0; t < st.count; ++t) {
+                if (t == skip) continue;
+                const int32_t j = kidx[t * 64 + lane];
+                const float* line = tblk_g + (int64_t)(j >> 3) * kLeafFloats + (j & 7);
+                const float da[3] = {line[0] - qx, line[8] - qy, line[16] - qz};
+                const float h = dot3(da, nt);
+                const float v[3] = {(line[0] - h * nt[0]) - qx, (line[8] - h * nt[1]) - qy,
+                                    (line[16] - h * nt[2]) - qz};
+                const float di = tnrm[j].w - it;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int c2 = 0; c2 < 3; ++c2) A.m[r][c2] += v[r] * v[c2];
+                    b[r] += di * v[r];
+                }
+            }
+            const int nn = st.count - 1;
+            const float w = (float)((nn - 1) * (nn - 1));
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c2 = 0; c2 < 3; ++c2) A.m[r][c2] += w * nt[r] * nt[c2];
+                A.m[r][r] += 1.0e-6f;
+            }
+            M3 Ai;
+            inverse3(A, Ai);
+            gx = Ai.m[0][0] * b[0] + Ai.m[0][1] * b[1] + Ai.m[0][2] * b[2];
+            gy = Ai.m[1][0] * b[0] + Ai.m[1][1] * b[1] + Ai.m[1][2] * b[2];
+            gz = Ai.m[2][0] * b[0] + Ai.m[2][1] * b[1] + Ai.m[2][2] * b[2];
+        }
+        tgrad[i] = make_float4(gx, gy, gz, 0.0f);
+        if (normals_out) {
+            normals_out[(int64_t)orig * 3] = gx;
+            normals_out[(int64_t)orig * 3 + 1] = gy;
+            normals_out[(int64_t)orig * 3 + 2] = gz;
+        }
+        return;
+    }
+    // ---- C: covariance of the neighbours -> normal ------------------------------------
     float nx = 0.0f, ny = 0.0f, nz = 1.0f;
     if (k > 0 && st.count >= 3) {
         float cum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};

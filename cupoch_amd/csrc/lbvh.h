@@ -239,6 +239,7 @@ struct SourceArrays {
     int32_t* sperm;
     float4* snrm;  // may be null
     float* scov;   // may be null
+    float* sint;   // may be null
     int32_t* nn_idx;
     float* nn_d2;
 };
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(256) void permute_source(const uint32_t* __restrict
     out.nn_idx[p] = in.nn_idx[o];
     out.nn_d2[p] = in.nn_d2[o];
     if (in.snrm) out.snrm[p] = in.snrm[o];
+    if (in.sint) out.sint[p] = in.sint[o];
     if (in.scov) {
 #pragma unroll
         for (int e = 0; e < 9; ++e) out.scov[p * 9 + e] = in.scov[o * 9 + e];

@@ -49,7 +49,7 @@ __host__ __device__ inline host::Mat4 solve_update(int est, bool ready, const do
     host::Mat4 update = host::identity4();
     if (!(sys[29] > 0.0) || !ready) return update;
     if (est == 1) return host::kabsch_from_sums(sys, (long long)n_model);
-    if (est == 2) {
+    if (est == 2 || est == 4) {  // point-to-plane, colored ICP (colored_icp.cu:239-243)
         host::solve_system(sys, det_thresh, update);
     } else if (est == 3) {
         host::Mat4 half;

@@ -79,16 +79,17 @@ struct mi_icp_ctx {
     int64_t nt = 0;
     int nleaf = 0;
     uint32_t leaf_first = 1, nrecords = 0;  // 8-ary tree: first last-level node id, record count
-    bool t_has_nrm = false, t_has_cov = false;
-    DevBuf tblk, tnrm, tcov, nodes, inv_t, tbounds;
+    bool t_has_nrm = false, t_has_cov = false, t_has_int = false, t_has_grad = false;
+    DevBuf tblk, tnrm, tcov, tgrad, nodes, inv_t, tbounds;
     int tbits = 0;  // Morton quantisation of the target (reused for the source, see set_source)
     bool inv_t_valid = false;
 
     // ---- source (Morton order) ----
     int64_t ns = 0, ns_global = 0;
-    bool s_has_nrm = false, s_has_cov = false;
-    DevBuf sx, sy, sz, sperm, snrm, scov, nn_idx, nn_d2, inv_s;
-    DevBuf alt[8];  // second set of the source arrays (match-order re-sort ping-pong)
+    bool s_has_nrm = false, s_has_cov = false, s_has_int = false;
+    float lambda_geometric = 0.968f;  // colored ICP (colored_icp.cu:47-51)
+    DevBuf sx, sy, sz, sperm, snrm, scov, sint, nn_idx, nn_d2, inv_s;
+    DevBuf alt[9];  // second set of the source arrays (match-order re-sort ping-pong)
     bool inv_s_valid = false;
     bool nn_valid = false;  // nn_idx holds a search result (usable as seed / correspondences)
 
@@ -388,12 +389,18 @@ void launch_reduce_t(mi_icp_ctx* c, const ReduceArgs& a, const Xform& X, const D
     reduce_kernel<EST, MODE><<<grid, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, out);
 }
 
+bool known_estimator(int est) {
+    return est == kEstP2P || est == kEstPt2Pl || est == kEstSym || est == kEstColored || est == kEstGICP;
+}
+
 bool estimator_ready(const mi_icp_ctx* c, int est) {
     switch (est) {
         case kEstP2P: return true;
         case kEstPt2Pl: return c->t_has_nrm;                  // transformation_estimation.cu:199-200
         case kEstSym: return c->t_has_nrm && c->s_has_nrm;    // :293-294
         case kEstGICP: return c->t_has_cov && c->s_has_cov;   // generalized_icp.cu:156-159
+        case kEstColored:                                     // colored_icp.cu:222-224
+            return c->t_has_nrm && c->t_has_int && c->t_has_grad && c->s_has_int;
         default: return false;
     }
 }
@@ -419,6 +426,10 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, const DevLoop
     a.tblk = (const float*)c->tblk.p;
     a.tnrm = (const float4*)c->tnrm.p;
     a.tcov = (const float*)c->tcov.p;
+    a.tgrad = (const float4*)c->tgrad.p;
+    a.sint = (const float*)c->sint.p;
+    a.sqrt_lambda_geometric = std::sqrt(c->lambda_geometric);
+    a.sqrt_lambda_photometric = std::sqrt(1.0f - c->lambda_geometric);
     a.nn_idx = (const int32_t*)c->nn_idx.p;
     a.pairs = nullptr;
     a.inv_s = a.inv_t = nullptr;
@@ -450,6 +461,8 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, const DevLoop
             case kEstPt2Pl * 2 + 1: launch_reduce_t<kEstPt2Pl, 1>(c, a, X, loop, grid, partial, ticket, sys); break;
             case kEstSym * 2 + 0: launch_reduce_t<kEstSym, 0>(c, a, X, loop, grid, partial, ticket, sys); break;
             case kEstSym * 2 + 1: launch_reduce_t<kEstSym, 1>(c, a, X, loop, grid, partial, ticket, sys); break;
+            case kEstColored * 2 + 0: launch_reduce_t<kEstColored, 0>(c, a, X, loop, grid, partial, ticket, sys); break;
+            case kEstColored * 2 + 1: launch_reduce_t<kEstColored, 1>(c, a, X, loop, grid, partial, ticket, sys); break;
             case kEstGICP * 2 + 0: launch_reduce_t<kEstGICP, 0>(c, a, X, loop, grid, partial, ticket, sys); break;
             case kEstGICP * 2 + 1: launch_reduce_t<kEstGICP, 1>(c, a, X, loop, grid, partial, ticket, sys); break;
             default: return fail(c, MI_ICP_ERR_INVALID, "unknown estimation type %d", est);
@@ -534,12 +547,12 @@ void mi_icp_destroy(mi_icp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    DevBuf* all[] = {&c->tblk, &c->tnrm, &c->tcov, &c->nodes, &c->inv_t, &c->tbounds, &c->sx, &c->sy, &c->sz,
+    DevBuf* all[] = {&c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->tbounds, &c->sx, &c->sy, &c->sz,
                      &c->sperm, &c->snrm, &c->scov, &c->nn_idx, &c->nn_d2, &c->inv_s,
                      &c->user_pairs, &c->keys0, &c->keys1, &c->vals0, &c->vals1, &c->hist,
                      &c->scan_tmp, &c->bounds_part, &c->bounds, &c->partial, &c->sys_dev,
                      &c->dense_idx, &c->flags, &c->pairs_out, &c->seg_start, &c->loop_dev, &c->ticket, &c->alt[0],
-                     &c->alt[1], &c->alt[2], &c->alt[3], &c->alt[4], &c->alt[5], &c->alt[6], &c->alt[7], &c->stage[0],
+                     &c->alt[1], &c->alt[2], &c->alt[3], &c->alt[4], &c->alt[5], &c->alt[6], &c->alt[7], &c->alt[8], &c->stage[0],
                      &c->stage[1], &c->stage[2], &c->stage[3], &c->stage[4], &c->stage[5]};
     for (DevBuf* b : all) release(*b);
     if (c->sys_host) (void)hipHostFree(c->sys_host);
@@ -596,6 +609,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     c->n_user_pairs = -1;
     c->t_has_nrm = normals != nullptr && n > 0;
     c->t_has_cov = covs != nullptr && n > 0;
+    c->t_has_int = c->t_has_grad = false;
     if (n == 0) return MI_ICP_OK;
     hipEvent_t e0 = c->ev[2], e1 = c->ev[3];
     if (c->profiling) {
@@ -670,6 +684,7 @@ int mi_icp_set_source(mi_icp_ctx* c, const float* xyz, const float* normals, con
     c->n_user_pairs = -1;
     c->s_has_nrm = normals != nullptr && n > 0;
     c->s_has_cov = covs != nullptr && n > 0;
+    c->s_has_int = false;
     if (c->nranks == 1) c->ns_global = 0;
     if (n == 0) return MI_ICP_OK;
     hipEvent_t e0 = c->ev[2], e1 = c->ev[3];
@@ -827,7 +842,7 @@ int mi_icp_set_correspondences(mi_icp_ctx* c, const int32_t* pairs, int64_t coun
 int mi_icp_compute_system(mi_icp_ctx* c, int est, const float* T, double* out32) {
     TRY(check_ctx(c));
     if (!out32) return fail(c, MI_ICP_ERR_INVALID, "compute_system: out is null");
-    if (est != kEstP2P && est != kEstPt2Pl && est != kEstSym && est != kEstGICP)
+    if (!known_estimator(est))
         return fail(c, MI_ICP_ERR_INVALID, "unknown estimation type %d", est);
     if (!estimator_ready(c, est))
         return fail(c, MI_ICP_ERR_STATE, "estimation type %d needs normals/covariances that were not set", est);
@@ -840,7 +855,7 @@ int mi_icp_compute_transformation(mi_icp_ctx* c, int est, const float* T, float 
                                   float* update16) {
     TRY(check_ctx(c));
     if (!update16) return fail(c, MI_ICP_ERR_INVALID, "compute_transformation: out is null");
-    if (est != kEstP2P && est != kEstPt2Pl && est != kEstSym && est != kEstGICP)
+    if (!known_estimator(est))
         return fail(c, MI_ICP_ERR_INVALID, "unknown estimation type %d", est);
     const Mat4 M = load_T(T);
     double sys[kSysSize];
@@ -854,7 +869,7 @@ int mi_icp_compute_transformation(mi_icp_ctx* c, int est, const float* T, float 
 int mi_icp_compute_rmse(mi_icp_ctx* c, int est, const float* T, float* rmse) {
     TRY(check_ctx(c));
     if (!rmse) return fail(c, MI_ICP_ERR_INVALID, "compute_rmse: out is null");
-    if (est != kEstP2P && est != kEstPt2Pl && est != kEstSym && est != kEstGICP)
+    if (!known_estimator(est))
         return fail(c, MI_ICP_ERR_INVALID, "unknown estimation type %d", est);
     *rmse = 0.0f;
     if (!estimator_ready(c, est)) return MI_ICP_OK;  // the reference returns 0.0
@@ -862,7 +877,11 @@ int mi_icp_compute_rmse(mi_icp_ctx* c, int est, const float* T, float* rmse) {
     double sys[kSysSize];
     TRY(launch_reduce(c, est, 1, M));
     TRY(fetch_system(c, sys));
-    if (sys[29] > 0.0) *rmse = std::sqrt((float)sys[27] / (float)sys[29]);
+    if (est == kEstColored) {
+        *rmse = (float)sys[27];  // the reference returns the plain sum (colored_icp.cu:302-306)
+    } else if (sys[29] > 0.0) {
+        *rmse = std::sqrt((float)sys[27] / (float)sys[29]);
+    }
     return MI_ICP_OK;
 }
 
@@ -930,6 +949,7 @@ static int resort_source_by_match(mi_icp_ctx* c) {
     in.sperm = (int32_t*)c->sperm.p;
     in.snrm = c->s_has_nrm ? (float4*)c->snrm.p : nullptr;
     in.scov = c->s_has_cov ? (float*)c->scov.p : nullptr;
+    in.sint = c->s_has_int ? (float*)c->sint.p : nullptr;
     in.nn_idx = (int32_t*)c->nn_idx.p; in.nn_d2 = (float*)c->nn_d2.p;
     TRY(ensure(c, c->alt[0], (size_t)n, &out.sx));
     TRY(ensure(c, c->alt[1], (size_t)n, &out.sy));
@@ -939,8 +959,10 @@ static int resort_source_by_match(mi_icp_ctx* c) {
     TRY(ensure(c, c->alt[5], (size_t)n, &out.nn_d2));
     out.snrm = nullptr;
     out.scov = nullptr;
+    out.sint = nullptr;
     if (in.snrm) TRY(ensure(c, c->alt[6], (size_t)n, &out.snrm));
     if (in.scov) TRY(ensure(c, c->alt[7], (size_t)n * 9, &out.scov));
+    if (in.sint) TRY(ensure(c, c->alt[8], (size_t)n, &out.sint));
     permute_source<<<blocks_for(n), 256, 0, c->stream>>>(ord, (int)n, in, out);
     KCHK(c);
     std::swap(c->sx, c->alt[0]);
@@ -951,6 +973,7 @@ static int resort_source_by_match(mi_icp_ctx* c) {
     std::swap(c->nn_d2, c->alt[5]);
     if (in.snrm) std::swap(c->snrm, c->alt[6]);
     if (in.scov) std::swap(c->scov, c->alt[7]);
+    if (in.sint) std::swap(c->sint, c->alt[8]);
     c->inv_s_valid = false;
     return MI_ICP_OK;
 }
@@ -1000,7 +1023,7 @@ static int loop_run(mi_icp_ctx* c, int budget) {
 
 static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* init, float det_thresh,
                       int max_iterations, float rel_fitness, float rel_rmse) {
-    if (est != kEstP2P && est != kEstPt2Pl && est != kEstSym && est != kEstGICP)
+    if (!known_estimator(est))
         return fail(c, MI_ICP_ERR_INVALID, "unknown estimation type %d", est);
     DevLoop& L = *c->loop_host;
     std::memset(&L, 0, sizeof(L));
@@ -1243,9 +1266,9 @@ static int estimate_normals_impl(mi_icp_ctx* c, const float* xyz, int64_t n, int
     if (mem_kind == MI_ICP_HOST) TRY(ensure(c, c->stage[1], (size_t)n * 3, &dn));
     const uint32_t nblocks = (uint32_t)((c->nleaf + kKnnLeavesPerBlock - 1) / kKnnLeavesPerBlock);
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
-    knn_normals_kernel<<<grid, kKnnThreads, 0, c->stream>>>((const float*)c->nodes.p, (const float*)c->tblk.p,
-                                                            c->leaf_first, (int)n, c->nleaf, knn, r2, nblocks,
-                                                            c->nrecords + 8u, dn);
+    knn_normals_kernel<0><<<grid, kKnnThreads, 0, c->stream>>>((const float*)c->nodes.p, (const float*)c->tblk.p,
+                                                               c->leaf_first, (int)n, c->nleaf, knn, r2, nblocks,
+                                                               c->nrecords + 8u, dn, nullptr, nullptr);
     KCHK(c);
     if (mem_kind == MI_ICP_HOST) TRY(from_device(c, (const float*)dn, normals, (size_t)n * 3, mem_kind));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1262,6 +1285,81 @@ int mi_icp_estimate_normals_knn(mi_icp_ctx* c, const float* xyz, int64_t n, int 
 int mi_icp_estimate_normals_radius(mi_icp_ctx* c, const float* xyz, int64_t n, float radius, int max_nn,
                                    float* normals, int mem_kind) {
     return estimate_normals_impl(c, xyz, n, max_nn, radius * radius, normals, mem_kind);
+}
+
+// ---------------------------------------------------------------------------
+// Colored ICP (registration/colored_icp.cu)
+int mi_icp_set_target_colors(mi_icp_ctx* c, const float* rgb, int mem_kind) {
+    TRY(check_ctx(c));
+    c->t_has_int = c->t_has_grad = false;
+    if (!rgb || c->nt <= 0) return MI_ICP_OK;
+    if (!c->t_has_nrm)  // the intensities ride in the normals' 4th lane; colored ICP needs normals anyway
+        return fail(c, MI_ICP_ERR_STATE, "set_target_colors: the target has no normals");
+    const float* d_rgb;
+    TRY(to_device(c, rgb, (size_t)c->nt * 3, mem_kind, c->stage[1], &d_rgb));
+    target_intensity<<<blocks_for(c->nt), 256, 0, c->stream>>>((const float*)c->tblk.p, d_rgb, (int)c->nt,
+                                                              (float4*)c->tnrm.p);
+    KCHK(c);
+    c->t_has_int = true;
+    return MI_ICP_OK;
+}
+
+int mi_icp_set_source_colors(mi_icp_ctx* c, const float* rgb, int mem_kind) {
+    TRY(check_ctx(c));
+    c->s_has_int = false;
+    if (!rgb || c->ns <= 0) return MI_ICP_OK;
+    const float* d_rgb;
+    float* sint;
+    TRY(to_device(c, rgb, (size_t)c->ns * 3, mem_kind, c->stage[4], &d_rgb));
+    TRY(ensure(c, c->sint, (size_t)c->ns, &sint));
+    source_intensity<<<blocks_for(c->ns), 256, 0, c->stream>>>((const int32_t*)c->sperm.p, d_rgb, (int)c->ns, sint);
+    KCHK(c);
+    c->s_has_int = true;
+    return MI_ICP_OK;
+}
+
+int mi_icp_set_lambda_geometric(mi_icp_ctx* c, float lambda_geometric) {
+    if (!c) return MI_ICP_ERR_INVALID;
+    // colored_icp.cu:49-50: out-of-range values fall back to the default
+    c->lambda_geometric = (lambda_geometric < 0.0f || lambda_geometric > 1.0f) ? 0.968f : lambda_geometric;
+    return MI_ICP_OK;
+}
+
+int mi_icp_compute_color_gradients(mi_icp_ctx* c, float radius, int max_nn, float* gradients_out, int mem_kind) {
+    TRY(check_ctx(c));
+    c->t_has_grad = false;
+    if (c->nt <= 0) return MI_ICP_OK;
+    if (!c->t_has_nrm || !c->t_has_int)
+        return fail(c, MI_ICP_ERR_STATE, "compute_color_gradients: the target needs normals and colours");
+    if (max_nn > kMaxKnn)
+        return fail(c, MI_ICP_ERR_INVALID, "compute_color_gradients: more than %d neighbours are not supported", kMaxKnn);
+    const int64_t n = c->nt;
+    float4* tgrad;
+    TRY(ensure(c, c->tgrad, (size_t)n, &tgrad));
+    float* dg = gradients_out;
+    if (gradients_out && mem_kind == MI_ICP_HOST) TRY(ensure(c, c->stage[1], (size_t)n * 3, &dg));
+    const uint32_t nblocks = (uint32_t)((c->nleaf + kKnnLeavesPerBlock - 1) / kKnnLeavesPerBlock);
+    const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
+    knn_normals_kernel<1><<<grid, kKnnThreads, 0, c->stream>>>(
+            (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, (int)n, c->nleaf, max_nn,
+            radius * radius, nblocks, c->nrecords + 8u, dg, (const float4*)c->tnrm.p, tgrad);
+    KCHK(c);
+    c->t_has_grad = true;
+    if (gradients_out) {
+        if (mem_kind == MI_ICP_HOST) TRY(from_device(c, (const float*)dg, gradients_out, (size_t)n * 3, mem_kind));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return MI_ICP_OK;
+}
+
+int mi_icp_registration_colored_icp(mi_icp_ctx* c, float max_distance, const float* init,
+                                    const mi_icp_params* params, float lambda_geometric, mi_icp_result* out) {
+    TRY(check_ctx(c));
+    TRY(mi_icp_set_lambda_geometric(c, lambda_geometric));
+    // colored_icp.cu:337-338: gradients over KDTreeSearchParamRadius(max_distance * 2, 30)
+    if (c->nt > 0 && c->t_has_nrm && c->t_has_int)
+        TRY(mi_icp_compute_color_gradients(c, max_distance * 2.0f, 30, nullptr, MI_ICP_DEVICE));
+    return mi_icp_registration_icp(c, kEstColored, max_distance, init, params, out);
 }
 
 // ---------------------------------------------------------------------------

@@ -11,6 +11,7 @@
 //   point-to-plane  registration/transformation_estimation.cu:34-56
 //   symmetric       registration/transformation_estimation.cu:58-90
 //   GICP            registration/generalized_icp.cu:63-105 (+ eigenvalue.inl)
+//   colored ICP     registration/colored_icp.cu:150-216 (two rows per correspondence)
 //   point-to-point  registration/kabsch.cu:42-104 (three thrust reductions)
 // The source point is transformed on load (no materialised
 // PointCloud::Transform), normals by R, covariances by R*C*R^T.
@@ -21,7 +22,7 @@
 
 namespace mi {
 
-constexpr int kEstP2P = 1, kEstPt2Pl = 2, kEstSym = 3, kEstGICP = 5;
+constexpr int kEstP2P = 1, kEstPt2Pl = 2, kEstSym = 3, kEstColored = 4, kEstGICP = 5;
 constexpr int kSysSize = 32;
 constexpr int kReduceThreads = 256;
 constexpr int kReduceBlocks = 1024;  // 4 per CU (measured: 512 blocks is 25% slower); finished by one 1024-thread block
@@ -63,7 +64,10 @@ struct ReduceArgs {
     const float4* snrm;   // sorted source normals (symmetric)
     const float* scov;    // sorted source covariances (GICP)
     const float* tblk;    // target leaf lines
-    const float4* tnrm;   // sorted target normals
+    const float4* tnrm;   // sorted target normals; .w = target intensity when colours are set
+    const float4* tgrad;  // sorted target colour gradients (colored ICP)
+    const float* sint;    // sorted source intensities (colored ICP)
+    float sqrt_lambda_geometric, sqrt_lambda_photometric;
     const float* tcov;    // sorted target covariances
     const int32_t* nn_idx;  // per sorted source position: sorted target position or -1
     const int32_t* pairs;   // explicit pairs (original indices) or nullptr
@@ -149,6 +153,49 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_kernel(ReduceArgs a, Xf
             } else {
                 const float e2 = r * r;  // transformation_estimation.cu:92-104 squares twice
                 acc[27] += (double)(e2 * e2);
+            }
+        } else if (EST == kEstColored) {
+            const float4 n4 = a.tnrm[j];
+            const float4 g4 = a.tgrad[j];
+            const float nt[3] = {n4.x, n4.y, n4.z};
+            const float dit[3] = {g4.x, g4.y, g4.z};
+            const float it = n4.w, is = a.sint[i];
+            const float slg = a.sqrt_lambda_geometric, slp = a.sqrt_lambda_photometric;
+            const float dn = dot3(d, nt);
+            const float r0 = slg * dn;
+            // vs projected into vt's tangent plane, intensity predicted there
+            const float e[3] = {(vs[0] - dn * nt[0]) - vt[0], (vs[1] - dn * nt[1]) - vt[1],
+                                (vs[2] - dn * nt[2]) - vt[2]};
+            const float r1 = slp * (is - (dot3(dit, e) + it));
+            if (MODE == 0) {
+                float J[6], cr[3];
+                cross3(vs, nt, cr);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    J[p] = slg * cr[p];
+                    J[3 + p] = slg * nt[p];
+                }
+                accum_row(acc, J, r0);
+                float ditM[3];  // -dit^T (I - nt nt^T)
+#pragma unroll
+                for (int col = 0; col < 3; ++col) {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int row = 0; row < 3; ++row) {
+                        const float m = (row == col) ? (1.0f - nt[row] * nt[col]) : (-(nt[row] * nt[col]));
+                        s += dit[row] * m;
+                    }
+                    ditM[col] = -s;
+                }
+                cross3(vs, ditM, cr);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    J[p] = slp * cr[p];
+                    J[3 + p] = slp * ditM[p];
+                }
+                accum_row(acc, J, r1);
+            } else {
+                acc[27] += (double)(r0 * r0 + r1 * r1);
             }
         } else if (EST == kEstGICP) {
             M3 Cs, M, Mi, W;

@@ -139,6 +139,47 @@ class Engine:
         self.synchronize()
         self.n_source = p.n
 
+    # -- colored ICP --------------------------------------------------------------------
+    def set_target_colors(self, colors):
+        b = _Buf(colors, np.float32, 3, self.device)
+        if b.n and b.n != self.n_target:
+            raise MiIcpError("set_target_colors: %d colours for %d target points" % (b.n, self.n_target))
+        self._chk(self._L.mi_icp_set_target_colors(self._ctx, b.ptr, b.kind))
+        self.synchronize()
+
+    def set_source_colors(self, colors):
+        b = _Buf(colors, np.float32, 3, self.device)
+        if b.n and b.n != self.n_source:
+            raise MiIcpError("set_source_colors: %d colours for %d source points" % (b.n, self.n_source))
+        self._chk(self._L.mi_icp_set_source_colors(self._ctx, b.ptr, b.kind))
+        self.synchronize()
+
+    def set_lambda_geometric(self, lambda_geometric):
+        self._chk(self._L.mi_icp_set_lambda_geometric(self._ctx, float(lambda_geometric)))
+
+    def compute_color_gradients(self, radius, max_nn=30, want_output=True):
+        """InitializePointCloudForColoredICP; returns the gradients (target's original
+        order, numpy) when want_output."""
+        out, optr = None, None
+        if want_output:
+            out = np.empty((self.n_target, 3), np.float32)
+            optr = out.ctypes.data_as(C.c_void_p)
+        self._chk(self._L.mi_icp_compute_color_gradients(self._ctx, float(radius), int(max_nn), optr,
+                                                         MI_ICP_HOST))
+        return out
+
+    def registration_colored_icp(self, max_distance, init=None, relative_fitness=1e-6,
+                                 relative_rmse=1e-6, max_iteration=30, lambda_geometric=0.968,
+                                 det_thresh=1e-6):
+        res = Result()
+        prm = Params(float(relative_fitness), float(relative_rmse), int(max_iteration),
+                     float(det_thresh))
+        _, tp = _T_in(init)
+        self._chk(self._L.mi_icp_registration_colored_icp(self._ctx, float(max_distance), tp,
+                                                          C.byref(prm), float(lambda_geometric),
+                                                          C.byref(res)))
+        return res
+
     def set_global_source_count(self, n_total):
         self._chk(self._L.mi_icp_set_global_source_count(self._ctx, int(n_total)))
 

@@ -200,6 +200,30 @@ def _generic_icp(source, target, max_dist, init, est, crit):
     return result
 
 
+def registration_colored_icp(source, target, max_correspondence_distance, init=None,
+                             criteria=None, lambda_geometric=0.968, det_thresh=1.0e-6):
+    """registration::RegistrationColoredICP (colored_icp.cu:329-341; pybind signature
+    registration.cpp:433-439).  The estimator class itself is private to the reference's
+    translation unit, so only this function is mirrored."""
+    init = np.eye(4, dtype=np.float32) if init is None else np.asarray(init, np.float32)
+    crit = ICPConvergenceCriteria() if criteria is None else criteria
+    if max_correspondence_distance <= 0.0:
+        print("[cupoch_amd] Error: Invalid max_correspondence_distance.")
+    if not target.has_normals():
+        print("[cupoch_amd] Error: TransformationEstimationPointToPlane and "
+              "TransformationEstimationColoredICP require pre-computed target normal vectors.")
+    eng = get_engine()
+    _load_clouds(eng, source, target)
+    if target.has_normals() and target.has_colors():
+        eng.set_target_colors(target.colors.tensor)
+    if source.has_colors():
+        eng.set_source_colors(source.colors.tensor)
+    res = eng.registration_colored_icp(max_correspondence_distance, init, crit.relative_fitness,
+                                       crit.relative_rmse, crit.max_iteration, lambda_geometric,
+                                       det_thresh)
+    return _result_from(eng, res)
+
+
 def _initialize_for_gicp(pcd, epsilon):
     """InitializePointCloudForGeneralizedICP (generalized_icp.cu:37-61)"""
     out = pcd.clone()

@@ -58,6 +58,7 @@ enum {
     MI_ICP_EST_POINT_TO_POINT = 1,
     MI_ICP_EST_POINT_TO_PLANE = 2,
     MI_ICP_EST_SYMMETRIC = 3,
+    MI_ICP_EST_COLORED = 4, /* TransformationEstimationType::ColoredICP */
     MI_ICP_EST_GENERALIZED = 5
 };
 
@@ -214,6 +215,35 @@ MI_ICP_API int mi_icp_estimate_normals_knn(mi_icp_ctx* ctx, const float* xyz, in
 MI_ICP_API int mi_icp_estimate_normals_radius(mi_icp_ctx* ctx, const float* xyz, int64_t n,
                                               float radius, int max_nn, float* normals,
                                               int mem_kind);
+
+/* ---- Colored ICP (registration/colored_icp.cu) -----------------------------
+ * Colours are float[n][3] RGB in the order of the cloud last given to
+ * mi_icp_set_target / mi_icp_set_source (call these afterwards; a new
+ * set_target / set_source drops them).  Only the intensity (r+g+b)/3 is kept,
+ * as the reference's functors only use that (colored_icp.cu:91,195-200).  The
+ * target needs normals (colored_icp.cu:222-224). */
+MI_ICP_API int mi_icp_set_target_colors(mi_icp_ctx* ctx, const float* rgb, int mem_kind);
+MI_ICP_API int mi_icp_set_source_colors(mi_icp_ctx* ctx, const float* rgb, int mem_kind);
+/* TransformationEstimationForColoredICP::lambda_geometric_ (default 0.968;
+ * values outside [0,1] fall back to it, colored_icp.cu:47-51).  Used by every
+ * MI_ICP_EST_COLORED evaluation. */
+MI_ICP_API int mi_icp_set_lambda_geometric(mi_icp_ctx* ctx, float lambda_geometric);
+/* InitializePointCloudForColoredICP (colored_icp.cu:108-148): per target point
+ * the intensity gradient in the tangent plane over the max_nn (<= 32) nearest
+ * points within `radius` (the nearest -- the point itself -- excluded; fewer
+ * than 4 others -> 0).  Kept on the device for MI_ICP_EST_COLORED;
+ * gradients_out (float[nt][3], target's original order) may be NULL. */
+MI_ICP_API int mi_icp_compute_color_gradients(mi_icp_ctx* ctx, float radius, int max_nn,
+                                              float* gradients_out, int mem_kind);
+/* registration::RegistrationColoredICP (colored_icp.cu:329-341) =
+ * compute_color_gradients(2 * max_distance, 30) + registration_icp(COLORED).
+ * params->det_thresh is the estimator's det_thresh (default 1e-6).
+ * NOTE the reference's ComputeRMSE for this estimator returns the plain sum of
+ * squared residuals (colored_icp.cu:302-306); mi_icp_compute_rmse(COLORED)
+ * does the same. */
+MI_ICP_API int mi_icp_registration_colored_icp(mi_icp_ctx* ctx, float max_distance,
+                                               const float* init, const mi_icp_params* params,
+                                               float lambda_geometric, mi_icp_result* out);
 
 /* ---- multi-GPU (new: the reference is single-GPU) -------------------------
  * One context per rank/GPU, each holding the full target and its own shard of

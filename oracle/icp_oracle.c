@@ -897,7 +897,60 @@ ORACLE_API void oracle_gicp_weight(const float *Cs, const float *Ct, float *W_ro
 /*   [27] sum |ps-pt|^2, [28] sum d2, [29] count.                      */
 /* ------------------------------------------------------------------ */
 
-enum { EST_P2P = 1, EST_PT2PL = 2, EST_SYM = 3, EST_GICP = 5 };
+enum { EST_P2P = 1, EST_PT2PL = 2, EST_SYM = 3, EST_COLORED = 4, EST_GICP = 5 };
+
+/* Inputs of TransformationEstimationForColoredICP (colored_icp.cu:150-216): per-point
+ * intensities (mean of r,g,b), the target's colour gradient, lambda_geometric.
+ * Kept in a context struct so that the other estimators' signatures stay as they are. */
+typedef struct {
+    const float *src_int;   /* is  per source point */
+    const float *tgt_int;   /* it  per target point */
+    const float *tgt_grad;  /* dit per target point (3 floats) */
+    float lambda_geometric;
+} colored_ctx;
+static colored_ctx g_colored = {0, 0, 0, 0.968f};
+
+ORACLE_API void oracle_set_colored_context(const float *src_int, const float *tgt_int,
+                                           const float *tgt_grad, float lambda_geometric) {
+    g_colored.src_int = src_int;
+    g_colored.tgt_int = tgt_int;
+    g_colored.tgt_grad = tgt_grad;
+    g_colored.lambda_geometric = (lambda_geometric < 0 || lambda_geometric > 1.0f) ? 0.968f : lambda_geometric;
+}
+
+/* the two rows of colored_icp.cu:183-215 */
+static void colored_rows(const float *vs, const float *vt, const float *nt, float is, float it,
+                         const float *dit, float slg, float slp, float J0[6], float *r0, float J1[6],
+                         float *r1) {
+    const float d[3] = {vs[0] - vt[0], vs[1] - vt[1], vs[2] - vt[2]};
+    const float dn = dot3(d, nt);
+    float c[3];
+    cross3(vs, nt, c);
+    for (int a = 0; a < 3; ++a) {
+        J0[a] = slg * c[a];
+        J0[3 + a] = slg * nt[a];
+    }
+    *r0 = slg * dn;
+    const float vs_proj[3] = {vs[0] - dn * nt[0], vs[1] - dn * nt[1], vs[2] - dn * nt[2]};
+    const float e[3] = {vs_proj[0] - vt[0], vs_proj[1] - vt[1], vs_proj[2] - vt[2]};
+    const float is0_proj = dot3(dit, e) + it;
+    /* M = I - nt nt^T ; ditM = -dit^T M */
+    float ditM[3];
+    for (int col = 0; col < 3; ++col) {
+        float s = 0.0f;
+        for (int row = 0; row < 3; ++row) {
+            const float m = ((row == col) ? 1.0f : 0.0f) - nt[row] * nt[col];
+            s += dit[row] * m;
+        }
+        ditM[col] = -s;
+    }
+    cross3(vs, ditM, c);
+    for (int a = 0; a < 3; ++a) {
+        J1[a] = slp * c[a];
+        J1[3 + a] = slp * ditM[a];
+    }
+    *r1 = slp * (is - is0_proj);
+}
 
 static inline void accum_row(double *sys, const float *J, float r) {
     int k = 0;
@@ -950,6 +1003,14 @@ ORACLE_API void oracle_compute_system(int est, const float *src, const float *sr
             J[4] = n[1];
             J[5] = n[2];
             accum_row(sys, J, r);
+        } else if (est == EST_COLORED) {
+            const float slg = sqrtf(g_colored.lambda_geometric);
+            const float slp = sqrtf(1.0f - g_colored.lambda_geometric);
+            float J0[6], J1[6], r0, r1;
+            colored_rows(vs, vt, tgt_nrm + 3 * (int64_t)j, g_colored.src_int[i], g_colored.tgt_int[j],
+                         g_colored.tgt_grad + 3 * (int64_t)j, slg, slp, J0, &r0, J1, &r1);
+            accum_row(sys, J0, r0);
+            accum_row(sys, J1, r1);
         } else if (est == EST_GICP) {
             float W[3][3];
             gicp_weight(src_cov + 9 * (int64_t)i, tgt_cov + 9 * (int64_t)j, W);
@@ -1011,7 +1072,14 @@ ORACLE_API float oracle_compute_rmse(int est, const float *src, const float *src
         const float *vs = src + 3 * (int64_t)i;
         const float *vt = tgt + 3 * (int64_t)j;
         float d[3] = {vs[0] - vt[0], vs[1] - vt[1], vs[2] - vt[2]};
-        if (est == EST_PT2PL) {
+        if (est == EST_COLORED) {
+            const float slg = sqrtf(g_colored.lambda_geometric);
+            const float slp = sqrtf(1.0f - g_colored.lambda_geometric);
+            float J0[6], J1[6], r0, r1;
+            colored_rows(vs, vt, tgt_nrm + 3 * (int64_t)j, g_colored.src_int[i], g_colored.tgt_int[j],
+                         g_colored.tgt_grad + 3 * (int64_t)j, slg, slp, J0, &r0, J1, &r1);
+            err += (double)(r0 * r0 + r1 * r1);
+        } else if (est == EST_PT2PL) {
             const float r = dot3(d, tgt_nrm + 3 * (int64_t)j);
             err += (double)(r * r);
         } else if (est == EST_SYM) {
@@ -1031,6 +1099,7 @@ ORACLE_API float oracle_compute_rmse(int est, const float *src, const float *src
             err += (double)dot3(d, d);
         }
     }
+    if (est == EST_COLORED) return (float)err; /* the reference returns the plain sum (colored_icp.cu:302-306) */
     return sqrtf((float)err / (float)c);
 }
 
@@ -1187,6 +1256,12 @@ ORACLE_API int oracle_registration_icp(
                             TM(update, r, 3) = TM(half, r, 3);
                         }
                     }
+                }
+            } else if (est == EST_COLORED) {
+                /* colored_icp.cu:222-224: needs target normals + colours on both clouds */
+                if (tgt_nrm && g_colored.src_int && g_colored.tgt_int && g_colored.tgt_grad) {
+                    oracle_compute_system(est, pts, nrm, cov, tgt, tgt_nrm, tgt_cov, corres_out, c, sys);
+                    oracle_solve_system(sys, det_thresh, update);
                 }
             } else if (est == EST_GICP) {
                 if (tgt_cov && cov) { /* generalized_icp.cu:156-159 */
@@ -1373,6 +1448,59 @@ static int estimate_normals_impl(const float *pts, int64_t n, int k, float r2, f
                 cum[8] += p[2] * p[2];
             }
             normal_from_cumulants(cum, r.count, out + 3 * i);
+        }
+        free(idx);
+        free(d2);
+    }
+    kd_free(t);
+    return 0;
+}
+
+/* InitializePointCloudForColoredICP (colored_icp.cu:74-148): per target point the
+ * least-squares gradient of the intensity over the tangent plane, from the max_nn
+ * nearest neighbours within radius (the first -- the point itself -- is skipped),
+ * fewer than 4 neighbours -> 0.  intensity[i] = (r+g+b)/3. */
+ORACLE_API int oracle_color_gradients(const float *pts, const float *nrm, const float *intensity,
+                                      int64_t n, float radius, int max_nn, float *grad_out) {
+    kd_tree *t = kd_build(pts, (int)n);
+    const float r2 = radius * radius;
+#pragma omp parallel
+    {
+        int *idx = (int *)malloc(sizeof(int) * (size_t)(max_nn > 0 ? max_nn : 1));
+        float *d2 = (float *)malloc(sizeof(float) * (size_t)(max_nn > 0 ? max_nn : 1));
+#pragma omp for schedule(dynamic, 256)
+        for (int64_t i = 0; i < n; ++i) {
+            float *g = grad_out + 3 * i;
+            g[0] = g[1] = g[2] = 0.0f;
+            if (max_nn <= 0) continue;
+            kd_result r = {max_nn, 0, r2, d2, idx};
+            kd_search_rec(t, 0, pts + 3 * i, &r);
+            const float *vt = pts + 3 * i, *nt = nrm + 3 * i;
+            const float it = intensity[i];
+            float AtA[3][3] = {{0}}, Atb[3] = {0, 0, 0};
+            int nn = 0;
+            for (int s = 1; s < r.count; ++s) {
+                const float *va = pts + 3 * (int64_t)idx[s];
+                const float da[3] = {va[0] - vt[0], va[1] - vt[1], va[2] - vt[2]};
+                const float h = dot3(da, nt);
+                const float v[3] = {va[0] - h * nt[0] - vt[0], va[1] - h * nt[1] - vt[1],
+                                    va[2] - h * nt[2] - vt[2]};
+                const float di = intensity[idx[s]] - it;
+                for (int a = 0; a < 3; ++a) {
+                    for (int b = 0; b < 3; ++b) AtA[a][b] += v[a] * v[b];
+                    Atb[a] += di * v[a];
+                }
+                ++nn;
+            }
+            if (nn < 4) continue;
+            const float w = (float)((nn - 1) * (nn - 1));
+            for (int a = 0; a < 3; ++a) {
+                for (int b = 0; b < 3; ++b) AtA[a][b] += w * nt[a] * nt[b];
+                AtA[a][a] += 1.0e-6f;
+            }
+            float inv[3][3];
+            inverse3(AtA, inv);
+            for (int a = 0; a < 3; ++a) g[a] = inv[a][0] * Atb[0] + inv[a][1] * Atb[1] + inv[a][2] * Atb[2];
         }
         free(idx);
         free(d2);

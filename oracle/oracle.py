@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liboracle.so")
 
 EST_P2P, EST_PT2PL, EST_SYM, EST_GICP = 1, 2, 3, 5
+EST_COLORED = 4
 
 
 def build(force=False):
@@ -256,6 +257,44 @@ def estimate_normals_knn(pts, k=30):
     out = np.empty_like(pts)
     lib().oracle_estimate_normals_knn(_p(pts), C.c_int64(len(pts)), C.c_int(k), _p(out))
     return out
+
+
+_colored_keep = []
+
+
+def intensity(colors):
+    """(c0 + c1 + c2) / 3.0 as colored_icp.cu:91 evaluates it: fp32 sum, division in double."""
+    c = np.asarray(colors, np.float32).reshape(-1, 3)
+    s = (c[:, 0] + c[:, 1]) + c[:, 2]
+    return _f32((s.astype(np.float64) / 3.0).astype(np.float32))
+
+
+def set_colored_context(src_colors, tgt_colors, tgt_grad, lambda_geometric=0.968):
+    """Inputs of the ColoredICP estimator for the following compute_system /
+    compute_rmse / registration_icp(est=EST_COLORED) calls."""
+    si, ti = intensity(src_colors), intensity(tgt_colors)
+    tg = _f32(tgt_grad, (-1, 3))
+    _colored_keep[:] = [si, ti, tg]
+    lib().oracle_set_colored_context(_p(si), _p(ti), _p(tg), C.c_float(lambda_geometric))
+
+
+def color_gradients(pts, nrm, colors, radius, max_nn=30):
+    """InitializePointCloudForColoredICP (colored_icp.cu:108-148)"""
+    pts, nrm = _f32(pts, (-1, 3)), _f32(nrm, (-1, 3))
+    inten = intensity(colors)
+    out = np.empty_like(pts)
+    lib().oracle_color_gradients(_p(pts), _p(nrm), _p(inten), C.c_int64(len(pts)), C.c_float(radius),
+                                 C.c_int(max_nn), _p(out))
+    return out
+
+
+def registration_colored_icp(src, tgt, max_dist, src_colors, tgt_colors, tgt_nrm, init=None,
+                             lambda_geometric=0.968, det_thresh=1e-6, **kw):
+    """registration::RegistrationColoredICP (colored_icp.cu:329-341)"""
+    grad = color_gradients(tgt, tgt_nrm, tgt_colors, max_dist * 2.0, 30)
+    set_colored_context(src_colors, tgt_colors, grad, lambda_geometric)
+    return registration_icp(src, tgt, max_dist, init=init, est=EST_COLORED, det_thresh=det_thresh,
+                            tgt_nrm=tgt_nrm, **kw)
 
 
 def estimate_normals_radius(pts, radius, max_nn=30):

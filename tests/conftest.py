@@ -65,3 +65,22 @@ def make_pair(n, seed=42, rot_scale=0.2, noise=0.0, permute=True):
     return dict(src=np.ascontiguousarray(src), tgt=tgt, tgt_nrm=nrm,
                 src_nrm=np.ascontiguousarray(src_nrm), T_gt=T.astype(np.float32),
                 spacing=s, max_dist=2.0 * s)
+
+
+def make_colored(n=20000, seed=0, scale=100.0, planar=False):
+    """Textured surface for colored-ICP cases: z = f(x, y) over a scale x scale patch
+    (or the plane z = 0), smooth intensity texture, and a small ground-truth motion.
+    `scale` ~ 100 keeps the reference's fp32 AtA.inverse() of the colour-gradient fit
+    well conditioned ((nn-1)^2 nt nt^T vs sum v v^T)."""
+    rng = np.random.default_rng(seed)
+    xy = rng.random((n, 2))
+    z = np.zeros(n) if planar else 0.1 * np.sin(4 * xy[:, 0]) * np.cos(3 * xy[:, 1])
+    tgt = (np.stack([xy[:, 0], xy[:, 1], z], 1) * scale).astype(np.float32)
+    q = tgt / scale
+    i = 0.5 + 0.4 * np.sin(9 * q[:, 0]) * np.cos(7 * q[:, 1])
+    col = np.stack([i, i * 0.9, np.minimum(i * 1.1, 1.0)], 1).astype(np.float32)
+    a = 0.01
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
+    T[:3, 3] = np.array([0.004, -0.003, 0.0 if planar else 0.001]) * scale
+    return tgt, col, T

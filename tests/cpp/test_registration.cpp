@@ -112,6 +112,30 @@ int main() {
                                                  registration::TransformationEstimationPointToPlane(), crit);
         std::printf("\"no_normals_is_identity\": %s, ", res.transformation_.isIdentity() ? "true" : "false");
     }
+    {   // RegistrationColoredICP on a textured plane: the in-plane motion is only visible in the colours
+        const int m = 20000;
+        std::vector<Vector3f> cp(m), cn(m, Vector3f(0, 0, 1)), cc(m);
+        for (int i = 0; i < m; ++i) {
+            const float x = U(rng), y = U(rng);
+            cp[i] = Vector3f(100 * x, 100 * y, 0);
+            const float in = 0.5f + 0.4f * std::sin(9 * x) * std::cos(7 * y);
+            cc[i] = Vector3f(in, 0.9f * in, 0.8f * in);
+        }
+        geometry::PointCloud ct(cp);
+        ct.SetNormals(cn);
+        ct.SetColors(cc);
+        const Matrix4f Tc = Rigid(0.01f, 0, 0, 1, 0.4f, -0.3f, 0.0f);
+        geometry::PointCloud cs = ct;
+        cs.Transform(utility::InverseTransform(Tc));
+        auto res = registration::RegistrationColoredICP(cs, ct, 3.0f);   // defaults: identity, 30 its, 0.968, 1e-6
+        auto pl = registration::RegistrationICP(cs, ct, 3.0f, Matrix4f::Identity(),
+                                                registration::TransformationEstimationPointToPlane(-1.0f), crit);
+        std::printf("\"colored_err\": %.3g, \"colored_vs_plane_err\": %.3g, \"colored_motion\": %.3g, ",
+                    Fro(res.transformation_, Tc), Fro(pl.transformation_, Tc), Fro(Matrix4f::Identity(), Tc));
+        geometry::PointCloud grey(cp);   // no colours on the source: identity updates (colored_icp.cu:222-224)
+        auto none = registration::RegistrationColoredICP(grey, ct, 3.0f);
+        std::printf("\"colored_no_colors_is_identity\": %s, ", none.transformation_.isIdentity() ? "true" : "false");
+    }
     {   // Kabsch golden shape (src/tests/registration/kabsch.cpp:35-55)
         std::vector<Vector3f> pts(20);
         for (auto& p : pts) p = Vector3f(1000 * U(rng), 1000 * U(rng), 1000 * U(rng));

@@ -32,5 +32,9 @@ def test_cpp_surface_end_to_end(tmp_path):
     assert r["p2p_fitness"] > 0.999 and r["eval_fitness"] > 0.999 and r["p2p_ncorr"] > 49000
     assert r["p2p_corr_ascending"] and r["kabsch_ok"] and r["no_normals_is_identity"]
     assert r["custom_calls"] >= 1
+    # colored ICP recovers the in-plane motion of a textured plane; point-to-plane cannot
+    assert r["colored_err"] < 0.05 * r["colored_motion"], r
+    assert r["colored_vs_plane_err"] > 10 * r["colored_err"], r
+    assert r["colored_no_colors_is_identity"]
     assert 1000 < r["voxels"] <= 9261 and r["voxel_normals_unit"] and r["voxel_zero_empty"] and r["has_normals"]
     assert "require pre-computed target normal vectors" in out.stderr      # LogError path

@@ -115,3 +115,52 @@ def test_icp_edge_cases():
     # default det_thresh 1e-6 with a large cloud overflows fp32 det: documented quirk 6
     ev = orc.evaluate_registration(d["src"], d["tgt"], d["max_dist"], d["T_gt"])
     assert ev.fitness == 1.0 and ev.inlier_rmse < 1e-5
+
+
+# ---- colored ICP (no reference golden vectors exist for it: parity unpinned, see oracle/README.md)
+def _colored_case(planar):
+    from conftest import make_colored
+    tgt, col, T = make_colored(12000, seed=3, planar=planar)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (len(tgt), 1)) if planar else None
+    if nrm is None:
+        nrm = orc.estimate_normals_knn(tgt, 20)
+        nrm[nrm[:, 2] < 0] *= -1
+    src = orc.transform_points(np.linalg.inv(T).astype(np.float32), tgt)
+    return src, tgt, col, nrm, T
+
+
+def test_colour_gradient_matches_the_analytic_texture_gradient():
+    src, tgt, col, nrm, T = _colored_case(planar=True)
+    g = orc.color_gradients(tgt, nrm, col, 6.0, 30)
+    q = tgt / 100.0
+    mean_w = (1.0 + 0.9 + 1.1) / 3.0
+    gx = 0.4 * 9 * np.cos(9 * q[:, 0]) * np.cos(7 * q[:, 1]) / 100.0 * mean_w
+    gy = -0.4 * 7 * np.sin(9 * q[:, 0]) * np.sin(7 * q[:, 1]) / 100.0 * mean_w
+    inner = (q[:, 0] > 0.1) & (q[:, 0] < 0.9) & (q[:, 1] > 0.1) & (q[:, 1] < 0.9)
+    clipped = col[:, 2] >= 1.0   # the blue channel saturates there
+    ok = inner & ~clipped
+    err = np.hypot(g[ok, 0] - gx[ok], g[ok, 1] - gy[ok])
+    assert np.median(err) < 2e-3 and np.abs(g[ok, 2]).max() < 1e-4, (np.median(err), np.abs(g[ok, 2]).max())
+
+
+def test_colored_icp_recovers_in_plane_motion_that_point_to_plane_cannot_see():
+    src, tgt, col, nrm, T = _colored_case(planar=True)
+    res_c = orc.registration_colored_icp(src, tgt, 3.0, col, col, nrm, det_thresh=-1.0)
+    res_p = orc.registration_icp(src, tgt, 3.0, est=orc.EST_PT2PL, tgt_nrm=nrm, det_thresh=-1.0)
+    err_c = np.linalg.norm(res_c.transformation - T)
+    err_p = np.linalg.norm(res_p.transformation - T)
+    assert err_c < 0.05 * np.linalg.norm(T - np.eye(4)), (err_c, err_p)
+    assert err_p > 10 * err_c, (err_c, err_p)
+
+
+def test_colored_rmse_is_the_plain_sum_of_squared_residuals():
+    src, tgt, col, nrm, T = _colored_case(planar=False)
+    g = orc.color_gradients(tgt, nrm, col, 6.0, 30)
+    orc.set_colored_context(col, col, g, 0.968)
+    _, idx, _ = orc.search_radius(tgt, src, 3.0, 1)
+    idx = idx[:, 0]
+    cor = np.stack([np.arange(len(src)), idx], 1)[idx >= 0].astype(np.int32)
+    whole = orc.compute_rmse(orc.EST_COLORED, src, tgt, cor, tgt_nrm=nrm)
+    half = orc.compute_rmse(orc.EST_COLORED, src, tgt, cor[: len(cor) // 2], tgt_nrm=nrm) + \
+        orc.compute_rmse(orc.EST_COLORED, src, tgt, cor[len(cor) // 2:], tgt_nrm=nrm)
+    assert whole > 0 and abs(whole - half) <= 1e-4 * whole   # additive: a sum, not a root-mean
