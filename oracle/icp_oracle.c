@@ -19,7 +19,8 @@
  *   - Kabsch, Transform, VoxelDownSample, EstimateNormals
  *                                : pinned by src/tests/registration/kabsch.cpp
  *                                  and src/tests/geometry/pointcloud.cpp.
- *   - RegistrationICP loop, JtJ/Jtr accumulation, 6x6 LDLT solve, GICP
+ *   - RegistrationICP loop, JtJ/Jtr accumulation, 6x6 LDLT solve, GICP,
+ *     Colored ICP (colour gradients, two-row estimator)
  *                                : PARITY UNPINNED by the reference's own
  *                                  tests (none exist); checked by
  *                                  self-consistency (recover a known T_gt).
