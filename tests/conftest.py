@@ -84,3 +84,23 @@ def make_colored(n=20000, seed=0, scale=100.0, planar=False):
     T[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
     T[:3, 3] = np.array([0.004, -0.003, 0.0 if planar else 0.001]) * scale
     return tgt, col, T
+
+
+def colored_fragment_pair():
+    """Two interleaved samplings of the reference's coloured RGB-D fragment
+    (tests/golden/frag115_every2nd.npz): target = even vertices, source = odd vertices
+    moved by the inverse of a known T."""
+    d = np.load(os.path.join(ROOT, "tests", "golden", "frag115_every2nd.npz"))
+    pts = np.ascontiguousarray(d["points"])
+    col = (d["colors"].astype(np.float32) / np.float32(255.0)).astype(np.float32)
+    ang = 0.03
+    ax = np.array([0.2, 1.0, 0.3])
+    ax /= np.linalg.norm(ax)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    T = np.eye(4)
+    T[:3, :3] = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+    T[:3, 3] = [0.02, -0.015, 0.01]
+    Ti = np.linalg.inv(T)
+    src = (pts[1::2].astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
+    return (np.ascontiguousarray(src), np.ascontiguousarray(col[1::2]), np.ascontiguousarray(pts[0::2]),
+            np.ascontiguousarray(col[0::2]), T.astype(np.float32))

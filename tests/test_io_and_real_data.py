@@ -57,3 +57,68 @@ def test_oracle_icp_on_real_scan():
     res = orc.registration_icp(src, pts, 0.02, est=orc.EST_PT2PL, tgt_nrm=nrm, det_thresh=-1.0)
     assert res.fitness > 0.99
     assert np.linalg.norm(res.transformation - T) < 2e-4
+
+
+def test_ply_and_pcd_writers_roundtrip(tmp_path):
+    from cupoch_amd import io
+    rng = np.random.default_rng(1)
+    pts = rng.random((77, 3), dtype=np.float32)
+    nrm = rng.random((77, 3), dtype=np.float32)
+    c8 = rng.integers(0, 256, (77, 3)).astype(np.float32) / np.float32(255.0)
+    for name, kw in (("b.ply", {}), ("a.ply", {"ascii": True})):
+        io.write_ply_arrays(str(tmp_path / name), pts, nrm, c8, **kw)
+        a = io.read_point_cloud_arrays(str(tmp_path / name))
+        np.testing.assert_array_equal(a["points"], pts)
+        np.testing.assert_array_equal(a["normals"], nrm)
+        np.testing.assert_allclose(a["colors"], c8, atol=1e-6)
+    io.write_pcd_arrays(str(tmp_path / "c.pcd"), pts, nrm, c8)
+    a = io.read_point_cloud_arrays(str(tmp_path / "c.pcd"))
+    np.testing.assert_array_equal(a["points"], pts)
+    np.testing.assert_array_equal(a["normals"], nrm)
+    np.testing.assert_allclose(a["colors"], c8, atol=1e-6)
+    io.write_ply_arrays(str(tmp_path / "p.ply"), pts)                 # points only
+    a = io.read_ply_arrays(str(tmp_path / "p.ply"))
+    assert a["normals"] is None and a["colors"] is None and len(a["points"]) == 77
+    with pytest.raises(ValueError):
+        io.read_point_cloud_arrays(str(tmp_path / "x.xyz"))
+
+
+def test_ply_reader_skips_faces_and_leading_elements(tmp_path):
+    from cupoch_amd.io import read_ply_arrays
+    # ascii, a camera element before the vertices and faces (a list property) after
+    (tmp_path / "m.ply").write_text(
+        "ply\nformat ascii 1.0\ncomment hand made\nelement camera 1\nproperty float fx\nproperty float fy\n"
+        "element vertex 3\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\n"
+        "property uchar green\nproperty uchar blue\nelement face 1\nproperty list uchar int vertex_indices\n"
+        "end_header\n500 500\n0 0 0 255 0 0\n1 0 0 0 255 0\n0 1 0 0 0 255\n3 0 1 2\n")
+    a = read_ply_arrays(str(tmp_path / "m.ply"))
+    np.testing.assert_array_equal(a["points"], [[0, 0, 0], [1, 0, 0], [0, 1, 0]])
+    np.testing.assert_array_equal(a["colors"], np.eye(3, dtype=np.float32))
+    # binary big endian with doubles
+    rec = np.zeros(2, dtype=[("x", ">f8"), ("y", ">f8"), ("z", ">f8")])
+    rec["x"], rec["y"], rec["z"] = [1.5, -2.0], [0.25, 4.0], [8.0, 16.0]
+    (tmp_path / "be.ply").write_bytes(b"ply\nformat binary_big_endian 1.0\nelement vertex 2\nproperty double x\n"
+                                      b"property double y\nproperty double z\nend_header\n" + rec.tobytes())
+    a = read_ply_arrays(str(tmp_path / "be.ply"))
+    np.testing.assert_array_equal(a["points"], [[1.5, 0.25, 8.0], [-2.0, 4.0, 16.0]])
+
+
+def colored_example_flow_oracle(src, scol, tgt, tcol, scales):
+    """examples/python/advanced/colored_pointcloud_registration.py with the oracle"""
+    cur = np.eye(4, dtype=np.float32)
+    res = None
+    for radius, iters in scales:
+        sp, _, sc = orc.voxel_downsample(src, radius, colors=scol)
+        tp, _, tc = orc.voxel_downsample(tgt, radius, colors=tcol)
+        tn = orc.estimate_normals_radius(tp, radius * 2, 30)
+        res = orc.registration_colored_icp(sp, tp, radius, sc, tc, tn, init=cur, max_iteration=iters)
+        cur = res.transformation
+    return res
+
+
+def test_oracle_colored_icp_example_flow_on_the_real_coloured_fragment():
+    from conftest import colored_fragment_pair
+    src, scol, tgt, tcol, T = colored_fragment_pair()
+    res = colored_example_flow_oracle(src, scol, tgt, tcol, [(0.04, 50), (0.02, 30)])
+    assert res.fitness > 0.95
+    assert np.linalg.norm(res.transformation - T) < 0.15 * np.linalg.norm(T - np.eye(4))
