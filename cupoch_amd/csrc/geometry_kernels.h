@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void target_intensity(const float* __restrict_
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
     const int32_t orig = __float_as_int(tblk[(s >> 3) * kLeafFloats + 24 + (s & 7)]);
-    tnrm[s].w = intensity_of(rgb + (int64_t)orig * 3);
+    if (orig >= 0) tnrm[s].w = intensity_of(rgb + (int64_t)orig * 3);  // n counts padding slots too
 }
 
 __global__ __launch_bounds__(256) void source_intensity(const int32_t* __restrict__ sperm,

@@ -1,0 +1,169 @@
+// kd_cells.h -- the TOP of the target's tree: a balanced kd partition into cells of at
+// most 4096 points, so that every node of the implicit 8-ary tree is a kd cell.
+//
+// Why.  A complete 8-ary tree over fixed-size runs of a MORTON-sorted cloud has loose
+// upper levels: a run of 4096*8^j consecutive points is not an octree cell, its AABB is
+// the box of an L-shaped union, and sibling boxes overlap.  Measured on MI355X (16.7M
+// uniform points, scripts/nn_census_aligned.py): a 64-query packet visits 22.8 records
+// when the runs are unaligned and 7.5 when every run is a cell -- the search kernel is
+// 2.1x faster.  kd_refine.h already makes everything INSIDE a 4096-point group a kd
+// cell; this file does the same for the levels above, without a global kd build
+// (a segmented sort per level, what the reference's FLANN builder does):
+//
+//   1. d = ceil(log2(N / 2731)) binary levels, C = 2^d cells (mean fill <= 2/3 of a
+//      group, so sampling noise does not overflow 4096);
+//   2. split planes from a stride sample of 128*C points, resolved <= 5 levels per stage:
+//      every cell of the current depth gets one workgroup that median-splits 4096 of
+//      its samples in LDS (kd_sort_levels) and writes the planes in heap order; the
+//      samples are then re-assigned and re-sorted by cell for the next stage;
+//   3. every point descends the d planes -> cell id; one short radix sort by cell id
+//      (ceil(d/8) passes instead of the 5 of a 39-bit Morton key);
+//   4. cell c owns max(1, ceil(count_c/4096)) groups of 4096 SLOTS, points left-packed,
+//      the rest padding (kNoPoint); kd_refine_groups + build_leaves take it from there.
+//
+// Cells are defined by planes, so the boxes of different cells -- and of the 8-ary
+// nodes above them, which are kd subtrees when no cell overflows -- are disjoint.
+// An overflowing cell (duplicates, adversarial input) just takes several groups; the
+// groups after it are shifted against the kd hierarchy, which costs speed, not
+// correctness (boxes are always computed from the points).
+// Sorted positions are slots from here on: arrays indexed by the target's order have
+// nslots = 4096 * groups entries, padding slots carry original index -1.
+#pragma once
+#include "device_utils.h"
+#include "kd_refine.h"
+
+namespace mi {
+
+constexpr int kCellTargetFill = 2731;     // mean points per cell <= 2/3 of a group
+constexpr int kCellSamples = 128;         // samples per final cell: count noise ~9 % (sigma)
+constexpr int kCellStageLevels = 5;       // 4096 samples / 2^5 = 128 per cell
+constexpr int kCellMaxLevels = 19;
+
+static inline int cell_levels_for(int64_t n) {
+    int d = 0;
+    while (d < kCellMaxLevels && ((int64_t)kCellTargetFill << d) < n) ++d;
+    return d;
+}
+
+// sample j = point floor(j * n / S)
+__global__ __launch_bounds__(256) void cells_sample_gather(const float* __restrict__ pts, int64_t n,
+                                                           int64_t S, float* __restrict__ samp) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= S) return;
+    const int64_t i = (int64_t)(((unsigned __int128)j * (unsigned __int128)n) / (unsigned __int128)S);
+    samp[j * 3] = pts[i * 3];
+    samp[j * 3 + 1] = pts[i * 3 + 1];
+    samp[j * 3 + 2] = pts[i * 3 + 2];
+}
+
+// cell of a point after `levels` planes: right of a plane <=> coordinate >= plane
+// (NaN and anything below go left)
+__device__ __forceinline__ uint32_t descend_cell(const float2* __restrict__ planes, int levels, float x,
+                                                 float y, float z) {
+    uint32_t node = 1u;
+    for (int l = 0; l < levels; ++l) {
+        const float2 pl = planes[node];
+        const int ax = __float_as_int(pl.y);
+        const float v = (ax == 0) ? x : ((ax == 1) ? y : z);
+        node = node * 2u + ((v >= pl.x) ? 1u : 0u);
+    }
+    return node - (1u << levels);
+}
+
+// keys[i] = cell of point i, vals[i] = i, count[cell] += 1 (count may be null)
+__global__ __launch_bounds__(256) void cells_assign(const float* __restrict__ pts, int64_t n,
+                                                    const float2* __restrict__ planes, int levels,
+                                                    uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                    uint32_t* __restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = descend_cell(planes, levels, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]);
+    keys[i] = c;
+    vals[i] = (uint32_t)i;
+    if (count) atomicAdd(count + c, 1u);
+}
+
+// One workgroup per cell b of depth `base_level`: takes 4096 of the cell's samples (a
+// stride subsample when it has more, wrapped around when fewer) and resolves `levels`
+// more levels.  keys/vals: the samples sorted by their depth-base_level cell (vals =
+// sample index); base_level == 0: all S samples in order.
+__global__ __launch_bounds__(kKdThreads) void cells_planes(const float* __restrict__ samp, int64_t S,
+                                                           const uint64_t* __restrict__ keys,
+                                                           const uint32_t* __restrict__ vals, int base_level,
+                                                           int levels, float2* __restrict__ planes) {
+    __shared__ KdShared s;
+    __shared__ int64_t s_range[2];
+    const int tid = (int)threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (tid < 2) {
+        int64_t r;
+        if (base_level == 0) {
+            r = tid ? S : 0;
+        } else {  // lower_bound(keys, b + tid)
+            const uint64_t want = (uint64_t)b + (uint64_t)tid;
+            int64_t lo = 0, hi = S;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (keys[mid] < want) lo = mid + 1;
+                else hi = mid;
+            }
+            r = lo;
+        }
+        s_range[tid] = r;
+    }
+    __syncthreads();
+    const int64_t s0 = s_range[0], m = s_range[1] - s_range[0];
+    for (int i = tid; i < kKdGroup; i += kKdThreads) {
+        float x = INFINITY, y = INFINITY, z = INFINITY;  // empty cell: every plane becomes +inf
+        if (m > 0) {
+            const int64_t k = s0 + ((m >= kKdGroup) ? (((int64_t)i * m) >> 12) : ((int64_t)i % m));
+            const int64_t j = (base_level == 0) ? k : (int64_t)vals[k];
+            x = samp[j * 3];
+            y = samp[j * 3 + 1];
+            z = samp[j * 3 + 2];
+            // non-finite coordinates would poison the segment extents; park them as padding
+            if (!(fabsf(x) < INFINITY) || !(fabsf(y) < INFINITY) || !(fabsf(z) < INFINITY)) x = y = z = INFINITY;
+        }
+        s.cx[i] = x;
+        s.cy[i] = y;
+        s.cz[i] = z;
+        s.key[i] = (uint32_t)i;
+    }
+    __syncthreads();
+    kd_sort_levels<true>(s, levels, planes, (1u << base_level) + b);
+}
+
+// groups per cell: max(1, ceil(count / 4096))
+__global__ __launch_bounds__(256) void cells_group_counts(const uint32_t* __restrict__ count, int ncells,
+                                                          uint32_t* __restrict__ gcount) {
+    const int c = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (c >= ncells) return;
+    const uint32_t k = count[c];
+    gcount[c] = (k + (uint32_t)kKdGroup - 1u) / (uint32_t)kKdGroup + ((k == 0u) ? 1u : 0u);
+}
+
+// total number of groups -> out[0]
+__global__ void cells_total(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gcount, int ncells,
+                            uint32_t* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = gstart[ncells - 1] + gcount[ncells - 1];
+}
+
+// sorted position p (cell-major, stable) -> slot gstart[cell] * 4096 + rank within the cell
+__global__ __launch_bounds__(256) void cells_scatter(const uint64_t* __restrict__ keys,
+                                                     const uint32_t* __restrict__ vals,
+                                                     const uint32_t* __restrict__ cstart,
+                                                     const uint32_t* __restrict__ gstart, int64_t n,
+                                                     uint32_t* __restrict__ order_padded) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t c = (uint32_t)keys[p];
+    const int64_t slot = (int64_t)gstart[c] * kKdGroup + (p - (int64_t)cstart[c]);
+    order_padded[slot] = vals[p];
+}
+
+__global__ __launch_bounds__(256) void fill_u32(uint32_t* __restrict__ a, int64_t n, uint32_t v) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) a[i] = v;
+}
+
+}  // namespace mi

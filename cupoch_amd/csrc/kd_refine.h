@@ -27,50 +27,41 @@ constexpr int kKdThreads = 1024;
 constexpr int kKdChunk = 8;                       // positions per bbox chunk
 constexpr int kKdChunks = kKdGroup / kKdChunk;    // 512
 
-// order_in / order_out: sorted position -> original index (distinct buffers)
+// LDS working set of one 4096-element group (80 KB)
+struct KdShared {
+    float cx[kKdGroup], cy[kKdGroup], cz[kKdGroup];  // coordinates by LOCAL index (fixed)
+    uint32_t key[kKdGroup];                          // (quantised coordinate << 12) | local index
+    float bb[6 * kKdChunks];                         // [min xyz | max xyz] per chunk
+    float seg_lo[kKdGroup / 16], seg_scale[kKdGroup / 16];
+    uint8_t seg_axis[kKdGroup / 16];
+};
+
+// `levels` rounds of {per-segment bbox -> longest axis -> bitonic sort of the segment
+// along it} over the group in s (cx/cy/cz loaded, key[i] = i; +inf = padding, sorts to
+// the end on every axis).  Segment sizes 4096, 2048, ...: after round r the group is
+// split at the medians of 2^r segments.
 //
-// The sort is LDS-instruction bound (354 compare-exchange stages per group), so an
+// The sort is LDS-instruction bound (354 compare-exchange stages for 9 levels), so an
 // element is ONE 32-bit word: 20 bits of the coordinate quantised over its segment's
 // extent, 12 bits of local index.  One ds_read per element, one ds_write per swapped
 // element, integer compare; equal quantised coordinates are ordered by index, which
 // only moves points between the two sides of a median they sit on.
-__global__ __launch_bounds__(kKdThreads) void kd_refine_groups(const float* __restrict__ pts,
-                                                               const uint32_t* __restrict__ order_in,
-                                                               uint32_t* __restrict__ order_out, int n) {
-    __shared__ float cx[kKdGroup], cy[kKdGroup], cz[kKdGroup];  // coordinates by LOCAL index (fixed)
-    __shared__ uint32_t key[kKdGroup];                          // (quantised coordinate << 12) | local index
-    __shared__ float bb[6 * kKdChunks];                         // [min xyz | max xyz] per chunk
-    __shared__ float seg_lo[kKdGroup / 16], seg_scale[kKdGroup / 16];
-    __shared__ uint8_t seg_axis[kKdGroup / 16];
-
+//
+// PLANES: also record every split as {coordinate of the segment's median element, axis}
+// at heap position (heap_root << round) + segment (kd_cells.h).
+template <bool PLANES>
+__device__ __forceinline__ void kd_sort_levels(KdShared& s, int levels, float2* __restrict__ planes,
+                                               uint32_t heap_root) {
     const int tid = (int)threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * kKdGroup;
-    const int count = (int)min((int64_t)kKdGroup, (int64_t)n - base);
-
-    for (int i = tid; i < kKdGroup; i += kKdThreads) {
-        float x = INFINITY, y = INFINITY, z = INFINITY;  // padding sorts to the end on every axis
-        if (i < count) {
-            const int64_t o = order_in[base + i];
-            x = pts[o * 3];
-            y = pts[o * 3 + 1];
-            z = pts[o * 3 + 2];
-        }
-        cx[i] = x;
-        cy[i] = y;
-        cz[i] = z;
-        key[i] = (uint32_t)i;
-    }
-    __syncthreads();
-
-    for (int lS = 12; lS >= 4; --lS) {  // S = 4096 .. 16 (log2 kept explicit: no integer divisions)
+    for (int lS = 12; lS > 12 - levels; --lS) {  // S = 4096, 2048, ... (log2 kept explicit: no integer divisions)
         const int S = 1 << lS;
         // ---- (a) bbox of every S-segment of the current arrangement -> longest axis
         if (tid < kKdChunks) {
             float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
             for (int e = 0; e < kKdChunk; ++e) {
-                const int li = (int)(key[tid * kKdChunk + e] & 4095u);
-                const float p[3] = {cx[li], cy[li], cz[li]};
+                const int li = (int)(s.key[tid * kKdChunk + e] & 4095u);
+                const float p[3] = {s.cx[li], s.cy[li], s.cz[li]};
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
                     if (p[d] < INFINITY) {
@@ -80,8 +71,8 @@ __global__ __launch_bounds__(kKdThreads) void kd_refine_groups(const float* __re
             }
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                bb[d * kKdChunks + tid] = mn[d];
-                bb[(3 + d) * kKdChunks + tid] = mx[d];
+                s.bb[d * kKdChunks + tid] = mn[d];
+                s.bb[(3 + d) * kKdChunks + tid] = mx[d];
             }
         }
         __syncthreads();
@@ -90,9 +81,9 @@ __global__ __launch_bounds__(kKdThreads) void kd_refine_groups(const float* __re
             if (tid < kKdChunks && (tid & (2 * stride - 1)) == 0) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
-                    bb[d * kKdChunks + tid] = fminf(bb[d * kKdChunks + tid], bb[d * kKdChunks + tid + stride]);
-                    bb[(3 + d) * kKdChunks + tid] =
-                            fmaxf(bb[(3 + d) * kKdChunks + tid], bb[(3 + d) * kKdChunks + tid + stride]);
+                    s.bb[d * kKdChunks + tid] = fminf(s.bb[d * kKdChunks + tid], s.bb[d * kKdChunks + tid + stride]);
+                    s.bb[(3 + d) * kKdChunks + tid] =
+                            fmaxf(s.bb[(3 + d) * kKdChunks + tid], s.bb[(3 + d) * kKdChunks + tid + stride]);
                 }
             }
             __syncthreads();
@@ -100,10 +91,10 @@ __global__ __launch_bounds__(kKdThreads) void kd_refine_groups(const float* __re
         const int nseg = kKdGroup >> lS;
         if (tid < nseg) {
             const int c0 = tid * chunks_per_seg;
-            const float lo[3] = {bb[0 * kKdChunks + c0], bb[1 * kKdChunks + c0], bb[2 * kKdChunks + c0]};
-            const float ex = bb[3 * kKdChunks + c0] - lo[0];
-            const float ey = bb[4 * kKdChunks + c0] - lo[1];
-            const float ez = bb[5 * kKdChunks + c0] - lo[2];
+            const float lo[3] = {s.bb[0 * kKdChunks + c0], s.bb[1 * kKdChunks + c0], s.bb[2 * kKdChunks + c0]};
+            const float ex = s.bb[3 * kKdChunks + c0] - lo[0];
+            const float ey = s.bb[4 * kKdChunks + c0] - lo[1];
+            const float ez = s.bb[5 * kKdChunks + c0] - lo[2];
             int ax = 0;
             float e = ex;
             if (ey > e) {
@@ -114,20 +105,20 @@ __global__ __launch_bounds__(kKdThreads) void kd_refine_groups(const float* __re
                 e = ez;
                 ax = 2;
             }
-            seg_axis[tid] = (uint8_t)ax;
-            seg_lo[tid] = lo[ax];
-            seg_scale[tid] = (e > 0.0f && e < INFINITY) ? 1048575.0f / e : 0.0f;
+            s.seg_axis[tid] = (uint8_t)ax;
+            s.seg_lo[tid] = lo[ax];
+            s.seg_scale[tid] = (e > 0.0f && e < INFINITY) ? 1048575.0f / e : 0.0f;
         }
         __syncthreads();
         // ---- (b) keys = quantised coordinate along the segment's axis | local index
         for (int i = tid; i < kKdGroup; i += kKdThreads) {
             const int sg = i >> lS;
-            const int ax = seg_axis[sg];
-            const uint32_t li = key[i] & 4095u;
-            const float v = (ax == 0) ? cx[li] : ((ax == 1) ? cy[li] : cz[li]);
-            float q = (v - seg_lo[sg]) * seg_scale[sg];
+            const int ax = s.seg_axis[sg];
+            const uint32_t li = s.key[i] & 4095u;
+            const float v = (ax == 0) ? s.cx[li] : ((ax == 1) ? s.cy[li] : s.cz[li]);
+            float q = (v - s.seg_lo[sg]) * s.seg_scale[sg];
             q = fminf(fmaxf(q, 0.0f), 1048575.0f);           // +inf padding -> top bucket, NaN -> 0
-            key[i] = ((v < INFINITY) ? ((uint32_t)q << 12) : 0xfffff000u) | li;
+            s.key[i] = ((v < INFINITY) ? ((uint32_t)q << 12) : 0xfffff000u) | li;
         }
         __syncthreads();
         // ---- (c) bitonic sort of every S-segment (ascending): lower half = below the median
@@ -141,10 +132,10 @@ __global__ __launch_bounds__(kKdThreads) void kd_refine_groups(const float* __re
                     const int i = ((p >> lj) << (lj + 1)) + (p & (j - 1));
                     const int l = i + j;
                     const bool asc = (k == S) || ((i & k) == 0);
-                    const uint32_t a = key[i], b = key[l];
+                    const uint32_t a = s.key[i], b = s.key[l];
                     if ((a > b) == asc) {
-                        key[i] = b;
-                        key[l] = a;
+                        s.key[i] = b;
+                        s.key[l] = a;
                     }
                 }
                 // a wave's 64 threads own an aligned block of 128 elements (per t) whenever
@@ -158,8 +149,49 @@ __global__ __launch_bounds__(kKdThreads) void kd_refine_groups(const float* __re
                     __builtin_amdgcn_wave_barrier();
             }
         }
+        if (PLANES) {
+            if (tid < nseg) {
+                const uint32_t li = s.key[tid * S + (S >> 1)] & 4095u;
+                const int ax = s.seg_axis[tid];
+                const float v = (ax == 0) ? s.cx[li] : ((ax == 1) ? s.cy[li] : s.cz[li]);
+                planes[(size_t)(heap_root << (12 - lS)) + (uint32_t)tid] = make_float2(v, __int_as_float(ax));
+            }
+            // the next round reads key[] only after its own barriers
+        }
     }
-    for (int i = tid; i < count; i += kKdThreads) order_out[base + i] = order_in[base + (key[i] & 4095u)];
+}
+
+constexpr uint32_t kNoPoint = 0xffffffffu;  // order[] entry of a padding slot
+
+// order_in / order_out: sorted position -> original index (distinct buffers); n = number
+// of positions (a multiple of 4096 when the layout is padded); kNoPoint entries are
+// padding and end up behind the group's points.
+__global__ __launch_bounds__(kKdThreads) void kd_refine_groups(const float* __restrict__ pts,
+                                                               const uint32_t* __restrict__ order_in,
+                                                               uint32_t* __restrict__ order_out, int64_t n) {
+    __shared__ KdShared s;
+    const int tid = (int)threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * kKdGroup;
+    const int count = (int)min((int64_t)kKdGroup, n - base);
+
+    for (int i = tid; i < kKdGroup; i += kKdThreads) {
+        float x = INFINITY, y = INFINITY, z = INFINITY;  // padding sorts to the end on every axis
+        if (i < count) {
+            const uint32_t o = order_in[base + i];
+            if (o != kNoPoint) {
+                x = pts[(int64_t)o * 3];
+                y = pts[(int64_t)o * 3 + 1];
+                z = pts[(int64_t)o * 3 + 2];
+            }
+        }
+        s.cx[i] = x;
+        s.cy[i] = y;
+        s.cz[i] = z;
+        s.key[i] = (uint32_t)i;
+    }
+    __syncthreads();
+    kd_sort_levels<false>(s, 9, nullptr, 0u);
+    for (int i = tid; i < count; i += kKdThreads) order_out[base + i] = order_in[base + (s.key[i] & 4095u)];
 }
 
 }  // namespace mi

@@ -73,7 +73,7 @@ __device__ __forceinline__ bool knn_offer(float* kd2, int32_t* kidx, int lane, i
 // normals with the intensity in .w.
 template <int OUT>
 __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
-        const float* __restrict__ records_g, const float* __restrict__ tblk_g, uint32_t leaf_first, int n,
+        const float* __restrict__ records_g, const float* __restrict__ tblk_g, uint32_t leaf_first, int64_t n,
         int nleaf,
         int k, float r2, uint32_t nblocks, uint32_t max_steps, float* __restrict__ normals_out,
         const float4* __restrict__ tnrm, float4* __restrict__ tgrad) {
@@ -90,16 +90,16 @@ __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
     const int leaf0 = pkt * 8;
     if (leaf0 >= nleaf) return;  // whole wave out of range (no block barriers below)
     const int64_t i = (int64_t)pkt * 64 + lane;
-    const bool valid = i < n;
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
     int32_t orig = -1;
-    if (valid) {
+    if (i < n) {  // n = sorted positions; padding slots carry original index -1
         const float* line = tblk_g + (i >> 3) * kLeafFloats + (i & 7);
         qx = line[0];
         qy = line[8];
         qz = line[16];
         orig = __float_as_int(line[24]);
     }
+    const bool valid = orig >= 0;
     KnnState st;
     // r2 = +inf: plain k-NN; finite: the k nearest with d2 < r2 (KDTreeSearchParamRadius)
     st.worst = (valid && k > 0) ? r2 : -1.0f;

@@ -130,10 +130,11 @@ __device__ __forceinline__ void store_box(float* __restrict__ records, uint32_t 
 // one thread per leaf slot L in [0, nslots), nslots = 8 * ceil(nleaf / 8): gathers the
 // leaf's <=8 points into the 128-B leaf line, sorted normals / covariances next
 // to them, and writes the leaf box into its parent's record.  Slots past nleaf
-// get the inverted box.
+// get the inverted box.  n = number of sorted positions; order[] entries equal to
+// kNoPoint are padding (kd_cells.h): +inf coordinates, original index -1.
 __global__ __launch_bounds__(256) void build_leaves(
         const uint32_t* __restrict__ order, const float* __restrict__ pts,
-        const float* __restrict__ nrm, const float* __restrict__ cov, int n, int nleaf, int nslots,
+        const float* __restrict__ nrm, const float* __restrict__ cov, int64_t n, int nleaf, int nslots,
         uint32_t leaf_first, float* __restrict__ tblk, float4* __restrict__ tnrm,
         float* __restrict__ tcov, float* __restrict__ records) {
     const int L = (int)(blockIdx.x * 256 + threadIdx.x);
@@ -147,8 +148,9 @@ __global__ __launch_bounds__(256) void build_leaves(
             const int64_t s = (int64_t)L * kLeaf + k;
             float p[3] = {INFINITY, INFINITY, INFINITY};
             int o = -1;
-            if (s < n) {
-                o = (int)order[s];
+            const uint32_t ou = (s < n) ? order[s] : 0xffffffffu;
+            if (ou != 0xffffffffu) {
+                o = (int)ou;
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
                     p[d] = pts[(int64_t)o * 3 + d];

@@ -24,6 +24,7 @@
 #include "device_utils.h"
 #include "geometry_kernels.h"
 #include "host_solver.h"
+#include "kd_cells.h"
 #include "kd_refine.h"
 #include "knn_normals.h"
 #include "lbvh.h"
@@ -78,10 +79,12 @@ struct mi_icp_ctx {
     // ---- target (Morton order) ----
     int64_t nt = 0;
     int nleaf = 0;
+    int64_t nts = 0;  // sorted positions of the target incl. padding slots (kd_cells.h)
     uint32_t leaf_first = 1, nrecords = 0;  // 8-ary tree: first last-level node id, record count
     bool t_has_nrm = false, t_has_cov = false, t_has_int = false, t_has_grad = false;
-    DevBuf tblk, tnrm, tcov, tgrad, nodes, inv_t, tbounds;
-    int tbits = 0;  // Morton quantisation of the target (reused for the source, see set_source)
+    DevBuf tblk, tnrm, tcov, tgrad, nodes, inv_t;
+    DevBuf cell_planes, cell_samples, cell_count, cell_gcount, cell_cstart, cell_gstart, cell_order[2];
+    uint32_t* cell_total_host = nullptr;  // pinned
     bool inv_t_valid = false;
 
     // ---- source (Morton order) ----
@@ -273,9 +276,77 @@ int morton_order(mi_icp_ctx* c, const float* pts, int64_t n, const uint32_t** or
     }
     // Morton runs -> kd cells inside every group of 4096 points (kd_refine.h)
     const int ngroups = (int)((n + kKdGroup - 1) / kKdGroup);
-    kd_refine_groups<<<ngroups, kKdThreads, 0, c->stream>>>(pts, sb.vals[cur], sb.vals[cur ^ 1], (int)n);
+    kd_refine_groups<<<ngroups, kKdThreads, 0, c->stream>>>(pts, sb.vals[cur], sb.vals[cur ^ 1], n);
     KCHK(c);
     *order = sb.vals[cur ^ 1];
+    return MI_ICP_OK;
+}
+
+// kd-cell order of the target (kd_cells.h): order[slot] = original index or kNoPoint,
+// *nslots = 4096 * groups.  One host synchronisation (the number of groups sizes the tree).
+int kd_cell_order(mi_icp_ctx* c, const float* pts, int64_t n, const uint32_t** order, int64_t* nslots) {
+    const int d = cell_levels_for(n);
+    const int ncells = 1 << d;
+    SortBuffers sb;
+    TRY(sort_buffers(c, n, &sb));
+    float2* planes;
+    TRY(ensure(c, c->cell_planes, (size_t)ncells * 2, &planes));
+    if (d > 0) {
+        const int64_t S = std::min<int64_t>(n, (int64_t)kCellSamples * ncells);
+        float* samp;
+        TRY(ensure(c, c->cell_samples, (size_t)S * 3, &samp));
+        cells_sample_gather<<<blocks_for(S), 256, 0, c->stream>>>(pts, n, S, samp);
+        KCHK(c);
+        const int stages = (d + kCellStageLevels - 1) / kCellStageLevels;
+        int base = 0;
+        int cur = 0;
+        for (int st = 0; st < stages; ++st) {
+            const int levels = (st == 0) ? d - kCellStageLevels * (stages - 1) : kCellStageLevels;
+            if (base > 0) {  // samples grouped by their depth-`base` cell
+                cells_assign<<<blocks_for(S), 256, 0, c->stream>>>(samp, S, planes, base, sb.keys[0], sb.vals[0], nullptr);
+                KCHK(c);
+                cur = radix_sort_pairs(c->stream, sb, S, base);
+                KCHK(c);
+            }
+            cells_planes<<<1 << base, kKdThreads, 0, c->stream>>>(samp, S, sb.keys[cur], sb.vals[cur], base, levels, planes);
+            KCHK(c);
+            base += levels;
+        }
+    }
+    uint32_t *count, *gcount, *cstart, *gstart;
+    TRY(ensure(c, c->cell_count, (size_t)ncells + 1, &count));
+    TRY(ensure(c, c->cell_gcount, (size_t)ncells, &gcount));
+    TRY(ensure(c, c->cell_cstart, (size_t)ncells, &cstart));
+    TRY(ensure(c, c->cell_gstart, (size_t)ncells, &gstart));
+    HIPCHK(c, hipMemsetAsync(count, 0, sizeof(uint32_t) * (size_t)ncells, c->stream));
+    cells_assign<<<blocks_for(n), 256, 0, c->stream>>>(pts, n, planes, d, sb.keys[0], sb.vals[0], count);
+    KCHK(c);
+    const int cur = radix_sort_pairs(c->stream, sb, n, d);
+    KCHK(c);
+    cells_group_counts<<<blocks_for(ncells), 256, 0, c->stream>>>(count, ncells, gcount);
+    KCHK(c);
+    exclusive_scan_u32(c->stream, count, cstart, ncells, sb.scan_tmp);
+    exclusive_scan_u32(c->stream, gcount, gstart, ncells, sb.scan_tmp);
+    cells_total<<<1, 64, 0, c->stream>>>(gstart, gcount, ncells, count + ncells);
+    KCHK(c);
+    if (!c->cell_total_host) HIPCHK(c, hipHostMalloc((void**)&c->cell_total_host, 64, hipHostMallocDefault));
+    HIPCHK(c, hipMemcpyAsync(c->cell_total_host, count + ncells, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int64_t ngroups = (int64_t)c->cell_total_host[0];
+    if (ngroups <= 0 || ngroups > (int64_t)ncells + n / kKdGroup + 1)
+        return fail(c, MI_ICP_ERR_HIP, "kd cell layout: implausible group count %lld", (long long)ngroups);
+    const int64_t slots = ngroups * kKdGroup;
+    uint32_t *o0, *o1;
+    TRY(ensure(c, c->cell_order[0], (size_t)slots, &o0));
+    TRY(ensure(c, c->cell_order[1], (size_t)slots, &o1));
+    fill_u32<<<blocks_for(slots), 256, 0, c->stream>>>(o0, slots, kNoPoint);
+    KCHK(c);
+    cells_scatter<<<blocks_for(n), 256, 0, c->stream>>>(sb.keys[cur], sb.vals[cur], cstart, gstart, n, o0);
+    KCHK(c);
+    kd_refine_groups<<<(unsigned)ngroups, kKdThreads, 0, c->stream>>>(pts, o0, o1, slots);
+    KCHK(c);
+    *order = o1;
+    *nslots = slots;
     return MI_ICP_OK;
 }
 
@@ -376,7 +447,8 @@ int ensure_inverse_maps(mi_icp_ctx* c) {
     if (!c->inv_t_valid && c->nt > 0) {
         int32_t* inv;
         TRY(ensure(c, c->inv_t, (size_t)c->nt, &inv));
-        invert_perm_target<<<blocks_for(c->nt), 256, 0, c->stream>>>((const float*)c->tblk.p, (int)c->nt, inv);
+        HIPCHK(c, hipMemsetAsync(inv, 0xff, sizeof(int32_t) * (size_t)c->nt, c->stream));
+        invert_perm_target<<<blocks_for(c->nts), 256, 0, c->stream>>>((const float*)c->tblk.p, (int)c->nts, inv);
         KCHK(c);
         c->inv_t_valid = true;
     }
@@ -547,7 +619,8 @@ void mi_icp_destroy(mi_icp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    DevBuf* all[] = {&c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->tbounds, &c->sx, &c->sy, &c->sz,
+    DevBuf* all[] = {&c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_count, &c->cell_gcount, &c->cell_cstart,
+                     &c->cell_gstart, &c->cell_order[0], &c->cell_order[1], &c->sx, &c->sy, &c->sz,
                      &c->sperm, &c->snrm, &c->scov, &c->nn_idx, &c->nn_d2, &c->inv_s,
                      &c->user_pairs, &c->keys0, &c->keys1, &c->vals0, &c->vals1, &c->hist,
                      &c->scan_tmp, &c->bounds_part, &c->bounds, &c->partial, &c->sys_dev,
@@ -556,6 +629,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
                      &c->stage[1], &c->stage[2], &c->stage[3], &c->stage[4], &c->stage[5]};
     for (DevBuf* b : all) release(*b);
     if (c->sys_host) (void)hipHostFree(c->sys_host);
+    if (c->cell_total_host) (void)hipHostFree(c->cell_total_host);
     if (c->f_host) (void)hipHostFree(c->f_host);
     if (c->u_host) (void)hipHostFree(c->u_host);
     if (c->loop_host) (void)hipHostFree(c->loop_host);
@@ -624,13 +698,16 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     TRY(to_device(c, covs, (size_t)n * 9, mem_kind, c->stage[2], &d_cov));
 
     const uint32_t* order;
-    float *own_bounds, *tb;
-    TRY(morton_order(c, d_pts, n, &order, nullptr, 0, &own_bounds));
-    TRY(ensure(c, c->tbounds, 8, &tb));
-    HIPCHK(c, hipMemcpyAsync(tb, own_bounds, 8 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-    c->tbits = morton_bits_for(n);
+    int64_t nts = 0;
+    static const bool no_cells = std::getenv("MI_ICP_NO_CELLS") != nullptr;  // A/B switch: Morton runs on top
+    if (no_cells) {
+        TRY(morton_order(c, d_pts, n, &order));
+        nts = n;
+    } else {
+        TRY(kd_cell_order(c, d_pts, n, &order, &nts));
+    }
 
-    const int nleaf = (int)((n + kLeaf - 1) / kLeaf);
+    const int nleaf = (int)((nts + kLeaf - 1) / kLeaf);
     int levels = 1;  // 8-ary levels of records above the leaves
     uint32_t leaf_first = 1u;
     while ((uint64_t)leaf_first * 8u < (uint64_t)nleaf) {
@@ -640,16 +717,18 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     if (levels > kMaxLevels) return fail(c, MI_ICP_ERR_INVALID, "set_target: cloud too large for the 64-bit traversal stack");
     const uint32_t used_last = (uint32_t)((nleaf + 7) / 8);
     const uint32_t nrecords = full_levels_below(leaf_first) + used_last;
+    if ((uint64_t)nrecords * kRecordFloats * sizeof(float) >= (1ull << 32))
+        return fail(c, MI_ICP_ERR_INVALID, "set_target: cloud too large for 32-bit record offsets");
     float* tblk;
     float4* tnrm = nullptr;
     float* tcov = nullptr;
     float* nodes;
     TRY(ensure(c, c->tblk, (size_t)nleaf * kLeafFloats, &tblk));
     TRY(ensure(c, c->nodes, (size_t)nrecords * kRecordFloats, &nodes));
-    if (d_nrm) TRY(ensure(c, c->tnrm, (size_t)n, &tnrm));
-    if (d_cov) TRY(ensure(c, c->tcov, (size_t)n * 9, &tcov));
+    if (d_nrm) TRY(ensure(c, c->tnrm, (size_t)nts, &tnrm));
+    if (d_cov) TRY(ensure(c, c->tcov, (size_t)nts * 9, &tcov));
     const int nslots = (int)used_last * 8;
-    build_leaves<<<blocks_for(nslots), 256, 0, c->stream>>>(order, d_pts, d_nrm, d_cov, (int)n, nleaf, nslots,
+    build_leaves<<<blocks_for(nslots), 256, 0, c->stream>>>(order, d_pts, d_nrm, d_cov, nts, nleaf, nslots,
                                                             leaf_first, tblk, tnrm, tcov, nodes);
     KCHK(c);
     {
@@ -662,6 +741,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
         }
     }
     c->nt = n;
+    c->nts = nts;
     c->nleaf = nleaf;
     c->leaf_first = leaf_first;
     c->nrecords = nrecords;
@@ -938,8 +1018,8 @@ static int resort_source_by_match(mi_icp_ctx* c) {
     SortBuffers sb;
     TRY(sort_buffers(c, n, &sb));
     int bits = 1;
-    while (bits < 32 && (1ull << bits) <= (uint64_t)c->nt) ++bits;  // keys 0..nt (nt = unmatched)
-    match_order_keys<<<blocks_for(n), 256, 0, c->stream>>>((const int32_t*)c->nn_idx.p, (int)n, (uint32_t)c->nt,
+    while (bits < 32 && (1ull << bits) <= (uint64_t)c->nts) ++bits;  // keys 0..nts (nts = unmatched)
+    match_order_keys<<<blocks_for(n), 256, 0, c->stream>>>((const int32_t*)c->nn_idx.p, (int)n, (uint32_t)c->nts,
                                                            sb.keys[0], sb.vals[0]);
     KCHK(c);
     const uint32_t* ord = sb.vals[radix_sort_pairs(c->stream, sb, n, bits)];
@@ -1267,7 +1347,7 @@ static int estimate_normals_impl(mi_icp_ctx* c, const float* xyz, int64_t n, int
     const uint32_t nblocks = (uint32_t)((c->nleaf + kKnnLeavesPerBlock - 1) / kKnnLeavesPerBlock);
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
     knn_normals_kernel<0><<<grid, kKnnThreads, 0, c->stream>>>((const float*)c->nodes.p, (const float*)c->tblk.p,
-                                                               c->leaf_first, (int)n, c->nleaf, knn, r2, nblocks,
+                                                               c->leaf_first, c->nts, c->nleaf, knn, r2, nblocks,
                                                                c->nrecords + 8u, dn, nullptr, nullptr);
     KCHK(c);
     if (mem_kind == MI_ICP_HOST) TRY(from_device(c, (const float*)dn, normals, (size_t)n * 3, mem_kind));
@@ -1297,7 +1377,7 @@ int mi_icp_set_target_colors(mi_icp_ctx* c, const float* rgb, int mem_kind) {
         return fail(c, MI_ICP_ERR_STATE, "set_target_colors: the target has no normals");
     const float* d_rgb;
     TRY(to_device(c, rgb, (size_t)c->nt * 3, mem_kind, c->stage[1], &d_rgb));
-    target_intensity<<<blocks_for(c->nt), 256, 0, c->stream>>>((const float*)c->tblk.p, d_rgb, (int)c->nt,
+    target_intensity<<<blocks_for(c->nts), 256, 0, c->stream>>>((const float*)c->tblk.p, d_rgb, (int)c->nts,
                                                               (float4*)c->tnrm.p);
     KCHK(c);
     c->t_has_int = true;
@@ -1335,13 +1415,13 @@ int mi_icp_compute_color_gradients(mi_icp_ctx* c, float radius, int max_nn, floa
         return fail(c, MI_ICP_ERR_INVALID, "compute_color_gradients: more than %d neighbours are not supported", kMaxKnn);
     const int64_t n = c->nt;
     float4* tgrad;
-    TRY(ensure(c, c->tgrad, (size_t)n, &tgrad));
+    TRY(ensure(c, c->tgrad, (size_t)c->nts, &tgrad));
     float* dg = gradients_out;
     if (gradients_out && mem_kind == MI_ICP_HOST) TRY(ensure(c, c->stage[1], (size_t)n * 3, &dg));
     const uint32_t nblocks = (uint32_t)((c->nleaf + kKnnLeavesPerBlock - 1) / kKnnLeavesPerBlock);
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
     knn_normals_kernel<1><<<grid, kKnnThreads, 0, c->stream>>>(
-            (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, (int)n, c->nleaf, max_nn,
+            (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, c->nts, c->nleaf, max_nn,
             radius * radius, nblocks, c->nrecords + 8u, dg, (const float4*)c->tnrm.p, tgrad);
     KCHK(c);
     c->t_has_grad = true;

@@ -178,9 +178,9 @@ __global__ __launch_bounds__(256) void invert_perm_source(const int32_t* __restr
 __global__ __launch_bounds__(256) void invert_perm_target(const float* __restrict__ tblk, int nt,
                                                           int32_t* __restrict__ inv) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s < nt) {
+    if (s < nt) {  // nt = sorted positions incl. padding slots (original index -1)
         const int32_t o = __float_as_int(tblk[(s >> 3) * kLeafFloats + 24 + (s & 7)]);
-        inv[o] = (int32_t)s;
+        if (o >= 0) inv[o] = (int32_t)s;
     }
 }
 

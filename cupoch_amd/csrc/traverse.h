@@ -35,7 +35,9 @@
 // (culled  =>  |q-p|_inf >= rb  =>  fl(d*d) >= best for every point p of the box).
 // The overlap test is 6 compares per box, issued as a v_cmpx chain that narrows
 // EXEC (measured on MI355X: plain fp32 VALU ~2.6 cycles/wave-instruction,
-// v_pk_*_f32 ~5, v_max3 ~4 -- compares are the cheapest way to test a box).
+// v_pk_*_f32 ~5, v_max3 ~4 -- compares are the cheapest way to test a box); each
+// lane collects its 8 results in a VGPR and one DPP OR-reduction per record turns
+// them into the wave-uniform hit mask.
 // The exact fp32 d2 comparison happens only on leaf points.
 #pragma once
 #include "device_utils.h"
@@ -81,53 +83,89 @@ __device__ __forceinline__ void set_cube(Cube& c, float qx, float qy, float qz, 
     c.loz = widen_down(qz - rb);
 }
 
-// hit = 2*hit + (any lane's cube overlaps box), for boxes B then A of one sibling pair.
-// A v_cmpx chain per box: EXEC shrinks to the lanes that still overlap; what is left
-// non-zero is "some lane hits".  EXEC is saved/restored inside the statement.
-__device__ __forceinline__ void pair_hits(uint32_t& hit, const Cube& c, float amnx, float amny,
+// One box: a v_cmpx chain narrows EXEC to the lanes whose cube overlaps it (on gfx9-family
+// parts v_cmpx also leaves that mask in VCC); EXEC is restored and the lane's own
+// history is shifted left with the hit as carry-in.  One SALU instruction per box: the
+// earlier s_cmp_lg_u64 / s_addc_u32 tail made the loop SALU-bound.
+#define MI_BOX_CHAIN(mnx, mny, mnz, mxx, mxy, mxz)      \
+    "v_cmpx_lt_f32_e32 %[" #mnx "], %[hix]\n\t"          \
+    "v_cmpx_lt_f32_e32 %[" #mny "], %[hiy]\n\t"          \
+    "v_cmpx_lt_f32_e32 %[" #mnz "], %[hiz]\n\t"          \
+    "v_cmpx_gt_f32_e32 %[" #mxx "], %[lox]\n\t"          \
+    "v_cmpx_gt_f32_e32 %[" #mxy "], %[loy]\n\t"          \
+    "v_cmpx_gt_f32_e32 %[" #mxz "], %[loz]\n\t"          \
+    "s_mov_b64 exec, %[sv]\n\t"                          \
+    "v_addc_co_u32_e32 %[vm], vcc, %[vm], %[vm], vcc\n\t"
+
+// vm = 4*vm + 2*(this lane's cube overlaps box B) + (... box A), for one sibling pair.
+// `sv` must hold the wave's EXEC.
+__device__ __forceinline__ void pair_hits(uint32_t& vm, uint64_t sv, const Cube& c, float amnx, float amny,
                                           float amnz, float amxx, float amxy, float amxz, float bmnx,
                                           float bmny, float bmnz, float bmxx, float bmxy, float bmxz) {
-    uint64_t sv;
+    asm volatile(MI_BOX_CHAIN(bmnx, bmny, bmnz, bmxx, bmxy, bmxz) MI_BOX_CHAIN(amnx, amny, amnz, amxx, amxy, amxz)
+                 : [vm] "+v"(vm)
+                 : [sv] "s"(sv), [amnx] "s"(amnx), [amny] "s"(amny), [amnz] "s"(amnz), [amxx] "s"(amxx),
+                   [amxy] "s"(amxy), [amxz] "s"(amxz), [bmnx] "s"(bmnx), [bmny] "s"(bmny), [bmnz] "s"(bmnz),
+                   [bmxx] "s"(bmxx), [bmxy] "s"(bmxy), [bmxz] "s"(bmxz), [lox] "v"(c.lox), [loy] "v"(c.loy),
+                   [loz] "v"(c.loz), [hix] "v"(c.hix), [hiy] "v"(c.hiy), [hiz] "v"(c.hiz)
+                 : "vcc");
+}
+
+// OR of the lanes' masks, wave-uniform: an inclusive OR-scan along each row of 16 lanes on
+// the DPP network, the row results carried across, read from the last lane.  The s_nops are
+// the wait states gfx9 requires (VALU write of EXEC -> DPP: 5; VALU write of a VGPR -> DPP
+// read of it: 2); inline asm is not covered by the compiler's hazard recogniser.
+__device__ __forceinline__ uint32_t wave_or_mask(uint32_t vm) {
+    uint32_t out;
     asm volatile(
-            "s_mov_b64 %[sv], exec\n\t"
-            "v_cmpx_lt_f32_e32 %[bmnx], %[hix]\n\t"
-            "v_cmpx_lt_f32_e32 %[bmny], %[hiy]\n\t"
-            "v_cmpx_lt_f32_e32 %[bmnz], %[hiz]\n\t"
-            "v_cmpx_gt_f32_e32 %[bmxx], %[lox]\n\t"
-            "v_cmpx_gt_f32_e32 %[bmxy], %[loy]\n\t"
-            "v_cmpx_gt_f32_e32 %[bmxz], %[loz]\n\t"
-            "s_cmp_lg_u64 exec, 0\n\t"
-            "s_mov_b64 exec, %[sv]\n\t"
-            "s_addc_u32 %[hit], %[hit], %[hit]\n\t"
-            "v_cmpx_lt_f32_e32 %[amnx], %[hix]\n\t"
-            "v_cmpx_lt_f32_e32 %[amny], %[hiy]\n\t"
-            "v_cmpx_lt_f32_e32 %[amnz], %[hiz]\n\t"
-            "v_cmpx_gt_f32_e32 %[amxx], %[lox]\n\t"
-            "v_cmpx_gt_f32_e32 %[amxy], %[loy]\n\t"
-            "v_cmpx_gt_f32_e32 %[amxz], %[loz]\n\t"
-            "s_cmp_lg_u64 exec, 0\n\t"
-            "s_mov_b64 exec, %[sv]\n\t"
-            "s_addc_u32 %[hit], %[hit], %[hit]\n\t"
-            : [hit] "+s"(hit), [sv] "=&s"(sv)
-            : [amnx] "s"(amnx), [amny] "s"(amny), [amnz] "s"(amnz), [amxx] "s"(amxx), [amxy] "s"(amxy),
-              [amxz] "s"(amxz), [bmnx] "s"(bmnx), [bmny] "s"(bmny), [bmnz] "s"(bmnz), [bmxx] "s"(bmxx),
-              [bmxy] "s"(bmxy), [bmxz] "s"(bmxz), [lox] "v"(c.lox), [loy] "v"(c.loy), [loz] "v"(c.loz),
-              [hix] "v"(c.hix), [hiy] "v"(c.hiy), [hiz] "v"(c.hiz)
-            : "vcc", "scc");
+            "s_nop 3\n\t"
+            "v_or_b32_dpp %[vm], %[vm], %[vm] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+            "s_nop 1\n\t"
+            "v_or_b32_dpp %[vm], %[vm], %[vm] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+            "s_nop 1\n\t"
+            "v_or_b32_dpp %[vm], %[vm], %[vm] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+            "s_nop 1\n\t"
+            "v_or_b32_dpp %[vm], %[vm], %[vm] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+            "s_nop 1\n\t"
+            "v_or_b32_dpp %[vm], %[vm], %[vm] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_or_b32_dpp %[vm], %[vm], %[vm] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_readlane_b32 %[out], %[vm], 63\n\t"
+            : [out] "=s"(out), [vm] "+v"(vm));
+    return out;
 }
 
 // leaf(L): processes leaf L for every lane and may shrink the lane's cube.
 // Returns the number of records visited (census).
+//
+// The loop is bound by the CU's single scalar ALU (measured: <= 0.97 SALU
+// instructions per cycle per CU, shared by the 4 SIMDs, against 1.43 VALU
+// wave-instructions; profiles/r01_ubench_salu_rate.txt), so the wave-uniform
+// bookkeeping is kept to a minimum:
+//  * the record's byte offset is 32-bit (id + off) << 8 with `off` =
+//    record_index(id) - id tracked per level (8*off + 1 one level down, an
+//    arithmetic shift back up), used as the SGPR offset of the s_loads;
+//  * no step limit: the walk consumes a finite stack of sibling bits and cannot
+//    cycle, whatever the boxes contain (max_steps is kept for the callers'
+//    signature and ignored);
+//  * pops take the next sibling from the same find-first-bit that found the level.
 template <class LeafFn>
 __device__ __forceinline__ uint32_t traverse_wide(const float* records_g, uint32_t leaf_first,
-                                                  const Cube& cube, uint32_t max_steps,
+                                                  const Cube& cube, uint32_t /*max_steps*/,
                                                   LeafFn&& leaf) {
-    const cf16_p recs = (cf16_p)(uintptr_t)records_g;
+    typedef const __attribute__((address_space(4))) char* cchar_p;
+    const cchar_p base = (cchar_p)(uintptr_t)records_g;
     uint32_t id = 1u, steps = 0u;
+    int32_t off = -1;  // level 0: record 0 = id 1
     uint64_t pend = 0ull;
-    while (steps++ < max_steps) {
+    const uint64_t full_exec = __builtin_amdgcn_read_exec();
+    for (;;) {
+        ++steps;
         id = __builtin_amdgcn_readfirstlane(id);
-        const cf16_p rec = recs + (size_t)record_index(id) * (kRecordFloats / 16);
+        off = __builtin_amdgcn_readfirstlane(off);
+        const uint32_t byte_off = (id + (uint32_t)off) << 8;  // kRecordFloats * 4 = 256
+        const cf16_p rec = (cf16_p)(base + byte_off);
         // the whole record in one round trip: 3 x s_load_dwordx16, then one wait
         const f16v r0 = rec[0], r1 = rec[1], r2 = rec[2];
         __builtin_amdgcn_sched_barrier(0);
@@ -138,36 +176,39 @@ __device__ __forceinline__ uint32_t traverse_wide(const float* records_g, uint32
             w[16 + e] = r1[e];
             w[32 + e] = r2[e];
         }
-        uint32_t hit = 0u;
+        uint32_t vm = 0u;
 #pragma unroll
         for (int p = 3; p >= 0; --p) {  // children 7..0, so that child c ends up in bit c
             const float* b = w + p * kPairStride;
-            pair_hits(hit, cube, b[0], b[2], b[4], b[6], b[8], b[10], b[1], b[3], b[5], b[7], b[9], b[11]);
+            pair_hits(vm, full_exec, cube, b[0], b[2], b[4], b[6], b[8], b[10], b[1], b[3], b[5], b[7], b[9],
+                      b[11]);
         }
-        bool pop = true;
-        if (id >= leaf_first) {  // children are leaves; later ones were tested before earlier
-                                 // ones shrank the bounds: at worst a wasted leaf
+        uint32_t hit = wave_or_mask(vm);
+        if (id < leaf_first) {
+            if (hit) {  // descend into the first hit child, remember the others
+                pend = (pend << 8) | (uint64_t)(hit & (hit - 1u));
+                id = id * 8u + (uint32_t)__builtin_ctz(hit);
+                off = off * 8 + 1;
+                continue;
+            }
+        } else {  // children are leaves; later ones were tested before earlier
+                  // ones shrank the bounds: at worst a wasted leaf
             const uint32_t lbase = (id - leaf_first) * 8u;
             while (hit) {
                 const uint32_t c = (uint32_t)__builtin_ctz(hit);
                 hit &= hit - 1u;
                 leaf(lbase + c);
             }
-        } else if (hit) {
-            const uint32_t c = (uint32_t)__builtin_ctz(hit);
-            pend = (pend << 8) | (uint64_t)(hit & (hit - 1u));
-            id = id * 8u + c;
-            pop = false;
         }
-        if (pop) {
-            if (pend == 0ull) break;
-            const uint32_t j = (uint32_t)__builtin_ctzll(pend) >> 3;  // levels to climb
-            id >>= 3u * j;
-            pend >>= 8u * j;
-            const uint32_t m = (uint32_t)pend & 255u;
-            id = (id & ~7u) | (uint32_t)__builtin_ctz(m);  // next pending sibling at that level
-            pend = (pend & ~255ull) | (uint64_t)(m & (m - 1u));
-        }
+        if (pend == 0ull) break;
+        const uint32_t z = (uint32_t)__builtin_ctzll(pend);  // lowest pending sibling, 8 bits per level
+        const uint32_t j3 = (z >> 3) * 3u;                   // 3 * levels to climb
+        pend >>= (z & 56u);
+        id = ((id >> j3) & ~7u) | (z & 7u);
+        off >>= j3;  // arithmetic: off_k = 8^j off_(k-j) + (8^j-1)/7, the remainder drops out
+        // clear that sibling: after the shift it sits in the low byte
+        const uint32_t lo = (uint32_t)pend;
+        pend = (pend & 0xffffffff00000000ull) | (uint64_t)(lo & (lo - 1u));
     }
     return steps;
 }
