@@ -70,17 +70,67 @@ __device__ __forceinline__ uint32_t descend_cell(const float2* __restrict__ plan
     return node - (1u << levels);
 }
 
-// keys[i] = cell of point i, vals[i] = i, count[cell] += 1 (count may be null)
+// keys[i] = cell of point i, vals[i] = i
 __global__ __launch_bounds__(256) void cells_assign(const float* __restrict__ pts, int64_t n,
                                                     const float2* __restrict__ planes, int levels,
-                                                    uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                    uint32_t* __restrict__ count) {
+                                                    uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t c = descend_cell(planes, levels, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]);
-    keys[i] = c;
+    keys[i] = descend_cell(planes, levels, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]);
     vals[i] = (uint32_t)i;
-    if (count) atomicAdd(count + c, 1u);
+}
+
+// cstart[c] = first sorted position with key >= c, for c in [0, ncells]  (cstart[ncells] = n).
+// The thread at every key change writes the cells in the gap; no atomics, no pre-fill.
+__global__ __launch_bounds__(256) void cells_starts(const uint64_t* __restrict__ keys, int64_t n, int ncells,
+                                                    uint32_t* __restrict__ cstart) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t k = (uint32_t)keys[p];
+    const int64_t prev = (p == 0) ? -1 : (int64_t)(uint32_t)keys[p - 1];
+    for (int64_t c = prev + 1; c <= (int64_t)k; ++c) cstart[c] = (uint32_t)p;
+    if (p == n - 1)
+        for (int64_t c = (int64_t)k + 1; c <= ncells; ++c) cstart[c] = (uint32_t)n;
+}
+
+// One block: groups per cell = max(1, ceil(count / 4096)), their exclusive prefix gstart,
+// and the total number of groups in total[0].
+__global__ __launch_bounds__(1024) void cells_layout(const uint32_t* __restrict__ cstart, int ncells,
+                                                     uint32_t* __restrict__ gstart, uint32_t* __restrict__ total) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t s_carry;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) s_carry = 0u;
+    __syncthreads();
+    for (int base = 0; base < ncells; base += 1024) {
+        const int c = base + tid;
+        uint32_t g = 0u;
+        if (c < ncells) {
+            const uint32_t k = cstart[c + 1] - cstart[c];
+            g = (k + (uint32_t)kKdGroup - 1u) / (uint32_t)kKdGroup + ((k == 0u) ? 1u : 0u);
+        }
+        uint32_t x = g;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wid] = x;
+        __syncthreads();
+        uint32_t woff = 0u, tot = 0u;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t sw = wsum[w];
+            if (w < wid) woff += sw;
+            tot += sw;
+        }
+        const uint32_t carry = s_carry;
+        if (c < ncells) gstart[c] = carry + woff + x - g;
+        __syncthreads();
+        if (tid == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (tid == 0) total[0] = s_carry;
 }
 
 // One workgroup per cell b of depth `base_level`: takes 4096 of the cell's samples (a
@@ -131,21 +181,6 @@ __global__ __launch_bounds__(kKdThreads) void cells_planes(const float* __restri
     }
     __syncthreads();
     kd_sort_levels<true>(s, levels, planes, (1u << base_level) + b);
-}
-
-// groups per cell: max(1, ceil(count / 4096))
-__global__ __launch_bounds__(256) void cells_group_counts(const uint32_t* __restrict__ count, int ncells,
-                                                          uint32_t* __restrict__ gcount) {
-    const int c = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (c >= ncells) return;
-    const uint32_t k = count[c];
-    gcount[c] = (k + (uint32_t)kKdGroup - 1u) / (uint32_t)kKdGroup + ((k == 0u) ? 1u : 0u);
-}
-
-// total number of groups -> out[0]
-__global__ void cells_total(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gcount, int ncells,
-                            uint32_t* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = gstart[ncells - 1] + gcount[ncells - 1];
 }
 
 // sorted position p (cell-major, stable) -> slot gstart[cell] * 4096 + rank within the cell

@@ -83,7 +83,7 @@ struct mi_icp_ctx {
     uint32_t leaf_first = 1, nrecords = 0;  // 8-ary tree: first last-level node id, record count
     bool t_has_nrm = false, t_has_cov = false, t_has_int = false, t_has_grad = false;
     DevBuf tblk, tnrm, tcov, tgrad, nodes, inv_t;
-    DevBuf cell_planes, cell_samples, cell_count, cell_gcount, cell_cstart, cell_gstart, cell_order[2];
+    DevBuf cell_planes, cell_samples, cell_cstart, cell_gstart, cell_order[2];
     uint32_t* cell_total_host = nullptr;  // pinned
     bool inv_t_valid = false;
 
@@ -303,7 +303,7 @@ int kd_cell_order(mi_icp_ctx* c, const float* pts, int64_t n, const uint32_t** o
         for (int st = 0; st < stages; ++st) {
             const int levels = (st == 0) ? d - kCellStageLevels * (stages - 1) : kCellStageLevels;
             if (base > 0) {  // samples grouped by their depth-`base` cell
-                cells_assign<<<blocks_for(S), 256, 0, c->stream>>>(samp, S, planes, base, sb.keys[0], sb.vals[0], nullptr);
+                cells_assign<<<blocks_for(S), 256, 0, c->stream>>>(samp, S, planes, base, sb.keys[0], sb.vals[0]);
                 KCHK(c);
                 cur = radix_sort_pairs(c->stream, sb, S, base);
                 KCHK(c);
@@ -313,24 +313,19 @@ int kd_cell_order(mi_icp_ctx* c, const float* pts, int64_t n, const uint32_t** o
             base += levels;
         }
     }
-    uint32_t *count, *gcount, *cstart, *gstart;
-    TRY(ensure(c, c->cell_count, (size_t)ncells + 1, &count));
-    TRY(ensure(c, c->cell_gcount, (size_t)ncells, &gcount));
-    TRY(ensure(c, c->cell_cstart, (size_t)ncells, &cstart));
+    uint32_t *cstart, *gstart;
+    TRY(ensure(c, c->cell_cstart, (size_t)ncells + 2, &cstart));
     TRY(ensure(c, c->cell_gstart, (size_t)ncells, &gstart));
-    HIPCHK(c, hipMemsetAsync(count, 0, sizeof(uint32_t) * (size_t)ncells, c->stream));
-    cells_assign<<<blocks_for(n), 256, 0, c->stream>>>(pts, n, planes, d, sb.keys[0], sb.vals[0], count);
+    cells_assign<<<blocks_for(n), 256, 0, c->stream>>>(pts, n, planes, d, sb.keys[0], sb.vals[0]);
     KCHK(c);
     const int cur = radix_sort_pairs(c->stream, sb, n, d);
     KCHK(c);
-    cells_group_counts<<<blocks_for(ncells), 256, 0, c->stream>>>(count, ncells, gcount);
+    cells_starts<<<blocks_for(n), 256, 0, c->stream>>>(sb.keys[cur], n, ncells, cstart);
     KCHK(c);
-    exclusive_scan_u32(c->stream, count, cstart, ncells, sb.scan_tmp);
-    exclusive_scan_u32(c->stream, gcount, gstart, ncells, sb.scan_tmp);
-    cells_total<<<1, 64, 0, c->stream>>>(gstart, gcount, ncells, count + ncells);
+    cells_layout<<<1, 1024, 0, c->stream>>>(cstart, ncells, gstart, cstart + ncells + 1);
     KCHK(c);
     if (!c->cell_total_host) HIPCHK(c, hipHostMalloc((void**)&c->cell_total_host, 64, hipHostMallocDefault));
-    HIPCHK(c, hipMemcpyAsync(c->cell_total_host, count + ncells, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->cell_total_host, cstart + ncells + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int64_t ngroups = (int64_t)c->cell_total_host[0];
     if (ngroups <= 0 || ngroups > (int64_t)ncells + n / kKdGroup + 1)
@@ -619,7 +614,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    DevBuf* all[] = {&c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_count, &c->cell_gcount, &c->cell_cstart,
+    DevBuf* all[] = {&c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
                      &c->cell_gstart, &c->cell_order[0], &c->cell_order[1], &c->sx, &c->sy, &c->sz,
                      &c->sperm, &c->snrm, &c->scov, &c->nn_idx, &c->nn_d2, &c->inv_s,
                      &c->user_pairs, &c->keys0, &c->keys1, &c->vals0, &c->vals1, &c->hist,
