@@ -1,0 +1,160 @@
+// kd_build.h -- one workgroup turns one 4096-slot group of a kd cell (kd_cells.h) into
+// its finished piece of the target tree: the points are median-split 9 times in LDS
+// (kd_sort_levels) and, still from LDS, written out as 512 leaf lines, the sorted
+// normals / covariances, and the 512 + 64 + 8 + 1 boxes of the group's three record
+// levels and of the group itself.  This replaces, for the target, the chain
+// cells_scatter -> kd_refine_groups -> build_leaves -> 3 x build_level and their
+// intermediate order[] arrays; build_leaves' per-leaf gathers of 8 scattered points were
+// the slowest single kernel of the build.
+#pragma once
+#include "kd_cells.h"
+#include "lbvh.h"
+
+namespace mi {
+
+struct GroupBuildArgs {
+    const float* pts;         // AoS cloud
+    const float* nrm;         // may be null
+    const float* cov;         // may be null
+    const uint32_t* vals;     // point indices sorted by cell (stable)
+    const uint32_t* cstart;   // [ncells + 1] first sorted position of every cell
+    const uint32_t* gstart;   // [ncells] first group of every cell
+    int ncells;
+    uint32_t ngroups;
+    uint32_t leaf_first;      // id of the first leaf-level node (8^k >= 64 * ngroups)
+    float* tblk;              // [ngroups * 512] leaf lines
+    float4* tnrm;             // [ngroups * 4096] or null
+    float* tcov;              // [ngroups * 4096 * 9] or null
+    float* records;
+};
+
+__global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) {
+    __shared__ KdShared s;
+    __shared__ uint32_t s_src[2];  // first sorted position, number of points of this group
+    const int tid = (int)threadIdx.x;
+    const uint32_t g = blockIdx.x;
+    if (tid == 0) {
+        // the cell that owns group g: last c with gstart[c] <= g
+        int lo = 0, hi = a.ncells - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a.gstart[mid] <= g) lo = mid;
+            else hi = mid - 1;
+        }
+        const uint32_t r = g - a.gstart[lo];
+        const uint32_t cnt = a.cstart[lo + 1] - a.cstart[lo];
+        const uint32_t first = r * (uint32_t)kKdGroup;
+        s_src[0] = a.cstart[lo] + first;
+        s_src[1] = (cnt > first) ? min(cnt - first, (uint32_t)kKdGroup) : 0u;
+    }
+    __syncthreads();
+    const uint32_t src0 = s_src[0];
+    const int count = (int)s_src[1];
+    for (int i = tid; i < kKdGroup; i += kKdThreads) {
+        float x = INFINITY, y = INFINITY, z = INFINITY;  // padding sorts to the end on every axis
+        if (i < count) {
+            const int64_t o = a.vals[src0 + i];
+            x = a.pts[o * 3];
+            y = a.pts[o * 3 + 1];
+            z = a.pts[o * 3 + 2];
+        }
+        s.cx[i] = x;
+        s.cy[i] = y;
+        s.cz[i] = z;
+        s.key[i] = (uint32_t)i;
+    }
+    __syncthreads();
+    kd_sort_levels<false>(s, 9, nullptr, 0u);
+
+    // ---- leaf lines + sorted attributes: position p of the group = slot g*4096 + p
+    const int64_t slot0 = (int64_t)g * kKdGroup;
+    for (int p = tid; p < kKdGroup; p += kKdThreads) {
+        const int li = (int)(s.key[p] & 4095u);
+        const bool real = li < count;
+        const int64_t o = real ? (int64_t)a.vals[src0 + li] : -1;
+        float* line = a.tblk + (slot0 + p) / kLeaf * kLeafFloats + (p & 7);
+        line[0] = s.cx[li];
+        line[8] = s.cy[li];
+        line[16] = s.cz[li];
+        line[24] = __int_as_float((int)o);
+        if (a.tnrm)
+            a.tnrm[slot0 + p] = real ? make_float4(a.nrm[o * 3], a.nrm[o * 3 + 1], a.nrm[o * 3 + 2], 0.0f)
+                                     : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (a.tcov) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) a.tcov[(slot0 + p) * 9 + e] = real ? a.cov[o * 9 + e] : 0.0f;
+        }
+    }
+    // ---- boxes: 512 leaves (= the 8-position chunks), then unions of 8, 64, 512
+    if (tid < kKdChunks) {
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int e = 0; e < kKdChunk; ++e) {
+            const int li = (int)(s.key[tid * kKdChunk + e] & 4095u);
+            if (li < count) {
+                const float p[3] = {s.cx[li], s.cy[li], s.cz[li]};
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {  // as build_leaves: every coordinate of a real point counts
+                    mn[d] = fminf(mn[d], p[d]);
+                    mx[d] = fmaxf(mx[d], p[d]);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            s.bb[d * kKdChunks + tid] = mn[d];
+            s.bb[(3 + d) * kKdChunks + tid] = mx[d];
+        }
+    }
+    __syncthreads();
+    // level j: 512 >> 3j boxes; box t of level j is node (leaf_first >> 3(j-1)) + g*(64 >> 3(j-1)) + t
+    // for j >= 1, and leaf g*512 + t (child of node leaf_first + (g*512 + t)/8) for j = 0
+    for (int j = 0; j < 4; ++j) {
+        const int nb = kKdChunks >> (3 * j);
+        if (j > 0) {  // union of 8 boxes of the level below, in place at index t*8^j
+            __syncthreads();  // the level below has been stored
+            if (tid < nb) {
+                const int stride = 1 << (3 * (j - 1));
+                const int b0 = tid * stride * 8;
+                float mn[3], mx[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    mn[d] = s.bb[d * kKdChunks + b0];
+                    mx[d] = s.bb[(3 + d) * kKdChunks + b0];
+                }
+                for (int c = 1; c < 8; ++c)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        mn[d] = fminf(mn[d], s.bb[d * kKdChunks + b0 + c * stride]);
+                        mx[d] = fmaxf(mx[d], s.bb[(3 + d) * kKdChunks + b0 + c * stride]);
+                    }
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    s.bb[d * kKdChunks + b0] = mn[d];
+                    s.bb[(3 + d) * kKdChunks + b0] = mx[d];
+                }
+            }
+            __syncthreads();
+        }
+        if (tid < nb) {
+            const int b0 = tid << (3 * j);
+            const float mn[3] = {s.bb[0 * kKdChunks + b0], s.bb[1 * kKdChunks + b0], s.bb[2 * kKdChunks + b0]};
+            const float mx[3] = {s.bb[3 * kKdChunks + b0], s.bb[4 * kKdChunks + b0], s.bb[5 * kKdChunks + b0]};
+            uint32_t id;
+            if (j == 0) id = a.leaf_first * 8u + g * 512u + (uint32_t)tid;  // (leaf_first + L/8)*8 + L%8
+            else id = (a.leaf_first >> (3 * (j - 1))) + g * (uint32_t)(64 >> (3 * (j - 1))) + (uint32_t)tid;
+            if (id > 1u) store_box(a.records, id, mn, mx);  // the root has no parent record
+        }
+    }
+    // the group nodes' parent records are padded to 8 children with inverted boxes
+    if (g == a.ngroups - 1u && tid < 8) {
+        const uint32_t first = a.leaf_first >> 6;
+        const uint32_t t = a.ngroups + (uint32_t)tid;
+        if (first >= 8u && t < ((a.ngroups + 7u) & ~7u)) {  // first == 1: the group is the root
+            const float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            store_box(a.records, first + t, mn, mx);
+        }
+    }
+}
+
+}  // namespace mi

@@ -24,6 +24,7 @@
 #include "device_utils.h"
 #include "geometry_kernels.h"
 #include "host_solver.h"
+#include "kd_build.h"
 #include "kd_cells.h"
 #include "kd_refine.h"
 #include "knn_normals.h"
@@ -83,7 +84,7 @@ struct mi_icp_ctx {
     uint32_t leaf_first = 1, nrecords = 0;  // 8-ary tree: first last-level node id, record count
     bool t_has_nrm = false, t_has_cov = false, t_has_int = false, t_has_grad = false;
     DevBuf tblk, tnrm, tcov, tgrad, nodes, inv_t;
-    DevBuf cell_planes, cell_samples, cell_cstart, cell_gstart, cell_order[2];
+    DevBuf cell_planes, cell_samples, cell_cstart, cell_gstart;
     uint32_t* cell_total_host = nullptr;  // pinned
     bool inv_t_valid = false;
 
@@ -282,9 +283,18 @@ int morton_order(mi_icp_ctx* c, const float* pts, int64_t n, const uint32_t** or
     return MI_ICP_OK;
 }
 
-// kd-cell order of the target (kd_cells.h): order[slot] = original index or kNoPoint,
-// *nslots = 4096 * groups.  One host synchronisation (the number of groups sizes the tree).
-int kd_cell_order(mi_icp_ctx* c, const float* pts, int64_t n, const uint32_t** order, int64_t* nslots) {
+// kd-cell layout of the target (kd_cells.h): point indices sorted by cell, the cells'
+// first positions and first groups.  One host synchronisation (the number of groups sizes
+// the tree).
+struct CellLayout {
+    const uint32_t* vals;
+    const uint32_t* cstart;
+    const uint32_t* gstart;
+    int ncells;
+    int64_t ngroups;
+};
+
+int kd_cell_layout(mi_icp_ctx* c, const float* pts, int64_t n, CellLayout* out) {
     const int d = cell_levels_for(n);
     const int ncells = 1 << d;
     SortBuffers sb;
@@ -330,18 +340,11 @@ int kd_cell_order(mi_icp_ctx* c, const float* pts, int64_t n, const uint32_t** o
     const int64_t ngroups = (int64_t)c->cell_total_host[0];
     if (ngroups <= 0 || ngroups > (int64_t)ncells + n / kKdGroup + 1)
         return fail(c, MI_ICP_ERR_HIP, "kd cell layout: implausible group count %lld", (long long)ngroups);
-    const int64_t slots = ngroups * kKdGroup;
-    uint32_t *o0, *o1;
-    TRY(ensure(c, c->cell_order[0], (size_t)slots, &o0));
-    TRY(ensure(c, c->cell_order[1], (size_t)slots, &o1));
-    fill_u32<<<blocks_for(slots), 256, 0, c->stream>>>(o0, slots, kNoPoint);
-    KCHK(c);
-    cells_scatter<<<blocks_for(n), 256, 0, c->stream>>>(sb.keys[cur], sb.vals[cur], cstart, gstart, n, o0);
-    KCHK(c);
-    kd_refine_groups<<<(unsigned)ngroups, kKdThreads, 0, c->stream>>>(pts, o0, o1, slots);
-    KCHK(c);
-    *order = o1;
-    *nslots = slots;
+    out->vals = sb.vals[cur];
+    out->cstart = cstart;
+    out->gstart = gstart;
+    out->ncells = ncells;
+    out->ngroups = ngroups;
     return MI_ICP_OK;
 }
 
@@ -615,7 +618,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     DevBuf* all[] = {&c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
-                     &c->cell_gstart, &c->cell_order[0], &c->cell_order[1], &c->sx, &c->sy, &c->sz,
+                     &c->cell_gstart, &c->sx, &c->sy, &c->sz,
                      &c->sperm, &c->snrm, &c->scov, &c->nn_idx, &c->nn_d2, &c->inv_s,
                      &c->user_pairs, &c->keys0, &c->keys1, &c->vals0, &c->vals1, &c->hist,
                      &c->scan_tmp, &c->bounds_part, &c->bounds, &c->partial, &c->sys_dev,
@@ -692,14 +695,15 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     TRY(to_device(c, normals, (size_t)n * 3, mem_kind, c->stage[1], &d_nrm));
     TRY(to_device(c, covs, (size_t)n * 9, mem_kind, c->stage[2], &d_cov));
 
-    const uint32_t* order;
-    int64_t nts = 0;
     static const bool no_cells = std::getenv("MI_ICP_NO_CELLS") != nullptr;  // A/B switch: Morton runs on top
+    const uint32_t* order = nullptr;
+    CellLayout lay = {};
+    int64_t nts = n;
     if (no_cells) {
         TRY(morton_order(c, d_pts, n, &order));
-        nts = n;
     } else {
-        TRY(kd_cell_order(c, d_pts, n, &order, &nts));
+        TRY(kd_cell_layout(c, d_pts, n, &lay));
+        nts = lay.ngroups * kKdGroup;
     }
 
     const int nleaf = (int)((nts + kLeaf - 1) / kLeaf);
@@ -722,18 +726,39 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     TRY(ensure(c, c->nodes, (size_t)nrecords * kRecordFloats, &nodes));
     if (d_nrm) TRY(ensure(c, c->tnrm, (size_t)nts, &tnrm));
     if (d_cov) TRY(ensure(c, c->tcov, (size_t)nts * 9, &tcov));
-    const int nslots = (int)used_last * 8;
-    build_leaves<<<blocks_for(nslots), 256, 0, c->stream>>>(order, d_pts, d_nrm, d_cov, nts, nleaf, nslots,
-                                                            leaf_first, tblk, tnrm, tcov, nodes);
-    KCHK(c);
-    {
-        uint32_t used = used_last;
-        for (uint32_t first = leaf_first; first > 1u; first /= 8u) {
-            const uint32_t count = ((used + 7u) / 8u) * 8u;
-            build_level<<<blocks_for(count), 256, 0, c->stream>>>(nodes, first, used, count);
-            KCHK(c);
-            used = (used + 7u) / 8u;
-        }
+    uint32_t first, used;  // the level whose nodes' boxes still have to be formed from their records
+    if (no_cells) {
+        const int nslots = (int)used_last * 8;
+        build_leaves<<<blocks_for(nslots), 256, 0, c->stream>>>(order, d_pts, d_nrm, d_cov, nts, nleaf, nslots,
+                                                                leaf_first, tblk, tnrm, tcov, nodes);
+        KCHK(c);
+        first = leaf_first;
+        used = used_last;
+    } else {
+        GroupBuildArgs ga;
+        ga.pts = d_pts;
+        ga.nrm = d_nrm;
+        ga.cov = d_cov;
+        ga.vals = lay.vals;
+        ga.cstart = lay.cstart;
+        ga.gstart = lay.gstart;
+        ga.ncells = lay.ncells;
+        ga.ngroups = (uint32_t)lay.ngroups;
+        ga.leaf_first = leaf_first;
+        ga.tblk = tblk;
+        ga.tnrm = tnrm;
+        ga.tcov = tcov;
+        ga.records = nodes;
+        kd_build_groups<<<(unsigned)lay.ngroups, kKdThreads, 0, c->stream>>>(ga);
+        KCHK(c);
+        first = leaf_first >> 9;  // the groups' own boxes sit in the records of this level
+        used = ((uint32_t)lay.ngroups + 7u) / 8u;
+    }
+    for (; first > 1u; first /= 8u) {
+        const uint32_t count = ((used + 7u) / 8u) * 8u;
+        build_level<<<blocks_for(count), 256, 0, c->stream>>>(nodes, first, used, count);
+        KCHK(c);
+        used = (used + 7u) / 8u;
     }
     c->nt = n;
     c->nts = nts;
