@@ -459,6 +459,13 @@ void launch_reduce_t(mi_icp_ctx* c, const ReduceArgs& a, const Xform& X, const D
     reduce_kernel<EST, MODE><<<grid, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, out);
 }
 
+// elements per thread below which the reduction uses fewer than its 1024 blocks: 16 measured best on
+// 1.25M-5M point shards (fewer partials for the finishing block); tuning knob MI_ICP_REDUCE_EPT
+static int reduce_elems_per_thread() {
+    static const int v = [] { const char* s = std::getenv("MI_ICP_REDUCE_EPT"); const int k = s ? std::atoi(s) : 16; return k > 0 ? k : 16; }();
+    return v;
+}
+
 bool known_estimator(int est) {
     return est == kEstP2P || est == kEstPt2Pl || est == kEstSym || est == kEstColored || est == kEstGICP;
 }
@@ -514,9 +521,9 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, const DevLoop
         a.count = c->n_user_pairs;
     }
     if (c->ns <= 0 || c->nt <= 0 || (!a.pairs && !c->nn_valid)) a.count = 0;
-    // ~4 elements per thread up to 1024 blocks: enough blocks to hide the gather latency,
+    // >= 16 elements per thread up to 1024 blocks: enough blocks to hide the gather latency,
     // few enough partials for the finishing block
-    const int grid = (int)std::min<int64_t>(kReduceBlocks, blocks_for(a.count, kReduceThreads * 4));
+    const int grid = (int)std::min<int64_t>(kReduceBlocks, blocks_for(a.count, kReduceThreads * reduce_elems_per_thread()));
     const Xform X = make_xform(T);
     if (!estimator_ready(c, est)) {
         est = kEstP2P;

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(kNNThreads) void nn_packet_kernel(
         atomicAdd(stats + 0, (unsigned long long)steps);
         atomicAdd(stats + 1, (unsigned long long)leaves);
         atomicAdd(stats + 2, 1ull);
+        atomicMax(stats + 3, (unsigned long long)steps + (unsigned long long)leaves);  // slowest packet
     }
 }
 

@@ -21,7 +21,8 @@ MI_ICP_API int mi_icp_debug_exclusive_scan(mi_icp_ctx* ctx, const uint32_t* in, 
 MI_ICP_API int mi_icp_debug_morton_order(mi_icp_ctx* ctx, const float* xyz, int64_t n,
                                          uint32_t* order);
 /* traversal census of one nearest-neighbour pass: out4 = {node visits summed over
- * packets, leaf visits, packets, 0}.  use_seed != 0 seeds from the previous pass. */
+ * packets, leaf visits, packets, visits (nodes + leaves) of the slowest packet}.
+ * use_seed != 0 seeds from the previous pass. */
 MI_ICP_API int mi_icp_debug_nn_stats(mi_icp_ctx* ctx, const float* T, float radius, int use_seed,
                                      uint64_t* out4);
 #ifdef __cplusplus

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""One rank's share of the N-GPU bench, emulated on one GPU: full 10M target, 1/N Morton
+shard of the source, 30 iterations (no all-reduce).  Predicts the compute part of the
+driver's multi-GPU runs."""
+import json, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import synth
+from cupoch_amd import _lib
+from cupoch_amd import distributed as D
+from cupoch_amd.engine import Engine
+n = 10_000_000
+src, tgt, nrm, T_gt, max_dist = synth(n)
+eng = Engine(0)
+d_tgt, d_nrm = torch.from_numpy(tgt).cuda(), torch.from_numpy(nrm).cuda()
+eng.set_target(d_tgt, d_nrm)
+for world in (1, 2, 4, 8):
+    mine = D.shard_source(src, 0, world)
+    d_src = torch.from_numpy(np.ascontiguousarray(src[mine])).cuda()
+    eng.set_source(d_src)
+    eng.set_global_source_count(n)
+    eng.set_profiling(False)
+    eng.icp_begin(_lib.EST_POINT_TO_PLANE, max_dist, None, -1.0)
+    eng.icp_iterate(3)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    eng.icp_iterate(30)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 30
+    print(json.dumps({"ranks": world, "source_points_on_this_rank": int(len(mine)), "ms_per_step_compute_only": round(dt * 1e3, 4),
+                      "ideal_speedup_if_allreduce_were_free": round(0.4194 / (dt * 1e3), 2)}), flush=True)
