@@ -125,3 +125,83 @@ def test_iteration_limits_and_immediate_convergence(eng):
     whole = eng.registration_icp(PT2PL, 0.04, None, 0.0, 0.0, 5, -1.0)
     assert a.iterations == 2 and b.iterations == 5 and whole.iterations == 5
     assert np.linalg.norm(T_of(b) - T_of(whole)) <= 1e-6
+
+
+# ---- the kd-cell layout of the target (kd_cells.h): group boundaries, overflowing cells
+@pytest.mark.parametrize("n", [2730, 2731, 2732, 4095, 4096, 4097, 5462, 5463, 8191, 8193, 21848, 21849, 43700])
+def test_search_around_cell_and_group_boundaries(eng, n):
+    # 2731 is the mean cell fill at which another level of planes is added; 4096 the group size
+    rng = np.random.default_rng(n)
+    tgt = rng.random((n, 3), dtype=np.float32)
+    src = (tgt[rng.permutation(n)[: max(1, n // 2)]] + rng.normal(0, 0.01, (max(1, n // 2), 3))).astype(np.float32)
+    eng.set_target(tgt)
+    eng.set_source(src)
+    for radius in (0.02, 2.0):
+        idx, d2, st = eng.search_radius_1nn(radius)
+        cnt, oi, od = orc.search_radius(tgt, src, radius, 1)
+        assert st[0] == cnt
+        check_nn(idx, d2, oi, od, src, tgt)
+
+
+def test_cells_that_overflow_a_group(eng):
+    """20 000 copies of ONE point cannot be split by any plane: their cell takes five
+    4096-slot groups and shifts the groups behind it against the kd hierarchy.  Speed
+    may suffer, answers may not."""
+    rng = np.random.default_rng(77)
+    base = rng.random((60000, 3), dtype=np.float32)
+    dup = np.tile(np.array([[0.31, 0.62, 0.47]], np.float32), (20000, 1))
+    line = np.stack([np.full(9000, 0.8, np.float32), np.full(9000, 0.1, np.float32),
+                     np.linspace(0, 1, 9000, dtype=np.float32) // 0.25 * 0.25], 1)   # 4 distinct points x 2250
+    tgt = np.concatenate([base[:30000], dup, base[30000:], line]).astype(np.float32)
+    src = np.concatenate([rng.random((30000, 3), dtype=np.float32),
+                          dup[:100] + rng.normal(0, 1e-3, (100, 3)).astype(np.float32),
+                          line[::50] + np.float32(1e-4)]).astype(np.float32)
+    eng.set_target(tgt)
+    eng.set_source(src)
+    for radius in (0.01, 0.2):
+        idx, d2, st = eng.search_radius_1nn(radius)
+        cnt, oi, od = orc.search_radius(tgt, src, radius, 1)
+        assert st[0] == cnt
+        # duplicates: the index may be ANY of the copies (same distance); d2 must be bit-exact
+        assert np.array_equal(d2[oi[:, 0] >= 0], od[:, 0][oi[:, 0] >= 0])
+        assert np.array_equal(idx < 0, oi[:, 0] < 0)
+        hit = idx >= 0
+        dd = src[hit] - tgt[idx[hit]]
+        d_chk = (dd[:, 2] * dd[:, 2] + (dd[:, 1] * dd[:, 1] + dd[:, 0] * dd[:, 0])).astype(np.float32)
+        assert np.allclose(d_chk, d2[hit], rtol=1e-6, atol=0)
+    # and a registration through it
+    nrm = unit(np.random.default_rng(78).standard_normal((len(tgt), 3)))
+    T = rigid(0.01, [1, 2, 3], [0.002, -0.001, 0.0015])
+    src2 = orc.transform_points(np.linalg.inv(T).astype(np.float32), tgt[::3])
+    eng.set_target(tgt, nrm)
+    eng.set_source(src2)
+    res = eng.registration_icp(PT2PL, 0.05, None, det_thresh=-1.0)
+    ores = orc.registration_icp(src2, tgt, 0.05, est=orc.EST_PT2PL, tgt_nrm=nrm, det_thresh=-1.0)
+    assert np.linalg.norm(T_of(res) - ores.transformation) <= 1e-5
+    assert res.iterations == ores.iterations
+
+
+def test_normals_and_correspondences_on_the_padded_layout(eng):
+    """everything that indexes the target's sorted order has to skip the padding slots:
+    EstimateNormals' queries, the correspondence export, explicit pairs (inverse map)."""
+    rng = np.random.default_rng(5)
+    n = 30000
+    tgt = rng.random((n, 3), dtype=np.float32)
+    nrm_g = np.asarray(eng.estimate_normals_knn(tgt, 12))
+    nrm_o = orc.estimate_normals_knn(tgt, 12)
+    agree = np.abs(np.sum(nrm_g * nrm_o, axis=1))
+    assert (agree > 0.999).mean() > 0.995
+    T = rigid(0.005, [0, 0, 1], [0.001, 0.001, -0.001])
+    src = orc.transform_points(np.linalg.inv(T).astype(np.float32), tgt[rng.permutation(n)[:20000]])
+    eng.set_target(tgt, nrm_o)
+    eng.set_source(src)
+    res = eng.evaluate_registration(0.01, T)
+    cor = eng.get_correspondences()
+    cnt, oi, _ = orc.search_radius(tgt, orc.transform_points(T, src), 0.01, 1)
+    assert len(cor) == cnt == res.n_correspondences
+    assert cor[:, 1].max() < n and cor[:, 1].min() >= 0
+    assert np.array_equal(cor[:, 1], oi[:, 0][oi[:, 0] >= 0])
+    eng.set_correspondences(cor[::2])
+    sys_g = eng.compute_system(PT2PL, T)
+    sys_o = orc.compute_system(PT2PL, orc.transform_points(T, src), tgt, cor[::2], tgt_nrm=nrm_o)
+    assert np.abs(sys_g[:30] - sys_o[:30]).max() <= 1e-9 * max(np.abs(sys_o[:27]).max(), 1.0)
