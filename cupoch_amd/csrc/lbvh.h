@@ -232,7 +232,8 @@ __global__ __launch_bounds__(256) void match_order_keys(const int32_t* __restric
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= ns) return;
     const int32_t j = nn_idx[i];
-    keys[i] = (j < 0) ? (uint64_t)unmatched_key : (uint64_t)(uint32_t)j;  // unmatched points keep their order at the end
+    // unmatched points keep their order at the end
+    keys[i] = (j < 0) ? (uint64_t)unmatched_key : (uint64_t)((uint32_t)j >> 3);
     vals[i] = (uint32_t)i;
 }
 

@@ -244,7 +244,10 @@ int compute_bounds(mi_icp_ctx* c, const float* pts, int64_t n, float** bounds_ou
 }
 
 int sort_buffers(mi_icp_ctx* c, int64_t n, SortBuffers* sb) {
-    const int nseg = sort_num_segments(n);
+    // the buffers also serve sorts of FEWER elements (samples), which may use smaller tiles
+    int nseg = sort_num_segments(n);
+    nseg = std::max(nseg, sort_num_segments(std::min<int64_t>(n, (1 << 21) - 1)));
+    nseg = std::max(nseg, sort_num_segments(std::min<int64_t>(n, (1 << 18) - 1)));
     TRY(ensure(c, c->keys0, (size_t)n, &sb->keys[0]));
     TRY(ensure(c, c->keys1, (size_t)n, &sb->keys[1]));
     TRY(ensure(c, c->vals0, (size_t)n, &sb->vals[0]));
@@ -523,7 +526,10 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, const DevLoop
     if (c->ns <= 0 || c->nt <= 0 || (!a.pairs && !c->nn_valid)) a.count = 0;
     // >= 16 elements per thread up to 1024 blocks: enough blocks to hide the gather latency,
     // few enough partials for the finishing block
-    const int grid = (int)std::min<int64_t>(kReduceBlocks, blocks_for(a.count, kReduceThreads * reduce_elems_per_thread()));
+    // ... but at least one block per CU while there is one element per thread to give it
+    const int64_t wide = std::min<int64_t>(256, blocks_for(a.count, kReduceThreads));
+    const int grid = (int)std::max<int64_t>(
+            wide, std::min<int64_t>(kReduceBlocks, blocks_for(a.count, kReduceThreads * reduce_elems_per_thread())));
     const Xform X = make_xform(T);
     if (!estimator_ready(c, est)) {
         est = kEstP2P;
@@ -1044,9 +1050,11 @@ static int resort_source_by_match(mi_icp_ctx* c) {
     if (n <= 0 || c->nt <= 0 || !c->nn_valid) return MI_ICP_OK;
     SortBuffers sb;
     TRY(sort_buffers(c, n, &sb));
+    // the key is the matched LEAF (the order inside a leaf does not matter to a packet, and
+    // three bits less can save a radix pass); leaves 0..nleaf-1, nleaf = unmatched
     int bits = 1;
-    while (bits < 32 && (1ull << bits) <= (uint64_t)c->nts) ++bits;  // keys 0..nts (nts = unmatched)
-    match_order_keys<<<blocks_for(n), 256, 0, c->stream>>>((const int32_t*)c->nn_idx.p, (int)n, (uint32_t)c->nts,
+    while (bits < 32 && (1ull << bits) <= (uint64_t)c->nleaf) ++bits;
+    match_order_keys<<<blocks_for(n), 256, 0, c->stream>>>((const int32_t*)c->nn_idx.p, (int)n, (uint32_t)c->nleaf,
                                                            sb.keys[0], sb.vals[0]);
     KCHK(c);
     const uint32_t* ord = sb.vals[radix_sort_pairs(c->stream, sb, n, bits)];

@@ -118,71 +118,82 @@ static inline void exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32
 
 // ---------------------------------------------------------------------------
 // LSD radix sort, 8 bits per pass, 64-bit keys + 32-bit payload, stable.
-// Work decomposition: each wave owns one contiguous segment of kSortSeg
-// elements and walks it in 64-element chunks, so the order inside a digit bin
-// is: segment, then chunk, then lane -- i.e. the input order.
-// Per pass: histogram [256][nseg]  ->  exclusive scan  ->  ranked scatter.
-// The in-chunk rank comes from wave ballots (8 ballots give each lane the mask
-// of its digit peers), not from atomics, which is what keeps the sort stable.
+// Work decomposition: a workgroup of 8 waves owns one contiguous TILE of 8192 elements;
+// wave w walks elements [w*1024, (w+1)*1024) of it in 64-element chunks, so the order
+// inside a digit bin is: tile, wave, chunk, lane -- i.e. the input order.
+// Per pass: histogram [256][ntiles]  ->  exclusive scan  ->  scatter.
+// The in-chunk rank comes from wave ballots (8 ballots give each lane the mask of its
+// digit peers), not from atomics, which is what keeps the sort stable.  The scatter is
+// LDS-staged: the tile is first ordered by digit LOCALLY (a uint16 permutation in LDS),
+// then written out position by position, so that consecutive threads write consecutive
+// addresses inside each of the tile's 256 digit runs (~32 elements = 256 B of keys);
+// the first version scattered 4-element runs straight from registers and was bound by
+// partially written 32-B sectors (255 us per pass at 10M elements).
 // ---------------------------------------------------------------------------
-constexpr int kSortChunks = 16;
-constexpr int kSortSeg = 64 * kSortChunks;
-constexpr int kSortThreads = 256;
+constexpr int kSortThreads = 512;
 constexpr int kSortWaves = kSortThreads / 64;
+constexpr int kSortMaxChunks = 16;  // 64-element chunks per wave: tiles of 8192 elements ...
 
-static inline int sort_num_segments(int64_t n) { return (int)((n + kSortSeg - 1) / kSortSeg); }
+// ... for large inputs; small ones use smaller tiles so that the pass still fills the chip
+// (a 300k-element sort would otherwise run on 37 of the 256 CUs)
+static inline int sort_chunks_for(int64_t n) { return n >= (1 << 21) ? 16 : (n >= (1 << 18) ? 4 : 1); }
+static inline int sort_num_segments(int64_t n) {
+    const int64_t tile = (int64_t)kSortThreads * sort_chunks_for(n);
+    return (int)((n + tile - 1) / tile);
+}
 
+template <int kSortChunks>
 __global__ __launch_bounds__(kSortThreads) void rs_histogram(const uint64_t* __restrict__ keys,
                                                              uint32_t* __restrict__ hist, int n,
                                                              int nseg, int shift) {
-    __shared__ uint32_t cnt[kSortWaves][256];
-    const int lane = lane_id();
-    const int wid = (int)(threadIdx.x >> 6);
-    const int seg = (int)blockIdx.x * kSortWaves + wid;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) cnt[wid][lane + 64 * k] = 0;
+    constexpr int kSortSeg = 64 * kSortChunks * kSortWaves;
+    __shared__ uint32_t cnt[256];
+    const int tid = (int)threadIdx.x;
+    const int seg = (int)blockIdx.x;
+    if (tid < 256) cnt[tid] = 0;
     __syncthreads();
-    if (seg < nseg) {
-        const int64_t base = (int64_t)seg * kSortSeg;
-        for (int c = 0; c < kSortChunks; ++c) {
-            const int64_t i = base + c * 64 + lane;
-            if (i < n) atomicAdd(&cnt[wid][(uint32_t)(keys[i] >> shift) & 255u], 1u);
-        }
+    const int64_t base = (int64_t)seg * kSortSeg;
+#pragma unroll 4
+    for (int c = 0; c < kSortSeg / kSortThreads; ++c) {
+        const int64_t i = base + c * kSortThreads + tid;
+        if (i < n) atomicAdd(&cnt[(uint32_t)(keys[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (seg < nseg) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int d = lane + 64 * k;
-            hist[(int64_t)d * nseg + seg] = cnt[wid][d];
-        }
-    }
+    if (tid < 256) hist[(int64_t)tid * nseg + seg] = cnt[tid];
 }
 
+template <int kSortChunks>
 __global__ __launch_bounds__(kSortThreads) void rs_scatter(const uint64_t* __restrict__ keys_in,
                                                            const uint32_t* __restrict__ vals_in,
                                                            uint64_t* __restrict__ keys_out,
                                                            uint32_t* __restrict__ vals_out,
                                                            const uint32_t* __restrict__ offs, int n,
                                                            int nseg, int shift) {
-    __shared__ uint32_t base[kSortWaves][256];
+    constexpr int kSortWaveSeg = 64 * kSortChunks;
+    constexpr int kSortSeg = kSortWaveSeg * kSortWaves;
+    __shared__ uint32_t wcnt[kSortWaves][256];  // per-wave bin counters, then the wave's offset inside the bin
+    __shared__ uint32_t tile_start[256];        // first local position of every digit run
+    __shared__ int32_t gdelta[256];             // global position - local position, per digit (mod 2^32)
+    __shared__ uint32_t wtot[kSortThreads / 64];
+    __shared__ uint16_t perm[kSortSeg];         // local sorted position -> element of the tile
+    const int tid = (int)threadIdx.x;
     const int lane = lane_id();
-    const int wid = (int)(threadIdx.x >> 6);
-    const int seg = (int)blockIdx.x * kSortWaves + wid;
-    if (seg >= nseg) return;  // no block-level barrier below: waves are independent
+    const int wid = tid >> 6;
+    const int seg = (int)blockIdx.x;
+    const int64_t tbase = (int64_t)seg * kSortSeg;
+    const int tile_n = (int)min((int64_t)kSortSeg, (int64_t)n - tbase);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int d = lane + 64 * k;
-        base[wid][d] = offs[(int64_t)d * nseg + seg];
-    }
+    for (int k = 0; k < 4; ++k) wcnt[wid][lane + 64 * k] = 0;
     __builtin_amdgcn_wave_barrier();
+
+    // ---- 1: rank of every element among the same-digit elements of its wave
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int64_t sbase = (int64_t)seg * kSortSeg;
+    uint32_t packed[kSortChunks];  // digit << 16 | position inside the wave's bin
+#pragma unroll
     for (int c = 0; c < kSortChunks; ++c) {
-        const int64_t i = sbase + c * 64 + lane;
-        const bool valid = i < n;
-        const uint64_t key = valid ? keys_in[i] : 0ull;
-        const uint32_t val = valid ? vals_in[i] : 0u;
+        const int e = wid * kSortWaveSeg + c * 64 + lane;
+        const bool valid = e < tile_n;
+        const uint64_t key = valid ? keys_in[tbase + e] : 0ull;
         const uint32_t digit = (uint32_t)(key >> shift) & 255u;
         uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -194,14 +205,65 @@ __global__ __launch_bounds__(kSortThreads) void rs_scatter(const uint64_t* __res
         const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
         const uint32_t cnt = (uint32_t)__popcll(peers);
         uint32_t pos = 0;
-        if (valid) pos = base[wid][digit] + rank;
-        __builtin_amdgcn_wave_barrier();  // every lane has read its bin base ...
-        if (valid && rank == 0) base[wid][digit] = pos + cnt;  // ... before the bin leader advances it
+        if (valid) pos = wcnt[wid][digit] + rank;
+        __builtin_amdgcn_wave_barrier();  // every lane has read its bin counter ...
+        if (valid && rank == 0) wcnt[wid][digit] = pos + cnt;  // ... before the bin leader advances it
         __builtin_amdgcn_wave_barrier();
-        if (valid) {
-            keys_out[pos] = key;
-            vals_out[pos] = val;
+        packed[c] = (digit << 16) | pos;
+    }
+    __syncthreads();
+
+    // ---- 2: digit runs of the tile: start of every run, every wave's offset inside it
+    uint32_t total = 0;
+    if (tid < 256) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) {
+            const uint32_t k = wcnt[w][tid];
+            wcnt[w][tid] = run;
+            run += k;
         }
+        total = run;
+    }
+    {   // exclusive scan of `total` over the 256 digits (threads 0..255 = waves 0..3)
+        uint32_t x = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wtot[wid] = x;
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t woff = 0;
+            for (int w = 0; w < wid; ++w) woff += wtot[w];
+            const uint32_t start = woff + x - total;
+            tile_start[tid] = start;
+            gdelta[tid] = (int32_t)(offs[(int64_t)tid * nseg + seg] - start);
+        }
+    }
+    __syncthreads();
+
+    // ---- 3: the local permutation
+#pragma unroll
+    for (int c = 0; c < kSortChunks; ++c) {
+        const int e = wid * kSortWaveSeg + c * 64 + lane;
+        if (e < tile_n) {
+            const uint32_t digit = packed[c] >> 16;
+            perm[tile_start[digit] + wcnt[wid][digit] + (packed[c] & 0xffffu)] = (uint16_t)e;
+        }
+    }
+    __syncthreads();
+
+    // ---- 4: write out in local order: consecutive threads -> consecutive addresses of a run
+    for (int p = tid; p < tile_n; p += kSortThreads) {
+        const int e = (int)perm[p];
+        const uint64_t key = keys_in[tbase + e];
+        const uint32_t val = vals_in[tbase + e];
+        const uint32_t digit = (uint32_t)(key >> shift) & 255u;
+        const uint32_t pos = (uint32_t)(gdelta[digit] + (int32_t)p);
+        keys_out[pos] = key;
+        vals_out[pos] = val;
     }
 }
 
@@ -217,15 +279,25 @@ struct SortBuffers {
 static inline int radix_sort_pairs(hipStream_t st, const SortBuffers& b, int64_t n, int key_bits) {
     if (n <= 0) return 0;
     const int nseg = sort_num_segments(n);
-    const int nblk = (nseg + kSortWaves - 1) / kSortWaves;
+    const int nblk = nseg;  // one workgroup per tile
+    const int chunks = sort_chunks_for(n);
     const int passes = (key_bits + 7) / 8;
     int cur = 0;
     for (int p = 0; p < passes; ++p) {
         const int shift = p * 8;
-        rs_histogram<<<nblk, kSortThreads, 0, st>>>(b.keys[cur], b.hist, (int)n, nseg, shift);
+        switch (chunks) {
+            case 16: rs_histogram<16><<<nblk, kSortThreads, 0, st>>>(b.keys[cur], b.hist, (int)n, nseg, shift); break;
+            case 4: rs_histogram<4><<<nblk, kSortThreads, 0, st>>>(b.keys[cur], b.hist, (int)n, nseg, shift); break;
+            default: rs_histogram<1><<<nblk, kSortThreads, 0, st>>>(b.keys[cur], b.hist, (int)n, nseg, shift); break;
+        }
         exclusive_scan_u32(st, b.hist, b.hist, (int64_t)256 * nseg, b.scan_tmp);
-        rs_scatter<<<nblk, kSortThreads, 0, st>>>(b.keys[cur], b.vals[cur], b.keys[cur ^ 1],
-                                                  b.vals[cur ^ 1], b.hist, (int)n, nseg, shift);
+#define MI_RS_ARGS b.keys[cur], b.vals[cur], b.keys[cur ^ 1], b.vals[cur ^ 1], b.hist, (int)n, nseg, shift
+        switch (chunks) {
+            case 16: rs_scatter<16><<<nblk, kSortThreads, 0, st>>>(MI_RS_ARGS); break;
+            case 4: rs_scatter<4><<<nblk, kSortThreads, 0, st>>>(MI_RS_ARGS); break;
+            default: rs_scatter<1><<<nblk, kSortThreads, 0, st>>>(MI_RS_ARGS); break;
+        }
+#undef MI_RS_ARGS
         cur ^= 1;
     }
     return cur;
