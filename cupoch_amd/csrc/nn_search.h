@@ -60,6 +60,62 @@ __device__ __forceinline__ void nn_leaf(const float* tblk_g, uint32_t L, float q
     }
 }
 
+// ---- leaf work compacted across the packet ---------------------------------------------
+// A wave that runs leaf L for all 64 lanes wastes most of them: a packet touches ~9 leaves,
+// a given lane's cube overlaps ~1.6 of them.  Instead every (lane, leaf) pair whose boxes
+// overlap becomes one ITEM in a wave-private LDS queue (grouped by leaf, so neighbouring
+// items read the same 128-B line), and 64 items at a time are evaluated one per lane: the
+// item's query comes over ds_bpermute, the leaf's 8 points over per-lane vector loads, the
+// result goes back with an LDS atomic min on (d2 bits << 32 | slot) -- d2 >= 0, so the
+// integer order is the float order and equal distances resolve to the lowest slot.
+constexpr int kItemQueue = 64 + 8 * 64;  // a drain leaves < 64 behind, one record adds <= 512
+
+struct PacketShared {
+    unsigned long long best[64];  // per lane: d2 bits << 32 | slot
+    uint32_t queue[kItemQueue];   // lane << 26 | leaf
+};
+
+// One batch: lane t evaluates item queue[first + t] (t < count).
+__device__ __forceinline__ void drain_items(PacketShared& sh, const float* tblk_g, uint32_t first, uint32_t count,
+                                            float qx, float qy, float qz, float r2) {
+    const int lane = lane_id();
+    const bool have = (uint32_t)lane < count;
+    const uint32_t item = have ? sh.queue[first + (uint32_t)lane] : 0u;
+    const int ql = (int)(item >> 26);
+    const uint32_t L = item & 0x3ffffffu;
+    // the owner's query point
+    const float ox = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(qx)));
+    const float oy = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(qy)));
+    const float oz = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(qz)));
+    if (have) {
+        const float4* line = reinterpret_cast<const float4*>(tblk_g + (size_t)L * kLeafFloats);
+        const float4 x0 = line[0], x1 = line[1], y0 = line[2], y1 = line[3], z0 = line[4], z1 = line[5];
+        const float px[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        const float py[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+        const float pz[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+        float d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float dx = ox - px[k], dy = oy - py[k], dz = oz - pz[k];
+            d[k] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        }
+        const float m = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+        if (m < r2) {  // strict radius test (also drops NaN); the minimum decides the rest
+            int k = 7;
+            k = (d[6] == m) ? 6 : k;
+            k = (d[5] == m) ? 5 : k;
+            k = (d[4] == m) ? 4 : k;
+            k = (d[3] == m) ? 3 : k;
+            k = (d[2] == m) ? 2 : k;
+            k = (d[1] == m) ? 1 : k;
+            k = (d[0] == m) ? 0 : k;
+            const unsigned long long cand =
+                    ((unsigned long long)__float_as_uint(m) << 32) | (unsigned long long)(L * (uint32_t)kLeaf + (uint32_t)k);
+            __hip_atomic_fetch_min(&sh.best[ql], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
 // `loop` != nullptr: the transform comes from the device-resident loop state and the
 // kernel is a no-op once that loop is done; otherwise Tv (by value) is used.
 template <bool SEED, bool STATS>
@@ -68,6 +124,7 @@ __global__ __launch_bounds__(kNNThreads) void nn_packet_kernel(
         int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
         uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, uint32_t nblocks, uint32_t max_steps, int32_t* __restrict__ nn_idx,
         float* __restrict__ nn_d2, unsigned long long* __restrict__ stats) {
+    __shared__ PacketShared s_pk[kNNPacketsPerBlock];
     uint32_t logical;
     if (!xcd_remap(nblocks, logical)) return;
     Xform T = Tv;
@@ -75,8 +132,10 @@ __global__ __launch_bounds__(kNNThreads) void nn_packet_kernel(
         if (loop->done) return;
         T = loop->X;
     }
+    PacketShared& sh = s_pk[threadIdx.x >> 6];
+    const int lane = lane_id();
 
-    const int64_t i = ((int64_t)logical * kNNPacketsPerBlock + (threadIdx.x >> 6)) * 64 + lane_id();
+    const int64_t i = ((int64_t)logical * kNNPacketsPerBlock + (threadIdx.x >> 6)) * 64 + lane;
     const bool valid = i < ns;
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
     if (valid) xform_point(T, sx[i], sy[i], sz[i], qx, qy, qz);
@@ -98,22 +157,54 @@ __global__ __launch_bounds__(kNNThreads) void nn_packet_kernel(
     }
     Cube cube;
     set_cube(cube, qx, qy, qz, best);  // invalid lanes: best = -1 -> empty cube
+    // the lane's running result lives in LDS, where any lane may improve it
+    sh.best[lane] = ((unsigned long long)__float_as_uint(fmaxf(best, 0.0f)) << 32) | (unsigned long long)(uint32_t)bidx;
+    __builtin_amdgcn_wave_barrier();
 
-    uint32_t leaves = 0u;
-    const uint32_t steps = traverse_wide(records_g, leaf_first, cube, max_steps, [&](uint32_t L) {
-        if (STATS) ++leaves;
-        nn_leaf(tblk_g, L, qx, qy, qz, best, bidx, cube);
+    uint32_t queued = 0u, batches = 0u;  // wave-uniform
+    auto drain = [&](uint32_t first, uint32_t count) {
+        if (STATS) ++batches;
+        drain_items(sh, tblk_g, first, count, qx, qy, qz, r2);
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long b = sh.best[lane];
+        const float nb = __uint_as_float((uint32_t)(b >> 32));
+        if (valid && (int32_t)(uint32_t)b != bidx) {
+            best = nb;
+            bidx = (int32_t)(uint32_t)b;
+            set_cube(cube, qx, qy, qz, best);
+        }
+    };
+    const uint32_t steps = traverse_records(records_g, leaf_first, cube, [&](uint32_t lbase, uint32_t vm, uint32_t hit) {
+        // one queue segment per hit leaf: the lanes that overlap it, in lane order
+        while (hit) {
+            const uint32_t c = (uint32_t)__builtin_ctz(hit);
+            hit &= hit - 1u;
+            const bool mine = (vm >> c) & 1u;
+            const uint64_t m = __ballot(mine);
+            if (mine) {
+                const uint32_t pos = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                sh.queue[pos] = ((uint32_t)lane << 26) | (lbase + c);
+            }
+            queued += (uint32_t)__popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        while (queued >= 64u) {  // newest 64 first; whatever stays is < 64
+            queued -= 64u;
+            drain(queued, 64u);
+        }
     });
+    if (queued) drain(0u, queued);
 
     if (valid) {
         nn_idx[i] = bidx;
         nn_d2[i] = (bidx >= 0) ? best : INFINITY;
     }
-    if (STATS && lane_id() == 0) {  // traversal census for tuning (mi_icp_debug_nn_stats)
+    if (STATS && lane == 0) {  // traversal census for tuning (mi_icp_debug_nn_stats)
         atomicAdd(stats + 0, (unsigned long long)steps);
-        atomicAdd(stats + 1, (unsigned long long)leaves);
+        atomicAdd(stats + 1, (unsigned long long)batches);  // 64-item leaf batches
         atomicAdd(stats + 2, 1ull);
-        atomicMax(stats + 3, (unsigned long long)steps + (unsigned long long)leaves);  // slowest packet
+        atomicMax(stats + 3, (unsigned long long)steps + (unsigned long long)batches);  // slowest packet
     }
 }
 

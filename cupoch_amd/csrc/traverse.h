@@ -136,7 +136,6 @@ __device__ __forceinline__ uint32_t wave_or_mask(uint32_t vm) {
     return out;
 }
 
-// leaf(L): processes leaf L for every lane and may shrink the lane's cube.
 // Returns the number of records visited (census).
 //
 // The loop is bound by the CU's single scalar ALU (measured: <= 0.97 SALU
@@ -150,10 +149,13 @@ __device__ __forceinline__ uint32_t wave_or_mask(uint32_t vm) {
 //    cycle, whatever the boxes contain (max_steps is kept for the callers'
 //    signature and ignored);
 //  * pops take the next sibling from the same find-first-bit that found the level.
-template <class LeafFn>
-__device__ __forceinline__ uint32_t traverse_wide(const float* records_g, uint32_t leaf_first,
-                                                  const Cube& cube, uint32_t /*max_steps*/,
-                                                  LeafFn&& leaf) {
+//
+// leaf_rec(lbase, vm, hit) is called once per visited LEAF-LEVEL record: lbase = index of
+// its first leaf, vm = this lane's 8-bit mask of the leaves its cube overlaps, hit = the
+// OR over the wave.
+template <class LeafRecFn>
+__device__ __forceinline__ uint32_t traverse_records(const float* records_g, uint32_t leaf_first,
+                                                     const Cube& cube, LeafRecFn&& leaf_rec) {
     typedef const __attribute__((address_space(4))) char* cchar_p;
     const cchar_p base = (cchar_p)(uintptr_t)records_g;
     uint32_t id = 1u, steps = 0u;
@@ -191,14 +193,8 @@ __device__ __forceinline__ uint32_t traverse_wide(const float* records_g, uint32
                 off = off * 8 + 1;
                 continue;
             }
-        } else {  // children are leaves; later ones were tested before earlier
-                  // ones shrank the bounds: at worst a wasted leaf
-            const uint32_t lbase = (id - leaf_first) * 8u;
-            while (hit) {
-                const uint32_t c = (uint32_t)__builtin_ctz(hit);
-                hit &= hit - 1u;
-                leaf(lbase + c);
-            }
+        } else if (hit) {
+            leaf_rec((id - leaf_first) * 8u, vm, hit);
         }
         if (pend == 0ull) break;
         const uint32_t z = (uint32_t)__builtin_ctzll(pend);  // lowest pending sibling, 8 bits per level
@@ -211,6 +207,21 @@ __device__ __forceinline__ uint32_t traverse_wide(const float* records_g, uint32
         pend = (pend & 0xffffffff00000000ull) | (uint64_t)(lo & (lo - 1u));
     }
     return steps;
+}
+
+// leaf(L): processes leaf L for every lane and may shrink the lane's cube (the leaves of a
+// record were all tested before the first of them shrank the bounds: at worst a wasted leaf).
+template <class LeafFn>
+__device__ __forceinline__ uint32_t traverse_wide(const float* records_g, uint32_t leaf_first,
+                                                  const Cube& cube, uint32_t /*max_steps*/,
+                                                  LeafFn&& leaf) {
+    return traverse_records(records_g, leaf_first, cube, [&](uint32_t lbase, uint32_t, uint32_t hit) {
+        while (hit) {
+            const uint32_t c = (uint32_t)__builtin_ctz(hit);
+            hit &= hit - 1u;
+            leaf(lbase + c);
+        }
+    });
 }
 
 }  // namespace mi
