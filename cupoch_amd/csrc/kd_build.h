@@ -30,7 +30,7 @@ struct GroupBuildArgs {
 
 __global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) {
     __shared__ KdShared s;
-    __shared__ uint32_t s_src[2];  // first sorted position, number of points of this group
+    __shared__ uint32_t s_src[3];  // first sorted position, number of points of this group, groups of its cell
     const int tid = (int)threadIdx.x;
     const uint32_t g = blockIdx.x;
     if (tid == 0) {
@@ -46,6 +46,8 @@ __global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) 
         const uint32_t first = r * (uint32_t)kKdGroup;
         s_src[0] = a.cstart[lo] + first;
         s_src[1] = (cnt > first) ? min(cnt - first, (uint32_t)kKdGroup) : 0u;
+        s_src[2] = ((lo + 1 < a.ncells) ? a.gstart[lo + 1] : a.ngroups) - a.gstart[lo];
+        s.clean = 1;
     }
     __syncthreads();
     const uint32_t src0 = s_src[0];
@@ -107,6 +109,17 @@ __global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) 
         }
     }
     __syncthreads();
+    // the last round's splits (16 -> 8 | 8): exact disjointness of the two leaves along the split axis
+    if (tid < kKdGroup / 16) {
+        const int ax = s.seg_axis[tid];
+        if (s.bb[(3 + ax) * kKdChunks + 2 * tid] > s.bb[ax * kKdChunks + 2 * tid + 1]) s.clean = 0;
+    }
+    __syncthreads();
+    // Every node's own record also carries the node's own box and a flag "the boxes of this
+    // node and of every node below it are disjoint from everything else in the tree" (the
+    // search's early stop, traverse.h): true when no split of this group left a sliver and
+    // the group is its cell's only one.
+    const uint32_t own_flag = (s.clean != 0 && s_src[2] == 1u) ? 1u : 0u;
     // level j: 512 >> 3j boxes; box t of level j is node (leaf_first >> 3(j-1)) + g*(64 >> 3(j-1)) + t
     // for j >= 1, and leaf g*512 + t (child of node leaf_first + (g*512 + t)/8) for j = 0
     for (int j = 0; j < 4; ++j) {
@@ -144,6 +157,7 @@ __global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) 
             if (j == 0) id = a.leaf_first * 8u + g * 512u + (uint32_t)tid;  // (leaf_first + L/8)*8 + L%8
             else id = (a.leaf_first >> (3 * (j - 1))) + g * (uint32_t)(64 >> (3 * (j - 1))) + (uint32_t)tid;
             if (id > 1u) store_box(a.records, id, mn, mx);  // the root has no parent record
+            if (j > 0) store_own(a.records, id, mn, mx, own_flag);
         }
     }
     // the group nodes' parent records are padded to 8 children with inverted boxes

@@ -34,6 +34,7 @@ struct KdShared {
     float bb[6 * kKdChunks];                         // [min xyz | max xyz] per chunk
     float seg_lo[kKdGroup / 16], seg_scale[kKdGroup / 16];
     uint8_t seg_axis[kKdGroup / 16];
+    int clean;  // stays 1 while no split has produced overlapping halves (set by the caller, see below)
 };
 
 // `levels` rounds of {per-segment bbox -> longest axis -> bitonic sort of the segment
@@ -49,6 +50,15 @@ struct KdShared {
 //
 // PLANES: also record every split as {coordinate of the segment's median element, axis}
 // at heap position (heap_root << round) + segment (kd_cells.h).
+//
+// s.clean: the sort orders by the QUANTISED coordinate, so two points that share the
+// median's bucket can end up on the wrong sides of it; the halves' boxes then overlap by a
+// sliver along the split axis.  That is harmless for culling (boxes are computed from the
+// points) but it breaks "the boxes of two nodes of one level are disjoint", which the
+// bottom-up search relies on to stop early (traverse.h).  Every round therefore compares,
+// exactly, max(left half) with min(right half) of the previous round's splits and clears
+// s.clean on overlap (~0.4 % of the splits at 4096 points); the caller checks the last
+// round's halves itself (kd_last_split_clean).
 template <bool PLANES>
 __device__ __forceinline__ void kd_sort_levels(KdShared& s, int levels, float2* __restrict__ planes,
                                                uint32_t heap_root) {
@@ -89,6 +99,14 @@ __device__ __forceinline__ void kd_sort_levels(KdShared& s, int levels, float2* 
             __syncthreads();
         }
         const int nseg = kKdGroup >> lS;
+        if (lS < 12) {  // the two halves of every split of the previous round
+            if (tid < nseg && (tid & 1) == 0) {
+                const int ax = s.seg_axis[tid >> 1];
+                const int cl = tid * chunks_per_seg, cr = cl + chunks_per_seg;
+                if (s.bb[(3 + ax) * kKdChunks + cl] > s.bb[ax * kKdChunks + cr]) s.clean = 0;
+            }
+            __syncthreads();  // seg_axis is rewritten below
+        }
         if (tid < nseg) {
             const int c0 = tid * chunks_per_seg;
             const float lo[3] = {s.bb[0 * kKdChunks + c0], s.bb[1 * kKdChunks + c0], s.bb[2 * kKdChunks + c0]};

@@ -127,6 +127,20 @@ __device__ __forceinline__ void store_box(float* __restrict__ records, uint32_t 
     }
 }
 
+// A node's own record also holds the node's OWN box (floats 48..53) and, at 54, the flag
+// "this box is disjoint from every point outside the node's subtree" (traverse.h).
+constexpr int kOwnBox = 48, kOwnFlag = 54;
+__device__ __forceinline__ void store_own(float* __restrict__ records, uint32_t id, const float* mn, const float* mx,
+                                          uint32_t flag) {
+    float* pr = records + (size_t)record_index(id) * kRecordFloats + kOwnBox;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        pr[d] = mn[d];
+        pr[3 + d] = mx[d];
+    }
+    pr[kOwnFlag - kOwnBox] = __uint_as_float(flag);
+}
+
 // one thread per leaf slot L in [0, nslots), nslots = 8 * ceil(nleaf / 8): gathers the
 // leaf's <=8 points into the 128-B leaf line, sorted normals / covariances next
 // to them, and writes the leaf box into its parent's record.  Slots past nleaf
@@ -179,7 +193,7 @@ __global__ __launch_bounds__(256) void build_leaves(
 // written into the parent's record; t >= used (padding up to a multiple of 8)
 // writes the inverted box.
 __global__ __launch_bounds__(256) void build_level(float* __restrict__ records, uint32_t first,
-                                                   uint32_t used, uint32_t count) {
+                                                   uint32_t used, uint32_t count, uint32_t own_flag) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= count) return;
     const uint32_t id = first + t;
@@ -194,6 +208,7 @@ __global__ __launch_bounds__(256) void build_level(float* __restrict__ records, 
                 mn[d] = fminf(mn[d], fminf(rec[p * kPairStride + 2 * d], rec[p * kPairStride + 2 * d + 1]));
                 mx[d] = fmaxf(mx[d], fmaxf(rec[p * kPairStride + 6 + 2 * d], rec[p * kPairStride + 6 + 2 * d + 1]));
             }
+        store_own(records, id, mn, mx, own_flag);
     }
     store_box(records, id, mn, mx);
 }

@@ -740,7 +740,11 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     if (d_nrm) TRY(ensure(c, c->tnrm, (size_t)nts, &tnrm));
     if (d_cov) TRY(ensure(c, c->tcov, (size_t)nts * 9, &tcov));
     uint32_t first, used;  // the level whose nodes' boxes still have to be formed from their records
+    // nodes above the groups are kd subtrees -- disjoint boxes -- when every cell has exactly one group
+    const uint32_t upper_flag = (!no_cells && lay.ngroups == (int64_t)lay.ncells) ? 1u : 0u;
     if (no_cells) {
+        // own boxes / flags of the leaf-level records stay zero: no early stop on a Morton-run tree
+        HIPCHK(c, hipMemsetAsync(nodes, 0, (size_t)nrecords * kRecordFloats * sizeof(float), c->stream));
         const int nslots = (int)used_last * 8;
         build_leaves<<<blocks_for(nslots), 256, 0, c->stream>>>(order, d_pts, d_nrm, d_cov, nts, nleaf, nslots,
                                                                 leaf_first, tblk, tnrm, tcov, nodes);
@@ -769,7 +773,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     }
     for (; first > 1u; first /= 8u) {
         const uint32_t count = ((used + 7u) / 8u) * 8u;
-        build_level<<<blocks_for(count), 256, 0, c->stream>>>(nodes, first, used, count);
+        build_level<<<blocks_for(count), 256, 0, c->stream>>>(nodes, first, used, count, upper_flag);
         KCHK(c);
         used = (used + 7u) / 8u;
     }

@@ -119,7 +119,7 @@ __device__ __forceinline__ void drain_items(PacketShared& sh, const float* tblk_
 // `loop` != nullptr: the transform comes from the device-resident loop state and the
 // kernel is a no-op once that loop is done; otherwise Tv (by value) is used.
 template <bool SEED, bool STATS>
-__global__ __launch_bounds__(kNNThreads) void nn_packet_kernel(
+__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_packet_kernel(
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
         int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
         uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, uint32_t nblocks, uint32_t max_steps, int32_t* __restrict__ nn_idx,
@@ -143,9 +143,15 @@ __global__ __launch_bounds__(kNNThreads) void nn_packet_kernel(
     float best = valid ? r2 : -1.0f;
     int32_t bidx = -1;
 
+    uint32_t start = 1u;  // node the search starts at (traverse.h): the root, or ...
     if (SEED) {
         // last iteration's match bounds this one's search radius
         const int32_t j = valid ? nn_idx[i] : -1;
+        // ... the leaf-level node of the first lane that has a previous match; taken from the raw
+        // index so that the first record's fetch does not wait for the gather below
+        const uint64_t seeded = __ballot(j >= 0);
+        if (seeded != 0ull)
+            start = leaf_first + ((uint32_t)__builtin_amdgcn_readlane(j, (int)__builtin_ctzll(seeded)) >> 6);
         if (j >= 0) {
             const float* line = tblk_g + (int64_t)(j >> 3) * kLeafFloats + (j & 7);
             const float d2 = sq3(qx - line[0], qy - line[8], qz - line[16]);
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(kNNThreads) void nn_packet_kernel(
             set_cube(cube, qx, qy, qz, best);
         }
     };
-    const uint32_t steps = traverse_records(records_g, leaf_first, cube, [&](uint32_t lbase, uint32_t vm, uint32_t hit) {
+    const uint32_t steps = traverse_from(records_g, leaf_first, start, cube, [&](uint32_t lbase, uint32_t vm, uint32_t hit) {
         // one queue segment per hit leaf: the lanes that overlap it, in lane order
         while (hit) {
             const uint32_t c = (uint32_t)__builtin_ctz(hit);

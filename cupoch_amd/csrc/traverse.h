@@ -153,14 +153,53 @@ __device__ __forceinline__ uint32_t wave_or_mask(uint32_t vm) {
 // leaf_rec(lbase, vm, hit) is called once per visited LEAF-LEVEL record: lbase = index of
 // its first leaf, vm = this lane's 8-bit mask of the leaves its cube overlaps, hit = the
 // OR over the wave.
+//
+// BOTTOM-UP START.  `start` is the node the walk begins at: 1 (the root) for a plain
+// top-down search, or the leaf-level node of a lane's previous match.  In the second case
+// the subtree of `start` is searched first, then the walk climbs: at every ancestor the
+// other seven children are tested (and searched where hit), until the root is done -- or
+// until ALL lanes' cubes lie inside the box of the subtree just completed AND that node
+// carries the "disjoint" flag (lbvh.h store_own): every point outside the subtree then
+// lies outside that box, hence outside every cube, hence cannot be closer than what the
+// lanes already hold.  With match-ordered packets the climb ends 1-3 levels above the
+// leaves instead of walking all 7 levels from the root.  The flag is what makes this
+// exact: boxes of kd cells are disjoint, boxes of Morton runs, of groups of an
+// overflowing cell, or of splits that left a sliver (kd_refine.h) are not, and there the
+// flag is 0 and the climb continues.
+__device__ __forceinline__ bool cubes_inside(const Cube& c, uint64_t full_exec, float mnx, float mny, float mnz,
+                                             float mxx, float mxy, float mxz) {
+    uint32_t all;
+    asm volatile(
+            "v_cmpx_le_f32_e32 %[mnx], %[lox]\n\t"
+            "v_cmpx_le_f32_e32 %[mny], %[loy]\n\t"
+            "v_cmpx_le_f32_e32 %[mnz], %[loz]\n\t"
+            "v_cmpx_ge_f32_e32 %[mxx], %[hix]\n\t"
+            "v_cmpx_ge_f32_e32 %[mxy], %[hiy]\n\t"
+            "v_cmpx_ge_f32_e32 %[mxz], %[hiz]\n\t"
+            "s_cmp_eq_u64 exec, %[sv]\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            "s_cselect_b32 %[all], 1, 0\n\t"
+            : [all] "=s"(all)
+            : [sv] "s"(full_exec), [mnx] "s"(mnx), [mny] "s"(mny), [mnz] "s"(mnz), [mxx] "s"(mxx), [mxy] "s"(mxy),
+              [mxz] "s"(mxz), [lox] "v"(c.lox), [loy] "v"(c.loy), [loz] "v"(c.loz), [hix] "v"(c.hix),
+              [hiy] "v"(c.hiy), [hiz] "v"(c.hiz)
+            : "vcc", "scc");
+    return all != 0u;
+}
+
 template <class LeafRecFn>
-__device__ __forceinline__ uint32_t traverse_records(const float* records_g, uint32_t leaf_first,
-                                                     const Cube& cube, LeafRecFn&& leaf_rec) {
+__device__ __forceinline__ uint32_t traverse_from(const float* records_g, uint32_t leaf_first, uint32_t start,
+                                                  const Cube& cube, LeafRecFn&& leaf_rec) {
     typedef const __attribute__((address_space(4))) char* cchar_p;
     const cchar_p base = (cchar_p)(uintptr_t)records_g;
-    uint32_t id = 1u, steps = 0u;
-    int32_t off = -1;  // level 0: record 0 = id 1
+    uint32_t id = __builtin_amdgcn_readfirstlane(start), steps = 0u;
+    // off = record_index(id) - id of id's level: -1 at the root, (8^k - 1)/7 - 8^k at the leaf level
+    int32_t off = (id == 1u) ? -1 : (int32_t)(full_levels_below(leaf_first) - leaf_first);
+    uint32_t top = id;      // the subtree being completed
+    int32_t top_off = off;
+    uint32_t skip = 8u;     // child of `top` that is already done (8: none)
     uint64_t pend = 0ull;
+    float ownv = 0.0f;  // lane k < 8: float 48 + k of top's record
     const uint64_t full_exec = __builtin_amdgcn_read_exec();
     for (;;) {
         ++steps;
@@ -168,8 +207,21 @@ __device__ __forceinline__ uint32_t traverse_records(const float* records_g, uin
         off = __builtin_amdgcn_readfirstlane(off);
         const uint32_t byte_off = (id + (uint32_t)off) << 8;  // kRecordFloats * 4 = 256
         const cf16_p rec = (cf16_p)(base + byte_off);
-        // the whole record in one round trip: 3 x s_load_dwordx16, then one wait
+        // the whole record in one round trip: 3 x s_load_dwordx16, then one wait.  The search is
+        // bound by these dependent round trips (~1 us each from L2 / Infinity Cache), so on the
+        // climbing path -- id == top -- the same round trip also brings top's own box and touches
+        // the four lines of its PARENT's record, which the next step of the climb will read.
         const f16v r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        if (id == top) {
+            // ONE vector load, consumed only when the subtree is complete: lanes 0..7 fetch top's
+            // own box + flag (floats 48..55 of its record), the other lanes touch the four lines
+            // of the parent's record.  (As scalar loads these sat in 12 SGPRs across the whole
+            // descent and made the compiler spill and wait.)
+            const uint32_t poff = (id > 1u) ? (((id >> 3) + (uint32_t)(off >> 3)) << 8) : byte_off;
+            const uint32_t ln = (uint32_t)lane_id();
+            const uint32_t boff = (ln < 8u) ? (byte_off + 192u + 4u * ln) : (poff + 64u * (ln & 3u));
+            ownv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(records_g) + boff);
+        }
         __builtin_amdgcn_sched_barrier(0);
         float w[48];
 #pragma unroll
@@ -186,6 +238,7 @@ __device__ __forceinline__ uint32_t traverse_records(const float* records_g, uin
                       b[11]);
         }
         uint32_t hit = wave_or_mask(vm);
+        if (id == top && skip < 8u) hit &= ~(1u << skip);  // climbing: that child's subtree is done
         if (id < leaf_first) {
             if (hit) {  // descend into the first hit child, remember the others
                 pend = (pend << 8) | (uint64_t)(hit & (hit - 1u));
@@ -196,17 +249,43 @@ __device__ __forceinline__ uint32_t traverse_records(const float* records_g, uin
         } else if (hit) {
             leaf_rec((id - leaf_first) * 8u, vm, hit);
         }
-        if (pend == 0ull) break;
-        const uint32_t z = (uint32_t)__builtin_ctzll(pend);  // lowest pending sibling, 8 bits per level
-        const uint32_t j3 = (z >> 3) * 3u;                   // 3 * levels to climb
-        pend >>= (z & 56u);
-        id = ((id >> j3) & ~7u) | (z & 7u);
-        off >>= j3;  // arithmetic: off_k = 8^j off_(k-j) + (8^j-1)/7, the remainder drops out
-        // clear that sibling: after the shift it sits in the low byte
-        const uint32_t lo = (uint32_t)pend;
-        pend = (pend & 0xffffffff00000000ull) | (uint64_t)(lo & (lo - 1u));
+        if (pend != 0ull) {
+            const uint32_t z = (uint32_t)__builtin_ctzll(pend);  // lowest pending sibling, 8 bits per level
+            const uint32_t j3 = (z >> 3) * 3u;                   // 3 * levels to climb
+            pend >>= (z & 56u);
+            id = ((id >> j3) & ~7u) | (z & 7u);
+            off >>= j3;  // arithmetic: off_k = 8^j off_(k-j) + (8^j-1)/7, the remainder drops out
+            // clear that sibling: after the shift it sits in the low byte
+            const uint32_t lo = (uint32_t)pend;
+            pend = (pend & 0xffffffff00000000ull) | (uint64_t)(lo & (lo - 1u));
+            continue;
+        }
+        // ---- the subtree of `top` is complete
+        top = __builtin_amdgcn_readfirstlane(top);
+        top_off = __builtin_amdgcn_readfirstlane(top_off);
+        if (top == 1u) break;
+        // own box + flag of `top` (fetched when top was visited)
+        if (__builtin_amdgcn_readlane(__float_as_int(ownv), 6) != 0 &&
+            cubes_inside(cube, full_exec, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ownv), 0)),
+                         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ownv), 1)),
+                         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ownv), 2)),
+                         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ownv), 3)),
+                         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ownv), 4)),
+                         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ownv), 5))))
+            break;
+        skip = top & 7u;
+        top >>= 3;
+        top_off >>= 3;  // off_(k-1) = (off_k - 1) / 8, exact; the arithmetic shift floors to it
+        id = top;
+        off = top_off;
     }
     return steps;
+}
+
+template <class LeafRecFn>
+__device__ __forceinline__ uint32_t traverse_records(const float* records_g, uint32_t leaf_first,
+                                                     const Cube& cube, LeafRecFn&& leaf_rec) {
+    return traverse_from(records_g, leaf_first, 1u, cube, leaf_rec);
 }
 
 // leaf(L): processes leaf L for every lane and may shrink the lane's cube (the leaves of a
