@@ -32,14 +32,14 @@ def census(seed, T=None):
     return steps / pk, leaves / pk, pk
 
 
-print("n=%d packets: unseeded identity  nodes/packet=%.1f leaves/packet=%.1f (%d packets)" % ((n,) + census(0)))
-print("seeded, same T                  nodes/packet=%.1f leaves/packet=%.1f" % census(1)[:2])
-print("seeded, T_gt (converged)        nodes/packet=%.1f leaves/packet=%.1f" % census(1, T_gt)[:2])
-print("seeded, T_gt again              nodes/packet=%.1f leaves/packet=%.1f" % census(1, T_gt)[:2])
-print("unseeded, T_gt                  nodes/packet=%.1f leaves/packet=%.1f" % census(0, T_gt)[:2])
+print("n=%d packets: unseeded identity  nodes/packet=%.1f leaf-batches/packet=%.1f (%d packets)" % ((n,) + census(0)))
+print("seeded, same T                  nodes/packet=%.1f leaf-batches/packet=%.1f" % census(1)[:2])
+print("seeded, T_gt (converged)        nodes/packet=%.1f leaf-batches/packet=%.1f" % census(1, T_gt)[:2])
+print("seeded, T_gt again              nodes/packet=%.1f leaf-batches/packet=%.1f" % census(1, T_gt)[:2])
+print("unseeded, T_gt                  nodes/packet=%.1f leaf-batches/packet=%.1f" % census(0, T_gt)[:2])
 
 # the registration loop re-orders the source by its matches after the first pass
 eng.icp_begin(_lib.EST_POINT_TO_PLANE, max_dist, T_gt, -1.0)
 print("after icp_begin (match-ordered source):")
-print("seeded, T_gt                    nodes/packet=%.1f leaves/packet=%.1f" % census(1, T_gt)[:2])
-print("unseeded, T_gt                  nodes/packet=%.1f leaves/packet=%.1f" % census(0, T_gt)[:2])
+print("seeded, T_gt                    nodes/packet=%.1f leaf-batches/packet=%.1f" % census(1, T_gt)[:2])
+print("unseeded, T_gt                  nodes/packet=%.1f leaf-batches/packet=%.1f" % census(0, T_gt)[:2])
