@@ -9,17 +9,16 @@
 // registration/registration.cu:160).
 //
 // The reference runs one query per thread, each thread chasing its own pointers
-// through the tree.  Here a WAVE owns a packet of 64 Morton-consecutive source
-// points (a compact blob in space, whatever rigid transform is applied) and
-// traverses the tree ONCE for all of them (traverse.h): node records arrive by
-// scalar loads, 8 children are tested per step with packed fp32 math, and a
-// lane holds only its query, best d2 / index and search radius.
-// A leaf is one 128-B line of 8 points: the 8 squared distances are formed two
-// at a time (v_pk_fma_f32), reduced with v_min3, and the index is resolved only
-// when some lane actually improved (rare once the search is seeded).
+// through the tree.  Here a WAVE owns a packet of 64 consecutive source points of the
+// staged order (a compact blob in space, whatever rigid transform is applied; after the
+// first pass: 64 points whose matches are consecutive target slots) and walks the tree
+// ONCE for all of them (traverse.h): node records arrive by scalar loads, the 8 children
+// of a record are tested with v_cmpx chains, and a lane holds only its query, best d2 /
+// index and search cube.  Leaf work -- 8 exact squared distances per (lane, leaf) pair --
+// is compacted across the packet through an LDS queue (below).
 // Accept test is the reference's: strict d2 < r2 with r2 = float(r*r); no
-// match -> idx -1, d2 +inf.  Equal-distance ties keep the first-visited point
-// (as FLANN does; the visit order differs).
+// match -> idx -1, d2 +inf.  Equal-distance ties resolve to the lowest slot of the
+// target's order (FLANN keeps the first visited).
 #pragma once
 #include "device_utils.h"
 #include "loop.h"
@@ -29,36 +28,6 @@ namespace mi {
 
 constexpr int kNNThreads = 256;
 constexpr int kNNPacketsPerBlock = kNNThreads / 64;
-
-// 8 leaf points against the lane's query: exact fp32 d2 = fma(dz,dz,fma(dy,dy,dx*dx))
-__device__ __forceinline__ void nn_leaf(const float* tblk_g, uint32_t L, float qx, float qy, float qz,
-                                        float& best, int32_t& bidx, Cube& cube) {
-    const cf2_p line = (cf2_p)(uintptr_t)(tblk_g + (size_t)L * kLeafFloats);
-    const f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
-    f2 d[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const f2 dx = qx2 - line[k], dy = qy2 - line[4 + k], dz = qz2 - line[8 + k];
-        d[k] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-    }
-    const float m = fminf(fminf(fminf(d[0].x, d[0].y), fminf(d[1].x, d[1].y)),
-                          fminf(fminf(d[2].x, d[2].y), fminf(d[3].x, d[3].y)));
-    if (__ballot(m < best) != 0ull) {
-        if (m < best) {  // first point of the line at distance m, as a sequential strict-< scan picks
-            int k = 7;
-            k = (d[3].x == m) ? 6 : k;
-            k = (d[2].y == m) ? 5 : k;
-            k = (d[2].x == m) ? 4 : k;
-            k = (d[1].y == m) ? 3 : k;
-            k = (d[1].x == m) ? 2 : k;
-            k = (d[0].y == m) ? 1 : k;
-            k = (d[0].x == m) ? 0 : k;
-            best = m;
-            bidx = (int32_t)(L * kLeaf) + k;
-            set_cube(cube, qx, qy, qz, m);
-        }
-    }
-}
 
 // ---- leaf work compacted across the packet ---------------------------------------------
 // A wave that runs leaf L for all 64 lanes wastes most of them: a packet touches ~9 leaves,
