@@ -1,4 +1,4 @@
-// kd_refine.h -- turns the Morton order into a locally kd-ordered one.
+// kd_refine.h -- exact median (kd) splits of a group of 4096 points, entirely in LDS.
 //
 // Fixed-size runs of a Morton-sorted cloud are not octree cells: a run straddles cell
 // boundaries, its AABB is an L-shaped union's bounding box, and neighbouring boxes
@@ -9,14 +9,16 @@
 // exactly (one record = three median splits).
 //
 // Building a global kd-tree costs a segmented sort per level (what the reference's
-// FLANN builder does).  Here the Morton sort does the coarse work and each group of
-// 4096 Morton-consecutive points is re-ordered ENTIRELY IN LDS by one workgroup:
-// 9 levels of {per-segment bbox -> longest axis -> bitonic sort of the segment along
-// it}, i.e. exact median splits down to the 8-point leaves.  After it a point lies in
-// 1.27 leaf boxes, 1.64 / 2.2 boxes at the 64 / 512 levels; the levels above the group
-// keep their Morton overlap but are few.  The same re-ordering is applied to the
-// source so that a packet of 64 queries is a compact kd cell too.
-// Cost: ~350 LDS compare-exchange stages per group, ~0.1 ms for 10M points.
+// FLANN builder does).  Here a coarse partition does the global work -- kd cells from
+// sampled planes for the target (kd_cells.h), the Morton order for the source -- and each
+// group of 4096 positions is then split by ONE workgroup in LDS (kd_sort_levels): 9 rounds
+// of {per-segment bbox -> longest axis -> bitonic sort of the segment along it}, i.e.
+// exact median splits down to the 8-point leaves.  After it a point lies in 1.27 leaf
+// boxes (1.64 / 2.2 at the 64 / 512 levels, for Morton groups).
+// Users: kd_build_groups (kd_build.h: the target's groups, written out as finished tree
+// pieces), kd_refine_groups (below: order only, the source, so that a packet of 64
+// queries is a compact kd cell), cells_planes (kd_cells.h: split planes from samples).
+// Cost: ~350 LDS compare-exchange stages per group; 1.2 ms for a 10M-point cloud.
 #pragma once
 #include "device_utils.h"
 

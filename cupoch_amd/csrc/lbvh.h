@@ -1,15 +1,18 @@
-// lbvh.h -- Morton ordering and LBVH construction for the target cloud, and
+// lbvh.h -- pieces of the target tree's construction that are not group-local, and the
 // Morton-ordered SoA staging of the source cloud.
 //
-// Replaces knn::KDTreeFlann::SetRawData + flann::CudaKdTreeBuilder::buildTree
+// The tree replaces knn::KDTreeFlann::SetRawData + flann::CudaKdTreeBuilder::buildTree
 // (knn/kdtree_flann.inl:124-144; third_party/flann/algorithms/
-// kdtree_cuda_builder.h:401-700), i.e. three thrust sorts plus ~10 thrust
-// passes per tree level with a host round trip per level, by:
-//   bounds -> 3*B-bit Morton keys -> one LSD radix sort -> leaves of 8
-//   consecutive points (one 128-B line each) -> implicit complete 8-ary tree
-//   refitted bottom-up, one small launch per level (7 at 10M points), no host sync.
-// Topology is implicit: a complete 8-ary tree over the leaves, one 256-B record of
-// 8 child boxes per node (see traverse.h).
+// kdtree_cuda_builder.h:401-700), i.e. three thrust sorts plus ~10 thrust passes per
+// tree level with a host round trip per level.  Topology is implicit: a complete 8-ary
+// tree over leaves of 8 points (one 128-B line each), one 256-B record of 8 child boxes
+// per node (traverse.h), refitted bottom-up.  The default build is
+//   kd cells (kd_cells.h) -> one workgroup per 4096-slot group writes its leaves and
+//   three record levels (kd_build.h) -> build_level once per level above the groups;
+// this file holds build_level, the record store helpers, and the Morton path
+//   bounds -> 3*B-bit Morton keys -> LSD radix sort -> build_leaves -> build_level ...
+// which stages the source (keys + gather_source) and remains as the A/B fallback for the
+// target (MI_ICP_NO_CELLS).
 #pragma once
 #include "device_utils.h"
 #include "traverse.h"

@@ -1,7 +1,7 @@
-// traverse.h -- wave-uniform traversal of the 8-wide LBVH shared by the 1-NN and
+// traverse.h -- wave-uniform traversal of the implicit 8-ary tree shared by the 1-NN and
 // k-NN kernels.
 //
-// Tree.  Leaves are the 128-B lines of 8 Morton-consecutive points.  Above them
+// Tree.  Leaves are the 128-B lines of 8 consecutive slots of the target's kd order.  Above them
 // sits a complete 8-ary tree: node ids are digit strings with a leading 1 (root
 // = 1, child c of id = 8*id + c), so the level-k ids are [8^k, 2*8^k) and the
 // ancestor j levels up is id >> 3j.  Node id owns one 256-B RECORD holding the
@@ -13,8 +13,9 @@
 // A record is 4 sibling pairs of 12 floats {Amin.x,Bmin.x, Amin.y,Bmin.y, Amin.z,
 // Bmin.z, Amax.x,Bmax.x, Amax.y,Bmax.y, Amax.z,Bmax.z} = 192 B, padded to 256 B.
 // Three s_load_dwordx16 fetch it in ONE round trip (they are issued together and
-// waited for once), and each lane tests two boxes per packed fp32 instruction
-// (v_pk_add_f32 on {A,B} register pairs).
+// waited for once).  Floats 48..53 hold the node's OWN box and float 54 the flag "this box
+// is disjoint from every point outside the subtree" (lbvh.h store_own) for the bottom-up
+// search below.
 //
 // Why 8-wide: the traversal is bound by dependent memory round trips (one wave
 // = one outstanding record; measured ~1000 cycles per step at 10M points), not
