@@ -128,6 +128,14 @@ __global__ __launch_bounds__(256) void voxel_heads(const float* __restrict__ pts
     head[i] = h;
 }
 
+// the same from the sorted PACKED keys (one key = one voxel): no gathers
+__global__ __launch_bounds__(256) void voxel_heads_keys(const uint64_t* __restrict__ keys, int64_t n,
+                                                        uint32_t* __restrict__ head) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
 // seg_start[rank of head i] = i ; seg_start[m] = n is written by the host side
 __global__ __launch_bounds__(256) void voxel_seg_starts(const uint32_t* __restrict__ head,
                                                         const uint32_t* __restrict__ pos,

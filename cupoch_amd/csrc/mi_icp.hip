@@ -1313,11 +1313,14 @@ int mi_icp_voxel_downsample(mi_icp_ctx* c, const float* xyz, const float* normal
     SortBuffers sb;
     TRY(sort_buffers(c, n, &sb));
     const uint32_t* order;
+    const uint64_t* packed_sorted = nullptr;  // sorted voxel keys when one key identifies the voxel
     const int nb = blocks_for(n);
     if (bits[0] + bits[1] + bits[2] <= 64) {
         voxel_keys<<<nb, 256, 0, c->stream>>>(dp, n, g, -1, nullptr, sb.keys[0], sb.vals[0]);
         KCHK(c);
-        order = sb.vals[radix_sort_pairs(c->stream, sb, n, bits[0] + bits[1] + bits[2])];
+        const int cur = radix_sort_pairs(c->stream, sb, n, bits[0] + bits[1] + bits[2]);
+        order = sb.vals[cur];
+        packed_sorted = sb.keys[cur];
     } else {
         // three stable sorts, least significant axis first
         const uint32_t* prev = nullptr;
@@ -1343,7 +1346,8 @@ int mi_icp_voxel_downsample(mi_icp_ctx* c, const float* xyz, const float* normal
     TRY(ensure(c, c->dense_idx, (size_t)n, (uint32_t**)&pos));
     // `order` may live in seg_start's buffer only in the fallback's intermediate rounds, never at the end
     TRY(ensure(c, c->scan_tmp, (size_t)scan_num_tiles(n) + 2, &tmp));
-    voxel_heads<<<nb, 256, 0, c->stream>>>(dp, n, g, order, head);
+    if (packed_sorted) voxel_heads_keys<<<nb, 256, 0, c->stream>>>(packed_sorted, n, head);
+    else voxel_heads<<<nb, 256, 0, c->stream>>>(dp, n, g, order, head);
     KCHK(c);
     exclusive_scan_u32(c->stream, head, pos, n, tmp);
     KCHK(c);
