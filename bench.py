@@ -196,7 +196,11 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "kernel_ms_avg": round(nn_ms, 4), "reduce_ms_avg": round(red_ms, 4)},
+                         "kernel_ms_avg": round(nn_ms, 4), "reduce_ms_avg": round(red_ms, 4),
+                         # a whole iteration moves 60 N_s + 20 N_t algorithmic bytes
+                         "iteration": {"algorithmic_bytes": 60.0 * n + 20.0 * nt,
+                                       "achieved": round((60.0 * n + 20.0 * nt) * args.steps / elapsed / 1e9, 2),
+                                       "frac": round((60.0 * n + 20.0 * nt) * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5)}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(src, tgt, nrm, max_dist, n)

@@ -77,6 +77,32 @@ def init_engine_comm(engine, n_source_total):
     return rank, world
 
 
+def gather_correspondences(local_pairs, shard_indices):
+    """The job's correspondence set from the ranks' shard-local ones: source indices are
+    mapped back through the shard (shard_source's result), everything is all-gathered and
+    ordered ascending in source index, as registration.cu:62-69 leaves a single-GPU set.
+    Every rank returns the same (n, 2) int32 array."""
+    import torch
+    import torch.distributed as dist
+    pairs = np.asarray(local_pairs, np.int32).reshape(-1, 2).copy()
+    if len(pairs):
+        pairs[:, 0] = np.asarray(shard_indices, np.int64)[pairs[:, 0]].astype(np.int32)
+    device = None
+    if dist.get_backend() == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
+    count = torch.tensor([len(pairs)], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(count) for _ in range(dist.get_world_size())]
+    dist.all_gather(counts, count)
+    cap = int(max(int(c.item()) for c in counts))
+    buf = torch.full((max(cap, 1), 2), -1, dtype=torch.int32, device=device)
+    if len(pairs):
+        buf[: len(pairs)] = torch.from_numpy(pairs).to(buf.device)
+    parts = [torch.empty_like(buf) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, buf)
+    out = np.concatenate([p.cpu().numpy()[: int(c.item())] for p, c in zip(parts, counts)], axis=0)
+    return out[np.argsort(out[:, 0], kind="stable")] if len(out) else out.reshape(0, 2)
+
+
 def allreduce_system(sys32):
     """Host-side equivalent of the in-library all-reduce, for any backend
     (used by the CPU/gloo tests and by Python-level estimators)."""

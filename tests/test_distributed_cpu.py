@@ -42,6 +42,9 @@ def _worker(rank, world, port, out_dir):
     np.save(os.path.join(out_dir, "sys_%d.npy" % rank), total)
     np.save(os.path.join(out_dir, "T_%d.npy" % rank), T)
     np.save(os.path.join(out_dir, "idx_%d.npy" % rank), mine)
+    # the job's correspondence set from the shard-local ones
+    allc = D.gather_correspondences(ev.correspondence_set, mine)
+    np.save(os.path.join(out_dir, "corr_%d.npy" % rank), allc)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,6 +61,9 @@ def test_two_rank_sharded_system_equals_single_process(tmp_path):
     np.testing.assert_array_equal(s0, s1)                       # every rank holds the same sum
     np.testing.assert_allclose(s0, full, rtol=1e-12, atol=1e-12 * np.abs(full).max())
     np.testing.assert_array_equal(np.load(tmp_path / "T_0.npy"), np.load(tmp_path / "T_1.npy"))
+    c0, c1 = np.load(tmp_path / "corr_0.npy"), np.load(tmp_path / "corr_1.npy")
+    np.testing.assert_array_equal(c0, c1)
+    np.testing.assert_array_equal(c0, ev.correspondence_set)    # = the single-process set, same order
     i0, i1 = np.load(tmp_path / "idx_0.npy"), np.load(tmp_path / "idx_1.npy")
     assert len(np.intersect1d(i0, i1)) == 0 and len(i0) + len(i1) == 6000
 
