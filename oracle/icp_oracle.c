@@ -1544,7 +1544,8 @@ static double now_s(void) {
 ORACLE_API int oracle_bench_iteration(const float *src, int64_t ns, const float *tgt,
                                       const float *tgt_nrm, int64_t nt, float max_dist,
                                       int64_t n_sample, int repeats, double *build_s,
-                                      double *iter_s, double *fitness) {
+                                      double *iter_s, double *fitness, int64_t n_single,
+                                      double *iter_single_s) {
     if (n_sample > ns) n_sample = ns;
     double t0 = now_s();
     kd_tree *tree = kd_build(tgt, (int)nt);
@@ -1566,6 +1567,29 @@ ORACLE_API int oracle_bench_iteration(const float *src, int64_t ns, const float 
     }
     *iter_s = best;
     *fitness = res.fitness;
+    /* the same iteration on ONE thread over the first n_single points (the reference's README
+     * quotes its CPU comparison single-threaded, README.md:124) */
+    if (iter_single_s) {
+        *iter_single_s = 0.0;
+        if (n_single > n_sample) n_single = n_sample;
+        if (n_single > 0) {
+#ifdef _OPENMP
+            const int saved = omp_get_max_threads();
+            omp_set_num_threads(1);
+#endif
+            oracle_result r1;
+            t0 = now_s();
+            eval_correspondences(tree, src, n_single, max_dist, cor, ti, td, &r1);
+            double sys[32];
+            float T[16];
+            oracle_compute_system(EST_PT2PL, src, NULL, NULL, tgt, tgt_nrm, NULL, cor, r1.n_corres, sys);
+            oracle_solve_system(sys, -1.0f, T);
+            *iter_single_s = now_s() - t0;
+#ifdef _OPENMP
+            omp_set_num_threads(saved);
+#endif
+        }
+    }
     kd_free(tree);
     free(ti);
     free(td);

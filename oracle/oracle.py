@@ -348,12 +348,16 @@ def ref_flann_radius(tgt, qry, radius, max_nn):
     return int(r), idx, d2
 
 
-def bench_iteration(src, tgt, tgt_nrm, max_dist, n_sample, repeats=1):
-    """(build_s, iter_s, fitness): wall-clock of one point-to-plane iteration over the
-    first n_sample source points against the full target (bench.py cpu_baseline)."""
+def bench_iteration(src, tgt, tgt_nrm, max_dist, n_sample, repeats=1, n_single=0):
+    """(build_s, iter_s, fitness[, iter_single_s]): wall-clock of one point-to-plane iteration
+    over the first n_sample source points against the full target (bench.py cpu_baseline);
+    n_single > 0 also times it on one thread over the first n_single points."""
     src, tgt, tn = _f32(src, (-1, 3)), _f32(tgt, (-1, 3)), _f32(tgt_nrm, (-1, 3))
-    b, t, f = C.c_double(0), C.c_double(0), C.c_double(0)
+    b, t, f, t1 = C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
     lib().oracle_bench_iteration(_p(src), C.c_int64(len(src)), _p(tgt), _p(tn),
                                  C.c_int64(len(tgt)), C.c_float(max_dist), C.c_int64(n_sample),
-                                 C.c_int(repeats), C.byref(b), C.byref(t), C.byref(f))
+                                 C.c_int(repeats), C.byref(b), C.byref(t), C.byref(f),
+                                 C.c_int64(n_single), C.byref(t1))
+    if n_single > 0:
+        return b.value, t.value, f.value, t1.value
     return b.value, t.value, f.value
