@@ -86,7 +86,7 @@ template <int OUT>
 __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
         const float* __restrict__ records_g, const float* __restrict__ tblk_g, uint32_t leaf_first, int64_t n,
         int nleaf,
-        int k, float r2, uint32_t nblocks, uint32_t max_steps, float* __restrict__ normals_out,
+        int k, float r2, uint32_t nblocks, float* __restrict__ normals_out,
         const float4* __restrict__ tnrm, float4* __restrict__ tgrad) {
     __shared__ float s_d2[kKnnWaves][kMaxKnn * 64];
     __shared__ int32_t s_idx[kKnnWaves][kMaxKnn * 64];
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
     set_cube(cube, qx, qy, qz, st.worst);
 
     // ---- B: traversal -------------------------------------------------------------
-    traverse_wide(records_g, leaf_first, cube, max_steps, [&](uint32_t Lu) {
+    traverse_wide(records_g, leaf_first, cube, [&](uint32_t Lu) {
         const int L = (int)Lu;
         if (L >= seed_lo && L < seed_hi) return;
         const cfloat_p line = tblk + (size_t)L * kLeafFloats;

@@ -417,11 +417,10 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
     const uint32_t npackets = (uint32_t)((c->ns + 63) / 64);
     const uint32_t nblocks = (npackets + kNNPacketsPerBlock - 1) / kNNPacketsPerBlock;
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
-    const uint32_t max_steps = c->nrecords + 8u;  // every record is visited at most once
     const Xform X = make_xform(T);
     EvTimer t(c, 0, loop != nullptr);
 #define MI_NN_ARGS (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns, \
-                   (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, X, loop, r2, nblocks, max_steps, idx, d2, stats
+                   (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, X, loop, r2, nblocks, idx, d2, stats
     const bool use_seed = seed && c->nn_valid;
     if (stats) {
         if (use_seed) nn_packet_kernel<true, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
@@ -1391,7 +1390,7 @@ static int estimate_normals_impl(mi_icp_ctx* c, const float* xyz, int64_t n, int
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
     knn_normals_kernel<0><<<grid, kKnnThreads, 0, c->stream>>>((const float*)c->nodes.p, (const float*)c->tblk.p,
                                                                c->leaf_first, c->nts, c->nleaf, knn, r2, nblocks,
-                                                               c->nrecords + 8u, dn, nullptr, nullptr);
+                                                               dn, nullptr, nullptr);
     KCHK(c);
     if (mem_kind == MI_ICP_HOST) TRY(from_device(c, (const float*)dn, normals, (size_t)n * 3, mem_kind));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1465,7 +1464,7 @@ int mi_icp_compute_color_gradients(mi_icp_ctx* c, float radius, int max_nn, floa
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
     knn_normals_kernel<1><<<grid, kKnnThreads, 0, c->stream>>>(
             (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, c->nts, c->nleaf, max_nn,
-            radius * radius, nblocks, c->nrecords + 8u, dg, (const float4*)c->tnrm.p, tgrad);
+            radius * radius, nblocks, dg, (const float4*)c->tnrm.p, tgrad);
     KCHK(c);
     c->t_has_grad = true;
     if (gradients_out) {

@@ -91,7 +91,7 @@ template <bool SEED, bool STATS>
 __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_packet_kernel(
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
         int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
-        uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, uint32_t nblocks, uint32_t max_steps, int32_t* __restrict__ nn_idx,
+        uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, uint32_t nblocks, int32_t* __restrict__ nn_idx,
         float* __restrict__ nn_d2, unsigned long long* __restrict__ stats) {
     __shared__ PacketShared s_pk[kNNPacketsPerBlock];
     uint32_t logical;

@@ -147,8 +147,7 @@ __device__ __forceinline__ uint32_t wave_or_mask(uint32_t vm) {
 //    record_index(id) - id tracked per level (8*off + 1 one level down, an
 //    arithmetic shift back up), used as the SGPR offset of the s_loads;
 //  * no step limit: the walk consumes a finite stack of sibling bits and cannot
-//    cycle, whatever the boxes contain (max_steps is kept for the callers'
-//    signature and ignored);
+//    cycle, whatever the boxes contain;
 //  * pops take the next sibling from the same find-first-bit that found the level.
 //
 // leaf_rec(lbase, vm, hit) is called once per visited LEAF-LEVEL record: lbase = index of
@@ -293,8 +292,7 @@ __device__ __forceinline__ uint32_t traverse_records(const float* records_g, uin
 // record were all tested before the first of them shrank the bounds: at worst a wasted leaf).
 template <class LeafFn>
 __device__ __forceinline__ uint32_t traverse_wide(const float* records_g, uint32_t leaf_first,
-                                                  const Cube& cube, uint32_t /*max_steps*/,
-                                                  LeafFn&& leaf) {
+                                                  const Cube& cube, LeafFn&& leaf) {
     return traverse_records(records_g, leaf_first, cube, [&](uint32_t lbase, uint32_t, uint32_t hit) {
         while (hit) {
             const uint32_t c = (uint32_t)__builtin_ctz(hit);
