@@ -260,7 +260,8 @@ int sort_buffers(mi_icp_ctx* c, int64_t n, SortBuffers* sb) {
 
 // Morton order of an AoS cloud: returns the device array order[sorted] = original.
 // grid_bounds/grid_bits: quantise on another cloud's grid instead of the cloud's own.
-int morton_order(mi_icp_ctx* c, const float* pts, int64_t n, const uint32_t** order,
+// kd_refine: also split every group of 4096 Morton-consecutive points into kd cells (kd_refine.h)
+int morton_order(mi_icp_ctx* c, const float* pts, int64_t n, const uint32_t** order, bool kd_refine,
                  const float* grid_bounds = nullptr, int grid_bits = 0, float** own_bounds = nullptr) {
     float* bnd = nullptr;
     if (!grid_bounds || own_bounds) TRY(compute_bounds(c, pts, n, &bnd));
@@ -273,8 +274,7 @@ int morton_order(mi_icp_ctx* c, const float* pts, int64_t n, const uint32_t** or
     KCHK(c);
     const int cur = radix_sort_pairs(c->stream, sb, n, 3 * bits);
     KCHK(c);
-    static const bool no_kd = std::getenv("MI_ICP_NO_KD") != nullptr;  // A/B switch for tuning
-    if (no_kd) {
+    if (!kd_refine) {
         *order = sb.vals[cur];
         return MI_ICP_OK;
     }
@@ -712,7 +712,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     CellLayout lay = {};
     int64_t nts = n;
     if (no_cells) {
-        TRY(morton_order(c, d_pts, n, &order));
+        TRY(morton_order(c, d_pts, n, &order, true));
     } else {
         TRY(kd_cell_layout(c, d_pts, n, &lay));
         nts = lay.ngroups * kKdGroup;
@@ -815,11 +815,13 @@ int mi_icp_set_source(mi_icp_ctx* c, const float* xyz, const float* normals, con
     TRY(to_device(c, normals, (size_t)n * 3, mem_kind, c->stage[4], &d_nrm));
     TRY(to_device(c, covs, (size_t)n * 9, mem_kind, c->stage[5], &d_cov));
 
-    // Packets are 64 consecutive points of this order (measured: ordering the source on
-    // the target's Morton grid instead of its own does not reduce the records a packet
-    // visits -- the ~2x overlap of neighbouring leaf boxes dominates, not grid alignment).
+    // Packets are 64 consecutive points of this order.  It only has to make the packets of the
+    // FIRST (unseeded) pass compact: the loop re-sorts the source by match right after it.
+    // Measured: the in-group kd split on top of the Morton order (kd_refine.h) costs more here
+    // (1.2 ms at 10M) than it saves in that one pass (0.15 ms); MI_ICP_SOURCE_KD=1 turns it on.
+    static const bool source_kd = std::getenv("MI_ICP_SOURCE_KD") != nullptr;
     const uint32_t* order;
-    TRY(morton_order(c, d_pts, n, &order));
+    TRY(morton_order(c, d_pts, n, &order, source_kd));
 
     float *sx, *sy, *sz, *scov = nullptr, *d2;
     int32_t *sperm, *idx;
@@ -1569,7 +1571,7 @@ int mi_icp_debug_morton_order(mi_icp_ctx* c, const float* xyz, int64_t n, uint32
     const float* d_pts;
     TRY(to_device(c, xyz, (size_t)n * 3, MI_ICP_HOST, c->stage[0], &d_pts));
     const uint32_t* order;
-    TRY(morton_order(c, d_pts, n, &order));
+    TRY(morton_order(c, d_pts, n, &order, false));
     HIPCHK(c, hipMemcpyAsync(order_out, order, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MI_ICP_OK;
