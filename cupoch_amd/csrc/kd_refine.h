@@ -16,8 +16,8 @@
 // exact median splits down to the 8-point leaves.  After it a point lies in 1.27 leaf
 // boxes (1.64 / 2.2 at the 64 / 512 levels, for Morton groups).
 // Users: kd_build_groups (kd_build.h: the target's groups, written out as finished tree
-// pieces), kd_refine_groups (below: order only, the source, so that a packet of 64
-// queries is a compact kd cell), cells_planes (kd_cells.h: split planes from samples).
+// pieces), cells_planes (kd_cells.h: split planes from samples), kd_refine_groups (below:
+// order only -- the Morton-run fallback tree, and the source when MI_ICP_SOURCE_KD is set).
 // Cost: ~350 LDS compare-exchange stages per group; 1.2 ms for a 10M-point cloud.
 #pragma once
 #include "device_utils.h"
