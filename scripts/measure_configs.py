@@ -73,11 +73,14 @@ t_cov = timed(lambda: eng.covariances_from_normals(d_nrm, 1e-3), 3)
 tcov = eng.covariances_from_normals(d_nrm, 1e-3)
 scov = eng.covariances_from_normals(gpu(src_nrm), 1e-3)
 emit(row="covariances_from_normals", n=n5, ms=t_cov * 1e3, GBps=(12 + 36) * n5 / t_cov / 1e9)
+eng.set_target(d_tgt, d_nrm, tcov)      # first call at this size: buffer growth (hipMalloc), not timed
+eng.set_source(d_src, None, scov)
+eng.synchronize()
 t0 = time.perf_counter()
 eng.set_target(d_tgt, d_nrm, tcov)
 eng.set_source(d_src, None, scov)
 eng.synchronize()
-emit(row="LBVH build + source staging (GICP, with covariances)", n=n5, ms=(time.perf_counter() - t0) * 1e3)
+emit(row="tree build + source staging (GICP, with covariances)", n=n5, ms=(time.perf_counter() - t0) * 1e3)
 eng.set_profiling(True)
 eng.icp_begin(_lib.EST_GENERALIZED, max_dist, None, -1.0)
 eng.icp_iterate(3)
