@@ -118,8 +118,18 @@ def main():
     eng.set_source(d_src)
     eng.synchronize()
     build_ms = (time.perf_counter() - t0) * 1e3
+    host_allreduce = False
     if world > 1:
-        D.init_engine_comm(eng, n)
+        try:
+            D.init_engine_comm(eng, n)
+        except Exception as e:   # noqa: BLE001 -- keep the scaling run alive, say what happened
+            host_allreduce = True
+            eng.set_global_source_count(n)
+            if rank == 0:
+                print("bench: in-library RCCL communicator unavailable (%s); falling back to a host-driven "
+                      "loop with torch.distributed all-reduce" % e, file=sys.stderr)
+    elif os.environ.get("MI_ICP_BENCH_HOST_LOOP") == "1":
+        host_allreduce = True      # exercises the fallback loop on one rank
     elif os.environ.get("MI_ICP_FORCE_COMM") == "1":
         # single-rank communicator: exercises the RCCL all-reduce path on a 1-GPU box
         from cupoch_amd.engine import comm_unique_id
@@ -134,8 +144,38 @@ def main():
     # pass of the same K steps right after.
     in_region_events = world == 1 and os.environ.get("MI_ICP_BENCH_NO_EVENTS") != "1"
     eng.set_profiling(in_region_events)
-    eng.icp_begin(_lib.EST_POINT_TO_PLANE, max_dist, None, -1.0)
-    eng.icp_iterate(args.warmup)
+
+    class _HostLoop:
+        """Fallback for N > 1 without the in-library communicator: the same iteration driven
+        from the host -- search + reduction per rank, torch.distributed all-reduce of the 32
+        doubles, 6x6 solve on the host.  One host round trip per iteration."""
+        def __init__(self):
+            self.T = np.eye(4, dtype=np.float32)
+            self.res = None
+
+        def iterate(self, k):
+            from cupoch_amd.engine import solve_system
+            for _ in range(k):
+                self.res = eng.evaluate_registration(max_dist, self.T)
+                sys32 = eng.compute_system(_lib.EST_POINT_TO_PLANE, self.T)
+                if world > 1:
+                    sys32 = D.allreduce_system(sys32)
+                ok, upd = solve_system(sys32, -1.0)
+                self.T = (upd @ self.T).astype(np.float32)
+            if world > 1:
+                stat = D.allreduce_system(np.array([self.res.fitness * len(src_local), 0.0]))
+                self.res.fitness = float(stat[0] / n)
+            self.res.transformation = (C.c_float * 16)(*self.T.T.reshape(-1))
+            return self.res
+
+    if host_allreduce:
+        import ctypes as C
+        hl = _HostLoop()
+        eng.icp_iterate = hl.iterate           # same call shape below
+        hl.iterate(args.warmup)
+    else:
+        eng.icp_begin(_lib.EST_POINT_TO_PLANE, max_dist, None, -1.0)
+        eng.icp_iterate(args.warmup)
     prof0 = eng.get_profile()
 
     if world > 1:
@@ -191,7 +231,8 @@ def main():
             "config": {"workload": "%s-vs-%s point-to-plane ICP, LBVH 1-NN, r=2*N^(-1/3), uniform random "
                                    "clouds (BASELINE.md section 3)" % (_fmt(n), _fmt(n)),
                        "points": n, "max_correspondence_distance": max_dist, "det_thresh": -1.0,
-                       "parallelism": "source sharded x%d, target+LBVH replicated, RCCL all-reduce of 32 f64/iter" % world
+                       "parallelism": ("source sharded x%d, target+tree replicated, %s all-reduce of 32 f64/iter"
+                                       % (world, "host-driven torch.distributed" if host_allreduce else "in-library RCCL"))
                        if world > 1 else "single GPU",
                        "accumulate": "f64", "build_ms": round(build_ms, 2),
                        "final_fitness": round(float(res.fitness), 6),

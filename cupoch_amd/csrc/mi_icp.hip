@@ -873,7 +873,7 @@ int mi_icp_search_radius_1nn(mi_icp_ctx* c, const float* T, float radius, int32_
     if (c->ns <= 0) return fail(c, MI_ICP_ERR_STATE, "search: no source set");
     const Mat4 M = load_T(T);
     const float r2 = radius * radius;  // kdtree_flann.inl:119-120
-    TRY(launch_nn(c, M, r2, false));
+    TRY(launch_nn(c, M, r2, true));  // seeded when a previous search exists (same result, see evaluate_registration)
     if (c->nt <= 0) {
         float* d2 = (float*)c->nn_d2.p;
         fill_i32<<<blocks_for(c->ns), 256, 0, c->stream>>>((int32_t*)d2, c->ns, 0x7f800000);
@@ -1038,7 +1038,9 @@ int mi_icp_evaluate_registration(mi_icp_ctx* c, float max_distance, const float*
     // registration.cu:114-116: the source is moved only when T is not (approximately) identity
     const Mat4 apply = host::is_identity4(M) ? host::identity4() : M;
     double sys[kSysSize];
-    TRY(launch_nn(c, apply, max_distance * max_distance, false));
+    // seeded by the previous search of the same clouds when there is one: the result is the
+    // same exact nearest neighbour (equal distances resolve to the lowest slot either way)
+    TRY(launch_nn(c, apply, max_distance * max_distance, true));
     TRY(launch_reduce(c, kEstP2P, 1, apply));
     TRY(fetch_system(c, sys));
     stats_from_system(c, sys, &out->fitness, &out->inlier_rmse);

@@ -109,5 +109,7 @@ def allreduce_system(sys32):
     import torch
     import torch.distributed as dist
     t = torch.from_numpy(np.ascontiguousarray(sys32, np.float64).copy())
+    if dist.get_backend() == "nccl":   # RCCL reduces device tensors only
+        t = t.to(torch.device("cuda", torch.cuda.current_device()))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t.numpy()
+    return t.cpu().numpy()
