@@ -94,8 +94,13 @@ void Check(int rc) {
 const float* Ptr(const utility::device_vector<Eigen::Vector3f>& v) { return v.empty() ? nullptr : v.data()->data(); }
 const float* Ptr(const utility::device_vector<Eigen::Matrix3f>& v) { return v.empty() ? nullptr : v.data()->data(); }
 
+// bumped whenever the engine's clouds are replaced: lets the generic ICP loop notice that a
+// user estimator has used the engine (and that its own target tree / seeds are gone)
+static unsigned long long g_load_generation = 0;
+
 void LoadClouds(const geometry::PointCloud& source, const geometry::PointCloud& target) {
     mi_icp_ctx* c = Engine();
+    ++g_load_generation;
     Check(mi_icp_set_target(c, Ptr(target.points_), target.HasNormals() ? Ptr(target.normals_) : nullptr,
                             target.HasCovariances() ? Ptr(target.covariances_) : nullptr,
                             (int64_t)target.points_.size(), MI_ICP_DEVICE));
@@ -298,14 +303,21 @@ RegistrationResult RegistrationICP(const geometry::PointCloud& source, const geo
         return MakeResult(r);
     }
 
-    // user-defined estimator: the reference loop verbatim (registration.cu:144-171)
+    // user-defined estimator: the reference loop (registration.cu:144-171).  The engine keeps the
+    // ORIGINAL source and the target tree and evaluates under the accumulated transformation
+    // (seeded by the previous iteration's matches); the estimator still sees the transformed copy.
+    // If the estimator itself goes through the engine, the clouds are simply loaded again.
     Eigen::Matrix4f transformation = init;
     geometry::PointCloud pcd = source;
     if (!init.isIdentity()) pcd.Transform(init);
+    unsigned long long loaded = 0;
     auto evaluate = [&](const Eigen::Matrix4f& T) {
-        LoadClouds(pcd, target);
+        if (loaded == 0 || loaded != g_load_generation) {
+            LoadClouds(source, target);
+            loaded = g_load_generation;
+        }
         mi_icp_result r;
-        Check(mi_icp_evaluate_registration(Engine(), max_correspondence_distance, nullptr, &r));
+        Check(mi_icp_evaluate_registration(Engine(), max_correspondence_distance, T.data(), &r));
         RegistrationResult res = MakeResult(r);
         res.transformation_ = T;
         return res;

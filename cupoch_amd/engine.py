@@ -122,6 +122,7 @@ class Engine:
 
     # -- clouds ------------------------------------------------------------------
     def set_target(self, points, normals=None, covariances=None):
+        self.generation = getattr(self, "generation", 0) + 1   # the clouds changed (registration._generic_icp)
         p = _Buf(points, np.float32, 3, self.device)
         n = _Buf(normals, np.float32, 3, self.device)
         c = _Buf(_cov_in(covariances), np.float32, 9, self.device)
@@ -131,6 +132,7 @@ class Engine:
         self.n_target = p.n
 
     def set_source(self, points, normals=None, covariances=None):
+        self.generation = getattr(self, "generation", 0) + 1
         p = _Buf(points, np.float32, 3, self.device)
         n = _Buf(normals, np.float32, 3, self.device)
         c = _Buf(_cov_in(covariances), np.float32, 9, self.device)

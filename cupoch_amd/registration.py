@@ -173,27 +173,33 @@ def registration_icp(source, target, max_correspondence_distance, init=None,
 
 
 def _generic_icp(source, target, max_dist, init, est, crit):
-    """The reference loop verbatim, for user-defined estimators."""
+    """The reference loop, for user-defined estimators.  The engine keeps the ORIGINAL source
+    and the target tree and evaluates under the accumulated transformation (seeded by the
+    previous iteration's matches); the estimator still sees the transformed copy.  If the
+    estimator itself goes through the engine, the clouds are simply loaded again."""
     eng = get_engine()
     pcd = source.clone()
     transformation = init.copy()
     if not np.allclose(init, np.eye(4), atol=1e-5, rtol=0):
         pcd.transform(init)
+    loaded = [None]
 
-    def evaluate():
-        _load_clouds(eng, pcd, target)
-        return _result_from(eng, eng.evaluate_registration(max_dist, None))
+    def evaluate(T):
+        if loaded[0] != getattr(eng, "generation", 0):
+            _load_clouds(eng, source, target)
+            loaded[0] = eng.generation
+        out = _result_from(eng, eng.evaluate_registration(max_dist, T))
+        out.transformation = T.copy()
+        return out
 
-    result = evaluate()
-    result.transformation = transformation.copy()
+    result = evaluate(transformation)
     for _ in range(crit.max_iteration):
         update = np.asarray(est.compute_transformation(pcd, target, result.correspondence_set),
                             np.float32)
         transformation = (update @ transformation).astype(np.float32)
         pcd.transform(update)
         backup = result
-        result = evaluate()
-        result.transformation = transformation.copy()
+        result = evaluate(transformation)
         if (abs(backup.fitness - result.fitness) < crit.relative_fitness and
                 abs(backup.inlier_rmse - result.inlier_rmse) < crit.relative_rmse):
             break
