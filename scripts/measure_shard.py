@@ -29,5 +29,11 @@ for world in (1, 2, 4, 8):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 30
     if base_ms is None:
         base_ms = dt * 1e3
+    eng.set_profiling(True)
+    p0 = eng.get_profile()
+    eng.icp_iterate(30)
+    p1 = eng.get_profile()
+    eng.set_profiling(False)
     print(json.dumps({"ranks": world, "source_points_on_this_rank": int(len(mine)), "ms_per_step_compute_only": round(dt * 1e3, 4),
+                      "nn_ms": round((p1["nn_ms"] - p0["nn_ms"]) / 30, 4), "reduce_ms": round((p1["reduce_ms"] - p0["reduce_ms"]) / 30, 4),
                       "ideal_speedup_if_allreduce_were_free": round(base_ms / (dt * 1e3), 2)}), flush=True)
