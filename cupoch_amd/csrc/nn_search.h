@@ -26,7 +26,7 @@
 
 namespace mi {
 
-constexpr int kNNThreads = 256;
+constexpr int kNNThreads = 64;   // one packet per workgroup: the dispatcher refills wave slots one at a time (3 % faster than 4)
 constexpr int kNNPacketsPerBlock = kNNThreads / 64;
 
 // ---- leaf work compacted across the packet ---------------------------------------------
