@@ -99,11 +99,12 @@ MI_ICP_API int mi_icp_synchronize(mi_icp_ctx* ctx);
  * mi_icp_set_target replaces knn::KDTreeFlann::KDTreeFlann(target.points_) /
  * SetRawData (knn/kdtree_flann.inl:124-144) and FLANN's
  * CudaKdTreeBuilder::buildTree (third_party/flann/algorithms/
- * kdtree_cuda_builder.h:401-700): Morton-sorts the target and builds the LBVH.
- * normals / covs may be NULL.
+ * kdtree_cuda_builder.h:401-700): partitions the target into kd cells and
+ * builds the implicit 8-ary tree over them.  normals / covs may be NULL.
+ * Synchronous (the tree's size is read back once); at most ~3e8 points.
  * mi_icp_set_source replaces `geometry::PointCloud pcd = source`
  * (registration/registration.cu:147): the engine keeps a Morton-sorted SoA
- * copy and never mutates the caller's cloud. */
+ * copy and never mutates the caller's cloud.  Stream-ordered. */
 MI_ICP_API int mi_icp_set_target(mi_icp_ctx* ctx, const float* xyz, const float* normals,
                                  const float* covs, int64_t n, int mem_kind);
 MI_ICP_API int mi_icp_set_source(mi_icp_ctx* ctx, const float* xyz, const float* normals,
@@ -118,7 +119,11 @@ MI_ICP_API int mi_icp_set_source(mi_icp_ctx* ctx, const float* xyz, const float*
  * idx -1, d2 +inf.  idx_out / d2_out are in ORIGINAL source order and hold
  * ORIGINAL target indices; either may be NULL.  stats[3] (optional) receives
  * {count, sum d2, n_source}.  T == NULL means identity.
- * The result also becomes the context's current correspondence set. */
+ * The result also becomes the context's current correspondence set.  Among
+ * target points at exactly the same distance the one with the lowest position
+ * in the tree's order is returned (FLANN returns the first one it visits).  A
+ * search on the same pair of clouds as the previous one starts from its matches;
+ * that only makes it faster. */
 MI_ICP_API int mi_icp_search_radius_1nn(mi_icp_ctx* ctx, const float* T, float radius,
                                         int32_t* idx_out, float* d2_out, int mem_kind,
                                         double* stats);
