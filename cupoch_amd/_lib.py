@@ -97,6 +97,7 @@ SIGNATURES = {
     "mi_icp_covariances_from_normals": (_I, [_P, _P, _L, _F, _P, _I]),
     "mi_icp_estimate_normals_knn": (_I, [_P, _P, _L, _I, _P, _I]),
     "mi_icp_estimate_normals_radius": (_I, [_P, _P, _L, _F, _I, _P, _I]),
+    "mi_icp_search_knn": (_I, [_P, _P, _L, _I, _F, _P, _P, C.POINTER(_L), _I]),
     "mi_icp_set_target_colors": (_I, [_P, _P, _I]),
     "mi_icp_set_source_colors": (_I, [_P, _P, _I]),
     "mi_icp_set_lambda_geometric": (_I, [_P, _F]),

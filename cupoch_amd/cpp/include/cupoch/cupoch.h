@@ -1,6 +1,7 @@
 // cupoch/cupoch.h -- aggregate header of the ICP path (reference: src/cupoch/cupoch.h)
 #pragma once
 #include "cupoch/geometry/pointcloud.h"
+#include "cupoch/knn/kdtree_flann.h"
 #include "cupoch/knn/kdtree_search_param.h"
 #include "cupoch/registration/generalized_icp.h"
 #include "cupoch/registration/registration.h"

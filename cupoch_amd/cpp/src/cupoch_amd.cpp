@@ -389,4 +389,106 @@ Eigen::Matrix4f_u Kabsch(const utility::device_vector<Eigen::Vector3f>& model,
 }
 
 }  // namespace registration
+// ============================================================================
+// knn::KDTreeFlann (knn/kdtree_flann.h:43-124)
+// ============================================================================
+namespace knn {
+
+static void CheckCtx(mi_icp_ctx* c, int rc) {
+    if (rc < 0) throw std::runtime_error(std::string("mi_icp: ") + mi_icp_last_error(c));
+}
+
+KDTreeFlann::KDTreeFlann() {}
+KDTreeFlann::KDTreeFlann(const utility::device_vector<Eigen::Vector3f>& data) { SetRawData(data); }
+KDTreeFlann::~KDTreeFlann() {
+    if (ctx_) mi_icp_destroy(ctx_);
+}
+
+bool KDTreeFlann::SetRawData(const utility::device_vector<Eigen::Vector3f>& data) {
+    dataset_size_ = 0;
+    if (data.empty()) {
+        LogWarning("[KDTreeFlann::SetRawData] Failed due to no data.");   // kdtree_flann.inl:129-132
+        return false;
+    }
+    if (!ctx_) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (mi_icp_create(dev, &ctx_) != MI_ICP_OK)
+            throw std::runtime_error("mi_icp_create failed: no MI355X device available (there is no CPU fallback)");
+    }
+    CheckCtx(ctx_, mi_icp_set_target(ctx_, data.data()->data(), nullptr, nullptr, (int64_t)data.size(), MI_ICP_DEVICE));
+    dataset_size_ = data.size();
+    return true;
+}
+
+int KDTreeFlann::SearchMany(const utility::device_vector<Eigen::Vector3f>& query, int knn, float radius,
+                            utility::device_vector<int>& indices, utility::device_vector<float>& distance2) const {
+    if (dataset_size_ == 0 || query.empty() || knn <= 0) return -1;   // kdtree_flann.cu:52-54,72-73
+    indices.resize(query.size() * (size_t)knn);
+    distance2.resize(query.size() * (size_t)knn);
+    int64_t found = 0;
+    CheckCtx(ctx_, mi_icp_search_knn(ctx_, query.data()->data(), (int64_t)query.size(), knn, radius, indices.data(),
+                                     distance2.data(), &found, MI_ICP_DEVICE));
+    return (int)found;
+}
+
+int KDTreeFlann::SearchKNN(const utility::device_vector<Eigen::Vector3f>& query, int knn,
+                           utility::device_vector<int>& indices, utility::device_vector<float>& distance2) const {
+    return SearchMany(query, knn, 0.0f, indices, distance2);
+}
+int KDTreeFlann::SearchRadius(const utility::device_vector<Eigen::Vector3f>& query, float radius, int max_nn,
+                              utility::device_vector<int>& indices, utility::device_vector<float>& distance2) const {
+    if (radius <= 0.0f) return -1;
+    return SearchMany(query, max_nn, radius, indices, distance2);
+}
+int KDTreeFlann::Search(const utility::device_vector<Eigen::Vector3f>& query, const KDTreeSearchParam& param,
+                        utility::device_vector<int>& indices, utility::device_vector<float>& distance2) const {
+    switch (param.GetSearchType()) {
+        case KDTreeSearchParam::SearchType::Knn:
+            return SearchKNN(query, ((const KDTreeSearchParamKNN&)param).knn_, indices, distance2);
+        case KDTreeSearchParam::SearchType::Radius:
+            return SearchRadius(query, ((const KDTreeSearchParamRadius&)param).radius_,
+                                ((const KDTreeSearchParamRadius&)param).max_nn_, indices, distance2);
+        default: return -1;
+    }
+}
+
+// single query: results trimmed to the neighbours found, like FLANN's host overloads
+static int One(const KDTreeFlann& tree, const Eigen::Vector3f& query, int knn, float radius, bool is_radius,
+               thrust::host_vector<int>& indices, thrust::host_vector<float>& distance2) {
+    utility::device_vector<Eigen::Vector3f> q(std::vector<Eigen::Vector3f>{query});
+    utility::device_vector<int> di;
+    utility::device_vector<float> dd;
+    const int k = is_radius ? tree.SearchRadius(q, radius, knn, di, dd) : tree.SearchKNN(q, knn, di, dd);
+    indices.clear();
+    distance2.clear();
+    if (k < 0) return k;
+    const auto hi = di.to_host();
+    const auto hd = dd.to_host();
+    indices.assign(hi.begin(), hi.begin() + k);
+    distance2.assign(hd.begin(), hd.begin() + k);
+    return k;
+}
+int KDTreeFlann::SearchKNN(const Eigen::Vector3f& query, int knn, thrust::host_vector<int>& indices,
+                           thrust::host_vector<float>& distance2) const {
+    return One(*this, query, knn, 0.0f, false, indices, distance2);
+}
+int KDTreeFlann::SearchRadiusOne(const Eigen::Vector3f& query, float radius, int max_nn,
+                                 thrust::host_vector<int>& indices, thrust::host_vector<float>& distance2) const {
+    return One(*this, query, max_nn, radius, true, indices, distance2);
+}
+int KDTreeFlann::Search(const Eigen::Vector3f& query, const KDTreeSearchParam& param, thrust::host_vector<int>& indices,
+                        thrust::host_vector<float>& distance2) const {
+    switch (param.GetSearchType()) {
+        case KDTreeSearchParam::SearchType::Knn:
+            return SearchKNN(query, ((const KDTreeSearchParamKNN&)param).knn_, indices, distance2);
+        case KDTreeSearchParam::SearchType::Radius:
+            return SearchRadiusOne(query, ((const KDTreeSearchParamRadius&)param).radius_,
+                                   ((const KDTreeSearchParamRadius&)param).max_nn_, indices, distance2);
+        default: return -1;
+    }
+}
+
+}  // namespace knn
+
 }  // namespace cupoch

@@ -254,4 +254,95 @@ __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
     normals_out[(int64_t)orig * 3 + 2] = nz;
 }
 
+// ---- knn::KDTreeFlann::SearchKNN / SearchRadius for arbitrary queries ---------------------
+// (knn/kdtree_flann.inl:46-122: FLANN knnSearch / radiusSearch with sorted results).
+// A wave owns 64 Morton-consecutive QUERIES (staged like the ICP source); candidates live
+// in the same LDS columns as above, the walk is top-down from the root (no seeds: a query
+// need not be near any particular leaf), and at the end every lane sorts its candidates in
+// registers -- a 32-input bitonic network on (d2, original index) -- and writes its row
+// [k] of indices / squared distances, padded with -1 / +inf, at the query's ORIGINAL index.
+__global__ __launch_bounds__(kKnnThreads) void knn_search_kernel(
+        const float* __restrict__ records_g, const float* __restrict__ tblk_g, uint32_t leaf_first,
+        const float* __restrict__ qx_g, const float* __restrict__ qy_g, const float* __restrict__ qz_g,
+        const int32_t* __restrict__ qperm, int nq, int k, float r2, uint32_t nblocks,
+        int32_t* __restrict__ idx_out, float* __restrict__ d2_out, unsigned long long* __restrict__ found) {
+    __shared__ float s_d2[kKnnWaves][kMaxKnn * 64];
+    __shared__ int32_t s_idx[kKnnWaves][kMaxKnn * 64];
+    uint32_t logical;
+    if (!xcd_remap(nblocks, logical)) return;
+    const cfloat_p tblk = (cfloat_p)(uintptr_t)tblk_g;
+    const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
+    float* kd2 = s_d2[wid];
+    int32_t* kidx = s_idx[wid];
+    const int64_t i = ((int64_t)logical * kKnnWaves + wid) * 64 + lane;
+    if (i - lane >= nq) return;  // whole wave out of range (no block barriers below)
+    const bool valid = i < nq;
+    float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+    if (valid) {
+        qx = qx_g[i];
+        qy = qy_g[i];
+        qz = qz_g[i];
+    }
+    KnnState st;
+    st.worst = (valid && k > 0) ? r2 : -1.0f;  // r2 = +inf: plain k-NN
+    st.count = 0;
+    st.worst_pos = 0;
+    Cube cube;
+    set_cube(cube, qx, qy, qz, st.worst);
+    traverse_wide(records_g, leaf_first, cube, [&](uint32_t Lu) {
+        const int L = (int)Lu;
+        const cfloat_p line = tblk + (size_t)L * kLeafFloats;
+        bool shrunk = false;
+#pragma unroll
+        for (int t = 0; t < kLeaf; ++t) {
+            const float d2 = sq3(qx - line[t], qy - line[8 + t], qz - line[16 + t]);
+            shrunk |= knn_offer(kd2, kidx, lane, k, st, d2, L * kLeaf + t);  // padding points: d2 = +inf
+        }
+        if (shrunk) set_cube(cube, qx, qy, qz, st.worst);
+    });
+    if (!valid) return;
+    // ---- sort (d2, original index) ascending in registers, unused slots last
+    float v[kMaxKnn];
+    int32_t p[kMaxKnn];
+#pragma unroll
+    for (int t = 0; t < kMaxKnn; ++t) {
+        v[t] = INFINITY;
+        p[t] = 0x7fffffff;
+        if (t < st.count) {
+            const int32_t j = kidx[t * 64 + lane];
+            v[t] = kd2[t * 64 + lane];
+            p[t] = __float_as_int(tblk_g[(int64_t)(j >> 3) * kLeafFloats + 24 + (j & 7)]);
+        }
+    }
+#pragma unroll
+    for (int kk = 2; kk <= kMaxKnn; kk <<= 1)
+#pragma unroll
+        for (int jj = kk >> 1; jj > 0; jj >>= 1)
+#pragma unroll
+            for (int t = 0; t < kMaxKnn; ++t) {
+                const int l = t ^ jj;
+                if (l > t) {
+                    const bool asc = (t & kk) == 0;
+                    const bool gt = (v[t] > v[l]) || (v[t] == v[l] && p[t] > p[l]);
+                    if (gt == asc) {
+                        const float tv = v[t];
+                        v[t] = v[l];
+                        v[l] = tv;
+                        const int32_t tp = p[t];
+                        p[t] = p[l];
+                        p[l] = tp;
+                    }
+                }
+            }
+    const int64_t row = (int64_t)qperm[i] * k;
+#pragma unroll
+    for (int t = 0; t < kMaxKnn; ++t)
+        if (t < k) {
+            const bool have = t < st.count;
+            idx_out[row + t] = have ? p[t] : -1;
+            d2_out[row + t] = have ? v[t] : INFINITY;
+        }
+    if (found) atomicAdd(found, (unsigned long long)st.count);
+}
+
 }  // namespace mi

@@ -1414,6 +1414,46 @@ int mi_icp_estimate_normals_radius(mi_icp_ctx* c, const float* xyz, int64_t n, f
 }
 
 // ---------------------------------------------------------------------------
+// knn::KDTreeFlann::SearchKNN / SearchRadius (knn/kdtree_flann.inl:46-122)
+int mi_icp_search_knn(mi_icp_ctx* c, const float* queries, int64_t nq, int knn, float radius, int32_t* idx_out,
+                      float* d2_out, int64_t* found, int mem_kind) {
+    TRY(check_ctx(c));
+    if (found) *found = 0;
+    if (nq < 0 || knn < 0 || (nq > 0 && (!queries || !idx_out || !d2_out)))
+        return fail(c, MI_ICP_ERR_INVALID, "search_knn: bad arguments");
+    if (knn > kMaxKnn) return fail(c, MI_ICP_ERR_INVALID, "search_knn: more than %d neighbours are not supported", kMaxKnn);
+    if (c->nt <= 0) return fail(c, MI_ICP_ERR_STATE, "search_knn: no target cloud (mi_icp_set_target)");
+    if (nq == 0 || knn == 0) return MI_ICP_OK;
+    // the queries are staged exactly like an ICP source (Morton-ordered SoA + permutation)
+    TRY(mi_icp_set_source(c, queries, nullptr, nullptr, nq, mem_kind));
+    int32_t* d_idx = idx_out;
+    float* d_d2 = d2_out;
+    if (mem_kind == MI_ICP_HOST) {
+        TRY(ensure(c, c->stage[4], (size_t)nq * knn, (int32_t**)&d_idx));
+        TRY(ensure(c, c->stage[5], (size_t)nq * knn, &d_d2));
+    }
+    unsigned long long* cnt;
+    TRY(ensure(c, c->flags, 8, (unsigned long long**)&cnt));
+    HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(unsigned long long), c->stream));
+    const uint32_t npackets = (uint32_t)((nq + 63) / 64);
+    const uint32_t nblocks = (npackets + kKnnWaves - 1) / kKnnWaves;
+    const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
+    knn_search_kernel<<<grid, kKnnThreads, 0, c->stream>>>(
+            (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, (const float*)c->sx.p,
+            (const float*)c->sy.p, (const float*)c->sz.p, (const int32_t*)c->sperm.p, (int)nq, knn,
+            radius > 0.0f ? radius * radius : INFINITY, nblocks, d_idx, d_d2, cnt);
+    KCHK(c);
+    if (mem_kind == MI_ICP_HOST) {
+        TRY(from_device(c, (const int32_t*)d_idx, idx_out, (size_t)nq * knn, mem_kind));
+        TRY(from_device(c, (const float*)d_d2, d2_out, (size_t)nq * knn, mem_kind));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->sys_host, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (found) *found = (int64_t) * reinterpret_cast<unsigned long long*>(c->sys_host);
+    return MI_ICP_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Colored ICP (registration/colored_icp.cu)
 int mi_icp_set_target_colors(mi_icp_ctx* c, const float* rgb, int mem_kind) {
     TRY(check_ctx(c));

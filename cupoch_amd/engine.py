@@ -141,6 +141,28 @@ class Engine:
         self.synchronize()
         self.n_source = p.n
 
+    # -- KDTreeFlann-style search against the target ---------------------------------------
+    def search_knn(self, queries, knn, radius=0.0):
+        """(found, idx[nq, knn] int32, d2[nq, knn] float32): the knn nearest target points of
+        every query (within `radius` when > 0), ascending; -1 / +inf padding.  Replaces the
+        context's source cloud."""
+        q = _Buf(queries, np.float32, 3, self.device)
+        knn = int(knn)
+        if q.kind == MI_ICP_DEVICE:
+            idx = torch.empty((q.n, knn), dtype=torch.int32, device=q.keep.device)
+            d2 = torch.empty((q.n, knn), dtype=torch.float32, device=q.keep.device)
+            ip, dp = C.c_void_p(idx.data_ptr()), C.c_void_p(d2.data_ptr())
+        else:
+            idx = np.empty((q.n, knn), np.int32)
+            d2 = np.empty((q.n, knn), np.float32)
+            ip, dp = idx.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p)
+        found = C.c_int64(0)
+        self._chk(self._L.mi_icp_search_knn(self._ctx, q.ptr, q.n, knn, float(radius), ip, dp,
+                                            C.byref(found), q.kind))
+        self.n_source = q.n
+        self.generation = getattr(self, "generation", 0) + 1
+        return int(found.value), idx, d2
+
     # -- colored ICP --------------------------------------------------------------------
     def set_target_colors(self, colors):
         b = _Buf(colors, np.float32, 3, self.device)

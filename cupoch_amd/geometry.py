@@ -38,6 +38,57 @@ class KDTreeSearchParamRadius:
         self.max_nn = int(max_nn)
 
 
+class KDTreeFlann:
+    """knn::KDTreeFlann (knn/kdtree_flann.h:43-124; python surface
+    cupoch_pybind/geometry/kdtree_flann.cpp:88-141).  Owns its own engine context, i.e. its
+    own tree; at most 32 neighbours per query."""
+
+    def __init__(self, geometry=None):
+        self._eng = None
+        self._n = 0
+        if geometry is not None:
+            self.set_geometry(geometry)
+
+    def set_geometry(self, geometry):
+        pts = geometry.points.tensor if isinstance(geometry, PointCloud) else _v3(geometry).tensor
+        if self._eng is None:
+            self._eng = Engine(pts.device.index if pts.is_cuda else utility.default_device())
+        self._eng.set_target(pts)
+        self._n = int(pts.shape[0])
+        return True
+
+    # batch forms: (found, idx[nq, k], d2[nq, k]) on the device
+    def search_knn(self, queries, knn):
+        if self._n == 0:
+            return -1, None, None
+        return self._eng.search_knn(_v3(queries).tensor if not isinstance(queries, utility.Vector3fVector)
+                                    else queries.tensor, knn)
+
+    def search_radius(self, queries, radius, max_nn):
+        if self._n == 0:
+            return -1, None, None
+        return self._eng.search_knn(_v3(queries).tensor if not isinstance(queries, utility.Vector3fVector)
+                                    else queries.tensor, max_nn, radius)
+
+    # single-query forms of the pybind module: (k, indices, distance2) as host lists of length k
+    def search_knn_vector_3f(self, query, knn):
+        if self._n == 0:
+            raise RuntimeError("search_knn_vector_3f() error!")
+        k, idx, d2 = self._eng.search_knn(np.asarray(query, np.float32).reshape(1, 3), knn)
+        return k, list(idx[0, :k]), list(d2[0, :k])
+
+    def search_radius_vector_3f(self, query, radius, max_nn):
+        if self._n == 0:
+            raise RuntimeError("search_radius_vector_3f() error!")
+        k, idx, d2 = self._eng.search_knn(np.asarray(query, np.float32).reshape(1, 3), max_nn, radius)
+        return k, list(idx[0, :k]), list(d2[0, :k])
+
+    def search_vector_3f(self, query, search_param):
+        if isinstance(search_param, KDTreeSearchParamRadius):
+            return self.search_radius_vector_3f(query, search_param.radius, search_param.max_nn)
+        return self.search_knn_vector_3f(query, search_param.knn)
+
+
 class PointCloud:
     def __init__(self, points=None):
         self._points = utility.Vector3fVector() if points is None else _v3(points)

@@ -221,6 +221,20 @@ MI_ICP_API int mi_icp_estimate_normals_radius(mi_icp_ctx* ctx, const float* xyz,
                                               float radius, int max_nn, float* normals,
                                               int mem_kind);
 
+/* ---- knn::KDTreeFlann as a search object (knn/kdtree_flann.h:43-124) ---------
+ * SearchKNN / SearchRadius (knn/kdtree_flann.inl:46-122) of arbitrary queries
+ * float[nq][3] against the cloud given to mi_icp_set_target: per query the knn
+ * (<= 32) nearest target points -- with d2 < radius^2 when radius > 0, i.e.
+ * SearchRadius(radius, max_nn = knn) -- ascending in distance (ties ascending in
+ * index).  idx_out / d2_out are [nq][knn] row-major in the caller's query order,
+ * original target indices, padded with -1 / +inf.  *found (optional) = number of
+ * neighbours over all queries (the reference's return value for one query).
+ * The queries are staged in the context's SOURCE slot: a cloud set with
+ * mi_icp_set_source is replaced. */
+MI_ICP_API int mi_icp_search_knn(mi_icp_ctx* ctx, const float* queries, int64_t nq, int knn,
+                                 float radius, int32_t* idx_out, float* d2_out, int64_t* found,
+                                 int mem_kind);
+
 /* ---- Colored ICP (registration/colored_icp.cu) -----------------------------
  * Colours are float[n][3] RGB in the order of the cloud last given to
  * mi_icp_set_target / mi_icp_set_source (call these afterwards; a new

@@ -1,6 +1,7 @@
 // C++ drop-in check: the same calls a cupoch user writes (examples/cpp/registration.cpp,
 // src/tests/registration/kabsch.cpp), against libcupoch_amd.so.  Prints one JSON
 // object; tests/test_gpu_cpp.py asserts on it.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <random>
@@ -135,6 +136,31 @@ int main() {
         geometry::PointCloud grey(cp);   // no colours on the source: identity updates (colored_icp.cu:222-224)
         auto none = registration::RegistrationColoredICP(grey, ct, 3.0f);
         std::printf("\"colored_no_colors_is_identity\": %s, ", none.transformation_.isIdentity() ? "true" : "false");
+    }
+    {   // knn::KDTreeFlann as a search object, against brute force
+        knn::KDTreeFlann tree(target.points_);
+        const Vector3f q(0.41f, 0.52f, 0.63f);
+        thrust::host_vector<int> idx;
+        thrust::host_vector<float> d2;
+        const int k = tree.SearchKNN(q, 10, idx, d2);
+        std::vector<std::pair<float, int>> all(n);
+        for (int i = 0; i < n; ++i) {
+            const Vector3f d = tgt[i] - q;
+            all[i] = {d[2] * d[2] + (d[1] * d[1] + d[0] * d[0]), i};
+        }
+        std::sort(all.begin(), all.end());
+        bool same = k == 10 && idx.size() == 10;
+        for (int i = 0; same && i < 10; ++i) same = idx[i] == all[i].second && std::fabs(d2[i] - all[i].first) < 1e-9f;
+        const int kr = tree.SearchRadius<Vector3f>(q, 0.03f, 32, idx, d2);
+        int expect = 0;
+        for (auto& a : all) expect += a.first < 0.03f * 0.03f ? 1 : 0;
+        utility::device_vector<int> di;
+        utility::device_vector<float> dd;
+        const int kb = tree.Search(source.points_, knn::KDTreeSearchParamKNN(4), di, dd);   // batch form
+        knn::KDTreeFlann empty;
+        const int kr_size = (int)idx.size();
+        std::printf("\"kdtree_knn_ok\": %s, \"kdtree_radius\": [%d, %d, %d], \"kdtree_batch\": %d, \"kdtree_empty\": %d, ",
+                    same ? "true" : "false", kr, kr_size, std::min(expect, 32), kb, empty.SearchKNN(q, 3, idx, d2));
     }
     {   // Kabsch golden shape (src/tests/registration/kabsch.cpp:35-55)
         std::vector<Vector3f> pts(20);

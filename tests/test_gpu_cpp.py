@@ -32,6 +32,8 @@ def test_cpp_surface_end_to_end(tmp_path):
     assert r["p2p_fitness"] > 0.999 and r["eval_fitness"] > 0.999 and r["p2p_ncorr"] > 49000
     assert r["p2p_corr_ascending"] and r["kabsch_ok"] and r["no_normals_is_identity"]
     assert r["custom_calls"] >= 1
+    assert r["kdtree_knn_ok"] and r["kdtree_batch"] == 4 * 50000 and r["kdtree_empty"] == -1
+    assert r["kdtree_radius"][0] == r["kdtree_radius"][1] == r["kdtree_radius"][2] > 0, r["kdtree_radius"]
     # colored ICP recovers the in-plane motion of a textured plane; point-to-plane cannot
     assert r["colored_err"] < 0.05 * r["colored_motion"], r
     assert r["colored_vs_plane_err"] > 10 * r["colored_err"], r

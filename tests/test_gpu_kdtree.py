@@ -1,0 +1,102 @@
+"""GPU: knn::KDTreeFlann as a search object (SearchKNN / SearchRadius with up to 32
+neighbours): the reference's own golden vectors (src/tests/knn/kdtree_flann.cpp:47-135)
+and the oracle's exact k-NN on random data, through the C ABI, the Python class and
+batches of queries."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from cupoch_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def test_golden_search_knn_and_radius(golden):
+    from cupoch_amd import geometry
+    g = golden["kdtree_search_knn"]                    # TEST(KDTreeFlann, SearchKNN)
+    pc = geometry.PointCloud(np.asarray(g["points"], np.float32))
+    tree = geometry.KDTreeFlann(pc)
+    k, idx, d2 = tree.search_knn_vector_3f(g["query"], g["knn"])
+    assert k == g["ref_return"] == 30
+    assert sorted(idx) == sorted(g["ref_indices"])     # what the reference test compares
+    assert [int(i) for i in idx] == g["ref_indices"]   # and the order, too
+    np.testing.assert_allclose(d2, g["ref_distance2"], atol=g["tol"])
+
+    g = golden["kdtree_search_radius"]                 # TEST(KDTreeFlann, SearchRadius)
+    tree.set_geometry(geometry.PointCloud(np.asarray(g["points"], np.float32)))
+    k, idx, d2 = tree.search_radius_vector_3f(g["query"], g["radius"], g["max_nn"])
+    assert k == g["ref_return"] == 15
+    assert [int(i) for i in idx] == g["ref_indices"]
+    np.testing.assert_allclose(d2, g["ref_distance2"], atol=g["tol"])
+    k2, idx2, _ = tree.search_vector_3f(g["query"], geometry.KDTreeSearchParamRadius(g["radius"], g["max_nn"]))
+    assert k2 == k and idx2 == idx
+    # empty tree
+    with pytest.raises(RuntimeError):
+        geometry.KDTreeFlann().search_knn_vector_3f([0, 0, 0], 3)
+
+
+def rows_equal_up_to_ties(idx, d2, oi, od, tgt, qry):
+    """distances bit-exact; indices equal wherever the row has no equal distances"""
+    fin = np.isfinite(od)
+    assert np.array_equal(np.isfinite(d2), fin)
+    assert np.array_equal(d2[fin], od[fin])
+    assert np.array_equal(idx < 0, oi < 0)
+    bad = np.flatnonzero((idx != oi).any(axis=1))
+    for r in bad:                                      # only ties may differ
+        k = int(fin[r].sum())
+        dd = tgt[idx[r, :k]] - qry[r]
+        chk = (dd[:, 2] * dd[:, 2] + (dd[:, 1] * dd[:, 1] + dd[:, 0] * dd[:, 0])).astype(np.float32)
+        assert np.array_equal(chk, od[r, :k]), r
+        assert len(np.unique(od[r, :k])) < k, r
+    assert len(bad) <= max(2, len(idx) // 200)
+
+
+@pytest.mark.parametrize("nt,nq,k", [(1, 5, 3), (7, 100, 8), (100, 1, 30), (5000, 3000, 1), (5000, 3000, 17),
+                                     (200000, 50000, 32), (200000, 50000, 20)])
+def test_search_knn_matches_oracle(eng, nt, nq, k):
+    rng = np.random.default_rng(nt * 31 + nq + k)
+    tgt = rng.random((nt, 3), dtype=np.float32)
+    qry = (rng.random((nq, 3), dtype=np.float32) * 1.2 - 0.1).astype(np.float32)
+    eng.set_target(tgt)
+    found, idx, d2 = eng.search_knn(qry, k)
+    ret, oi, od = orc.search_knn(tgt, qry, k)
+    assert found == ret == nq * min(k, nt)
+    rows_equal_up_to_ties(idx, d2, oi, od, tgt, qry)
+    # rows are ascending and padded at the end
+    assert np.all(np.diff(np.where(np.isfinite(d2), d2, np.float32(3e38)), axis=1) >= 0)
+
+
+@pytest.mark.parametrize("radius,max_nn", [(0.01, 10), (0.03, 32), (0.1, 5), (1e-4, 8)])
+def test_search_radius_matches_oracle(eng, radius, max_nn):
+    rng = np.random.default_rng(int(radius * 1e5) + max_nn)
+    tgt = rng.random((120000, 3), dtype=np.float32)
+    qry = tgt[rng.permutation(len(tgt))[:20000]] + rng.normal(0, 0.003, (20000, 3)).astype(np.float32)
+    eng.set_target(tgt)
+    found, idx, d2 = eng.search_knn(torch.from_numpy(qry).cuda(), max_nn, radius)     # device in, device out
+    idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+    ret, oi, od = orc.search_radius(tgt, qry, radius, max_nn)
+    assert found == ret
+    rows_equal_up_to_ties(idx, d2, oi, od, tgt, qry)
+    assert (d2[np.isfinite(d2)] < np.float32(radius * radius)).all()                   # strict
+
+
+def test_errors_and_limits(eng):
+    from cupoch_amd.engine import MiIcpError
+    eng.set_target(np.random.default_rng(0).random((100, 3), dtype=np.float32))
+    with pytest.raises(MiIcpError):
+        eng.search_knn(np.zeros((4, 3), np.float32), 33)
+    found, idx, d2 = eng.search_knn(np.zeros((0, 3), np.float32), 5)
+    assert found == 0 and idx.shape == (0, 5)
+    # duplicates in the target: ties come out ascending in index
+    tgt = np.tile(np.array([[0.5, 0.5, 0.5]], np.float32), (40, 1))
+    eng.set_target(tgt)
+    found, idx, d2 = eng.search_knn(np.array([[0.5, 0.5, 0.6]], np.float32), 8)
+    assert found == 8 and len(set(idx[0].tolist())) == 8 and np.all(d2[0] == d2[0, 0])
