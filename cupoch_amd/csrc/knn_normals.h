@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
 __global__ __launch_bounds__(kKnnThreads) void knn_search_kernel(
         const float* __restrict__ records_g, const float* __restrict__ tblk_g, uint32_t leaf_first,
         const float* __restrict__ qx_g, const float* __restrict__ qy_g, const float* __restrict__ qz_g,
-        const int32_t* __restrict__ qperm, int nq, int k, float r2, uint32_t nblocks,
+        const int32_t* __restrict__ qperm, int nq, int nleaf, int k, float r2, uint32_t nblocks,
         int32_t* __restrict__ idx_out, float* __restrict__ d2_out, unsigned long long* __restrict__ found) {
     __shared__ float s_d2[kKnnWaves][kMaxKnn * 64];
     __shared__ int32_t s_idx[kKnnWaves][kMaxKnn * 64];
@@ -287,9 +287,80 @@ __global__ __launch_bounds__(kKnnThreads) void knn_search_kernel(
     st.worst = (valid && k > 0) ? r2 : -1.0f;  // r2 = +inf: plain k-NN
     st.count = 0;
     st.worst_pos = 0;
+
+    // ---- A: a first bound.  A plain k-NN query starts with an infinite search cube, and a
+    // depth-first walk in child order would wade through the whole tree before the k-th
+    // distance means anything (measured: 2.8 s for 2M queries).  So the packet first descends
+    // greedily -- at every record into the child whose box is nearest (Linf) to the packet's
+    // first query -- and offers the 64 slots under the leaf-level node it arrives at to every
+    // lane; if some lane still holds fewer than k candidates, also the 448 slots under that
+    // node's seven siblings.  The packet is a compact blob, so what is near its first query
+    // bounds all of them usefully.  Leaves [seed_lo, seed_hi) are skipped by the walk below.
+    uint32_t seed_lo = 0u, seed_hi = 0u;
+    if (k > 0) {
+        typedef const __attribute__((address_space(4))) char* cchar_p;
+        const cchar_p base = (cchar_p)(uintptr_t)records_g;
+        uint32_t id = 1u;
+        int32_t off = -1;
+        while (id < leaf_first) {
+            id = __builtin_amdgcn_readfirstlane(id);
+            off = __builtin_amdgcn_readfirstlane(off);
+            const cf16_p rec = (cf16_p)(base + ((id + (uint32_t)off) << 8));
+            const f16v r0 = rec[0], r1 = rec[1], r2v = rec[2];
+            float w[48];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                w[e] = r0[e];
+                w[16 + e] = r1[e];
+                w[32 + e] = r2v[e];
+            }
+            float bestd = INFINITY;
+            int bestc = 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float* b = w + (c >> 1) * kPairStride + (c & 1);
+                // max over the axes of the distance to the slab; an empty (inverted) box gives +inf
+                const float dx = fmaxf(fmaxf(b[0] - qx, qx - b[6]), 0.0f);
+                const float dy = fmaxf(fmaxf(b[2] - qy, qy - b[8]), 0.0f);
+                const float dz = fmaxf(fmaxf(b[4] - qz, qz - b[10]), 0.0f);
+                const float d = fmaxf(dx, fmaxf(dy, dz));
+                if (d < bestd) {
+                    bestd = d;
+                    bestc = c;
+                }
+            }
+            id = id * 8u + (uint32_t)__builtin_amdgcn_readlane(bestc, 0);  // lane 0 is always a valid query
+            off = off * 8 + 1;
+        }
+        id = __builtin_amdgcn_readfirstlane(id);
+        const uint32_t own = (id - leaf_first) * 8u;          // first leaf under the node reached
+        const uint32_t par = ((id & ~7u) - leaf_first) * 8u;  // first leaf under its parent
+        const uint32_t nleaf_u = (uint32_t)nleaf;
+        auto offer_leaves = [&](uint32_t lb) {
+            for (uint32_t L = lb; L < lb + 8u && L < nleaf_u; ++L) {
+                const cfloat_p line = tblk + (size_t)L * kLeafFloats;
+#pragma unroll
+                for (int t = 0; t < kLeaf; ++t) {
+                    const float d2 = sq3(qx - line[t], qy - line[8 + t], qz - line[16 + t]);
+                    knn_offer(kd2, kidx, lane, k, st, d2, (int32_t)(L * kLeaf) + t);  // padding points: d2 = +inf
+                }
+            }
+        };
+        offer_leaves(own);
+        seed_lo = own;
+        seed_hi = own + 8u;
+        if (leaf_first > 1u && __ballot(valid && st.count < k) != 0ull) {
+            for (uint32_t s = 0; s < 8u; ++s)
+                if (par + 8u * s != own) offer_leaves(par + 8u * s);
+            seed_lo = par;
+            seed_hi = par + 64u;
+        }
+    }
     Cube cube;
     set_cube(cube, qx, qy, qz, st.worst);
+    // ---- B: the exact walk
     traverse_wide(records_g, leaf_first, cube, [&](uint32_t Lu) {
+        if (Lu >= seed_lo && Lu < seed_hi) return;
         const int L = (int)Lu;
         const cfloat_p line = tblk + (size_t)L * kLeafFloats;
         bool shrunk = false;

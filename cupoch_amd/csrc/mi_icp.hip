@@ -1440,7 +1440,7 @@ int mi_icp_search_knn(mi_icp_ctx* c, const float* queries, int64_t nq, int knn, 
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
     knn_search_kernel<<<grid, kKnnThreads, 0, c->stream>>>(
             (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, (const float*)c->sx.p,
-            (const float*)c->sy.p, (const float*)c->sz.p, (const int32_t*)c->sperm.p, (int)nq, knn,
+            (const float*)c->sy.p, (const float*)c->sz.p, (const int32_t*)c->sperm.p, (int)nq, c->nleaf, knn,
             radius > 0.0f ? radius * radius : INFINITY, nblocks, d_idx, d_d2, cnt);
     KCHK(c);
     if (mem_kind == MI_ICP_HOST) {
