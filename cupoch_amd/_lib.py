@@ -94,6 +94,8 @@ SIGNATURES = {
     "mi_icp_icp_iterate": (_I, [_P, _I, C.POINTER(Result)]),
     "mi_icp_transform": (_I, [_P, _P, _P, _P, _P, _L, _I]),
     "mi_icp_voxel_downsample": (_I, [_P, _P, _P, _P, _L, _F, _P, _P, _P, C.POINTER(_L), _I]),
+    "mi_icp_create_from_depth": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _F, _F, _F, _I, _I, _I, _I,
+                                      _P, _P, _P, C.POINTER(_L), _I]),
     "mi_icp_covariances_from_normals": (_I, [_P, _P, _L, _F, _P, _I]),
     "mi_icp_estimate_normals_knn": (_I, [_P, _P, _L, _I, _P, _I]),
     "mi_icp_estimate_normals_radius": (_I, [_P, _P, _L, _F, _I, _P, _I]),

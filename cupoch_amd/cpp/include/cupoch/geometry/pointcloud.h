@@ -5,6 +5,8 @@
 #pragma once
 #include <memory>
 
+#include "cupoch/camera/pinhole_camera_intrinsic.h"
+#include "cupoch/geometry/image.h"
 #include "cupoch/knn/kdtree_search_param.h"
 #include "cupoch/utility/device_vector.h"
 #include "cupoch/utility/eigen.h"
@@ -67,6 +69,20 @@ public:
     std::shared_ptr<PointCloud> VoxelDownSample(float voxel_size) const;
     /// estimate_normals.cu:82-127 (KNN search parameter; knn <= 32)
     bool EstimateNormals(const knn::KDTreeSearchParam& search_param = knn::KDTreeSearchParamKNN());
+
+    /// pointcloud_factory.cu:329-351 (float or uint16 depth)
+    static std::shared_ptr<PointCloud> CreateFromDepthImage(const Image& depth,
+                                                            const camera::PinholeCameraIntrinsic& intrinsic,
+                                                            const Eigen::Matrix4f& extrinsic = Eigen::Matrix4f::Identity(),
+                                                            float depth_scale = 1000.0, float depth_trunc = 1000.0,
+                                                            int stride = 1);
+    /// pointcloud_factory.cu:353-376 (colour uint8 x 3 or float x 1; an empty colour image
+    /// gives a cloud without colours)
+    static std::shared_ptr<PointCloud> CreateFromRGBDImage(const RGBDImage& image,
+                                                           const camera::PinholeCameraIntrinsic& intrinsic,
+                                                           const Eigen::Matrix4f& extrinsic = Eigen::Matrix4f::Identity(),
+                                                           bool project_valid_depth_only = true,
+                                                           float depth_cutoff = -1.0f, bool compute_normals = false);
 
 public:
     utility::device_vector<Eigen::Vector3f> points_;

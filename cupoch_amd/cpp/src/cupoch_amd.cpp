@@ -217,6 +217,64 @@ static Eigen::Vector3f Bound(const utility::device_vector<Eigen::Vector3f>& pts,
 Eigen::Vector3f PointCloud::GetMinBound() const { return Bound(points_, false); }
 Eigen::Vector3f PointCloud::GetMaxBound() const { return Bound(points_, true); }
 
+static std::shared_ptr<PointCloud> FromDepth(const Image& depth, const Image* color, int color_type,
+                                             const camera::PinholeCameraIntrinsic& intrinsic,
+                                             const Eigen::Matrix4f& extrinsic, float depth_scale, float depth_trunc,
+                                             float depth_cutoff, int stride, bool rgbd, bool compute_normals,
+                                             bool valid_only) {
+    auto out = std::make_shared<PointCloud>();
+    if (stride < 1 || depth.width_ <= 0 || depth.height_ <= 0) return out;
+    const size_t count = (size_t)(depth.width_ / stride) * (size_t)(depth.height_ / stride);
+    if (count == 0) return out;
+    out->points_.resize(count);
+    if (color) out->colors_.resize(count);
+    if (compute_normals) out->normals_.resize(count);
+    const float k4[4] = {intrinsic.fx_, intrinsic.fy_, intrinsic.cx_, intrinsic.cy_};
+    int64_t m = 0;
+    Check(mi_icp_create_from_depth(Engine(), depth.data_.data(),
+                                   depth.bytes_per_channel_ == 2 ? MI_ICP_DEPTH_U16 : MI_ICP_DEPTH_F32,
+                                   color ? color->data_.data() : nullptr, color_type, depth.width_, depth.height_, k4,
+                                   extrinsic.data(), depth_scale, depth_trunc, depth_cutoff, stride, rgbd ? 1 : 0,
+                                   compute_normals ? 1 : 0, valid_only ? 1 : 0, out->points_.data()->data(),
+                                   compute_normals ? out->normals_.data()->data() : nullptr,
+                                   color ? out->colors_.data()->data() : nullptr, &m, MI_ICP_DEVICE));
+    out->points_.resize((size_t)m);
+    if (color) out->colors_.resize((size_t)m);
+    if (compute_normals) out->normals_.resize((size_t)m);
+    return out;
+}
+
+std::shared_ptr<PointCloud> PointCloud::CreateFromDepthImage(const Image& depth,
+                                                             const camera::PinholeCameraIntrinsic& intrinsic,
+                                                             const Eigen::Matrix4f& extrinsic, float depth_scale,
+                                                             float depth_trunc, int stride) {
+    if (depth.num_of_channels_ == 1 && (depth.bytes_per_channel_ == 2 || depth.bytes_per_channel_ == 4))
+        return FromDepth(depth, nullptr, MI_ICP_COLOR_NONE, intrinsic, extrinsic, depth_scale, depth_trunc, -1.0f,
+                         stride, false, false, true);
+    LogError("[PointCloud::CreateFromDepthImage] Unsupported image format.");  // pointcloud_factory.cu:348-350
+    return std::make_shared<PointCloud>();
+}
+
+std::shared_ptr<PointCloud> PointCloud::CreateFromRGBDImage(const RGBDImage& image,
+                                                            const camera::PinholeCameraIntrinsic& intrinsic,
+                                                            const Eigen::Matrix4f& extrinsic,
+                                                            bool project_valid_depth_only, float depth_cutoff,
+                                                            bool compute_normals) {
+    const Image& c = image.color_;
+    const bool depth_ok = image.depth_.num_of_channels_ == 1 && image.depth_.bytes_per_channel_ == 4;
+    int color_type = -1;
+    if (c.data_.empty()) color_type = MI_ICP_COLOR_NONE;
+    else if (c.bytes_per_channel_ == 1 && c.num_of_channels_ == 3) color_type = MI_ICP_COLOR_U8X3;
+    else if (c.bytes_per_channel_ == 4 && c.num_of_channels_ == 1) color_type = MI_ICP_COLOR_F32X1;
+    if (!depth_ok || color_type < 0 ||
+        (color_type != MI_ICP_COLOR_NONE && (c.width_ != image.depth_.width_ || c.height_ != image.depth_.height_))) {
+        LogError("[PointCloud::CreateFromRGBDImage] Unsupported image format.");  // pointcloud_factory.cu:373-375
+        return std::make_shared<PointCloud>();
+    }
+    return FromDepth(image.depth_, color_type == MI_ICP_COLOR_NONE ? nullptr : &c, color_type, intrinsic, extrinsic,
+                     1000.0f, 1000.0f, depth_cutoff, 1, true, compute_normals, project_valid_depth_only);
+}
+
 }  // namespace geometry
 
 // ---------------------------------------------------------------- registration
@@ -490,5 +548,52 @@ int KDTreeFlann::Search(const Eigen::Vector3f& query, const KDTreeSearchParam& p
 }
 
 }  // namespace knn
+
+// ---------------------------------------------------------------- kinfu
+namespace kinfu {
+
+PointCloudPyramid CreatePointCloudPyramid(const std::vector<geometry::RGBDImage>& image_pyramid,
+                                          const camera::PinholeCameraIntrinsic& intrinsic,
+                                          const KinfuOption& option) {
+    PointCloudPyramid out((size_t)option.num_pyramid_levels_);
+    for (int i = 0; i < option.num_pyramid_levels_; ++i)
+        out[(size_t)i] = geometry::PointCloud::CreateFromRGBDImage(image_pyramid[(size_t)i],
+                                                                   intrinsic.CreatePyramidLevel((size_t)i),
+                                                                   Eigen::Matrix4f::Identity(), true,
+                                                                   option.depth_cutoff_, true);
+    return out;
+}
+
+std::tuple<Eigen::Matrix4f, bool> PoseEstimation(const KinfuOption& option, const Eigen::Matrix4f& extrinsic,
+                                                 const PointCloudPyramid& frame_data,
+                                                 const PointCloudPyramid& target_data) {
+    Eigen::Matrix4f cur = extrinsic;
+    for (int level = option.num_pyramid_levels_ - 1; level >= 0; --level) {
+        registration::ICPConvergenceCriteria criteria;
+        criteria.max_iteration_ = option.icp_iterations_[(size_t)level];
+        switch (option.tf_type_) {
+            case registration::TransformationEstimationType::PointToPlane: {
+                auto res = registration::RegistrationICP(*frame_data[(size_t)level], *target_data[(size_t)level],
+                                                         option.distance_threshold_, cur,
+                                                         registration::TransformationEstimationPointToPlane(100000),
+                                                         criteria);
+                cur = res.transformation_;
+                break;
+            }
+            case registration::TransformationEstimationType::ColoredICP: {
+                auto res = registration::RegistrationColoredICP(*frame_data[(size_t)level], *target_data[(size_t)level],
+                                                                option.distance_threshold_, cur, criteria, 0.968f, 100000);
+                cur = res.transformation_;
+                break;
+            }
+            default:
+                LogError("[KinfuPipeline::PoseEstimation] Unsupported transformation type.");
+                break;
+        }
+    }
+    return std::make_tuple(cur, true);
+}
+
+}  // namespace kinfu
 
 }  // namespace cupoch

@@ -32,12 +32,103 @@ constexpr int kKdChunks = kKdGroup / kKdChunk;    // 512
 // LDS working set of one 4096-element group (80 KB)
 struct KdShared {
     float cx[kKdGroup], cy[kKdGroup], cz[kKdGroup];  // coordinates by LOCAL index (fixed)
-    uint32_t key[kKdGroup];                          // (quantised coordinate << 12) | local index
+    alignas(16) uint32_t key[kKdGroup];              // (quantised coordinate << 12) | local index
     float bb[6 * kKdChunks];                         // [min xyz | max xyz] per chunk
     float seg_lo[kKdGroup / 16], seg_scale[kKdGroup / 16];
     uint8_t seg_axis[kKdGroup / 16];
     int clean;  // stays 1 while no split has produced overlapping halves (set by the caller, see below)
 };
+
+// ---- the bitonic network, 4 consecutive keys per thread held in registers ---------------
+// Element e = 4*tid + c.  A compare-exchange stage with stride j pairs e with e ^ j:
+//   j = 1, 2    : both keys sit in the same thread            -> no data movement at all
+//   j = 4 .. 128: the partner is lane ^ (j/4) of the same wave -> one cross-lane move per key
+//   j >= 256    : another wave                                -> through LDS, two stages per
+//                                                                round trip (4 keys per thread)
+// Only 20 of the 354 stages of a 9-level group (10 + 6 + 3 + 1 in the rounds with segments
+// of 4096 .. 512) go through LDS with block barriers; an earlier all-LDS version (2 reads
+// + 2 writes per pair and 35 block barriers per group) spent 156 us per group, latency-bound
+// with one workgroup per CU on small clouds.
+__device__ __forceinline__ void kd_ce(uint32_t& lo, uint32_t& hi, bool asc) {
+    const uint32_t mn = min(lo, hi), mx = max(lo, hi);
+    lo = asc ? mn : mx;
+    hi = asc ? mx : mn;
+}
+
+// stages lj_top .. 0 (lj_top <= 7) of the merge k = 2^lk; top: the segment's last merge (ascending)
+__device__ __forceinline__ void kd_reg_stages(uint32_t v[4], int tid, int lk, bool top, int lj_top) {
+    const bool asc4 = top || ((tid & ((1 << lk) >> 2)) == 0);  // direction of the thread's keys when k >= 4
+    for (int lj = lj_top; lj >= 2; --lj) {
+        const int m = 1 << (lj - 2);
+        const bool keep_min = (((tid & m) == 0) == asc4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)v[c], m, 64);
+            v[c] = keep_min ? min(v[c], o) : max(v[c], o);
+        }
+    }
+    if (lj_top >= 1) {  // j = 2
+        kd_ce(v[0], v[2], asc4);
+        kd_ce(v[1], v[3], asc4);
+    }
+    if (lk == 1) {      // k = 2: e & 2 decides
+        kd_ce(v[0], v[1], true);
+        kd_ce(v[2], v[3], top);
+    } else {
+        kd_ce(v[0], v[1], asc4);
+        kd_ce(v[2], v[3], asc4);
+    }
+}
+
+__device__ __forceinline__ void kd_bitonic_sort(KdShared& s, uint32_t v[4], int tid, int lS) {
+    uint32_t* key = s.key;
+    for (int lk = 1; lk <= lS; ++lk) {
+        const bool top = (lk == lS);
+        const uint32_t kbit = 1u << lk;
+        int lj = lk - 1;
+        if (lj >= 8) {  // cross-wave stages
+            __syncthreads();  // (readers of key[] from the previous merge / the caller are done)
+            reinterpret_cast<uint4*>(key)[tid] = make_uint4(v[0], v[1], v[2], v[3]);
+            __syncthreads();
+            while (lj >= 9) {  // stages lj and lj-1: keys base + {0, h, 2h, 3h}, h = 2^(lj-1)
+                const int h = 1 << (lj - 1);
+                const int base = ((tid >> (lj - 1)) << (lj + 1)) | (tid & (h - 1));
+                const bool asc = top || (((uint32_t)base & kbit) == 0u);
+                uint32_t x0 = key[base], x1 = key[base + h], x2 = key[base + 2 * h], x3 = key[base + 3 * h];
+                kd_ce(x0, x2, asc);
+                kd_ce(x1, x3, asc);
+                kd_ce(x0, x1, asc);
+                kd_ce(x2, x3, asc);
+                key[base] = x0;
+                key[base + h] = x1;
+                key[base + 2 * h] = x2;
+                key[base + 3 * h] = x3;
+                __syncthreads();
+                lj -= 2;
+            }
+            if (lj == 8) {  // one stage left above the wave: two pairs per thread
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int p = tid + t * kKdThreads;
+                    const int i = ((p >> 8) << 9) | (p & 255);
+                    const bool asc = top || (((uint32_t)i & kbit) == 0u);
+                    uint32_t a = key[i], b = key[i + 256];
+                    kd_ce(a, b, asc);
+                    key[i] = a;
+                    key[i + 256] = b;
+                }
+                __syncthreads();
+                lj = 7;
+            }
+            const uint4 r = reinterpret_cast<const uint4*>(key)[tid];
+            v[0] = r.x;
+            v[1] = r.y;
+            v[2] = r.z;
+            v[3] = r.w;
+        }
+        kd_reg_stages(v, tid, lk, top, lj);
+    }
+}
 
 // `levels` rounds of {per-segment bbox -> longest axis -> bitonic sort of the segment
 // along it} over the group in s (cx/cy/cz loaded, key[i] = i; +inf = padding, sorts to
@@ -130,45 +221,29 @@ __device__ __forceinline__ void kd_sort_levels(KdShared& s, int levels, float2* 
             s.seg_scale[tid] = (e > 0.0f && e < INFINITY) ? 1048575.0f / e : 0.0f;
         }
         __syncthreads();
-        // ---- (b) keys = quantised coordinate along the segment's axis | local index
-        for (int i = tid; i < kKdGroup; i += kKdThreads) {
-            const int sg = i >> lS;
+        // ---- (b) keys = quantised coordinate along the segment's axis | local index, built
+        // straight into registers: thread t owns positions 4t .. 4t+3 (one segment: S >= 16)
+        uint32_t v[4];
+        {
+            const uint4 old = reinterpret_cast<const uint4*>(s.key)[tid];
+            const uint32_t o[4] = {old.x, old.y, old.z, old.w};
+            const int sg = (4 * tid) >> lS;
             const int ax = s.seg_axis[sg];
-            const uint32_t li = s.key[i] & 4095u;
-            const float v = (ax == 0) ? s.cx[li] : ((ax == 1) ? s.cy[li] : s.cz[li]);
-            float q = (v - s.seg_lo[sg]) * s.seg_scale[sg];
-            q = fminf(fmaxf(q, 0.0f), 1048575.0f);           // +inf padding -> top bucket, NaN -> 0
-            s.key[i] = ((v < INFINITY) ? ((uint32_t)q << 12) : 0xfffff000u) | li;
-        }
-        __syncthreads();
-        // ---- (c) bitonic sort of every S-segment (ascending): lower half = below the median
-        for (int lk = 1; lk <= lS; ++lk) {
-            const int k = 1 << lk;
-            for (int lj = lk - 1; lj >= 0; --lj) {
-                const int j = 1 << lj;
+            const float lo = s.seg_lo[sg], sc = s.seg_scale[sg];
 #pragma unroll
-                for (int t = 0; t < kKdGroup / 2 / kKdThreads; ++t) {
-                    const int p = tid + t * kKdThreads;
-                    const int i = ((p >> lj) << (lj + 1)) + (p & (j - 1));
-                    const int l = i + j;
-                    const bool asc = (k == S) || ((i & k) == 0);
-                    const uint32_t a = s.key[i], b = s.key[l];
-                    if ((a > b) == asc) {
-                        s.key[i] = b;
-                        s.key[l] = a;
-                    }
-                }
-                // a wave's 64 threads own an aligned block of 128 elements (per t) whenever
-                // j <= 64, so consecutive stages with j <= 64 only need wave-level ordering
-                // (LDS executes a wave's accesses in order); a block barrier is needed after
-                // the cross-wave stages and at the end of each k (next stage is cross-wave or
-                // the keys get rebuilt).  35 block barriers per group instead of 354.
-                if (j > 64 || j == 1)
-                    __syncthreads();
-                else
-                    __builtin_amdgcn_wave_barrier();
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t li = o[c] & 4095u;
+                const float x = (ax == 0) ? s.cx[li] : ((ax == 1) ? s.cy[li] : s.cz[li]);
+                float q = (x - lo) * sc;
+                q = fminf(fmaxf(q, 0.0f), 1048575.0f);           // +inf padding -> top bucket, NaN -> 0
+                v[c] = ((x < INFINITY) ? ((uint32_t)q << 12) : 0xfffff000u) | li;
             }
         }
+        // ---- (c) bitonic sort of every S-segment (ascending): lower half = below the median
+        kd_bitonic_sort(s, v, tid, lS);
+        __syncthreads();  // every reader of the previous arrangement is done
+        reinterpret_cast<uint4*>(s.key)[tid] = make_uint4(v[0], v[1], v[2], v[3]);
+        __syncthreads();
         if (PLANES) {
             if (tid < nseg) {
                 const uint32_t li = s.key[tid * S + (S >> 1)] & 4095u;

@@ -22,6 +22,7 @@
 #include "../../include/mi_icp.h"
 #include "../../include/mi_icp_debug.h"
 #include "device_utils.h"
+#include "depth_kernels.h"
 #include "geometry_kernels.h"
 #include "host_solver.h"
 #include "kd_build.h"
@@ -1377,6 +1378,117 @@ int mi_icp_voxel_downsample(mi_icp_ctx* c, const float* xyz, const float* normal
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *m = nvox;
+    return MI_ICP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// PointCloud::CreateFromDepthImage / CreateFromRGBDImage (geometry/pointcloud_factory.cu)
+static bool invert4(const float* M, float* out) {  // column-major general inverse, in double
+    double a[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int k = 0; k < 4; ++k) {
+            a[r][k] = (double)M[k * 4 + r];
+            a[r][4 + k] = (r == k) ? 1.0 : 0.0;
+        }
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 4; ++r)
+            if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+        if (!(std::fabs(a[piv][col]) > 0.0)) return false;
+        if (piv != col)
+            for (int k = 0; k < 8; ++k) std::swap(a[piv][k], a[col][k]);
+        const double d = a[col][col];
+        for (int k = 0; k < 8; ++k) a[col][k] /= d;
+        for (int r = 0; r < 4; ++r) {
+            if (r == col) continue;
+            const double f = a[r][col];
+            if (f != 0.0)
+                for (int k = 0; k < 8; ++k) a[r][k] -= f * a[col][k];
+        }
+    }
+    for (int r = 0; r < 4; ++r)
+        for (int k = 0; k < 4; ++k) out[k * 4 + r] = (float)a[r][4 + k];
+    return true;
+}
+
+int mi_icp_create_from_depth(mi_icp_ctx* c, const void* depth, int depth_type, const void* color, int color_type,
+                             int width, int height, const float* intrinsic4, const float* extrinsic,
+                             float depth_scale, float depth_trunc, float depth_cutoff, int stride, int rgbd,
+                             int compute_normals, int valid_only, float* out_xyz, float* out_normals,
+                             float* out_colors, int64_t* m, int mem_kind) {
+    TRY(check_ctx(c));
+    if (!m) return fail(c, MI_ICP_ERR_INVALID, "create_from_depth: m is null");
+    *m = 0;
+    if (width < 0 || height < 0 || stride < 1 || !intrinsic4 || (depth_type != MI_ICP_DEPTH_F32 && depth_type != MI_ICP_DEPTH_U16) ||
+        (color_type != MI_ICP_COLOR_NONE && color_type != MI_ICP_COLOR_U8X3 && color_type != MI_ICP_COLOR_F32X1))
+        return fail(c, MI_ICP_ERR_INVALID, "create_from_depth: bad arguments");
+    if (rgbd && (stride != 1 || depth_type != MI_ICP_DEPTH_F32))
+        return fail(c, MI_ICP_ERR_INVALID, "create_from_depth: an RGB-D image has a float depth and stride 1");
+    if (!rgbd && (color || compute_normals || !valid_only))
+        return fail(c, MI_ICP_ERR_INVALID, "create_from_depth: colours, normals and valid_only = 0 belong to the RGB-D form");
+    if ((color != nullptr) != (color_type != MI_ICP_COLOR_NONE))
+        return fail(c, MI_ICP_ERR_INVALID, "create_from_depth: color and color_type disagree");
+    const int64_t npix = (int64_t)width * height;
+    const int64_t count = (int64_t)(width / stride) * (height / stride);
+    if (npix > 0x7fffff00ll) return fail(c, MI_ICP_ERR_INVALID, "create_from_depth: image too large");
+    if (count == 0) return MI_ICP_OK;
+    if (!depth || !out_xyz || (color && !out_colors) || (compute_normals && !out_normals))
+        return fail(c, MI_ICP_ERR_INVALID, "create_from_depth: null buffer");
+
+    DepthArgs a;
+    const size_t dbytes = (size_t)npix * (depth_type == MI_ICP_DEPTH_U16 ? 2 : 4);
+    const size_t cbytes = color ? (size_t)npix * (color_type == MI_ICP_COLOR_U8X3 ? 3 : 4) : 0;
+    const uint8_t *dd, *dc;
+    TRY(to_device(c, (const uint8_t*)depth, dbytes, mem_kind, c->stage[0], &dd));
+    TRY(to_device(c, (const uint8_t*)color, cbytes, mem_kind, c->stage[1], &dc));
+    a.depth = dd;
+    a.color = dc;
+    a.width = width;
+    a.height = height;
+    a.stride = stride;
+    a.depth_u16 = depth_type == MI_ICP_DEPTH_U16;
+    a.color_kind = color_type;
+    a.rgbd = rgbd ? 1 : 0;
+    a.depth_scale = (int)depth_scale;  // image.cu:340-343 holds both as int
+    a.depth_trunc = (int)depth_trunc;
+    a.depth_cutoff = depth_cutoff;
+    a.fx = intrinsic4[0];
+    a.fy = intrinsic4[1];
+    a.cx = intrinsic4[2];
+    a.cy = intrinsic4[3];
+    const Mat4 E = load_T(extrinsic);
+    if (!invert4(E.data(), a.pose)) return fail(c, MI_ICP_ERR_INVALID, "create_from_depth: singular extrinsic");
+
+    const int nb = blocks_for(count);
+    uint32_t* pos = nullptr;
+    int64_t kept = count;
+    if (valid_only) {
+        uint32_t* tmp;
+        TRY(ensure(c, c->flags, (size_t)count, &pos));
+        TRY(ensure(c, c->scan_tmp, (size_t)scan_num_tiles(count) + 2, &tmp));
+        depth_valid_flags<<<nb, 256, 0, c->stream>>>(a, count, pos);
+        KCHK(c);
+        exclusive_scan_u32(c->stream, pos, pos, count, tmp);
+        KCHK(c);
+        HIPCHK(c, hipMemcpyAsync(c->u_host, tmp + scan_num_tiles(count), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        kept = (int64_t)c->u_host[0];
+    }
+    float *op = out_xyz, *on = compute_normals ? out_normals : nullptr, *oc = color ? out_colors : nullptr;
+    if (mem_kind == MI_ICP_HOST) {
+        TRY(ensure(c, c->stage[3], (size_t)count * 3, &op));
+        if (on) TRY(ensure(c, c->stage[4], (size_t)count * 3, &on));
+        if (oc) TRY(ensure(c, c->stage[5], (size_t)count * 3, &oc));
+    }
+    depth_emit<<<nb, 256, 0, c->stream>>>(a, count, pos, op, on, oc);
+    KCHK(c);
+    if (mem_kind == MI_ICP_HOST) {
+        TRY(from_device(c, (const float*)op, out_xyz, (size_t)kept * 3, mem_kind));
+        if (on) TRY(from_device(c, (const float*)on, out_normals, (size_t)kept * 3, mem_kind));
+        if (oc) TRY(from_device(c, (const float*)oc, out_colors, (size_t)kept * 3, mem_kind));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *m = kept;
     return MI_ICP_OK;
 }
 

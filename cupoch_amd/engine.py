@@ -319,6 +319,75 @@ class Engine:
         cut = lambda t: None if t is None else t[:k]
         return cut(op) if op is not None else np.empty((0, 3), np.float32), cut(on), cut(oc)
 
+    def create_from_depth(self, depth, intrinsic4, extrinsic=None, color=None, depth_scale=1000.0,
+                          depth_trunc=1000.0, depth_cutoff=-1.0, stride=1, rgbd=False,
+                          compute_normals=False, valid_only=True):
+        """PointCloud::CreateFromDepthImage (rgbd=False) / CreateFromRGBDImage (rgbd=True),
+        geometry/pointcloud_factory.cu:286-376.  depth: [H, W] float32 or uint16; color: None,
+        [H, W, 3] uint8 or [H, W] float32; numpy or torch (all on the same side).
+        Returns (points, normals or None, colors or None)."""
+        on_dev = torch.is_tensor(depth) and depth.is_cuda
+        def prep(x, kinds):
+            if x is None:
+                return None, None
+            if torch.is_tensor(x):
+                if x.dtype not in kinds:
+                    raise TypeError("unsupported image dtype %s" % x.dtype)
+                if x.is_cuda != on_dev:
+                    raise ValueError("depth and color must live on the same side")
+                x = x.contiguous() if on_dev else np.ascontiguousarray(x.numpy())
+            else:
+                if on_dev:
+                    raise ValueError("depth and color must live on the same side")
+                x = np.ascontiguousarray(x)
+            return x, (C.c_void_p(x.data_ptr()) if on_dev else x.ctypes.data_as(C.c_void_p))
+        if torch.is_tensor(depth):
+            dkinds, ckinds = (torch.float32, torch.uint16), (torch.uint8, torch.float32)
+        else:
+            dkinds = ckinds = None
+        d, dptr = prep(depth, dkinds)
+        col, cptr = prep(color, ckinds)
+        if d.ndim != 2:
+            raise ValueError("depth must be [H, W]")
+        dname = str(d.dtype).replace("torch.", "")
+        if dname not in ("float32", "uint16"):
+            raise TypeError("depth must be float32 or uint16")
+        h, w = int(d.shape[0]), int(d.shape[1])
+        ctype = 0
+        if col is not None:
+            cname = str(col.dtype).replace("torch.", "")
+            if cname == "uint8" and tuple(col.shape) == (h, w, 3):
+                ctype = 1
+            elif cname == "float32" and tuple(col.shape)[:2] == (h, w) and \
+                    (col.numel() if on_dev else col.size) == h * w:
+                ctype = 2
+            else:
+                raise TypeError("[PointCloud::CreateFromRGBDImage] Unsupported image format.")
+        K = (C.c_float * 4)(*[float(v) for v in intrinsic4])
+        E = None
+        if extrinsic is not None:
+            E = np.ascontiguousarray(np.asarray(extrinsic, np.float32).reshape(4, 4).T)
+            Eptr = E.ctypes.data_as(C.c_void_p)
+        else:
+            Eptr = None
+        count = (w // int(stride)) * (h // int(stride)) if stride >= 1 else 0
+        kind = MI_ICP_DEVICE if on_dev else MI_ICP_HOST
+        if on_dev:
+            mk = lambda want: torch.empty((count, 3), dtype=torch.float32, device=d.device) if want else None
+            ptr = lambda t_: None if t_ is None else C.c_void_p(t_.data_ptr())
+        else:
+            mk = lambda want: np.empty((count, 3), np.float32) if want else None
+            ptr = lambda t_: None if t_ is None else t_.ctypes.data_as(C.c_void_p)
+        op, on, oc = mk(True), mk(bool(compute_normals)), mk(col is not None)
+        m = C.c_int64(0)
+        self._chk(self._L.mi_icp_create_from_depth(
+            self._ctx, dptr, 1 if dname == "uint16" else 0, cptr, ctype, w, h, K, Eptr,
+            float(depth_scale), float(depth_trunc), float(depth_cutoff), int(stride), int(bool(rgbd)),
+            int(bool(compute_normals)), int(bool(valid_only)), ptr(op), ptr(on), ptr(oc), C.byref(m), kind))
+        k = int(m.value)
+        cut = lambda t_: None if t_ is None else t_[:k]
+        return cut(op), cut(on), cut(oc)
+
     def covariances_from_normals(self, normals, epsilon=1e-3):
         n = _Buf(normals, np.float32, 3, self.device)
         if n.kind == MI_ICP_DEVICE:

@@ -195,5 +195,77 @@ class PointCloud:
         return True
 
 
+class Image:
+    """geometry::Image as the factories below see it (geometry/image.h:52-110): a [H, W] or
+    [H, W, C] array (numpy, or a torch tensor on either side); float32 / uint16 depth,
+    uint8 x 3 or float32 x 1 colour.  Image processing (pyramids, filters) is out of scope."""
+
+    def __init__(self, data=None):
+        self.data = data
+
+    @property
+    def height(self):
+        return 0 if self.data is None else int(self.data.shape[0])
+
+    @property
+    def width(self):
+        return 0 if self.data is None else int(self.data.shape[1])
+
+
+def _img(x):
+    return x.data if isinstance(x, Image) else x
+
+
+class RGBDImage:
+    """geometry::RGBDImage (geometry/rgbdimage.h:38-120): color + float depth."""
+
+    def __init__(self, color=None, depth=None):
+        self.color = _img(color)
+        self.depth = _img(depth)
+
+
+def _create_from_depth_image(depth, intrinsic, extrinsic=None, depth_scale=1000.0, depth_trunc=1000.0, stride=1):
+    """PointCloud::CreateFromDepthImage (pointcloud_factory.cu:329-351)"""
+    d = _img(depth)
+    name = str(d.dtype).replace("torch.", "")
+    out = PointCloud()
+    if d.ndim != 2 or name not in ("float32", "uint16"):
+        print("[cupoch_amd] Error: [PointCloud::CreateFromDepthImage] Unsupported image format.")
+        return out
+    dev = d.device.index if (torch is not None and torch.is_tensor(d) and d.is_cuda) else None
+    p, _, _ = get_engine(dev).create_from_depth(d, intrinsic.as4(), extrinsic, None, depth_scale, depth_trunc,
+                                                -1.0, stride, False, False, True)
+    out._points = utility.Vector3fVector(p)
+    return out
+
+
+def _create_from_rgbd_image(image, intrinsic, extrinsic=None, project_valid_depth_only=True, depth_cutoff=-1.0,
+                            compute_normals=False):
+    """PointCloud::CreateFromRGBDImage (pointcloud_factory.cu:353-376).  image.color may be
+    None (depth-only frames, as KinFu's point-to-plane tracking uses them)."""
+    out = PointCloud()
+    d, c = image.depth, image.color
+    if str(d.dtype).replace("torch.", "") != "float32":
+        print("[cupoch_amd] Error: [PointCloud::CreateFromRGBDImage] Unsupported image format.")
+        return out
+    dev = d.device.index if (torch is not None and torch.is_tensor(d) and d.is_cuda) else None
+    try:
+        p, n, col = get_engine(dev).create_from_depth(d, intrinsic.as4(), extrinsic, c, 1000.0, 1000.0, depth_cutoff,
+                                                      1, True, compute_normals, project_valid_depth_only)
+    except TypeError:
+        print("[cupoch_amd] Error: [PointCloud::CreateFromRGBDImage] Unsupported image format.")
+        return out
+    out._points = utility.Vector3fVector(p)
+    if n is not None:
+        out._normals = utility.Vector3fVector(n)
+    if col is not None:
+        out._colors = utility.Vector3fVector(col)
+    return out
+
+
+PointCloud.create_from_depth_image = staticmethod(_create_from_depth_image)
+PointCloud.create_from_rgbd_image = staticmethod(_create_from_rgbd_image)
+
+
 def _v3(v):
     return v if isinstance(v, utility.Vector3fVector) else utility.Vector3fVector(v)

@@ -204,6 +204,39 @@ MI_ICP_API int mi_icp_voxel_downsample(mi_icp_ctx* ctx, const float* xyz, const 
                                        const float* colors, int64_t n, float voxel_size,
                                        float* out_xyz, float* out_normals, float* out_colors,
                                        int64_t* m, int mem_kind);
+/* PointCloud::CreateFromDepthImage and PointCloud::CreateFromRGBDImage
+ * (geometry/pointcloud_factory.cu:43-110,117-220,286-376) incl. the
+ * RemoveNoneFinitePoints pass that follows (geometry/pointcloud.cu:40-54,360-385):
+ * the depth-image side of the path's tracker callers (kinfu/kinfu.cpp:87-104).
+ *   depth       [height][width], MI_ICP_DEPTH_F32 or MI_ICP_DEPTH_U16 (then value /
+ *               (int)depth_scale, values >= (int)depth_trunc dropped, image.cu:339-348;
+ *               both are truncated to int as the reference does)
+ *   color       NULL, MI_ICP_COLOR_U8X3 [h][w][3] (scaled by 1/255) or
+ *               MI_ICP_COLOR_F32X1 [h][w] (replicated to 3 channels)
+ *   intrinsic4  fx, fy, cx, cy;   extrinsic: 4x4 column-major or NULL (identity);
+ *               points are mapped by extrinsic^-1
+ *   rgbd = 0    CreateFromDepthImage: pixel (row*stride, col*stride) of a
+ *               (width/stride) x (height/stride) grid, depth <= 0 dropped, no
+ *               colours or normals; non-finite points always removed
+ *   rgbd = 1    CreateFromRGBDImage: stride must be 1; a pixel is kept when
+ *               depth > 0 and (depth_cutoff <= 0 or depth < depth_cutoff);
+ *               compute_normals: cross product of the 4-neighbourhood differences,
+ *               flipped to z <= 0 (:161-199); valid_only = 0 keeps one point per
+ *               pixel, rejected ones +inf.
+ * Outputs must hold (width/stride)*(height/stride) points; *m = points written, in
+ * pixel order. */
+#define MI_ICP_DEPTH_F32 0
+#define MI_ICP_DEPTH_U16 1
+#define MI_ICP_COLOR_NONE 0
+#define MI_ICP_COLOR_U8X3 1
+#define MI_ICP_COLOR_F32X1 2
+MI_ICP_API int mi_icp_create_from_depth(mi_icp_ctx* ctx, const void* depth, int depth_type,
+                                        const void* color, int color_type, int width, int height,
+                                        const float* intrinsic4, const float* extrinsic,
+                                        float depth_scale, float depth_trunc, float depth_cutoff,
+                                        int stride, int rgbd, int compute_normals, int valid_only,
+                                        float* out_xyz, float* out_normals, float* out_colors,
+                                        int64_t* m, int mem_kind);
 /* InitializePointCloudForGeneralizedICP's normals -> covariances
  * (registration/generalized_icp.cu:18-30,52-59). */
 MI_ICP_API int mi_icp_covariances_from_normals(mi_icp_ctx* ctx, const float* normals,

@@ -1372,6 +1372,112 @@ ORACLE_API int64_t oracle_voxel_downsample(const float *pts, const float *nrm,
 }
 
 /* ------------------------------------------------------------------ */
+/* PointCloud::CreateFromDepthImage / CreateFromRGBDImage               */
+/* (pointcloud_factory.cu:43-110,117-220,286-376), in the reference's   */
+/* own order: a structured cloud of one point per pixel (+inf where the */
+/* depth is rejected), normals from that cloud's 4-neighbourhood        */
+/* (:161-199), then RemoveNoneFinitePoints (pointcloud.cu:40-54).       */
+/* depth is float; the uint16 conversion (image.cu:339-348: divide by   */
+/* (int)scale, >= (int)trunc -> 0) is oracle_depth_u16_to_float.        */
+/* pose = extrinsic^-1, column-major.  rgbd = 0: :43-82 (stride, d <= 0 */
+/* rejected); rgbd = 1: :117-160 (cutoff, colours, optional normals).   */
+/* The last row's lower neighbour is past the end of the reference's    */
+/* buffer (its bounds test is i >= height, :173); taken as zero here,   */
+/* the value the functor gives any non-finite neighbour.                */
+/* color_kind: 0 none, 1 uint8 x 3, 2 float x 1.  Returns the count.    */
+/* ------------------------------------------------------------------ */
+ORACLE_API void oracle_depth_u16_to_float(const uint16_t *in, int64_t n, float depth_scale,
+                                          float depth_trunc, float *out) {
+    const int iscale = (int)depth_scale, itrunc = (int)depth_trunc;
+    for (int64_t i = 0; i < n; ++i) {
+        float f = (float)in[i];
+        f /= (float)iscale;
+        if (f >= (float)itrunc) f = 0.0f;
+        out[i] = f;
+    }
+}
+
+static int all_finite3(const float *p) { return isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]); }
+
+ORACLE_API int64_t oracle_create_from_depth(const float *depth, const void *color, int color_kind,
+                                            int width, int height, const float *intrinsic4,
+                                            const float *pose, float depth_cutoff, int stride,
+                                            int rgbd, int compute_normals, int valid_only,
+                                            float *out_pts, float *out_nrm, float *out_col) {
+    const float fx = intrinsic4[0], fy = intrinsic4[1], cx = intrinsic4[2], cy = intrinsic4[3];
+    const int sw = width / stride, sh = height / stride;
+    const int64_t count = (int64_t)sw * sh;
+    if (count <= 0) return 0;
+    float *P = (float *)malloc(sizeof(float) * 3 * (size_t)count);
+    float *Cc = color ? (float *)malloc(sizeof(float) * 3 * (size_t)count) : NULL;
+    float *Nn = compute_normals ? (float *)malloc(sizeof(float) * 3 * (size_t)count) : NULL;
+    for (int64_t idx = 0; idx < count; ++idx) {
+        const int row = (int)(idx / sw) * stride, col = (int)(idx % sw) * stride;
+        const int64_t pix = (int64_t)row * width + col;
+        const float d = depth[pix];
+        const int ok = rgbd ? (d > 0.0f && (depth_cutoff <= 0.0f || depth_cutoff > d)) : !(d <= 0.0f);
+        float *p = P + 3 * idx;
+        if (!ok) {
+            p[0] = p[1] = p[2] = INFINITY;
+            if (Cc) Cc[3 * idx] = Cc[3 * idx + 1] = Cc[3 * idx + 2] = INFINITY;
+            continue;
+        }
+        const float z = d;
+        const float x = ((float)col - cx) * z / fx;
+        const float y = ((float)row - cy) * z / fy;
+        for (int r = 0; r < 3; ++r)
+            p[r] = TM(pose, r, 0) * x + TM(pose, r, 1) * y + TM(pose, r, 2) * z + TM(pose, r, 3);
+        if (Cc) {
+            if (color_kind == 1) {
+                const uint8_t *pc = (const uint8_t *)color + pix * 3;
+                for (int k = 0; k < 3; ++k) Cc[3 * idx + k] = (float)pc[k] / 255.0f;
+            } else {
+                const float v = ((const float *)color)[pix] / 1.0f;
+                Cc[3 * idx] = Cc[3 * idx + 1] = Cc[3 * idx + 2] = v;
+            }
+        }
+    }
+    if (Nn) {
+        for (int64_t idx = 0; idx < count; ++idx) {
+            const int i = (int)(idx / width), j = (int)(idx % width);
+            float *n = Nn + 3 * idx;
+            n[0] = n[1] = n[2] = 0.0f;
+            if (i < 1 || i >= height || j < 1 || j >= width) continue;
+            const float zero[3] = {0.0f, 0.0f, 0.0f};
+            const float *l = P + 3 * (idx - 1);
+            const float *r = (idx + 1 < count) ? P + 3 * (idx + 1) : zero;
+            const float *u = P + 3 * (idx - width);
+            const float *lo = (idx + width < count) ? P + 3 * (idx + width) : zero;
+            if (!all_finite3(l)) l = zero;
+            if (!all_finite3(r)) r = zero;
+            if (!all_finite3(u)) u = zero;
+            if (!all_finite3(lo)) lo = zero;
+            const float hor[3] = {l[0] - r[0], l[1] - r[1], l[2] - r[2]};
+            const float ver[3] = {u[0] - lo[0], u[1] - lo[1], u[2] - lo[2]};
+            float c[3];
+            cross3(hor, ver, c);
+            const float norm = sqrtf(dot3(c, c));
+            if (norm == 0.0f) continue;
+            for (int k = 0; k < 3; ++k) n[k] = c[k] / norm;
+            if (n[2] > 0.0f)
+                for (int k = 0; k < 3; ++k) n[k] *= -1.0f;
+        }
+    }
+    int64_t m = 0;
+    for (int64_t idx = 0; idx < count; ++idx) {
+        if (valid_only && !all_finite3(P + 3 * idx)) continue;
+        memcpy(out_pts + 3 * m, P + 3 * idx, 3 * sizeof(float));
+        if (Nn) memcpy(out_nrm + 3 * m, Nn + 3 * idx, 3 * sizeof(float));
+        if (Cc) memcpy(out_col + 3 * m, Cc + 3 * idx, 3 * sizeof(float));
+        ++m;
+    }
+    free(P);
+    free(Cc);
+    free(Nn);
+    return m;
+}
+
+/* ------------------------------------------------------------------ */
 /* PointCloud::EstimateNormals(KNN k) (estimate_normals.cu:38-127,     */
 /* geometry_functor.h:35-55): neighbours include the point itself,     */
 /* covariance from raw second moments in fp32, smallest-eigenvalue      */

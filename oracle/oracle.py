@@ -49,6 +49,7 @@ def lib():
         _lib.oracle_search_radius.restype = C.c_int64
         _lib.oracle_search_bruteforce.restype = C.c_int64
         _lib.oracle_voxel_downsample.restype = C.c_int64
+        _lib.oracle_create_from_depth.restype = C.c_int64
         _lib.oracle_compute_rmse.restype = C.c_float
     return _lib
 
@@ -295,6 +296,68 @@ def registration_colored_icp(src, tgt, max_dist, src_colors, tgt_colors, tgt_nrm
     set_colored_context(src_colors, tgt_colors, grad, lambda_geometric)
     return registration_icp(src, tgt, max_dist, init=init, est=EST_COLORED, det_thresh=det_thresh,
                             tgt_nrm=tgt_nrm, **kw)
+
+
+def pyramid_level_intrinsic(width, height, fx, fy, cx, cy, level):
+    """PinholeCameraIntrinsic::CreatePyramidLevel (camera/pinhole_camera_intrinsic.cpp:82-92)"""
+    if level == 0 or width <= 0 or height <= 0:
+        return width, height, np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy)
+    s = np.float32(np.float32(0.5) ** np.float32(level))
+    h = np.float32(0.5)
+    return (width >> level, height >> level, np.float32(fx) * s, np.float32(fy) * s,
+            (np.float32(cx) + h) * s - h, (np.float32(cy) + h) * s - h)
+
+
+def create_from_depth(depth, intrinsic4, extrinsic=None, color=None, depth_scale=1000.0,
+                      depth_trunc=1000.0, depth_cutoff=-1.0, stride=1, rgbd=False,
+                      compute_normals=False, valid_only=True):
+    """PointCloud::CreateFromDepthImage / CreateFromRGBDImage (pointcloud_factory.cu:286-376)."""
+    depth = np.ascontiguousarray(depth)
+    h, w = depth.shape
+    if depth.dtype == np.uint16:
+        f = np.empty((h, w), np.float32)
+        lib().oracle_depth_u16_to_float(depth.ctypes.data_as(C.c_void_p), C.c_int64(h * w),
+                                        C.c_float(depth_scale), C.c_float(depth_trunc), _p(f))
+        depth = f
+    depth = _f32(depth)
+    kind = 0
+    if color is not None:
+        color = np.ascontiguousarray(color)
+        kind = 1 if color.dtype == np.uint8 else 2
+    E = np.eye(4) if extrinsic is None else np.asarray(extrinsic, np.float64).reshape(4, 4)
+    pose = np.ascontiguousarray(np.linalg.inv(E).astype(np.float32).T)   # column-major
+    K = _f32(np.asarray(intrinsic4, np.float32))
+    count = (w // stride) * (h // stride)
+    op = np.empty((count, 3), np.float32)
+    on = np.empty((count, 3), np.float32) if compute_normals else None
+    oc = np.empty((count, 3), np.float32) if color is not None else None
+    m = int(lib().oracle_create_from_depth(
+        _p(depth), None if color is None else color.ctypes.data_as(C.c_void_p), C.c_int(kind),
+        C.c_int(w), C.c_int(h), _p(K), _p(pose), C.c_float(depth_cutoff), C.c_int(stride),
+        C.c_int(int(rgbd)), C.c_int(int(compute_normals)), C.c_int(int(valid_only)),
+        _p(op), _p(on), _p(oc)))
+    return op[:m].copy(), (None if on is None else on[:m].copy()), (None if oc is None else oc[:m].copy())
+
+
+def kinfu_pose_estimation(extrinsic, frame_pyramid, model_pyramid, distance_threshold=0.5,
+                          icp_iterations=(20, 20, 20, 20), colored=False):
+    """KinfuPipeline::PoseEstimation (kinfu/kinfu.cpp:105-143): coarse-to-fine RegistrationICP,
+    point-to-plane with det_thresh 100000 (or Colored ICP, lambda 0.968), every level started
+    from the level above's result.  Pyramids: lists of dicts {points, normals[, colors]},
+    level 0 = finest."""
+    T = np.asarray(extrinsic, np.float32).reshape(4, 4)
+    for level in range(len(frame_pyramid) - 1, -1, -1):
+        f, g = frame_pyramid[level], model_pyramid[level]
+        if colored:
+            res = registration_colored_icp(f["points"], g["points"], distance_threshold, f["colors"],
+                                           g["colors"], g["normals"], init=T, lambda_geometric=0.968,
+                                           det_thresh=100000.0, max_iteration=icp_iterations[level])
+        else:
+            res = registration_icp(f["points"], g["points"], distance_threshold, init=T, est=EST_PT2PL,
+                                   det_thresh=100000.0, tgt_nrm=g["normals"],
+                                   max_iteration=icp_iterations[level])
+        T = res.transformation
+    return T
 
 
 def estimate_normals_radius(pts, radius, max_nn=30):

@@ -104,3 +104,54 @@ def colored_fragment_pair():
     src = (pts[1::2].astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
     return (np.ascontiguousarray(src), np.ascontiguousarray(col[1::2]), np.ascontiguousarray(pts[0::2]),
             np.ascontiguousarray(col[0::2]), T.astype(np.float32))
+
+
+def render_depth(width, height, K4, cam_pose, holes=0.0, seed=0, scale=1.0):
+    """Analytic depth frame (z in the camera frame, float32) of a box room
+    [-2,2] x [-1.5,1.5] x [-0.5,4] with two spheres inside, seen from cam_pose
+    (camera -> world, 4x4).  holes: fraction of pixels zeroed at random; scale: the
+    scene's unit (100 = centimetres)."""
+    fx, fy, cx, cy = [float(v) for v in K4]
+    P = np.asarray(cam_pose, np.float64).reshape(4, 4)
+    v, u = np.meshgrid(np.arange(height, dtype=np.float64), np.arange(width, dtype=np.float64), indexing="ij")
+    dirs_c = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u)], -1)        # z = 1 along the axis
+    dirs = dirs_c @ P[:3, :3].T
+    o = P[:3, 3]
+    t_best = np.full((height, width), np.inf)
+    lo, hi = np.array([-2.0, -1.5, -0.5]) * scale, np.array([2.0, 1.5, 4.0]) * scale
+    for ax in range(3):
+        for bound in (lo[ax], hi[ax]):
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = (bound - o[ax]) / dirs[..., ax]
+            hit = o + t[..., None] * dirs
+            ok = (t > 1e-6 * scale)
+            for b in range(3):
+                if b != ax:
+                    ok &= (hit[..., b] >= lo[b] - 1e-9 * scale) & (hit[..., b] <= hi[b] + 1e-9 * scale)
+            t_best = np.where(ok & (t < t_best), t, t_best)
+    for c, r in ((np.array([0.6, 0.4, 2.2]) * scale, 0.55 * scale), (np.array([-0.9, -0.3, 2.8]) * scale, 0.7 * scale)):
+        oc = o - c
+        a = (dirs * dirs).sum(-1)
+        b = 2.0 * (dirs * oc).sum(-1)
+        cc = (oc * oc).sum() - r * r
+        disc = b * b - 4 * a * cc
+        with np.errstate(invalid="ignore"):
+            t = (-b - np.sqrt(disc)) / (2 * a)
+        ok = (disc > 0) & (t > 1e-6 * scale)
+        t_best = np.where(ok & (t < t_best), t, t_best)
+    depth = np.where(np.isfinite(t_best), t_best, 0.0).astype(np.float32)         # t scales z = 1
+    if holes > 0:
+        rng = np.random.default_rng(seed)
+        depth[rng.random(depth.shape) < holes] = 0.0
+    return depth
+
+
+def small_pose(angle=0.02, shift=0.03):
+    """camera -> world pose: a small rotation about (1,2,3) and a translation"""
+    ax = np.array([1.0, 2.0, 3.0]) / np.sqrt(14.0)
+    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(angle) * Kx + (1 - np.cos(angle)) * (Kx @ Kx)
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = shift * np.array([1.0, -1.0, 0.5]) / 1.5
+    return T.astype(np.float32)

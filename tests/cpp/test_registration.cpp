@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -22,6 +23,31 @@ static Matrix4f Rigid(float angle, float ax, float ay, float az, float tx, float
 }
 
 static float Fro(const Matrix4f& a, const Matrix4f& b) { return (a - b).norm(); }
+
+
+// depth frame (z in the camera frame) of the height field z = f(x, y) seen from `pose` (camera -> world)
+static float Surface(float x, float y) { return 3.0f + 0.3f * std::sin(1.5f * x) + 0.3f * std::cos(1.2f * y) + 0.1f * x * y; }
+static geometry::Image RenderDepth(const camera::PinholeCameraIntrinsic& k, const Matrix4f& pose) {
+    std::vector<float> d((size_t)k.width_ * k.height_);
+    for (int v = 0; v < k.height_; ++v)
+        for (int u = 0; u < k.width_; ++u) {
+            const float dc[3] = {(u - k.cx_) / k.fx_, (v - k.cy_) / k.fy_, 1.0f};
+            float dir[3];
+            for (int r = 0; r < 3; ++r) dir[r] = pose(r, 0) * dc[0] + pose(r, 1) * dc[1] + pose(r, 2) * dc[2];
+            float s = 3.0f;
+            for (int it = 0; it < 40; ++it) {
+                const float px = pose(0, 3) + s * dir[0], py = pose(1, 3) + s * dir[1], pz = pose(2, 3) + s * dir[2];
+                s += (Surface(px, py) - pz) / dir[2];
+            }
+            d[(size_t)v * k.width_ + u] = s;
+        }
+    geometry::Image img;
+    img.Prepare(k.width_, k.height_, 1, 4);
+    std::vector<uint8_t> bytes(d.size() * 4);
+    std::memcpy(bytes.data(), d.data(), bytes.size());
+    img.SetData(bytes);
+    return img;
+}
 
 // a user-defined estimator: exercises the virtual interface / generic loop
 class MyPointToPlane : public registration::TransformationEstimation {
@@ -161,6 +187,33 @@ int main() {
         const int kr_size = (int)idx.size();
         std::printf("\"kdtree_knn_ok\": %s, \"kdtree_radius\": [%d, %d, %d], \"kdtree_batch\": %d, \"kdtree_empty\": %d, ",
                     same ? "true" : "false", kr, kr_size, std::min(expect, 32), kb, empty.SearchKNN(q, 3, idx, d2));
+    }
+    {   // tracker-side callers: depth frames -> cloud pyramids -> kinfu::PoseEstimation (kinfu.cpp:87-143)
+        const camera::PinholeCameraIntrinsic k0(320, 240, 262.5f, 262.5f, 159.5f, 119.5f);
+        const Matrix4f pose_b = Rigid(0.02f, 1, 2, 3, 0.02f, -0.02f, 0.01f);
+        kinfu::KinfuOption opt(2, 6.0f, 0.03f, {10, 10});
+        std::vector<geometry::RGBDImage> fa, fb;
+        for (int l = 0; l < 2; ++l) {
+            const auto kl = k0.CreatePyramidLevel((size_t)l);
+            fa.emplace_back(geometry::Image(), RenderDepth(kl, Matrix4f::Identity()));
+            fb.emplace_back(geometry::Image(), RenderDepth(kl, pose_b));
+        }
+        auto model = kinfu::CreatePointCloudPyramid(fa, k0, opt);
+        auto frame = kinfu::CreatePointCloudPyramid(fb, k0, opt);
+        Matrix4f T;
+        bool ok;
+        std::tie(T, ok) = kinfu::PoseEstimation(opt, Matrix4f::Identity(), frame, model);
+        const size_t n0 = model[0]->points_.size(), n1 = model[1]->points_.size();
+        const bool has_n = model[0]->HasNormals() && !model[0]->HasColors();
+        std::printf("\"kinfu_err\": %.3g, \"kinfu_ok\": %s, \"kinfu_points\": [%zu, %zu], \"kinfu_normals\": %s, ",
+                    Fro(T, pose_b), ok ? "true" : "false", n0, n1, has_n ? "true" : "false");
+        // CreateFromDepthImage: stride, and the reference's error path for a 3-channel "depth"
+        auto strided = geometry::PointCloud::CreateFromDepthImage(fa[0].depth_, k0, Matrix4f::Identity(), 1000.0f, 1000.0f, 4);
+        geometry::Image bad;
+        bad.Prepare(8, 8, 3, 1);
+        auto none = geometry::PointCloud::CreateFromDepthImage(bad, k0);
+        const size_t ns = strided->points_.size();
+        std::printf("\"depth_strided\": %zu, \"depth_bad_empty\": %s, ", ns, none->IsEmpty() ? "true" : "false");
     }
     {   // Kabsch golden shape (src/tests/registration/kabsch.cpp:35-55)
         std::vector<Vector3f> pts(20);

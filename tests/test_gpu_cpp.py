@@ -40,3 +40,8 @@ def test_cpp_surface_end_to_end(tmp_path):
     assert r["colored_no_colors_is_identity"]
     assert 1000 < r["voxels"] <= 9261 and r["voxel_normals_unit"] and r["voxel_zero_empty"] and r["has_normals"]
     assert "require pre-computed target normal vectors" in out.stderr      # LogError path
+    # depth frames -> cloud pyramids -> kinfu::PoseEstimation recovers the camera motion
+    assert r["kinfu_ok"] and r["kinfu_err"] < 2e-3, r["kinfu_err"]
+    assert r["kinfu_points"] == [320 * 240, 160 * 120] and r["kinfu_normals"]
+    assert r["depth_strided"] == 80 * 60 and r["depth_bad_empty"]
+    assert "[PointCloud::CreateFromDepthImage] Unsupported image format." in out.stderr

@@ -164,3 +164,68 @@ def test_colored_rmse_is_the_plain_sum_of_squared_residuals():
     half = orc.compute_rmse(orc.EST_COLORED, src, tgt, cor[: len(cor) // 2], tgt_nrm=nrm) + \
         orc.compute_rmse(orc.EST_COLORED, src, tgt, cor[len(cor) // 2:], tgt_nrm=nrm)
     assert whole > 0 and abs(whole - half) <= 1e-4 * whole   # additive: a sum, not a root-mean
+
+
+# --- depth image -> point cloud (pointcloud_factory.cu) and the KinFu pose estimation -------------
+def test_depth_restatement_obeys_the_pinhole_model_and_the_reference_rules():
+    from conftest import render_depth, small_pose
+    K = [525.0, 525.0, 319.5, 239.5]
+    d = render_depth(640, 480, K, np.eye(4), holes=0.1, seed=2)
+    p, _, _ = orc.create_from_depth(d, K, stride=1)
+    assert len(p) == int((d > 0).sum())                      # d <= 0 dropped, pixel order kept
+    v, u = np.nonzero(d > 0)
+    np.testing.assert_allclose(p[:, 2], d[v, u], rtol=1e-6)
+    np.testing.assert_allclose(p[:, 0] / p[:, 2] * K[0] + K[2], u, atol=2e-3)     # projects back onto its pixel
+    np.testing.assert_allclose(p[:, 1] / p[:, 2] * K[1] + K[3], v, atol=2e-3)
+    # extrinsic: points are mapped by its inverse
+    E = np.linalg.inv(small_pose(0.4, 0.3))
+    q, _, _ = orc.create_from_depth(d, K, E)
+    np.testing.assert_allclose(q, orc.transform_points(np.linalg.inv(E).astype(np.float32), p), atol=2e-6)
+    # stride: pixel (row*stride, col*stride) of a (w/stride) x (h/stride) grid
+    s3, _, _ = orc.create_from_depth(d, K, stride=3)
+    sub = d[: (480 // 3) * 3: 3, : (640 // 3) * 3: 3]
+    assert len(s3) == int((sub > 0).sum())
+    # uint16 depth: / (int)scale, >= (int)trunc dropped
+    d16 = (np.clip(d, 0, 60) * 1000).astype(np.uint16)
+    a, _, _ = orc.create_from_depth(d16, K, depth_scale=1000.9, depth_trunc=2.9)
+    assert len(a) == int(((d16 > 0) & (d16.astype(np.float32) / np.float32(1000) < 2)).sum())
+    # RGB-D form: cutoff, colours scaled by 1/255, rejected pixels +inf when not compacted
+    col = np.random.default_rng(0).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    p2, n2, c2 = orc.create_from_depth(d, K, color=col, depth_cutoff=2.5, rgbd=True, compute_normals=True,
+                                       valid_only=False)
+    keep = (d > 0) & (d < 2.5)
+    assert len(p2) == 640 * 480 and (np.isfinite(p2[:, 0]) == keep.ravel()).all()
+    assert np.isinf(c2[~keep.ravel()]).all()
+    np.testing.assert_allclose(c2[keep.ravel()], col[keep] / 255.0, atol=1e-7)
+    # normals of the back wall (z = 4, seen head-on) point at the camera: (0, 0, -1)
+    clean = render_depth(640, 480, K, np.eye(4))
+    _, n3, _ = orc.create_from_depth(clean, K, rgbd=True, compute_normals=True, valid_only=False)
+    n3 = n3.reshape(480, 640, 3)
+    assert np.abs(clean[84:131, 479:526] - 4.0).max() < 1e-5
+    np.testing.assert_allclose(n3[85:130, 480:525].reshape(-1, 3), np.tile([0, 0, -1.0], (45 * 45, 1)), atol=1e-4)
+    assert (n2[:, 2] <= 0).all()
+
+
+def test_pyramid_intrinsics_follow_the_half_pixel_convention():
+    w, h, fx, fy, cx, cy = orc.pyramid_level_intrinsic(640, 480, 525.0, 525.0, 319.5, 239.5, 1)
+    assert (w, h) == (320, 240) and fx == 262.5 and cx == 159.5 and cy == 119.5
+    assert orc.pyramid_level_intrinsic(640, 480, 525.0, 525.0, 319.5, 239.5, 0)[2] == 525.0
+
+
+def test_kinfu_pose_estimation_recovers_the_camera_motion():
+    from conftest import render_depth, small_pose
+    K0 = (640, 480, 525.0, 525.0, 319.5, 239.5)
+    pose_b = small_pose(0.02, 0.03)
+    frames, models = [], []
+    for level in range(3):       # every level rendered with its own intrinsics (half-pixel convention)
+        w, h, fx, fy, cx, cy = orc.pyramid_level_intrinsic(*K0, level)
+        k = [fx, fy, cx, cy]
+        for pose, dst in ((np.eye(4), models), (pose_b, frames)):
+            p, n, _ = orc.create_from_depth(render_depth(w, h, k, pose), k, rgbd=True, compute_normals=True,
+                                            depth_cutoff=6.0)
+            dst.append(dict(points=p, normals=n))
+    # a threshold above the occlusion shadows' width lets their wrong matches bias the result
+    # (7e-3 at 0.1); 0.03 keeps them out
+    T = orc.kinfu_pose_estimation(np.eye(4, dtype=np.float32), frames, models, distance_threshold=0.03,
+                                  icp_iterations=(10, 10, 10))
+    assert np.linalg.norm(T - pose_b) < 2e-3, np.linalg.norm(T - pose_b)
