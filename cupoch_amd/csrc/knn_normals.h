@@ -290,29 +290,29 @@ __global__ __launch_bounds__(kKnnThreads) void knn_search_kernel(
 
     // ---- A: a first bound.  A plain k-NN query starts with an infinite search cube, and a
     // depth-first walk in child order would wade through the whole tree before the k-th
-    // distance means anything (measured: 2.8 s for 2M queries).  So the packet first descends
-    // greedily -- at every record into the child whose box is nearest (Linf) to the packet's
-    // first query -- and offers the 64 slots under the leaf-level node it arrives at to every
-    // lane; if some lane still holds fewer than k candidates, also the 448 slots under that
-    // node's seven siblings.  The packet is a compact blob, so what is near its first query
-    // bounds all of them usefully.  Leaves [seed_lo, seed_hi) are skipped by the walk below.
+    // distance means anything (measured: 2.8 s for 2M queries).  So every LANE first descends
+    // greedily on its own -- at each record into the child whose box is nearest (Linf) to its
+    // query; neighbouring lanes read the same records, so the divergent loads hit L1 -- and
+    // offers itself the 64 slots under the leaf-level node it arrives at: the k-th distance
+    // among a query's own 64 nearest-cell points is within a small factor of the true one.
+    // (A packet-level seed -- one descent for the
+    // packet's first query -- left the far lanes with a packet-diameter bound and the walk
+    // 10x wider: 92 ms instead of ~10 for 2M queries at k = 8.)  Each lane skips its own
+    // seeded leaves [seed_lo, seed_hi) in the walk below.
     uint32_t seed_lo = 0u, seed_hi = 0u;
     if (k > 0) {
-        typedef const __attribute__((address_space(4))) char* cchar_p;
-        const cchar_p base = (cchar_p)(uintptr_t)records_g;
         uint32_t id = 1u;
         int32_t off = -1;
-        while (id < leaf_first) {
-            id = __builtin_amdgcn_readfirstlane(id);
-            off = __builtin_amdgcn_readfirstlane(off);
-            const cf16_p rec = (cf16_p)(base + ((id + (uint32_t)off) << 8));
-            const f16v r0 = rec[0], r1 = rec[1], r2v = rec[2];
+        while (id < leaf_first) {  // same depth for every lane
+            const float4* rec = reinterpret_cast<const float4*>(records_g + ((size_t)(id + (uint32_t)off) << 6));
             float w[48];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                w[e] = r0[e];
-                w[16 + e] = r1[e];
-                w[32 + e] = r2v[e];
+            for (int e = 0; e < 12; ++e) {
+                const float4 f = rec[e];
+                w[4 * e] = f.x;
+                w[4 * e + 1] = f.y;
+                w[4 * e + 2] = f.z;
+                w[4 * e + 3] = f.w;
             }
             float bestd = INFINITY;
             int bestc = 0;
@@ -329,44 +329,68 @@ __global__ __launch_bounds__(kKnnThreads) void knn_search_kernel(
                     bestc = c;
                 }
             }
-            id = id * 8u + (uint32_t)__builtin_amdgcn_readlane(bestc, 0);  // lane 0 is always a valid query
+            id = id * 8u + (uint32_t)bestc;
             off = off * 8 + 1;
         }
-        id = __builtin_amdgcn_readfirstlane(id);
         const uint32_t own = (id - leaf_first) * 8u;          // first leaf under the node reached
         const uint32_t par = ((id & ~7u) - leaf_first) * 8u;  // first leaf under its parent
         const uint32_t nleaf_u = (uint32_t)nleaf;
-        auto offer_leaves = [&](uint32_t lb) {
-            for (uint32_t L = lb; L < lb + 8u && L < nleaf_u; ++L) {
-                const cfloat_p line = tblk + (size_t)L * kLeafFloats;
+        // leaf lb + s of every lane that takes part, s = 0..7
+        auto offer_leaves = [&](uint32_t lb, bool take) {
+            if (__ballot(take) == 0ull) return;
+            for (uint32_t s = 0; s < 8u; ++s) {
+                const uint32_t L = lb + s;
+                const bool on = take && L < nleaf_u;
+                const float4* line = reinterpret_cast<const float4*>(tblk_g + (size_t)(on ? L : 0u) * kLeafFloats);
+                float c[24];
 #pragma unroll
-                for (int t = 0; t < kLeaf; ++t) {
-                    const float d2 = sq3(qx - line[t], qy - line[8 + t], qz - line[16 + t]);
-                    knn_offer(kd2, kidx, lane, k, st, d2, (int32_t)(L * kLeaf) + t);  // padding points: d2 = +inf
+                for (int e = 0; e < 6; ++e) {
+                    const float4 f = line[e];
+                    c[4 * e] = f.x;
+                    c[4 * e + 1] = f.y;
+                    c[4 * e + 2] = f.z;
+                    c[4 * e + 3] = f.w;
+                }
+#pragma unroll
+                for (int u = 0; u < kLeaf; ++u) {
+                    const float d2 = on ? sq3(qx - c[u], qy - c[8 + u], qz - c[16 + u]) : INFINITY;
+                    knn_offer(kd2, kidx, lane, k, st, d2, (int32_t)(L * kLeaf) + u);  // padding points: d2 = +inf
                 }
             }
         };
-        offer_leaves(own);
+        offer_leaves(own, valid);
         seed_lo = own;
         seed_hi = own + 8u;
-        if (leaf_first > 1u && __ballot(valid && st.count < k) != 0ull) {
-            for (uint32_t s = 0; s < 8u; ++s)
-                if (par + 8u * s != own) offer_leaves(par + 8u * s);
-            seed_lo = par;
-            seed_hi = par + 64u;
+        // Lanes still short of k candidates (a node in a group's padded tail can hold any number
+        // of real points, down to one) widen to the node's parent, grandparent, ... -- without
+        // this their bound stays infinite and the walk below offers them the whole cloud (a
+        // handful of such packets cost 90 ms at k = 4).
+        const uint32_t all = leaf_first * 8u;  // leaves under the root
+        for (uint32_t nspan = 64u; nspan <= all; nspan *= 8u) {
+            const bool more = valid && st.count < k && st.worst == INFINITY;  // (a radius search is bounded anyway)
+            if (__ballot(more) == 0ull) break;
+            const uint32_t nlo = own & ~(nspan - 1u);
+            for (uint32_t s = 0; s < nspan; s += 8u) {
+                const uint32_t lb = nlo + s;
+                offer_leaves(lb, more && (lb < seed_lo || lb >= seed_hi));
+            }
+            if (more) {
+                seed_lo = nlo;
+                seed_hi = nlo + nspan;
+            }
         }
     }
     Cube cube;
     set_cube(cube, qx, qy, qz, st.worst);
     // ---- B: the exact walk
     traverse_wide(records_g, leaf_first, cube, [&](uint32_t Lu) {
-        if (Lu >= seed_lo && Lu < seed_hi) return;
+        const bool seeded = Lu >= seed_lo && Lu < seed_hi;  // this lane has these points already
         const int L = (int)Lu;
         const cfloat_p line = tblk + (size_t)L * kLeafFloats;
         bool shrunk = false;
 #pragma unroll
         for (int t = 0; t < kLeaf; ++t) {
-            const float d2 = sq3(qx - line[t], qy - line[8 + t], qz - line[16 + t]);
+            const float d2 = seeded ? INFINITY : sq3(qx - line[t], qy - line[8 + t], qz - line[16 + t]);
             shrunk |= knn_offer(kd2, kidx, lane, k, st, d2, L * kLeaf + t);  // padding points: d2 = +inf
         }
         if (shrunk) set_cube(cube, qx, qy, qz, st.worst);

@@ -10,7 +10,10 @@ eng = Engine(0)
 src, tgt, nrm, T, md = synth(10_000_000)
 d_t, d_q = torch.from_numpy(tgt).cuda(), torch.from_numpy(src[:2_000_000]).cuda()
 eng.set_target(d_t)
-for k, r in ((1, 0.0), (8, 0.0), (30, 0.0), (30, 0.01)):
+CASES = ((1, 0.0), (8, 0.0), (30, 0.0), (30, 0.01))
+if len(sys.argv) > 1:
+    CASES = [tuple(float(x) if "." in x else int(x) for x in a.split(",")) for a in sys.argv[1:]]
+for k, r in CASES:
     eng.search_knn(d_q, k, r); torch.cuda.synchronize()
     t0 = time.perf_counter(); found, idx, d2 = eng.search_knn(d_q, k, r); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(json.dumps({"row": "KDTreeFlann search, 2M queries vs 10M points", "knn": k, "radius": r, "ms": dt * 1e3,

@@ -44,7 +44,7 @@ def test_golden_search_knn_and_radius(golden):
 
 
 def rows_equal_up_to_ties(idx, d2, oi, od, tgt, qry):
-    """distances bit-exact; indices equal wherever the row has no equal distances"""
+    """distances bit-exact; indices equal except where equal distances allow a choice"""
     fin = np.isfinite(od)
     assert np.array_equal(np.isfinite(d2), fin)
     assert np.array_equal(d2[fin], od[fin])
@@ -54,8 +54,9 @@ def rows_equal_up_to_ties(idx, d2, oi, od, tgt, qry):
         k = int(fin[r].sum())
         dd = tgt[idx[r, :k]] - qry[r]
         chk = (dd[:, 2] * dd[:, 2] + (dd[:, 1] * dd[:, 1] + dd[:, 0] * dd[:, 0])).astype(np.float32)
-        assert np.array_equal(chk, od[r, :k]), r
-        assert len(np.unique(od[r, :k])) < k, r
+        np.testing.assert_allclose(chk, od[r, :k], rtol=5e-7, err_msg=str(r))   # (numpy has no fma: last-ulp slack)
+        # (a tie inside the row, or between its last entry and the first point left out: the
+        # distances are the oracle's bit for bit either way, so this is a valid answer)
     assert len(bad) <= max(2, len(idx) // 200)
 
 
@@ -100,3 +101,40 @@ def test_errors_and_limits(eng):
     eng.set_target(tgt)
     found, idx, d2 = eng.search_knn(np.array([[0.5, 0.5, 0.6]], np.float32), 8)
     assert found == 8 and len(set(idx[0].tolist())) == 8 and np.all(d2[0] == d2[0, 0])
+
+
+def test_sparse_and_clustered_targets_stay_exact_and_fast(eng):
+    """Nodes in a group's padded tail hold any number of real points and a radius search may
+    find fewer than max_nn: neither may leave a query with an unbounded walk (the seeding in
+    knn_search_kernel widens through the ancestors / keeps the radius bound).  Exactness on
+    strongly non-uniform data, and a wall-clock guard: the unbounded walk takes seconds."""
+    import time
+    rng = np.random.default_rng(77)
+    # 60 tight clusters of very different sizes + a sparse background
+    sizes = rng.integers(1, 4000, 60)
+    centres = rng.random((60, 3)).astype(np.float32)
+    tgt = np.concatenate([c + rng.normal(0, 0.002, (s, 3)).astype(np.float32) for c, s in zip(centres, sizes)] +
+                         [rng.random((300, 3), dtype=np.float32)])
+    qry = np.concatenate([tgt[rng.permutation(len(tgt))[:20000]] + rng.normal(0, 0.001, (20000, 3)).astype(np.float32),
+                          rng.random((5000, 3), dtype=np.float32) * 3 - 1])
+    eng.set_target(tgt)
+    for k in (1, 4, 9, 32):
+        found, idx, d2 = eng.search_knn(qry, k)
+        ret, oi, od = orc.search_knn(tgt, qry, k)
+        assert found == ret
+        rows_equal_up_to_ties(idx, d2, oi, od, tgt, qry)
+    found, idx, d2 = eng.search_knn(qry, 32, 0.004)
+    ret, oi, od = orc.search_radius(tgt, qry, 0.004, 32)
+    assert found == ret
+    rows_equal_up_to_ties(idx, d2, oi, od, tgt, qry)
+
+    big = rng.random((2_000_000, 3), dtype=np.float32)
+    q = torch.from_numpy(big[:400_000] + np.float32(1e-3)).cuda()
+    eng.set_target(torch.from_numpy(big).cuda())
+    for k, r in ((4, 0.0), (30, 0.0), (30, 0.004)):       # radius 0.004: ~0.5 neighbours per query
+        eng.search_knn(q, k, r)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.search_knn(q, k, r)
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 0.5, (k, r)
