@@ -20,7 +20,8 @@
  *                                : pinned by src/tests/registration/kabsch.cpp
  *                                  and src/tests/geometry/pointcloud.cpp.
  *   - RegistrationICP loop, JtJ/Jtr accumulation, 6x6 LDLT solve, GICP,
- *     Colored ICP (colour gradients, two-row estimator)
+ *     Colored ICP (colour gradients, two-row estimator), depth-image ->
+ *     point-cloud factories, KinFu pose estimation
  *                                : PARITY UNPINNED by the reference's own
  *                                  tests (none exist); checked by
  *                                  self-consistency (recover a known T_gt).
