@@ -19,6 +19,8 @@ struct GroupBuildArgs {
     const uint32_t* vals;     // point indices sorted by cell (stable)
     const uint32_t* cstart;   // [ncells + 1] first sorted position of every cell
     const uint32_t* gstart;   // [ncells] first group of every cell
+    const float2* planes;     // the cells' split planes in heap order (kd_cells.h)
+    int cell_levels;          // ncells = 2^cell_levels
     int ncells;
     uint32_t ngroups;
     uint32_t leaf_first;      // id of the first leaf-level node (8^k >= 64 * ngroups)
@@ -31,6 +33,7 @@ struct GroupBuildArgs {
 __global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) {
     __shared__ KdShared s;
     __shared__ uint32_t s_src[3];  // first sorted position, number of points of this group, groups of its cell
+    __shared__ float s_region[6];
     const int tid = (int)threadIdx.x;
     const uint32_t g = blockIdx.x;
     if (tid == 0) {
@@ -48,6 +51,14 @@ __global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) 
         s_src[1] = (cnt > first) ? min(cnt - first, (uint32_t)kKdGroup) : 0u;
         s_src[2] = ((lo + 1 < a.ncells) ? a.gstart[lo + 1] : a.ngroups) - a.gstart[lo];
         s.clean = 1;
+        // the cell's region: every point of another cell lies on or beyond one of its faces
+        float reg[6];
+        cell_region(a.planes, a.cell_levels, a.cell_levels, (uint32_t)lo, reg);
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            s.safe[e * 64] = reg[e];
+            s_region[e] = reg[e];
+        }
     }
     __syncthreads();
     const uint32_t src0 = s_src[0];
@@ -66,7 +77,7 @@ __global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) 
         s.key[i] = (uint32_t)i;
     }
     __syncthreads();
-    kd_sort_levels<false>(s, 9, nullptr, 0u);
+    kd_sort_levels<false, true>(s, 9, nullptr, 0u);
 
     // ---- leaf lines + sorted attributes: position p of the group = slot g*4096 + p
     const int64_t slot0 = (int64_t)g * kKdGroup;
@@ -109,17 +120,11 @@ __global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) 
         }
     }
     __syncthreads();
-    // the last round's splits (16 -> 8 | 8): exact disjointness of the two leaves along the split axis
-    if (tid < kKdGroup / 16) {
-        const int ax = s.seg_axis[tid];
-        if (s.bb[(3 + ax) * kKdChunks + 2 * tid] > s.bb[ax * kKdChunks + 2 * tid + 1]) s.clean = 0;
-    }
-    __syncthreads();
-    // Every node's own record also carries the node's own box and a flag "the boxes of this
-    // node and of every node below it are disjoint from everything else in the tree" (the
-    // search's early stop, traverse.h): true when no split of this group left a sliver and
-    // the group is its cell's only one.
-    const uint32_t own_flag = (s.clean != 0 && s_src[2] == 1u) ? 1u : 0u;
+    // Every node's own record also carries the node's REGION (kd_refine.h: free of points of
+    // any other node, larger than the points' box by the gaps to the neighbours) and a flag
+    // that it may be used to end a search early (traverse.h).  A cell that needed several
+    // groups has no such regions: its groups are not separated by a split.
+    const uint32_t own_flag = (s_src[2] == 1u) ? 1u : 0u;
     // level j: 512 >> 3j boxes; box t of level j is node (leaf_first >> 3(j-1)) + g*(64 >> 3(j-1)) + t
     // for j >= 1, and leaf g*512 + t (child of node leaf_first + (g*512 + t)/8) for j = 0
     for (int j = 0; j < 4; ++j) {
@@ -157,7 +162,18 @@ __global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) 
             if (j == 0) id = a.leaf_first * 8u + g * 512u + (uint32_t)tid;  // (leaf_first + L/8)*8 + L%8
             else id = (a.leaf_first >> (3 * (j - 1))) + g * (uint32_t)(64 >> (3 * (j - 1))) + (uint32_t)tid;
             if (id > 1u) store_box(a.records, id, mn, mx);  // the root has no parent record
-            if (j > 0) store_own(a.records, id, mn, mx, own_flag);
+            if (j > 0) {
+                float rmn[3] = {mn[0], mn[1], mn[2]}, rmx[3] = {mx[0], mx[1], mx[2]};
+                if (own_flag) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        rmn[d] = (j == 1) ? s.safe[d * 64 + tid] : ((j == 2) ? s.safe512[d * 8 + tid] : s_region[d]);
+                        rmx[d] = (j == 1) ? s.safe[(3 + d) * 64 + tid]
+                                          : ((j == 2) ? s.safe512[(3 + d) * 8 + tid] : s_region[3 + d]);
+                    }
+                }
+                store_own(a.records, id, rmn, rmx, own_flag);
+            }
         }
     }
     // the group nodes' parent records are padded to 8 children with inverted boxes

@@ -37,6 +37,11 @@ struct KdShared {
     float seg_lo[kKdGroup / 16], seg_scale[kKdGroup / 16];
     uint8_t seg_axis[kKdGroup / 16];
     int clean;  // stays 1 while no split has produced overlapping halves (set by the caller, see below)
+    // SAFE regions (kd_sort_levels<.., true>): [min xyz | max xyz][segment] of the current
+    // round while it has <= 64 segments; the 8-segment stage is kept in safe512, the caller's
+    // starting region in safe[e * 64 + 0]
+    float safe[6 * 64];
+    float safe512[6 * 8];
 };
 
 // ---- the bitonic network, 4 consecutive keys per thread held in registers ---------------
@@ -152,7 +157,18 @@ __device__ __forceinline__ void kd_bitonic_sort(KdShared& s, uint32_t v[4], int 
 // exactly, max(left half) with min(right half) of the previous round's splits and clears
 // s.clean on overlap (~0.4 % of the splits at 4096 points); the caller checks the last
 // round's halves itself (kd_last_split_clean).
-template <bool PLANES>
+//
+// SAFE: also track, per segment, the REGION that is free of points of any other segment.
+// The caller puts the group's own region (its kd cell) into s.safe[e * 64 + 0]; a split of
+// a segment along `ax` hands the region down with one face moved: the lower half's upper
+// face becomes the smallest coordinate of the upper half, the upper half's lower face the
+// largest coordinate of the lower half (both exact, from the chunk boxes of the next
+// round).  Every point outside a segment then lies outside the segment's region (on or
+// beyond one of its faces), whatever the quantised sort did with near-equal coordinates --
+// this is the box the search tests a query's cube against to end early (traverse.h), and
+// it is larger than the points' bounding box by the gaps to the neighbouring cells.
+// Kept for 2 .. 64 segments (safe512: the 8-segment stage).
+template <bool PLANES, bool SAFE = false>
 __device__ __forceinline__ void kd_sort_levels(KdShared& s, int levels, float2* __restrict__ planes,
                                                uint32_t heap_root) {
     const int tid = (int)threadIdx.x;
@@ -193,12 +209,35 @@ __device__ __forceinline__ void kd_sort_levels(KdShared& s, int levels, float2* 
         }
         const int nseg = kKdGroup >> lS;
         if (lS < 12) {  // the two halves of every split of the previous round
-            if (tid < nseg && (tid & 1) == 0) {
-                const int ax = s.seg_axis[tid >> 1];
+            const bool pair = tid < nseg && (tid & 1) == 0;
+            const bool track = SAFE && nseg <= 64;
+            int ax = 0;
+            float lmax = 0.0f, rmin = 0.0f, P[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            if (pair) {
+                ax = s.seg_axis[tid >> 1];
                 const int cl = tid * chunks_per_seg, cr = cl + chunks_per_seg;
-                if (s.bb[(3 + ax) * kKdChunks + cl] > s.bb[ax * kKdChunks + cr]) s.clean = 0;
+                lmax = s.bb[(3 + ax) * kKdChunks + cl];
+                rmin = s.bb[ax * kKdChunks + cr];
+                if (lmax > rmin) s.clean = 0;
+                if (track) {
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) P[e] = s.safe[e * 64 + (tid >> 1)];
+                }
             }
-            __syncthreads();  // seg_axis is rewritten below
+            __syncthreads();  // seg_axis is rewritten below; the parents' regions have been read
+            if (track && pair) {
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    const float l = (e == 3 + ax) ? fminf(P[e], rmin) : P[e];
+                    const float r = (e == ax) ? fmaxf(P[e], lmax) : P[e];
+                    s.safe[e * 64 + tid] = l;
+                    s.safe[e * 64 + tid + 1] = r;
+                    if (nseg == 8) {
+                        s.safe512[e * 8 + tid] = l;
+                        s.safe512[e * 8 + tid + 1] = r;
+                    }
+                }
+            }
         }
         if (tid < nseg) {
             const int c0 = tid * chunks_per_seg;

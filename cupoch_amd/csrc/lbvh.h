@@ -195,8 +195,36 @@ __global__ __launch_bounds__(256) void build_leaves(
 // level-k nodes first + t, t in [0, count): box = union of the node's 8 child slots,
 // written into the parent's record; t >= used (padding up to a multiple of 8)
 // writes the inverted box.
+// Region of the heap node (depth, index) of a `levels`-deep plane tree: [min xyz | max xyz].
+// A point is right of a plane iff coordinate >= plane (descend_cell), so every point outside
+// the node's subtree lies on or beyond one of the region's faces.  depth <= 0: all of space.
+__device__ __forceinline__ void cell_region(const float2* __restrict__ planes, int levels, int depth, uint32_t index,
+                                            float reg[6]) {
+    reg[0] = reg[1] = reg[2] = -INFINITY;
+    reg[3] = reg[4] = reg[5] = INFINITY;
+    (void)levels;
+    uint32_t node = 1u;
+    for (int l = 0; l < depth; ++l) {
+        const float2 pl = planes[node];
+        const int ax = __float_as_int(pl.y);
+        const uint32_t bit = (index >> (depth - 1 - l)) & 1u;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (d == ax) {
+                if (bit) reg[d] = fmaxf(reg[d], pl.x);
+                else reg[3 + d] = fminf(reg[3 + d], pl.x);
+            }
+        node = node * 2u + bit;
+    }
+}
+
+// own_flag: the nodes are kd subtrees of the cells' plane tree (every cell has one group):
+// node t of this level is the plane tree's node (region_depth, t), and its REGION
+// (kd_cells.h cell_region) is stored as the own box instead of the points' box.
 __global__ __launch_bounds__(256) void build_level(float* __restrict__ records, uint32_t first,
-                                                   uint32_t used, uint32_t count, uint32_t own_flag) {
+                                                   uint32_t used, uint32_t count, uint32_t own_flag,
+                                                   const float2* __restrict__ planes, int cell_levels,
+                                                   int region_depth) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= count) return;
     const uint32_t id = first + t;
@@ -211,7 +239,13 @@ __global__ __launch_bounds__(256) void build_level(float* __restrict__ records, 
                 mn[d] = fminf(mn[d], fminf(rec[p * kPairStride + 2 * d], rec[p * kPairStride + 2 * d + 1]));
                 mx[d] = fmaxf(mx[d], fmaxf(rec[p * kPairStride + 6 + 2 * d], rec[p * kPairStride + 6 + 2 * d + 1]));
             }
-        store_own(records, id, mn, mx, own_flag);
+        if (own_flag) {
+            float reg[6];
+            cell_region(planes, cell_levels, region_depth, t, reg);
+            store_own(records, id, reg, reg + 3, 1u);
+        } else {
+            store_own(records, id, mn, mx, 0u);
+        }
     }
     store_box(records, id, mn, mx);
 }

@@ -296,6 +296,8 @@ struct CellLayout {
     const uint32_t* gstart;
     int ncells;
     int64_t ngroups;
+    const float2* planes;  // split planes, heap order
+    int levels;            // ncells = 2^levels
 };
 
 int kd_cell_layout(mi_icp_ctx* c, const float* pts, int64_t n, CellLayout* out) {
@@ -349,6 +351,8 @@ int kd_cell_layout(mi_icp_ctx* c, const float* pts, int64_t n, CellLayout* out) 
     out->gstart = gstart;
     out->ncells = ncells;
     out->ngroups = ngroups;
+    out->planes = planes;
+    out->levels = d;
     return MI_ICP_OK;
 }
 
@@ -760,6 +764,8 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
         ga.cstart = lay.cstart;
         ga.gstart = lay.gstart;
         ga.ncells = lay.ncells;
+        ga.planes = lay.planes;
+        ga.cell_levels = lay.levels;
         ga.ngroups = (uint32_t)lay.ngroups;
         ga.leaf_first = leaf_first;
         ga.tblk = tblk;
@@ -771,9 +777,11 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
         first = leaf_first >> 9;  // the groups' own boxes sit in the records of this level
         used = ((uint32_t)lay.ngroups + 7u) / 8u;
     }
-    for (; first > 1u; first /= 8u) {
+    int above_groups = 1;  // 8-ary levels between `first` and the groups' level
+    for (; first > 1u; first /= 8u, ++above_groups) {
         const uint32_t count = ((used + 7u) / 8u) * 8u;
-        build_level<<<blocks_for(count), 256, 0, c->stream>>>(nodes, first, used, count, upper_flag);
+        build_level<<<blocks_for(count), 256, 0, c->stream>>>(nodes, first, used, count, upper_flag, lay.planes,
+                                                              lay.levels, lay.levels - 3 * above_groups);
         KCHK(c);
         used = (used + 7u) / 8u;
     }

@@ -112,16 +112,14 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     float best = valid ? r2 : -1.0f;
     int32_t bidx = -1;
 
-    uint32_t start = 1u;  // node the search starts at (traverse.h): the root, or ...
+    uint32_t my_node = 0u;  // leaf-level node of the lane's previous match (traverse_seeded), 0: none
     if (SEED) {
-        // last iteration's match bounds this one's search radius
+        // last iteration's match bounds this one's search radius, and its leaf-level node is
+        // where this lane's search starts (taken from the raw index: the first record's fetch
+        // does not wait for the gather below)
         const int32_t j = valid ? nn_idx[i] : -1;
-        // ... the leaf-level node of the first lane that has a previous match; taken from the raw
-        // index so that the first record's fetch does not wait for the gather below
-        const uint64_t seeded = __ballot(j >= 0);
-        if (seeded != 0ull)
-            start = leaf_first + ((uint32_t)__builtin_amdgcn_readlane(j, (int)__builtin_ctzll(seeded)) >> 6);
         if (j >= 0) {
+            my_node = leaf_first + ((uint32_t)j >> 6);
             const float* line = tblk_g + (int64_t)(j >> 3) * kLeafFloats + (j & 7);
             const float d2 = sq3(qx - line[0], qy - line[8], qz - line[16]);
             if (d2 < best) {
@@ -137,6 +135,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     __builtin_amdgcn_wave_barrier();
 
     uint32_t queued = 0u, batches = 0u;  // wave-uniform
+    bool retired = !valid;               // traverse_seeded: this lane's search is complete
     auto drain = [&](uint32_t first, uint32_t count) {
         if (STATS) ++batches;
         drain_items(sh, tblk_g, first, count, qx, qy, qz, r2);
@@ -146,10 +145,10 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
         if (valid && (int32_t)(uint32_t)b != bidx) {
             best = nb;
             bidx = (int32_t)(uint32_t)b;
-            set_cube(cube, qx, qy, qz, best);
+            if (!retired) set_cube(cube, qx, qy, qz, best);  // a retired lane's cube stays empty
         }
     };
-    const uint32_t steps = traverse_from(records_g, leaf_first, start, cube, [&](uint32_t lbase, uint32_t vm, uint32_t hit) {
+    auto on_leaf_record = [&](uint32_t lbase, uint32_t vm, uint32_t hit) {
         // one queue segment per hit leaf: the lanes that overlap it, in lane order
         while (hit) {
             const uint32_t c = (uint32_t)__builtin_ctz(hit);
@@ -168,7 +167,9 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
             queued -= 64u;
             drain(queued, 64u);
         }
-    });
+    };
+    const uint32_t steps = SEED ? traverse_seeded(records_g, leaf_first, my_node, cube, retired, on_leaf_record)
+                                : traverse_from(records_g, leaf_first, 1u, cube, on_leaf_record);
     if (queued) drain(0u, queued);
 
     if (valid) {
