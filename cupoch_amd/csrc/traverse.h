@@ -319,7 +319,9 @@ __device__ __forceinline__ uint32_t traverse_seeded(const float* records_g, uint
     int32_t top_off = off;
     uint32_t skip = 8u;
     uint64_t pend = 0ull;
-    uint32_t done0 = 0u, done1 = 0u, done2 = 0u, ndone = 0u;  // leaf-level nodes searched as starts
+    // starts searched before the last one: parent id and the hit-mask that removes them there
+    uint32_t dpar0 = 0u, dpar1 = 0u, dmask0 = ~0u, dmask1 = ~0u, ndone = 0u;
+    bool climbing = false;
     float ownv = 0.0f;
     const uint64_t full_exec = __builtin_amdgcn_read_exec();
     for (;;) {
@@ -352,10 +354,9 @@ __device__ __forceinline__ uint32_t traverse_seeded(const float* records_g, uint
         }
         uint32_t hit = wave_or_mask(vm);
         if (id == top && skip < 8u) hit &= ~(1u << skip);
-        if (ndone != 0u) {  // starts already searched, as children of this node
-            if ((done0 >> 3) == id) hit &= ~(1u << (done0 & 7u));
-            if ((done1 >> 3) == id) hit &= ~(1u << (done1 & 7u));
-            if ((done2 >> 3) == id) hit &= ~(1u << (done2 & 7u));
+        if (climbing) {  // starts already searched, as children of this node (the last one is `skip`)
+            if (dpar0 == id) hit &= dmask0;
+            if (dpar1 == id) hit &= dmask1;
         }
         if (id < leaf_first) {
             if (hit) {
@@ -398,22 +399,26 @@ __device__ __forceinline__ uint32_t traverse_seeded(const float* records_g, uint
         }
         const uint64_t active = __ballot(!retired);
         if (active == 0ull) break;
-        if (top >= leaf_first) {  // a start: remember it, and take the next one if a lane still waits for its own
-            if (ndone == 0u) done0 = top;
-            else if (ndone == 1u) done1 = top;
-            else done2 = top;
-            ++ndone;
-            seeds &= active;
-            if (seeds != 0ull && ndone < kSeedStarts) {
-                top = (uint32_t)__builtin_amdgcn_readlane((int)my_node, (int)__builtin_ctzll(seeds));
-                seeds &= ~__ballot(my_node == top);
-                top_off = leaf_off;
-                skip = 8u;
-                id = top;
-                off = top_off;
-                continue;
+        seeds &= active;
+        if (top >= leaf_first && seeds != 0ull && ndone + 1u < kSeedStarts) {
+            // a start, and a lane still waits for its own: remember this one, take that one next
+            if (ndone == 0u) {
+                dpar0 = top >> 3;
+                dmask0 = ~(1u << (top & 7u));
+            } else {
+                dpar1 = top >> 3;
+                dmask1 = ~(1u << (top & 7u));
             }
+            ++ndone;
+            top = (uint32_t)__builtin_amdgcn_readlane((int)my_node, (int)__builtin_ctzll(seeds));
+            seeds &= ~__ballot(my_node == top);
+            top_off = leaf_off;
+            skip = 8u;
+            id = top;
+            off = top_off;
+            continue;
         }
+        climbing = true;
         skip = top & 7u;
         top >>= 3;
         top_off >>= 3;
