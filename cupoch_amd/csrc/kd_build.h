@@ -50,7 +50,6 @@ __global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) 
         s_src[0] = a.cstart[lo] + first;
         s_src[1] = (cnt > first) ? min(cnt - first, (uint32_t)kKdGroup) : 0u;
         s_src[2] = ((lo + 1 < a.ncells) ? a.gstart[lo + 1] : a.ngroups) - a.gstart[lo];
-        s.clean = 1;
         // the cell's region: every point of another cell lies on or beyond one of its faces
         float reg[6];
         cell_region(a.planes, a.cell_levels, a.cell_levels, (uint32_t)lo, reg);

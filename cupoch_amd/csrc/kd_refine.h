@@ -36,7 +36,6 @@ struct KdShared {
     float bb[6 * kKdChunks];                         // [min xyz | max xyz] per chunk
     float seg_lo[kKdGroup / 16], seg_scale[kKdGroup / 16];
     uint8_t seg_axis[kKdGroup / 16];
-    int clean;  // stays 1 while no split has produced overlapping halves (set by the caller, see below)
     // SAFE regions (kd_sort_levels<.., true>): [min xyz | max xyz][segment] of the current
     // round while it has <= 64 segments; the 8-segment stage is kept in safe512, the caller's
     // starting region in safe[e * 64 + 0]
@@ -149,14 +148,10 @@ __device__ __forceinline__ void kd_bitonic_sort(KdShared& s, uint32_t v[4], int 
 // PLANES: also record every split as {coordinate of the segment's median element, axis}
 // at heap position (heap_root << round) + segment (kd_cells.h).
 //
-// s.clean: the sort orders by the QUANTISED coordinate, so two points that share the
-// median's bucket can end up on the wrong sides of it; the halves' boxes then overlap by a
-// sliver along the split axis.  That is harmless for culling (boxes are computed from the
-// points) but it breaks "the boxes of two nodes of one level are disjoint", which the
-// bottom-up search relies on to stop early (traverse.h).  Every round therefore compares,
-// exactly, max(left half) with min(right half) of the previous round's splits and clears
-// s.clean on overlap (~0.4 % of the splits at 4096 points); the caller checks the last
-// round's halves itself (kd_last_split_clean).
+// The sort orders by the QUANTISED coordinate, so two points that share the median's bucket
+// can end up on the wrong sides of it; the halves' boxes then overlap by a sliver along the
+// split axis.  That is harmless for culling (boxes are computed from the points); the
+// regions below are built from the exact extremes of the halves and do not care either.
 //
 // SAFE: also track, per segment, the REGION that is free of points of any other segment.
 // The caller puts the group's own region (its kd cell) into s.safe[e * 64 + 0]; a split of
@@ -218,7 +213,6 @@ __device__ __forceinline__ void kd_sort_levels(KdShared& s, int levels, float2* 
                 const int cl = tid * chunks_per_seg, cr = cl + chunks_per_seg;
                 lmax = s.bb[(3 + ax) * kKdChunks + cl];
                 rmin = s.bb[ax * kKdChunks + cr];
-                if (lmax > rmin) s.clean = 0;
                 if (track) {
 #pragma unroll
                     for (int e = 0; e < 6; ++e) P[e] = s.safe[e * 64 + (tid >> 1)];

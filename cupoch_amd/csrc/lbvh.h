@@ -130,8 +130,9 @@ __device__ __forceinline__ void store_box(float* __restrict__ records, uint32_t 
     }
 }
 
-// A node's own record also holds the node's OWN box (floats 48..53) and, at 54, the flag
-// "this box is disjoint from every point outside the node's subtree" (traverse.h).
+// A node's own record also holds the node's REGION (floats 48..53: the part of space free of
+// points of any other node, kd_refine.h / cell_region below) and, at 54, the flag that it is
+// valid; flag 0: the points' box, not usable for the early stop (traverse.h).
 constexpr int kOwnBox = 48, kOwnFlag = 54;
 __device__ __forceinline__ void store_own(float* __restrict__ records, uint32_t id, const float* mn, const float* mx,
                                           uint32_t flag) {

@@ -13,9 +13,9 @@
 // A record is 4 sibling pairs of 12 floats {Amin.x,Bmin.x, Amin.y,Bmin.y, Amin.z,
 // Bmin.z, Amax.x,Bmax.x, Amax.y,Bmax.y, Amax.z,Bmax.z} = 192 B, padded to 256 B.
 // Three s_load_dwordx16 fetch it in ONE round trip (they are issued together and
-// waited for once).  Floats 48..53 hold the node's OWN box and float 54 the flag "this box
-// is disjoint from every point outside the subtree" (lbvh.h store_own) for the bottom-up
-// search below.
+// waited for once).  Floats 48..53 hold the node's REGION -- the part of space free of points
+// of any other node -- and float 54 the flag that it is valid (lbvh.h store_own; the points'
+// box and 0 otherwise), for the early stop of the seeded search below.
 //
 // Why 8-wide: the traversal is bound by dependent memory round trips (one wave
 // = one outstanding record; measured ~1000 cycles per step at 10M points), not
@@ -154,18 +154,15 @@ __device__ __forceinline__ uint32_t wave_or_mask(uint32_t vm) {
 // its first leaf, vm = this lane's 8-bit mask of the leaves its cube overlaps, hit = the
 // OR over the wave.
 //
-// BOTTOM-UP START.  `start` is the node the walk begins at: 1 (the root) for a plain
-// top-down search, or the leaf-level node of a lane's previous match.  In the second case
-// the subtree of `start` is searched first, then the walk climbs: at every ancestor the
+// START NODE.  `start` is the node the walk begins at: 1 (the root) for a plain top-down
+// search -- what the unseeded first pass and the k-NN kernels use -- or any other node, in
+// which case its subtree is searched first and the walk then climbs: at every ancestor the
 // other seven children are tested (and searched where hit), until the root is done -- or
-// until ALL lanes' cubes lie inside the box of the subtree just completed AND that node
-// carries the "disjoint" flag (lbvh.h store_own): every point outside the subtree then
-// lies outside that box, hence outside every cube, hence cannot be closer than what the
-// lanes already hold.  With match-ordered packets the climb ends 1-3 levels above the
-// leaves instead of walking all 7 levels from the root.  The flag is what makes this
-// exact: boxes of kd cells are disjoint, boxes of Morton runs, of groups of an
-// overflowing cell, or of splits that left a sliver (kd_refine.h) are not, and there the
-// flag is 0 and the climb continues.
+// until ALL lanes' cubes lie inside the REGION of the subtree just completed (record floats
+// 48..54, lbvh.h store_own): every point outside the subtree lies on or beyond a face of
+// that region, hence outside every cube, hence cannot be closer than what the lanes already
+// hold.  The seeded ICP search uses the refinement of this further down (traverse_seeded:
+// several starts, lanes retire one by one).
 __device__ __forceinline__ bool cubes_inside(const Cube& c, uint64_t full_exec, float mnx, float mny, float mnz,
                                              float mxx, float mxy, float mxz) {
     uint32_t all;
