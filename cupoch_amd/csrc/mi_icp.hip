@@ -1753,4 +1753,22 @@ int mi_icp_debug_nn_stats(mi_icp_ctx* c, const float* T, float radius, int use_s
     return MI_ICP_OK;
 }
 
+int mi_icp_debug_get_tree(mi_icp_ctx* c, int64_t* info5, float* records_out, float* leaf_lines_out) {
+    TRY(check_ctx(c));
+    if (!info5 || c->nt <= 0) return fail(c, MI_ICP_ERR_INVALID, "debug_get_tree: no target / bad arguments");
+    info5[0] = c->nts;
+    info5[1] = c->nleaf;
+    info5[2] = (int64_t)c->leaf_first;
+    info5[3] = (int64_t)c->nrecords;
+    info5[4] = c->nt;
+    if (records_out)
+        HIPCHK(c, hipMemcpyAsync(records_out, c->nodes.p, (size_t)c->nrecords * kRecordFloats * sizeof(float),
+                                 hipMemcpyDeviceToHost, c->stream));
+    if (leaf_lines_out)
+        HIPCHK(c, hipMemcpyAsync(leaf_lines_out, c->tblk.p, (size_t)c->nleaf * kLeafFloats * sizeof(float),
+                                 hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MI_ICP_OK;
+}
+
 }  // extern "C"

@@ -4,6 +4,7 @@
  * hand-written device primitives (radix sort, exclusive scan) that replace
  * thrust::sort_by_key / exclusive_scan inside the engine, so that the parity
  * tests can pin them on their own.  Buffers are host memory.
+ * (and the built tree, for invariant tests)
  */
 #ifndef MI_ICP_DEBUG_H_
 #define MI_ICP_DEBUG_H_
@@ -25,6 +26,14 @@ MI_ICP_API int mi_icp_debug_morton_order(mi_icp_ctx* ctx, const float* xyz, int6
  * use_seed != 0 seeds from the previous pass. */
 MI_ICP_API int mi_icp_debug_nn_stats(mi_icp_ctx* ctx, const float* T, float radius, int use_seed,
                                      uint64_t* out4);
+/* The target's tree as built by mi_icp_set_target, for invariant tests.  info5 = {slots
+ * (padded sorted positions), leaves, leaf_first (id of the first leaf-level node), records,
+ * points}.  records_out (records * 64 floats: 8 child boxes as 4 sibling pairs of 12,
+ * floats 48..53 the node's region, 54 its validity flag) and leaf_lines_out (leaves * 32
+ * floats: x[8] y[8] z[8] original index[8], padding = +inf / -1) may be NULL to query the
+ * sizes only. */
+MI_ICP_API int mi_icp_debug_get_tree(mi_icp_ctx* ctx, int64_t* info5, float* records_out,
+                                     float* leaf_lines_out);
 #ifdef __cplusplus
 }
 #endif

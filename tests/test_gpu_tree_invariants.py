@@ -1,0 +1,132 @@
+"""GPU: invariants of the target tree as built (mi_icp_debug_get_tree) -- the facts the search's
+exactness argument rests on (cupoch_amd/csrc/traverse.h):
+  * the leaf lines hold every point exactly once, padding elsewhere;
+  * a record's child boxes are the exact bounding boxes of the children's points;
+  * a node's REGION (record floats 48..53, flag 54) contains no point of any other node in its
+    interior -- what lets a lane whose search cube lies inside it stop looking elsewhere."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from cupoch_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def get_tree(eng):
+    info = (C.c_int64 * 5)()
+    eng._chk(eng._L.mi_icp_debug_get_tree(eng._ctx, info, None, None))
+    nts, nleaf, leaf_first, nrec, nt = [int(v) for v in info]
+    rec = np.empty((nrec, 64), np.float32)
+    lines = np.empty((nleaf, 32), np.float32)
+    eng._chk(eng._L.mi_icp_debug_get_tree(eng._ctx, info, rec.ctypes.data_as(C.c_void_p), lines.ctypes.data_as(C.c_void_p)))
+    return nts, nleaf, leaf_first, rec, lines, nt
+
+
+def record_index(node):
+    h = 1
+    while h * 8 <= node:
+        h *= 8
+    return node - h + (h - 1) // 7
+
+
+def check_tree(eng, pts, expect_all_flagged):
+    eng.set_target(pts)
+    nts, nleaf, leaf_first, rec, lines, nt = get_tree(eng)
+    assert nt == len(pts) and nleaf == (nts + 7) // 8      # (the Morton-run fallback tree does not pad to groups)
+    nts = nleaf * 8
+    xyz = np.stack([lines[:, 0:8], lines[:, 8:16], lines[:, 16:24]], -1).reshape(-1, 3)      # slot -> coordinates
+    orig = lines[:, 24:32].copy().view(np.int32).reshape(-1)
+    real = orig >= 0
+    assert np.array_equal(np.sort(orig[real]), np.arange(len(pts)))                           # a permutation
+    assert np.array_equal(xyz[real], pts[orig[real]])
+    assert np.isinf(xyz[~real]).all()
+
+    # leaf-level records: child c of node leaf_first + a is leaf 8a + c
+    n_ll = (nleaf + 7) // 8
+    for a in np.random.default_rng(0).permutation(n_ll)[:300]:
+        r = rec[record_index(leaf_first + a)]
+        for c in range(8):
+            L = 8 * a + c
+            p = xyz[L * 8:(L + 1) * 8][real[L * 8:(L + 1) * 8]] if L < nleaf else np.zeros((0, 3), np.float32)
+            pair, ab = c >> 1, c & 1
+            mn = r[pair * 12 + np.array([0, 2, 4]) + ab]
+            mx = r[pair * 12 + np.array([6, 8, 10]) + ab]
+            if len(p):
+                assert np.array_equal(mn, p.min(0)) and np.array_equal(mx, p.max(0))
+            else:
+                assert (mn > mx).all()                                                        # inverted: never hit
+
+    # regions, level by level: node `first + t` covers slots [t * span, (t + 1) * span)
+    finite = np.isfinite(xyz).all(1) & real
+    flagged = total = 0
+    first, span = leaf_first, 64
+    while first >= 1:
+        count = (nts + span - 1) // span
+        for t in range(count):
+            r = rec[record_index(first + t)]
+            lo, hi, flag = r[48:51], r[51:54], r[54:55].view(np.uint32)[0]
+            mine = np.zeros(len(xyz), bool)
+            mine[t * span:(t + 1) * span] = True
+            if not (mine & real).any() or first == 1:      # (the root's own record is never consulted)
+                continue
+            total += 1
+            if flag == 0:
+                continue
+            flagged += 1
+            others = xyz[finite & ~mine]
+            strictly_inside = ((others > lo) & (others < hi)).all(1)
+            assert not strictly_inside.any(), (first, t, int(strictly_inside.sum()))
+            own = xyz[finite & mine]
+            inside = ((own >= lo) & (own <= hi)).all(1)
+            assert inside.mean() > 0.99                                                       # (near-ties at a median may sit outside)
+        if first == 1:
+            break
+        first //= 8
+        span *= 8
+    if expect_all_flagged:
+        assert flagged == total
+    return flagged, total
+
+
+def test_regions_uniform_cloud(eng):
+    rng = np.random.default_rng(1)
+    f, t = check_tree(eng, rng.random((60000, 3), dtype=np.float32), os.environ.get("MI_ICP_NO_CELLS") is None)
+    assert t > 900
+
+
+def test_regions_small_and_tiny_clouds(eng):
+    rng = np.random.default_rng(2)
+    for n in (1, 9, 100, 2731, 2732, 4097, 9000):
+        check_tree(eng, rng.random((n, 3), dtype=np.float32), os.environ.get("MI_ICP_NO_CELLS") is None)
+
+
+def test_regions_clustered_planar_and_quantised(eng):
+    rng = np.random.default_rng(3)
+    clustered = np.concatenate([c + rng.normal(0, 0.003, (s, 3)).astype(np.float32)
+                                for c, s in zip(rng.random((40, 3)).astype(np.float32), rng.integers(5, 3000, 40))])
+    check_tree(eng, clustered, False)
+    planar = rng.random((30000, 3), dtype=np.float32)
+    planar[:, 2] = 0.25                                                                       # one axis constant
+    check_tree(eng, planar, False)
+    grid = np.round(rng.random((40000, 3)) * 32).astype(np.float32) / 32                      # many equal coordinates
+    check_tree(eng, grid, False)
+
+
+def test_overflowing_cell_has_no_regions_but_the_rest_does(eng):
+    rng = np.random.default_rng(4)
+    pts = np.concatenate([rng.random((30000, 3), dtype=np.float32),
+                          np.tile(np.array([[0.5, 0.5, 0.5]], np.float32), (20000, 1))])    # 20k copies: several groups
+    flagged, total = check_tree(eng, pts, False)
+    if os.environ.get("MI_ICP_NO_CELLS") is None:
+        assert 0 < flagged < total
+    else:
+        assert flagged == 0                      # Morton runs are not kd cells: no regions at all
