@@ -1141,7 +1141,8 @@ static int loop_enqueue_evaluation(mi_icp_ctx* c, bool seed) {
 static int loop_run(mi_icp_ctx* c, int budget) {
     constexpr int kChunk = 8;
     while (budget > 0) {
-        const int n = std::min(budget, kChunk);
+        // (a short remainder rides along: one host synchronisation less than it would cost)
+        const int n = (budget <= kChunk + kChunk / 2) ? budget : kChunk;
         const int passes_before = c->loop_host->passes;
         for (int i = 0; i < n; ++i) TRY(loop_enqueue_evaluation(c, true));
         TRY(loop_pull(c));
