@@ -35,44 +35,79 @@ constexpr int kKnnLeavesPerBlock = kKnnWaves * 8;
 constexpr int kKnnSeedBefore = 4, kKnnSeedAfter = 12;  // leaves around the packet's first leaf
 
 struct KnnState {
-    float worst;  // current bound: +inf until k candidates are held
+    float worst;  // current bound: +inf (or the search radius) until k candidates are held
     int count;
     int worst_pos;
+    // the largest distance (and its slot) within each group of 8 candidate slots
+    float gmax[kMaxKnn / 8];
+    int gpos[kMaxKnn / 8];
+    __device__ __forceinline__ void init(float bound) {
+        worst = bound;
+        count = 0;
+        worst_pos = 0;
+#pragma unroll
+        for (int g = 0; g < kMaxKnn / 8; ++g) {
+            gmax[g] = -1.0f;  // below every d2
+            gpos[g] = g * 8;
+        }
+    }
 };
 
+// Offer candidate (d2, j) to this lane's list of the k nearest (LDS columns kd2 / kidx, slot
+// t of lane l at [t * 64 + l]).  A full list replaces its largest entry; the new largest is
+// found in two steps -- the replaced slot's group of 8 is re-read, then the 4 group maxima
+// are compared in registers -- instead of re-reading all 32 slots (which cost 32 LDS reads +
+// ~130 VALU per accepted candidate, and the wave executes this path whenever ANY lane
+// accepts).  Ties resolve to the lowest slot either way, so the results are unchanged.
 __device__ __forceinline__ bool knn_offer(float* kd2, int32_t* kidx, int lane, int k, KnnState& s,
                                           float d2, int32_t j) {
+    constexpr int kGroups = kMaxKnn / 8;
     bool shrunk = false;
     if (d2 < s.worst) {
-        kd2[s.worst_pos * 64 + lane] = d2;
-        kidx[s.worst_pos * 64 + lane] = j;
-        if (s.count < k) {
+        const int pos = s.worst_pos;
+        const int g = pos >> 3;
+        kd2[pos * 64 + lane] = d2;
+        kidx[pos * 64 + lane] = j;
+        bool full;
+        if (s.count < k) {  // filling: the group's maximum only grows
             ++s.count;
             s.worst_pos = s.count;
-        }
-        if (s.count >= k) {  // buffer full: the bound becomes the k-th (largest) distance held
-            // All kMaxKnn slots are read at once and reduced in registers: as a loop over k with
-            // a running maximum this was a chain of k dependent LDS round trips (~100 cycles
-            // each at 2-3 waves per SIMD); 15.5 -> 9.7 ms for 2M points at k = 30.
-            float v[kMaxKnn];
 #pragma unroll
-            for (int t = 0; t < kMaxKnn; ++t) v[t] = kd2[t * 64 + lane];
-            int p[kMaxKnn];
+            for (int q = 0; q < kGroups; ++q) {
+                const bool up = (q == g) && (d2 > s.gmax[q]);  // ties keep the lower slot
+                s.gmax[q] = up ? d2 : s.gmax[q];
+                s.gpos[q] = up ? pos : s.gpos[q];
+            }
+            full = s.count >= k;
+        } else {  // the list's largest entry (in group g) was replaced: re-read that group
+            float m = -1.0f;
+            int mp = g * 8;
 #pragma unroll
-            for (int t = 0; t < kMaxKnn; ++t) {
-                p[t] = t;
-                if (t >= k) v[t] = -1.0f;  // unused slots never win (d2 >= 0)
+            for (int u = 0; u < 8; ++u) {
+                const int slot = g * 8 + u;
+                const float v = (slot < k) ? kd2[slot * 64 + lane] : -1.0f;  // unused slots never win (d2 >= 0)
+                const bool hi = v > m;
+                m = hi ? v : m;
+                mp = hi ? slot : mp;
             }
 #pragma unroll
-            for (int w = kMaxKnn / 2; w > 0; w >>= 1)
+            for (int q = 0; q < kGroups; ++q) {
+                s.gmax[q] = (q == g) ? m : s.gmax[q];
+                s.gpos[q] = (q == g) ? mp : s.gpos[q];
+            }
+            full = true;
+        }
+        if (full) {  // the bound becomes the k-th (largest) distance held
+            float m = s.gmax[0];
+            int mp = s.gpos[0];
 #pragma unroll
-                for (int t = 0; t < w; ++t) {
-                    const bool hi = v[t + w] > v[t];  // ties keep the lower slot, like the ascending scan
-                    v[t] = hi ? v[t + w] : v[t];
-                    p[t] = hi ? p[t + w] : p[t];
-                }
-            s.worst = v[0];
-            s.worst_pos = p[0];
+            for (int q = 1; q < kGroups; ++q) {
+                const bool hi = s.gmax[q] > m;
+                m = hi ? s.gmax[q] : m;
+                mp = hi ? s.gpos[q] : mp;
+            }
+            s.worst = m;
+            s.worst_pos = mp;
             shrunk = true;
         }
     }
@@ -113,9 +148,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
     const bool valid = orig >= 0;
     KnnState st;
     // r2 = +inf: plain k-NN; finite: the k nearest with d2 < r2 (KDTreeSearchParamRadius)
-    st.worst = (valid && k > 0) ? r2 : -1.0f;
-    st.count = 0;
-    st.worst_pos = 0;
+    st.init((valid && k > 0) ? r2 : -1.0f);
 
     // ---- A: seed from the Morton neighbourhood ---------------------------------
     const int seed_lo = max(0, leaf0 - kKnnSeedBefore);
@@ -284,9 +317,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_search_kernel(
         qz = qz_g[i];
     }
     KnnState st;
-    st.worst = (valid && k > 0) ? r2 : -1.0f;  // r2 = +inf: plain k-NN
-    st.count = 0;
-    st.worst_pos = 0;
+    st.init((valid && k > 0) ? r2 : -1.0f);  // r2 = +inf: plain k-NN
 
     // ---- A: a first bound.  A plain k-NN query starts with an infinite search cube, and a
     // depth-first walk in child order would wade through the whole tree before the k-th
