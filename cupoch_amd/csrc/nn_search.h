@@ -44,18 +44,10 @@ struct PacketShared {
     uint32_t queue[kItemQueue];   // lane << 26 | leaf
 };
 
-// One batch: lane t evaluates item queue[first + t] (t < count).
-__device__ __forceinline__ void drain_items(PacketShared& sh, const float* tblk_g, uint32_t first, uint32_t count,
-                                            float qx, float qy, float qz, float r2) {
-    const int lane = lane_id();
-    const bool have = (uint32_t)lane < count;
-    const uint32_t item = have ? sh.queue[first + (uint32_t)lane] : 0u;
-    const int ql = (int)(item >> 26);
-    const uint32_t L = item & 0x3ffffffu;
-    // the owner's query point
-    const float ox = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(qx)));
-    const float oy = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(qy)));
-    const float oz = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(qz)));
+// One item: the 8 points of leaf L against query (ox, oy, oz) of lane ql; the result goes to
+// that lane's slot of sh.best.
+__device__ __forceinline__ void eval_item(PacketShared& sh, const float* tblk_g, bool have, int ql, uint32_t L,
+                                          float ox, float oy, float oz, float r2) {
     if (have) {
         const float4* line = reinterpret_cast<const float4*>(tblk_g + (size_t)L * kLeafFloats);
         const float4 x0 = line[0], x1 = line[1], y0 = line[2], y1 = line[3], z0 = line[4], z1 = line[5];
@@ -83,6 +75,21 @@ __device__ __forceinline__ void drain_items(PacketShared& sh, const float* tblk_
             __hip_atomic_fetch_min(&sh.best[ql], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
+}
+
+// One batch: lane t evaluates item queue[first + t] (t < count).
+__device__ __forceinline__ void drain_items(PacketShared& sh, const float* tblk_g, uint32_t first, uint32_t count,
+                                            float qx, float qy, float qz, float r2) {
+    const int lane = lane_id();
+    const bool have = (uint32_t)lane < count;
+    const uint32_t item = have ? sh.queue[first + (uint32_t)lane] : 0u;
+    const int ql = (int)(item >> 26);
+    const uint32_t L = item & 0x3ffffffu;
+    // the owner's query point
+    const float ox = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(qx)));
+    const float oy = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(qy)));
+    const float oz = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(qz)));
+    eval_item(sh, tblk_g, have, ql, L, ox, oy, oz, r2);
 }
 
 // `loop` != nullptr: the transform comes from the device-resident loop state and the
@@ -136,9 +143,10 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
 
     uint32_t queued = 0u, batches = 0u;  // wave-uniform
     bool retired = !valid;               // traverse_seeded: this lane's search is complete
-    auto drain = [&](uint32_t first, uint32_t count) {
-        if (STATS) ++batches;
-        drain_items(sh, tblk_g, first, count, qx, qy, qz, r2);
+    constexpr uint32_t kNoItem = 0xffffffffu;
+    uint32_t held = kNoItem;             // this lane's one pending leaf while no lane has had a second
+    bool spilled = false;                // wave-uniform: the held items have moved into the LDS queue
+    auto take_results = [&]() {  // what the evaluated items left in this lane's slot
         __builtin_amdgcn_wave_barrier();
         const unsigned long long b = sh.best[lane];
         const float nb = __uint_as_float((uint32_t)(b >> 32));
@@ -148,7 +156,35 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
             if (!retired) set_cube(cube, qx, qy, qz, best);  // a retired lane's cube stays empty
         }
     };
+    auto drain = [&](uint32_t first, uint32_t count) {
+        if (STATS) ++batches;
+        drain_items(sh, tblk_g, first, count, qx, qy, qz, r2);
+        take_results();
+    };
     auto on_leaf_record = [&](uint32_t lbase, uint32_t vm, uint32_t hit) {
+        // The steady state of a converged loop: every lane overlaps ONE leaf in the whole walk
+        // (its match's).  A lane's first item therefore stays in a register; only when some
+        // lane gets a second one do the held items move into the LDS queue (below), where items
+        // are grouped per leaf and rebalanced over the lanes.  Evaluation is deferred to the
+        // end either way: evaluating per record would put a memory round trip per record into
+        // the packet's dependent chain (measured: 0.44 instead of 0.31 ms per iteration).
+        if (!spilled) {
+            const bool more = (vm & (vm - 1u)) != 0u || (vm != 0u && held != kNoItem);
+            if (__ballot(more) == 0ull) {
+                if (vm != 0u) held = lbase + (uint32_t)__builtin_ctz(vm);
+                return;
+            }
+            spilled = true;
+            const bool h = held != kNoItem;
+            const uint64_t m = __ballot(h);
+            if (h) {
+                const uint32_t pos = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                sh.queue[pos] = ((uint32_t)lane << 26) | held;
+            }
+            queued += (uint32_t)__popcll(m);
+            held = kNoItem;
+        }
         // one queue segment per hit leaf: the lanes that overlap it, in lane order
         while (hit) {
             const uint32_t c = (uint32_t)__builtin_ctz(hit);
@@ -170,7 +206,15 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     };
     const uint32_t steps = SEED ? traverse_seeded(records_g, leaf_first, my_node, cube, retired, on_leaf_record)
                                 : traverse_from(records_g, leaf_first, 1u, cube, on_leaf_record);
-    if (queued) drain(0u, queued);
+    if (!spilled) {  // one item per lane at most: each lane evaluates its own
+        if (__ballot(held != kNoItem) != 0ull) {
+            if (STATS) ++batches;
+            eval_item(sh, tblk_g, held != kNoItem, lane, held, qx, qy, qz, r2);
+            take_results();
+        }
+    } else if (queued) {
+        drain(0u, queued);
+    }
 
     if (valid) {
         nn_idx[i] = bidx;
