@@ -218,7 +218,9 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "ICP iterations/sec (incl. kNN), point-to-plane, %s-vs-%s points" % (_fmt(n), _fmt(n)),
+            # BASELINE.json's metric, verbatim, when run on its configuration (--points changes the name)
+            "metric": ("ICP iterations/sec (incl. kNN) on 10M-pt point-to-plane, 1/2/4/8 MI355X" if n == 10_000_000 else
+                       "ICP iterations/sec (incl. kNN), point-to-plane, %s-vs-%s points" % (_fmt(n), _fmt(n))),
             "value": round(args.steps / elapsed, 3),
             "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
