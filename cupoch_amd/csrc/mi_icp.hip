@@ -224,10 +224,13 @@ Mat4 load_T(const float* T) {
     return m;
 }
 
+// Morton grid: 2^bits cells per axis, ~4 per mean point spacing -- fine enough that almost every
+// point has a cell of its own (ties keep the input order), and every 8 key bits saved is a radix
+// pass less (10M points: 30-bit keys, 4 passes; 100k points: 24 bits, 3 passes)
 int morton_bits_for(int64_t n) {
     int lg = 0;
     while ((1ll << lg) < n) ++lg;
-    return std::min(21, std::max(6, (lg + 2) / 3 + 5));
+    return std::min(21, std::max(6, (lg + 2) / 3 + 2));
 }
 
 // bounds (min/max/extent) of an AoS cloud into c->bounds (8 floats, device)
