@@ -9,12 +9,12 @@ from . import _lib, utility                                    # noqa: F401
 from ._lib import MiIcpError, build                           # noqa: F401
 from .utility import initialize_allocator                     # noqa: F401
 
-__all__ = ["geometry", "registration", "utility", "io", "engine", "distributed", "camera", "kinfu", "build",
+__all__ = ["geometry", "registration", "utility", "io", "engine", "distributed", "camera", "kinfu", "odometry", "build",
            "initialize_allocator", "MiIcpError"]
 
 
 def __getattr__(name):
-    if name in ("geometry", "registration", "io", "engine", "distributed", "camera", "kinfu"):
+    if name in ("geometry", "registration", "io", "engine", "distributed", "camera", "kinfu", "odometry"):
         import importlib
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

@@ -68,6 +68,11 @@ class Result(C.Structure):
                 ("iterations", C.c_int32), ("nn_passes", C.c_int32)]
 
 
+class OdometryOption(C.Structure):
+    _fields_ = [("num_levels", C.c_int32), ("iterations", C.c_int32 * 8), ("max_depth_diff", C.c_float),
+                ("min_depth", C.c_float), ("max_depth", C.c_float)]
+
+
 # name -> (restype, argtypes); must list every MI_ICP_API symbol of include/mi_icp.h
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
@@ -96,6 +101,7 @@ SIGNATURES = {
     "mi_icp_voxel_downsample": (_I, [_P, _P, _P, _P, _L, _F, _P, _P, _P, C.POINTER(_L), _I]),
     "mi_icp_create_from_depth": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _F, _F, _F, _I, _I, _I, _I,
                                       _P, _P, _P, C.POINTER(_L), _I]),
+    "mi_icp_compute_rgbd_odometry": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P, C.POINTER(_I), _P, _P, _I]),
     "mi_icp_covariances_from_normals": (_I, [_P, _P, _L, _F, _P, _I]),
     "mi_icp_estimate_normals_knn": (_I, [_P, _P, _L, _I, _P, _I]),
     "mi_icp_estimate_normals_radius": (_I, [_P, _P, _L, _F, _I, _P, _I]),

@@ -4,6 +4,7 @@
 #include "cupoch/geometry/image.h"
 #include "cupoch/geometry/pointcloud.h"
 #include "cupoch/kinfu/kinfu.h"
+#include "cupoch/odometry/odometry.h"
 #include "cupoch/knn/kdtree_flann.h"
 #include "cupoch/knn/kdtree_search_param.h"
 #include "cupoch/registration/generalized_icp.h"

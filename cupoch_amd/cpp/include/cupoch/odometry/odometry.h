@@ -1,0 +1,56 @@
+// cupoch/odometry/odometry.h -- odometry::ComputeRGBDOdometry (reference: odometry/odometry.h:43-53,
+// odometry_option.h:30-62, rgbdodometry_jacobian.h:33-134).  The images are geometry::Image
+// containers (float intensity + float depth, as RGBDImage::CreateFromColorAndDepth leaves them);
+// everything runs in libmi_icp.so (mi_icp_compute_rgbd_odometry).  Not provided:
+// ComputeWeightedRGBDOdometry.
+#pragma once
+#include <tuple>
+#include <vector>
+
+#include "cupoch/camera/pinhole_camera_intrinsic.h"
+#include "cupoch/geometry/image.h"
+#include "cupoch/utility/eigen.h"
+
+namespace cupoch {
+namespace odometry {
+
+class OdometryOption {
+public:
+    OdometryOption(const std::vector<int>& iteration_number_per_pyramid_level = {20, 10, 5},
+                   float max_depth_diff = 0.03, float min_depth = 0.0, float max_depth = 4.0)
+        : iteration_number_per_pyramid_level_(iteration_number_per_pyramid_level),
+          max_depth_diff_(max_depth_diff),
+          min_depth_(min_depth),
+          max_depth_(max_depth) {}
+    std::vector<int> iteration_number_per_pyramid_level_;
+    float max_depth_diff_;
+    float min_depth_;
+    float max_depth_;
+};
+
+class RGBDOdometryJacobian {
+public:
+    enum OdometryJacobianType { COLOR_TERM = 0, HYBRID_TERM = 1 };
+    explicit RGBDOdometryJacobian(OdometryJacobianType jacobian_type) : jacobian_type_(jacobian_type) {}
+    virtual ~RGBDOdometryJacobian() {}
+    OdometryJacobianType jacobian_type_;
+};
+class RGBDOdometryJacobianFromColorTerm : public RGBDOdometryJacobian {
+public:
+    RGBDOdometryJacobianFromColorTerm() : RGBDOdometryJacobian(COLOR_TERM) {}
+};
+class RGBDOdometryJacobianFromHybridTerm : public RGBDOdometryJacobian {
+public:
+    RGBDOdometryJacobianFromHybridTerm() : RGBDOdometryJacobian(HYBRID_TERM) {}
+};
+
+/// (is_success, transformation mapping the source frame onto the target frame, information matrix)
+std::tuple<bool, Eigen::Matrix4f, Eigen::Matrix6f> ComputeRGBDOdometry(
+        const geometry::RGBDImage& source, const geometry::RGBDImage& target,
+        const camera::PinholeCameraIntrinsic& pinhole_camera_intrinsic = camera::PinholeCameraIntrinsic(),
+        const Eigen::Matrix4f& odo_init = Eigen::Matrix4f::Identity(),
+        const RGBDOdometryJacobian& jacobian_method = RGBDOdometryJacobianFromHybridTerm(),
+        const OdometryOption& option = OdometryOption());
+
+}  // namespace odometry
+}  // namespace cupoch

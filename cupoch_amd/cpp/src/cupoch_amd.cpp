@@ -549,6 +549,44 @@ int KDTreeFlann::Search(const Eigen::Vector3f& query, const KDTreeSearchParam& p
 
 }  // namespace knn
 
+// ---------------------------------------------------------------- odometry
+namespace odometry {
+
+std::tuple<bool, Eigen::Matrix4f, Eigen::Matrix6f> ComputeRGBDOdometry(
+        const geometry::RGBDImage& source, const geometry::RGBDImage& target,
+        const camera::PinholeCameraIntrinsic& intrinsic, const Eigen::Matrix4f& odo_init,
+        const RGBDOdometryJacobian& jacobian_method, const OdometryOption& option) {
+    auto is_float_image = [](const geometry::Image& im) { return im.num_of_channels_ == 1 && im.bytes_per_channel_ == 4; };
+    const geometry::Image &sc = source.color_, &sd = source.depth_, &tc = target.color_, &td = target.depth_;
+    const bool same = sc.width_ == tc.width_ && sc.height_ == tc.height_ && sd.width_ == td.width_ &&
+                      sd.height_ == td.height_ && sc.width_ == sd.width_ && sc.height_ == sd.height_;
+    if (!same || !is_float_image(sc) || !is_float_image(sd) || !is_float_image(tc) || !is_float_image(td)) {
+        LogWarning("[RGBDOdometry] Two RGBD pairs should be same in size.");  // odometry.cu:845-851
+        return std::make_tuple(false, Eigen::Matrix4f::Identity(), Eigen::Matrix6f::Zero());
+    }
+    mi_icp_odometry_option opt = {};
+    opt.num_levels = (int32_t)option.iteration_number_per_pyramid_level_.size();
+    for (int i = 0; i < opt.num_levels && i < MI_ICP_ODOMETRY_MAX_LEVELS; ++i)
+        opt.iterations[i] = option.iteration_number_per_pyramid_level_[(size_t)i];
+    opt.max_depth_diff = option.max_depth_diff_;
+    opt.min_depth = option.min_depth_;
+    opt.max_depth = option.max_depth_;
+    const float k4[4] = {intrinsic.fx_, intrinsic.fy_, intrinsic.cx_, intrinsic.cy_};
+    int ok = 0;
+    Eigen::Matrix4f T;
+    double info[36];
+    Check(mi_icp_compute_rgbd_odometry(Engine(), (const float*)sc.data_.data(), (const float*)sd.data_.data(),
+                                       (const float*)tc.data_.data(), (const float*)td.data_.data(), sc.width_,
+                                       sc.height_, k4, odo_init.data(), (int)jacobian_method.jacobian_type_, &opt, &ok,
+                                       T.data(), info, MI_ICP_DEVICE));
+    Eigen::Matrix6f I;
+    for (int r = 0; r < 6; ++r)
+        for (int c2 = 0; c2 < 6; ++c2) I(r, c2) = (float)info[r * 6 + c2];
+    return std::make_tuple(ok != 0, T, I);
+}
+
+}  // namespace odometry
+
 // ---------------------------------------------------------------- kinfu
 namespace kinfu {
 

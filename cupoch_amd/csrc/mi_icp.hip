@@ -32,6 +32,7 @@
 #include "lbvh.h"
 #include "loop.h"
 #include "nn_search.h"
+#include "odometry.h"
 #include "primitives.h"
 #include "reduce.h"
 
@@ -603,6 +604,68 @@ int check_ctx(mi_icp_ctx* c) {
 // ============================================================================
 // C ABI
 // ============================================================================
+// ---------------------------------------------------------------------------
+// odometry::ComputeRGBDOdometry (odometry/odometry.cu)
+namespace {
+
+struct OdCamera {
+    float k[9];  // row-major
+};
+
+void od_inverse3(const float* M, float* I) {  // Eigen's 3x3 inverse by cofactors, fp32
+    const float c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+    const float det = M[0] * c00 + M[1] * c01 + M[2] * c02, id = 1.0f / det;
+    I[0] = c00 * id;
+    I[1] = (M[2] * M[7] - M[1] * M[8]) * id;
+    I[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+    I[3] = c01 * id;
+    I[4] = (M[0] * M[8] - M[2] * M[6]) * id;
+    I[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+    I[6] = c02 * id;
+    I[7] = (M[1] * M[6] - M[0] * M[7]) * id;
+    I[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+}
+
+void od_mul3(const float* A, const float* B, float* C) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) C[r * 3 + c] = (A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c]) + A[r * 3 + 2] * B[6 + c];
+}
+
+// projection terms of ComputeCorrespondence (odometry.cu:225-229) + the Jacobians' camera terms
+void od_set_camera(OdArgs& a, const OdCamera& cam, const Mat4& E) {
+    float Kinv[9], R[9], KR[9];
+    od_inverse3(cam.k, Kinv);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) R[r * 3 + c] = host::at(E, r, c);
+    od_mul3(cam.k, R, KR);
+    od_mul3(KR, Kinv, a.krk);
+    for (int r = 0; r < 3; ++r)
+        a.kt[r] = (cam.k[r * 3] * host::at(E, 0, 3) + cam.k[r * 3 + 1] * host::at(E, 1, 3)) + cam.k[r * 3 + 2] * host::at(E, 2, 3);
+    for (int i = 0; i < 9; ++i) a.e[i] = R[i];
+    for (int r = 0; r < 3; ++r) a.e[9 + r] = host::at(E, r, 3);
+    a.fx = cam.k[0];
+    a.fy = cam.k[4];
+    a.ox = cam.k[2];
+    a.oy = cam.k[5];
+    a.inv_fx = (float)(1.0 / (double)cam.k[0]);
+    a.inv_fy = (float)(1.0 / (double)cam.k[4]);
+}
+
+template <int MODE>
+int od_run(mi_icp_ctx* c, OdArgs& a, double* host32) {
+    HIPCHK(c, hipMemsetAsync(a.out, 0, 32 * sizeof(double), c->stream));
+    const int64_t n = (int64_t)a.w * a.h;
+    const int grid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + kOdThreads - 1) / kOdThreads));
+    od_accumulate<MODE><<<grid, kOdThreads, 0, c->stream>>>(a);
+    KCHK(c);
+    HIPCHK(c, hipMemcpyAsync(c->sys_host, a.out, 32 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(host32, c->sys_host, 32 * sizeof(double));
+    return MI_ICP_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 const char* mi_icp_version(void) { return "mi_icp 0.1 (gfx950)"; }
@@ -1501,6 +1564,165 @@ int mi_icp_create_from_depth(mi_icp_ctx* c, const void* depth, int depth_type, c
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *m = kept;
+    return MI_ICP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// odometry::ComputeRGBDOdometry (odometry/odometry.cu); helpers above the extern "C" block
+int mi_icp_compute_rgbd_odometry(mi_icp_ctx* c, const float* source_color, const float* source_depth,
+                                 const float* target_color, const float* target_depth, int width, int height,
+                                 const float* intrinsic4, const float* odo_init, int jacobian,
+                                 const mi_icp_odometry_option* option, int* success, float* transformation16,
+                                 double* information36, int mem_kind) {
+    TRY(check_ctx(c));
+    if (!success || !transformation16 || !information36 || !intrinsic4 || !option)
+        return fail(c, MI_ICP_ERR_INVALID, "compute_rgbd_odometry: null argument");
+    *success = 0;
+    const Mat4 I4 = host::identity4();
+    std::memcpy(transformation16, I4.data(), 16 * sizeof(float));
+    for (int i = 0; i < 36; ++i) information36[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    if (width <= 0 || height <= 0 || (int64_t)width * height > 0x3fffffffll || !source_color || !source_depth ||
+        !target_color || !target_depth)
+        return fail(c, MI_ICP_ERR_INVALID, "compute_rgbd_odometry: bad image arguments");
+    if (jacobian != MI_ICP_ODOMETRY_COLOR_TERM && jacobian != MI_ICP_ODOMETRY_HYBRID_TERM)
+        return fail(c, MI_ICP_ERR_INVALID, "compute_rgbd_odometry: unknown jacobian type %d", jacobian);
+    const int L = option->num_levels;
+    if (L < 1 || L > MI_ICP_ODOMETRY_MAX_LEVELS || (width >> (L - 1)) < 1 || (height >> (L - 1)) < 1)
+        return fail(c, MI_ICP_ERR_INVALID, "compute_rgbd_odometry: bad number of pyramid levels");
+
+    const int64_t n0 = (int64_t)width * height;
+    const float *in_sc, *in_sd, *in_tc, *in_td;
+    TRY(to_device(c, source_color, (size_t)n0, mem_kind, c->stage[0], &in_sc));
+    TRY(to_device(c, source_depth, (size_t)n0, mem_kind, c->stage[1], &in_sd));
+    TRY(to_device(c, target_color, (size_t)n0, mem_kind, c->stage[2], &in_tc));
+    TRY(to_device(c, target_depth, (size_t)n0, mem_kind, c->stage[3], &in_td));
+
+    // one arena: per level colour + depth of both frames, a scratch image, and (target) 4 gradient images
+    int lw[MI_ICP_ODOMETRY_MAX_LEVELS], lh[MI_ICP_ODOMETRY_MAX_LEVELS];
+    size_t total = 0;
+    for (int l = 0; l < L; ++l) {
+        lw[l] = l ? lw[l - 1] / 2 : width;
+        lh[l] = l ? lh[l - 1] / 2 : height;
+        total += (size_t)lw[l] * lh[l] * 8;
+    }
+    total += (size_t)n0 + 64;
+    float* arena;
+    TRY(ensure(c, c->stage[4], total, &arena));
+    double* sums;
+    TRY(ensure(c, c->sys_dev, kSysSize, &sums));
+    float *col[2][MI_ICP_ODOMETRY_MAX_LEVELS], *dep[2][MI_ICP_ODOMETRY_MAX_LEVELS], *grad[4][MI_ICP_ODOMETRY_MAX_LEVELS];
+    {
+        float* p = arena;
+        for (int l = 0; l < L; ++l) {
+            const size_t n = (size_t)lw[l] * lh[l];
+            for (int s = 0; s < 2; ++s) {
+                col[s][l] = p;
+                p += n;
+                dep[s][l] = p;
+                p += n;
+            }
+            for (int g = 0; g < 4; ++g) {
+                grad[g][l] = p;
+                p += n;
+            }
+        }
+    }
+    float* scratch = arena + (total - (size_t)n0 - 64);
+    auto blocks = [](int64_t n) { return (int)((n + kOdThreads - 1) / kOdThreads); };
+
+    // ---- InitializeRGBDOdometry (odometry.cu:498-528)
+    for (int s = 0; s < 2; ++s) {
+        od_filter3<0, false><<<blocks(n0), kOdThreads, 0, c->stream>>>(s ? in_tc : in_sc, width, height, col[s][0], 0.0f, 0.0f);
+        od_filter3<0, true><<<blocks(n0), kOdThreads, 0, c->stream>>>(s ? in_td : in_sd, width, height, dep[s][0],
+                                                                       option->min_depth, option->max_depth);
+    }
+    KCHK(c);
+    OdCamera cam[MI_ICP_ODOMETRY_MAX_LEVELS];
+    {
+        const float k0[9] = {intrinsic4[0], 0.0f, intrinsic4[2], 0.0f, intrinsic4[1], intrinsic4[3], 0.0f, 0.0f, 1.0f};
+        std::memcpy(cam[0].k, k0, sizeof(k0));
+        for (int l = 1; l < L; ++l) {  // CreateCameraMatrixPyramid (:332-347)
+            for (int i = 0; i < 9; ++i) cam[l].k[i] = (float)(0.5 * (double)cam[l - 1].k[i]);
+            cam[l].k[8] = 1.0f;
+        }
+    }
+    const Mat4 init = load_T(odo_init);
+    OdArgs a{};
+    a.out = sums;
+    a.max_depth_diff = option->max_depth_diff;
+    double sys[32];
+    auto level_args = [&](int l, const Mat4& E) {
+        a.depth_s = dep[0][l];
+        a.depth_t = dep[1][l];
+        a.color_s = col[0][l];
+        a.color_t = col[1][l];
+        a.dx_color = grad[0][l];
+        a.dy_color = grad[1][l];
+        a.dx_depth = grad[2][l];
+        a.dy_depth = grad[3][l];
+        a.w = lw[l];
+        a.h = lh[l];
+        od_set_camera(a, cam[l], E);
+    };
+    {   // NormalizeIntensity (:416-436) over the correspondences under odo_init
+        level_args(0, init);
+        TRY(od_run<kOdMeans>(c, a, sys));
+        const float nc = (float)sys[29];
+        const float mean_s = (float)sys[0] / nc, mean_t = (float)sys[1] / nc;
+        od_scale<<<blocks(n0), kOdThreads, 0, c->stream>>>(col[0][0], n0, (float)(0.5 / (double)mean_s));
+        od_scale<<<blocks(n0), kOdThreads, 0, c->stream>>>(col[1][0], n0, (float)(0.5 / (double)mean_t));
+        KCHK(c);
+    }
+    // ---- pyramids (rgbdimage.cu:96-112, image_factory.cu:251-278): colour Gaussian3 + Downsample,
+    // depth Downsample only; Sobel3Dx / Sobel3Dy of the target per level (RGBDImage::FilterPyramid)
+    for (int l = 1; l < L; ++l) {
+        const int64_t np = (int64_t)lw[l - 1] * lh[l - 1], nn = (int64_t)lw[l] * lh[l];
+        for (int s = 0; s < 2; ++s) {
+            od_filter3<0, false><<<blocks(np), kOdThreads, 0, c->stream>>>(col[s][l - 1], lw[l - 1], lh[l - 1], scratch, 0.0f, 0.0f);
+            od_downsample<<<blocks(nn), kOdThreads, 0, c->stream>>>(scratch, lw[l - 1], lh[l - 1], col[s][l]);
+            od_downsample<<<blocks(nn), kOdThreads, 0, c->stream>>>(dep[s][l - 1], lw[l - 1], lh[l - 1], dep[s][l]);
+        }
+    }
+    for (int l = 0; l < L; ++l) {
+        const int64_t n = (int64_t)lw[l] * lh[l];
+        od_filter3<1, false><<<blocks(n), kOdThreads, 0, c->stream>>>(col[1][l], lw[l], lh[l], grad[0][l], 0.0f, 0.0f);
+        od_filter3<2, false><<<blocks(n), kOdThreads, 0, c->stream>>>(col[1][l], lw[l], lh[l], grad[1][l], 0.0f, 0.0f);
+        od_filter3<1, false><<<blocks(n), kOdThreads, 0, c->stream>>>(dep[1][l], lw[l], lh[l], grad[2][l], 0.0f, 0.0f);
+        od_filter3<2, false><<<blocks(n), kOdThreads, 0, c->stream>>>(dep[1][l], lw[l], lh[l], grad[3][l], 0.0f, 0.0f);
+    }
+    KCHK(c);
+
+    // ---- ComputeMultiscale (:708-764)
+    Mat4 T = init;
+    {
+        bool zero = true;
+        for (int i = 0; i < 16; ++i) zero = zero && (T.data()[i] == 0.0f);
+        if (zero) T = I4;
+    }
+    bool ok = true;
+    for (int level = L - 1; level >= 0 && ok; --level) {
+        for (int iter = 0; iter < option->iterations[L - level - 1] && ok; ++iter) {
+            level_args(level, T);
+            if (jacobian == MI_ICP_ODOMETRY_COLOR_TERM) TRY(od_run<kOdColor>(c, a, sys));
+            else TRY(od_run<kOdHybrid>(c, a, sys));
+            Mat4 update;
+            ok = host::solve_system(sys, -1.0f, update);  // det_thresh default -1 (utility/eigen.h:84)
+            if (ok) T = host::mul4(update, T);
+        }
+    }
+    if (ok) {
+        // CreateInformationMatrix (:349-394): I + sum G^T G over the final correspondences
+        level_args(0, T);
+        TRY(od_run<kOdInformation>(c, a, sys));
+        int k = 0;
+        for (int r = 0; r < 6; ++r)
+            for (int q = r; q < 6; ++q, ++k) {
+                information36[r * 6 + q] += sys[k];
+                if (q != r) information36[q * 6 + r] += sys[k];
+            }
+        std::memcpy(transformation16, T.data(), 16 * sizeof(float));
+        *success = 1;
+    }
     return MI_ICP_OK;
 }
 

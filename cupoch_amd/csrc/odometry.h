@@ -1,0 +1,223 @@
+// odometry.h -- RGB-D odometry (odometry::ComputeRGBDOdometry, odometry/odometry.cu), the other
+// in-repo caller of ComputeJTJandJTr / SolveJacobianSystemAndObtainExtrinsicMatrix next to the
+// ICP estimators.
+//
+// The reference runs, per iteration: a correspondence-map pass, a merge pass, a transform to
+// (u_s,v_s,u_t,v_t) tuples, a stream compaction, and then transform_reduce over the compacted
+// list with a 172-byte accumulator; per call: separable filters as horizontal pass + transpose
+// + horizontal pass + transpose, each a launch with its own W x H temporary.  Here:
+//   * od_filter3: the separable 3x3 filters (Gaussian3, Sobel3Dx, Sobel3Dy) in ONE pass, in
+//     the reference's arithmetic order (three clamped row sums, then their column sum), with
+//     PreprocessDepth's NaN rule applied on load where asked;
+//   * od_accumulate: ONE kernel per iteration -- every source pixel applies the
+//     correspondence rule, evaluates its Jacobian rows and adds them to fp64 register
+//     accumulators; wave sums on the DPP network, 29 fp64 atomics per block.  No
+//     correspondence list exists; the same kernel (other MODEs) forms NormalizeIntensity's
+//     means and the information matrix.
+// Per-pixel arithmetic is fp32 in the reference's order (the library is built with
+// -ffp-contract=off), sums over pixels are fp64.
+#pragma once
+#include "device_utils.h"
+
+namespace mi {
+
+constexpr int kOdThreads = 256;
+
+// Image::Filter(type) (geometry/image.cu:30-75,176-205,557-570): clamp-to-edge, horizontal
+// pass with kx, then vertical pass with ky.  TYPE 0 Gaussian3, 1 Sobel3Dx, 2 Sobel3Dy.
+// PRE: the source is a raw depth image; values outside [min_depth, max_depth] or <= 0 read
+// as NaN (PreprocessDepth, odometry.cu:444-474).
+template <int TYPE, bool PRE>
+__global__ __launch_bounds__(kOdThreads) void od_filter3(const float* __restrict__ src, int w, int h,
+                                                         float* __restrict__ dst, float min_depth,
+                                                         float max_depth) {
+    const int64_t idx = (int64_t)blockIdx.x * kOdThreads + threadIdx.x;
+    if (idx >= (int64_t)w * h) return;
+    const int y = (int)(idx / w), x = (int)(idx % w);
+    const float g3[3] = {0.25f, 0.5f, 0.25f}, s1[3] = {-1.0f, 0.0f, 1.0f}, s2[3] = {1.0f, 2.0f, 1.0f};
+    const float* kx = TYPE == 0 ? g3 : (TYPE == 1 ? s1 : s2);
+    const float* ky = TYPE == 0 ? g3 : (TYPE == 1 ? s2 : s1);
+    float out = 0.0f;
+#pragma unroll
+    for (int j = -1; j <= 1; ++j) {
+        const int ys = min(max(0, y + j), h - 1);
+        float row = 0.0f;
+#pragma unroll
+        for (int i = -1; i <= 1; ++i) {
+            const int xs = min(max(0, x + i), w - 1);
+            float v = src[(int64_t)ys * w + xs];
+            if (PRE && (v < min_depth || v > max_depth || v <= 0.0f)) v = __builtin_nanf("");
+            row += v * kx[i + 1];
+        }
+        out += row * ky[j + 1];
+    }
+    dst[idx] = out;
+}
+
+// Image::Downsample, float (image.cu:121-145): 2x2 mean into floor(w/2) x floor(h/2)
+__global__ __launch_bounds__(kOdThreads) void od_downsample(const float* __restrict__ src, int w, int h,
+                                                            float* __restrict__ dst) {
+    const int hw = w / 2, hh = h / 2;
+    const int64_t idx = (int64_t)blockIdx.x * kOdThreads + threadIdx.x;
+    if (idx >= (int64_t)hw * hh) return;
+    const int y = (int)(idx / hw), x = (int)(idx % hw);
+    const float* p = src + (int64_t)(y * 2) * w + x * 2;
+    dst[idx] = (p[0] + p[1] + p[w] + p[w + 1]) / 4.0f;
+}
+
+// Image::LinearTransform(scale, 0) (image.cu:111-119)
+__global__ __launch_bounds__(kOdThreads) void od_scale(float* __restrict__ img, int64_t n, float scale) {
+    const int64_t idx = (int64_t)blockIdx.x * kOdThreads + threadIdx.x;
+    if (idx < n) img[idx] = scale * img[idx] + 0.0f;
+}
+
+struct OdArgs {
+    const float* depth_s;
+    const float* depth_t;
+    const float* color_s;
+    const float* color_t;
+    const float* dx_color;  // Sobel3Dx / Sobel3Dy of the target's colour and depth (this level)
+    const float* dy_color;
+    const float* dx_depth;
+    const float* dy_depth;
+    int w, h;
+    float krk[9];   // K R K^-1, row-major
+    float kt[3];    // K t
+    float e[12];    // R (row-major 3x3) and t of the current extrinsic
+    float fx, fy, ox, oy, inv_fx, inv_fy;
+    float max_depth_diff;
+    double* out;    // 32 doubles, zeroed by the host: the layout of the ICP system (reduce.h)
+};
+
+constexpr int kOdColor = 0, kOdHybrid = 1, kOdMeans = 2, kOdInformation = 3;
+
+__device__ __forceinline__ void od_accum_row(double* acc, const float* J, float r) {
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b, ++k) acc[k] = __builtin_fma((double)J[a], (double)J[b], acc[k]);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] = __builtin_fma((double)J[a], (double)r, acc[21 + a]);
+    acc[27] = __builtin_fma((double)r, (double)r, acc[27]);
+}
+
+// MODE kOdColor / kOdHybrid: out[0..20] upper triangle of J^T J, [21..26] J^T r, [27] sum r^2,
+//   [29] correspondences (DoSingleIteration, odometry.cu:584-631 over
+//   rgbdodometry_jacobian.inl:41-172 and compute_correspondence_map :182-203);
+// MODE kOdMeans: [0] sum of source colour, [1] sum of target colour over the correspondences,
+//   [29] count (NormalizeIntensity :416-436);
+// MODE kOdInformation: [0..20] upper triangle of sum G^T G, [29] count
+//   (CreateInformationMatrix :349-394; the host adds the identity).
+template <int MODE>
+__global__ __launch_bounds__(kOdThreads) void od_accumulate(OdArgs a) {
+    constexpr int kAcc = (MODE == kOdMeans) ? 2 : ((MODE == kOdInformation) ? 21 : 28);
+    double acc[kAcc];
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
+    double count = 0.0;
+    const int64_t n = (int64_t)a.w * a.h;
+    for (int64_t idx = (int64_t)blockIdx.x * kOdThreads + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * kOdThreads) {
+        const int v_s = (int)(idx / a.w), u_s = (int)(idx % a.w);
+        const float d_s = a.depth_s[idx];
+        if (d_s != d_s) continue;
+        float uv[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {  // d_s * KRK_inv * (u, v, 1) + Kt: the matrix is scaled first
+            const float m0 = d_s * a.krk[r * 3], m1 = d_s * a.krk[r * 3 + 1], m2 = d_s * a.krk[r * 3 + 2];
+            uv[r] = ((m0 * (float)u_s + m1 * (float)v_s) + m2 * 1.0f) + a.kt[r];
+        }
+        const float tz = uv[2];
+        const int u_t = (int)((double)(uv[0] / tz) + 0.5), v_t = (int)((double)(uv[1] / tz) + 0.5);
+        if (!(u_t >= 0 && u_t < a.w && v_t >= 0 && v_t < a.h)) continue;
+        const int64_t it = (int64_t)v_t * a.w + u_t;
+        const float d_t = a.depth_t[it];
+        if (d_t != d_t || !(fabsf(tz - d_t) <= a.max_depth_diff)) continue;
+        count += 1.0;
+        if (MODE == kOdMeans) {
+            acc[0] += (double)a.color_s[idx];
+            acc[1] += (double)a.color_t[it];
+            continue;
+        }
+        if (MODE == kOdInformation) {  // xyz of the TARGET pixel (ConvertDepthImageToXYZImage :273-330)
+            const float z = d_t;
+            const float x = ((float)u_t - a.ox) * z * a.inv_fx, y = ((float)v_t - a.oy) * z * a.inv_fy;
+            const float g[3][6] = {{0.0f, z, -y, 1.0f, 0.0f, 0.0f}, {-z, 0.0f, x, 0.0f, 1.0f, 0.0f}, {y, -x, 0.0f, 0.0f, 0.0f, 1.0f}};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                int k = 0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = r; c < 6; ++c, ++k) acc[k] = __builtin_fma((double)g[q][r], (double)g[q][c], acc[k]);
+            }
+            continue;
+        }
+        // source point of the pixel, moved by the current extrinsic
+        const float z = d_s;
+        const float p0 = ((float)u_s - a.ox) * z * a.inv_fx, p1 = ((float)v_s - a.oy) * z * a.inv_fy, p2 = z;
+        float pt[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) pt[r] = ((a.e[r * 3] * p0 + a.e[r * 3 + 1] * p1) + a.e[r * 3 + 2] * p2) + a.e[9 + r];
+        const float diff_photo = a.color_t[it] - a.color_s[idx];
+        const float dIdx = 0.125f * a.dx_color[it], dIdy = 0.125f * a.dy_color[it];
+        const float invz = (float)(1.0 / (double)pt[2]);
+        const float c0 = dIdx * a.fx * invz, c1 = dIdy * a.fy * invz;
+        const float c2 = -(c0 * pt[0] + c1 * pt[1]) * invz;
+        float J[6];
+        if (MODE == kOdColor) {
+            J[0] = -pt[2] * c1 + pt[1] * c2;
+            J[1] = pt[2] * c0 - pt[0] * c2;
+            J[2] = -pt[1] * c0 + pt[0] * c1;
+            J[3] = c0;
+            J[4] = c1;
+            J[5] = c2;
+            od_accum_row(acc, J, diff_photo);
+        } else {
+            const float sl_dep = 0.98386991f;   // sqrt(0.968f)
+            const float sl_img = 0.17888546f;   // (float)sqrt(1.0 - (double)0.968f)
+            float dDdx = 0.125f * a.dx_depth[it], dDdy = 0.125f * a.dy_depth[it];
+            if (dDdx != dDdx) dDdx = 0.0f;
+            if (dDdy != dDdy) dDdy = 0.0f;
+            const float diff_geo = d_t - pt[2];
+            const float d0 = dDdx * a.fx * invz, d1 = dDdy * a.fy * invz;
+            const float d2 = -(d0 * pt[0] + d1 * pt[1]) * invz;
+            J[0] = sl_img * (-pt[2] * c1 + pt[1] * c2);
+            J[1] = sl_img * (pt[2] * c0 - pt[0] * c2);
+            J[2] = sl_img * (-pt[1] * c0 + pt[0] * c1);
+            J[3] = sl_img * c0;
+            J[4] = sl_img * c1;
+            J[5] = sl_img * c2;
+            od_accum_row(acc, J, sl_img * diff_photo);
+            J[0] = sl_dep * ((-pt[2] * d1 + pt[1] * d2) - pt[1]);
+            J[1] = sl_dep * ((pt[2] * d0 - pt[0] * d2) + pt[0]);
+            J[2] = sl_dep * (-pt[1] * d0 + pt[0] * d1);
+            J[3] = sl_dep * d0;
+            J[4] = sl_dep * d1;
+            J[5] = sl_dep * (d2 - 1.0f);
+            od_accum_row(acc, J, sl_dep * diff_geo);
+        }
+    }
+    // block totals: DPP wave sums -> LDS -> one fp64 atomic per value
+    __shared__ double red[kOdThreads / 64][30];
+    const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == kWaveSumLane) red[wid][k] = v;
+    }
+    {
+        const double v = wave_sum(count);
+        if (lane == kWaveSumLane) red[wid][29] = v;
+    }
+    __syncthreads();
+    const int k = (int)threadIdx.x;
+    if (k < kAcc || k == 29) {
+        double t = 0.0;
+#pragma unroll
+        for (int p = 0; p < kOdThreads / 64; ++p) t += red[p][k];
+        if (t != 0.0) atomicAdd(a.out + k, t);
+    }
+}
+
+}  // namespace mi

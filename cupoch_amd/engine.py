@@ -388,6 +388,49 @@ class Engine:
         cut = lambda t_: None if t_ is None else t_[:k]
         return cut(op), cut(on), cut(oc)
 
+    def compute_rgbd_odometry(self, source_color, source_depth, target_color, target_depth, intrinsic4,
+                              odo_init=None, jacobian=1, iterations=(20, 10, 5), max_depth_diff=0.03,
+                              min_depth=0.0, max_depth=4.0):
+        """odometry::ComputeRGBDOdometry (odometry/odometry.cu:833-943).  Images: [H, W] float32,
+        numpy or torch (all on the same side).  Returns (success, 4x4 transformation, 6x6 information)."""
+        imgs = [source_color, source_depth, target_color, target_depth]
+        on_dev = torch.is_tensor(imgs[0]) and imgs[0].is_cuda
+        keep, ptrs = [], []
+        for x in imgs:
+            if torch.is_tensor(x):
+                if x.is_cuda != on_dev or x.dtype != torch.float32:
+                    raise TypeError("odometry images must be float32 and live on the same side")
+                x = x.contiguous() if on_dev else np.ascontiguousarray(x.numpy())
+            else:
+                if on_dev:
+                    raise TypeError("odometry images must live on the same side")
+                x = np.ascontiguousarray(x)
+                if x.dtype != np.float32:
+                    raise TypeError("odometry images must be float32")
+            keep.append(x)
+            ptrs.append(C.c_void_p(x.data_ptr()) if on_dev else x.ctypes.data_as(C.c_void_p))
+        shape = tuple(keep[0].shape)
+        if len(shape) != 2 or any(tuple(k.shape) != shape for k in keep):
+            raise ValueError("[RGBDOdometry] Two RGBD pairs should be same in size.")
+        from ._lib import OdometryOption
+        opt = OdometryOption()
+        opt.num_levels = len(iterations)
+        for i, v in enumerate(list(iterations)[:8]):   # (more than 8 levels: the library reports it)
+            opt.iterations[i] = int(v)
+        opt.max_depth_diff, opt.min_depth, opt.max_depth = float(max_depth_diff), float(min_depth), float(max_depth)
+        K = (C.c_float * 4)(*[float(v) for v in intrinsic4])
+        init = None
+        if odo_init is not None:
+            init = np.ascontiguousarray(np.asarray(odo_init, np.float32).reshape(4, 4).T)
+        ok = C.c_int(0)
+        T = np.empty(16, np.float32)
+        info = np.empty(36, np.float64)
+        self._chk(self._L.mi_icp_compute_rgbd_odometry(
+            self._ctx, ptrs[0], ptrs[1], ptrs[2], ptrs[3], int(shape[1]), int(shape[0]), K,
+            None if init is None else init.ctypes.data_as(C.c_void_p), int(jacobian), C.byref(opt), C.byref(ok),
+            T.ctypes.data_as(C.c_void_p), info.ctypes.data_as(C.c_void_p), MI_ICP_DEVICE if on_dev else MI_ICP_HOST))
+        return bool(ok.value), T.reshape(4, 4).T.copy(), info.reshape(6, 6).copy()
+
     def covariances_from_normals(self, normals, epsilon=1e-3):
         n = _Buf(normals, np.float32, 3, self.device)
         if n.kind == MI_ICP_DEVICE:

@@ -237,6 +237,37 @@ MI_ICP_API int mi_icp_create_from_depth(mi_icp_ctx* ctx, const void* depth, int 
                                         int stride, int rgbd, int compute_normals, int valid_only,
                                         float* out_xyz, float* out_normals, float* out_colors,
                                         int64_t* m, int mem_kind);
+/* odometry::ComputeRGBDOdometry (odometry/odometry.cu:833-943, odometry.h:43-53): the
+ * transformation that maps the source RGB-D frame onto the target frame, and the 6x6
+ * information matrix of the result.  The other in-repo caller of ComputeJTJandJTr /
+ * SolveJacobianSystemAndObtainExtrinsicMatrix (utility/eigen.h:79-115) besides the ICP
+ * estimators.
+ *   colors / depths  [height][width] float32 (intensity in [0,1], depth in the scene's unit);
+ *   intrinsic4       fx, fy, cx, cy;   odo_init: 4x4 column-major or NULL (identity);
+ *   jacobian         MI_ICP_ODOMETRY_COLOR_TERM (rgbdodometry_jacobian.inl:41-94) or
+ *                    MI_ICP_ODOMETRY_HYBRID_TERM (:96-172, the reference's default);
+ *   option           OdometryOption (odometry_option.h:30-62); iterations[] coarsest level
+ *                    first, as iteration_number_per_pyramid_level_.
+ * Outputs: *success (0: the reference's failure result -- identity transformation and
+ * identity information), transformation16 column-major, information36 row-major.
+ * Not provided: ComputeWeightedRGBDOdometry (the t-distribution weighted variant). */
+#define MI_ICP_ODOMETRY_COLOR_TERM 0
+#define MI_ICP_ODOMETRY_HYBRID_TERM 1
+#define MI_ICP_ODOMETRY_MAX_LEVELS 8
+typedef struct mi_icp_odometry_option {
+    int32_t num_levels;                               /* 3 */
+    int32_t iterations[MI_ICP_ODOMETRY_MAX_LEVELS];   /* {20, 10, 5} */
+    float max_depth_diff;                             /* 0.03 */
+    float min_depth;                                  /* 0.0 */
+    float max_depth;                                  /* 4.0 */
+} mi_icp_odometry_option;
+MI_ICP_API int mi_icp_compute_rgbd_odometry(mi_icp_ctx* ctx, const float* source_color,
+                                            const float* source_depth, const float* target_color,
+                                            const float* target_depth, int width, int height,
+                                            const float* intrinsic4, const float* odo_init,
+                                            int jacobian, const mi_icp_odometry_option* option,
+                                            int* success, float* transformation16,
+                                            double* information36, int mem_kind);
 /* InitializePointCloudForGeneralizedICP's normals -> covariances
  * (registration/generalized_icp.cu:18-30,52-59). */
 MI_ICP_API int mi_icp_covariances_from_normals(mi_icp_ctx* ctx, const float* normals,

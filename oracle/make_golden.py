@@ -103,6 +103,34 @@ def main():
         "points": orc.ref_rand_vec3f(40, [0, 0, 0], [1000, 1000, 1000], 0).tolist(),
         "knn": 30, "ref_normals": vec3_pushes(b, "ref"), "tol": 1e-4}
 
+    def vec6_rows(body, var):
+        pat = r"%s\[\d+\]\s*<<([^;]*);" % var
+        return [[float(v) for v in m.replace("\n", " ").split(",")] for m in re.findall(pat, body)]
+
+    # the two Jacobian functors of the RGB-D odometry: inputs as the tests build them
+    # (odometry_tools.cpp GenerateImage / ShiftLeft / ShiftUp over unit_test::Rand)
+    img = lambda vmin, vmax, seed: orc.ref_rand_floats(100, vmin, vmax, seed).reshape(10, 10)
+    shift_left = lambda a, s: np.stack([[a[h, (w + s) % 10] for w in range(10)] for h in range(10)]).astype(np.float32)
+    shift_up = lambda a, s: np.stack([[a[(h + s) % 10, w] for w in range(10)] for h in range(10)]).astype(np.float32)
+    for name, case, hybrid in (("odometry_jacobian_color", "RGBDOdometryJacobianFromColorTerm", 0),
+                               ("odometry_jacobian_hybrid", "RGBDOdometryJacobianFromHybridTerm", 1)):
+        path = "src/tests/odometry/rgbdodometry_jacobian_from_%s_term.cpp" % ("hybrid" if hybrid else "color")
+        b = test_body(path, case, "ComputeJacobianAndResidual")
+        tgt_color = shift_up(shift_left(img(0.0, 1.0, 1), 10), 5)
+        dx_color, dy_color = shift_left(img(0.0, 1.0, 1), 10), shift_up(img(0.0, 1.0, 1), 5)
+        tgt_depth = img(1.0, 2.0, 0)
+        # (both tests pass the target depth image as the depth-gradient images)
+        g[name] = {
+            "cite": path + ":31-" + ("134" if hybrid else "112"), "hybrid": hybrid,
+            "source_color": img(0.0, 1.0, 1).tolist(), "source_depth": img(0.0, 1.0, 0).tolist(),
+            "target_color": tgt_color.tolist(), "target_depth": tgt_depth.tolist(),
+            "dx_color": dx_color.tolist(), "dy_color": dy_color.tolist(),
+            "source_xyz": orc.ref_rand_floats(300, 0.0, 1.0, 0).reshape(10, 10, 3).tolist(),
+            "intrinsic": [[0.5, 0, 0.75], [0, 0.65, 0.35], [0, 0, 0]],
+            "extrinsic": [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 0]],
+            "corresps": orc.ref_rand_vec4i(10, 0, 3, 0).tolist(),
+            "ref_J_r": vec6_rows(b, "ref_J_r"), "ref_r": brace_list(b, "ref_r_raw"), "tol": 1e-4}
+
     for k, v in g.items():
         for name in ("ref_points", "ref_normals", "ref_colors", "ref_indices"):
             if name in v:

@@ -21,8 +21,8 @@ EST_COLORED = 4
 
 def build(force=False):
     """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
-    src = os.path.join(_HERE, "icp_oracle.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("icp_oracle.c", "odometry_oracle.c")]
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
     ref = os.environ.get("CUPOCH_REFERENCE", "/root/reference")
     if os.path.isdir(os.path.join(ref, "src", "tests", "test_utility")):
@@ -50,6 +50,7 @@ def lib():
         _lib.oracle_search_bruteforce.restype = C.c_int64
         _lib.oracle_voxel_downsample.restype = C.c_int64
         _lib.oracle_create_from_depth.restype = C.c_int64
+        _lib.oracle_od_correspondence.restype = C.c_int64
         _lib.oracle_compute_rmse.restype = C.c_float
     return _lib
 
@@ -369,6 +370,72 @@ def estimate_normals_radius(pts, radius, max_nn=30):
 
 
 # ---------------------------------------------------------------------------
+# RGB-D odometry (oracle/odometry_oracle.c)
+# ---------------------------------------------------------------------------
+OD_COLOR_TERM, OD_HYBRID_TERM = 0, 1
+
+
+def od_filter(img, kind):
+    """Image::Filter: kind 0 Gaussian3, 1 Sobel3Dx, 2 Sobel3Dy"""
+    img = _f32(img)
+    h, w = img.shape
+    out = np.empty_like(img)
+    lib().oracle_od_filter(_p(img), C.c_int(w), C.c_int(h), C.c_int(kind), _p(out))
+    return out
+
+
+def od_downsample(img):
+    img = _f32(img)
+    h, w = img.shape
+    out = np.empty((h // 2, w // 2), np.float32)
+    lib().oracle_od_downsample(_p(img), C.c_int(w), C.c_int(h), _p(out))
+    return out
+
+
+def od_correspondence(K, extrinsic, depth_s, depth_t, max_depth_diff):
+    depth_s, depth_t = _f32(depth_s), _f32(depth_t)
+    h, w = depth_s.shape
+    K = _f32(np.asarray(K, np.float32).reshape(3, 3))
+    out = np.empty((h * w, 4), np.int32)
+    n = lib().oracle_od_correspondence(_p(K), _p(_T_in(extrinsic)), _p(depth_s), _p(depth_t), C.c_int(w), C.c_int(h),
+                                       C.c_float(max_depth_diff), out.ctypes.data_as(C.c_void_p))
+    return out[:int(n)].copy()
+
+
+def od_jacobian(hybrid, row, corr, source_color, target_color, target_depth, source_xyz, dx_color, dx_depth,
+                dy_color, dy_depth, K, extrinsic):
+    """RGBDOdometryJacobianFrom{Color,Hybrid}Term::ComputeJacobianAndResidual"""
+    w = np.asarray(source_color).shape[1]
+    corr = np.ascontiguousarray(corr, np.int32)
+    J0, J1 = np.zeros(6, np.float32), np.zeros(6, np.float32)
+    r0, r1 = C.c_float(0), C.c_float(0)
+    f = lambda a: _p(_f32(a))
+    K = _f32(np.asarray(K, np.float32).reshape(3, 3))
+    lib().oracle_od_jacobian(C.c_int(int(hybrid)), C.c_int(row), corr.ctypes.data_as(C.c_void_p), f(source_color),
+                             f(target_color), f(target_depth), f(source_xyz), f(dx_color), f(dx_depth), f(dy_color),
+                             f(dy_depth), C.c_int(w), _p(K), _p(_T_in(extrinsic)), _p(J0), C.byref(r0), _p(J1),
+                             C.byref(r1))
+    return J0, float(r0.value), J1, float(r1.value)
+
+
+def compute_rgbd_odometry(src_color, src_depth, tgt_color, tgt_depth, intrinsic4, odo_init=None,
+                          jacobian=OD_HYBRID_TERM, iterations=(20, 10, 5), max_depth_diff=0.03, min_depth=0.0,
+                          max_depth=4.0):
+    """odometry::ComputeRGBDOdometry -> (success, 4x4 transformation, 6x6 information)"""
+    sc, sd, tc, td = _f32(src_color), _f32(src_depth), _f32(tgt_color), _f32(tgt_depth)
+    h, w = sc.shape
+    init = np.eye(4, dtype=np.float32) if odo_init is None else odo_init
+    it = (C.c_int * len(iterations))(*[int(v) for v in iterations])
+    T = np.empty(16, np.float32)
+    info = np.empty(36, np.float64)
+    ok = lib().oracle_od_compute(_p(sc), _p(sd), _p(tc), _p(td), C.c_int(w), C.c_int(h),
+                                 _p(_f32(np.asarray(intrinsic4, np.float32))), _p(_T_in(init)), C.c_int(int(jacobian)),
+                                 it, C.c_int(len(iterations)), C.c_float(max_depth_diff), C.c_float(min_depth),
+                                 C.c_float(max_depth), _p(T), info.ctypes.data_as(C.c_void_p))
+    return bool(ok), T.reshape(4, 4).T.copy(), info.reshape(6, 6).copy()
+
+
+# ---------------------------------------------------------------------------
 # oracle/_ref : the reference's own code compiled where it lies (optional)
 # ---------------------------------------------------------------------------
 def _ref_lib(name):
@@ -384,6 +451,25 @@ def ref_rand_vec3f(n, vmin, vmax, seed):
     out = np.empty((n, 3), np.float32)
     vmin, vmax = _f32(vmin, (3,)), _f32(vmax, (3,))
     L.ref_rand_vec3f(_p(out), C.c_int(n), _p(vmin), _p(vmax), C.c_int(seed))
+    return out
+
+
+def ref_rand_floats(n, vmin, vmax, seed):
+    """unit_test::Rand(float*, n, vmin, vmax, seed) driven by the reference's Raw generator."""
+    L = _ref_lib("libref_raw.so")
+    if L is None:
+        raise FileNotFoundError("oracle/_ref/libref_raw.so not built (needs /root/reference)")
+    out = np.empty(n, np.float32)
+    L.ref_rand_floats(_p(out), C.c_int(n), C.c_float(vmin), C.c_float(vmax), C.c_int(seed))
+    return out
+
+
+def ref_rand_vec4i(n, vmin, vmax, seed):
+    L = _ref_lib("libref_raw.so")
+    if L is None:
+        raise FileNotFoundError("oracle/_ref/libref_raw.so not built (needs /root/reference)")
+    out = np.empty((n, 4), np.int32)
+    L.ref_rand_vec4i(out.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_int(vmin), C.c_int(vmax), C.c_int(seed))
     return out
 
 

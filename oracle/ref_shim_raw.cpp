@@ -21,4 +21,18 @@ void ref_rand_vec3f(float* out, int n, const float* vmin, const float* vmax, int
             out[3 * i + d] = vmin[d] + raw.Next<float>() * factor[d];
 }
 
+// unit_test::Rand(float* const, size, vmin, vmax, seed) (rand.cpp:241-252)
+void ref_rand_floats(float* out, int n, float vmin, float vmax, int seed) {
+    unit_test::Raw raw(seed);
+    const float factor = vmax - vmin;
+    for (int i = 0; i < n; ++i) out[i] = vmin + raw.Next<float>() * factor;
+}
+
+// unit_test::Rand(host_vector<Vector4i>&, int vmin, int vmax, seed) (rand.cpp:137-151)
+void ref_rand_vec4i(int* out, int n, int vmin, int vmax, int seed) {
+    unit_test::Raw raw(seed);
+    const double factor = (double)(vmax - vmin) / unit_test::Raw::VMAX;
+    for (int i = 0; i < 4 * n; ++i) out[i] = vmin + (int)(raw.Next<int>() * factor);
+}
+
 }  // extern "C"

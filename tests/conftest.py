@@ -155,3 +155,17 @@ def small_pose(angle=0.02, shift=0.03):
     T[:3, :3] = R
     T[:3, 3] = shift * np.array([1.0, -1.0, 0.5]) / 1.5
     return T.astype(np.float32)
+
+
+def render_rgbd(width, height, K4, cam_pose, holes=0.0, seed=0):
+    """(intensity, depth) of the render_depth scene: the intensity is a smooth world-space
+    texture, so that two frames of the same surface point agree."""
+    depth = render_depth(width, height, K4, cam_pose, holes=holes, seed=seed)
+    fx, fy, cx, cy = [float(v) for v in K4]
+    v, u = np.meshgrid(np.arange(height, dtype=np.float64), np.arange(width, dtype=np.float64), indexing="ij")
+    z = depth.astype(np.float64)
+    pc = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], -1)
+    P = np.asarray(cam_pose, np.float64).reshape(4, 4)
+    pw = pc @ P[:3, :3].T + P[:3, 3]
+    tex = 0.5 + 0.2 * np.sin(3.0 * pw[..., 0]) * np.cos(2.5 * pw[..., 1]) + 0.2 * np.cos(2.0 * pw[..., 1] + 1.5 * pw[..., 2])
+    return np.clip(tex, 0.0, 1.0).astype(np.float32), depth

@@ -49,6 +49,28 @@ static geometry::Image RenderDepth(const camera::PinholeCameraIntrinsic& k, cons
     return img;
 }
 
+// intensity frame that goes with RenderDepth: a smooth world-space texture
+static geometry::Image RenderIntensity(const camera::PinholeCameraIntrinsic& k, const Matrix4f& pose) {
+    std::vector<float> c((size_t)k.width_ * k.height_);
+    for (int v = 0; v < k.height_; ++v)
+        for (int u = 0; u < k.width_; ++u) {
+            const float dc[3] = {(u - k.cx_) / k.fx_, (v - k.cy_) / k.fy_, 1.0f};
+            float dir[3];
+            for (int r = 0; r < 3; ++r) dir[r] = pose(r, 0) * dc[0] + pose(r, 1) * dc[1] + pose(r, 2) * dc[2];
+            float s = 3.0f;
+            for (int it = 0; it < 40; ++it)
+                s += (Surface(pose(0, 3) + s * dir[0], pose(1, 3) + s * dir[1]) - (pose(2, 3) + s * dir[2])) / dir[2];
+            const float px = pose(0, 3) + s * dir[0], py = pose(1, 3) + s * dir[1];
+            c[(size_t)v * k.width_ + u] = 0.5f + 0.2f * std::sin(3.0f * px) * std::cos(2.5f * py) + 0.2f * std::cos(2.0f * py + px);
+        }
+    geometry::Image img;
+    img.Prepare(k.width_, k.height_, 1, 4);
+    std::vector<uint8_t> bytes(c.size() * 4);
+    std::memcpy(bytes.data(), c.data(), bytes.size());
+    img.SetData(bytes);
+    return img;
+}
+
 // a user-defined estimator: exercises the virtual interface / generic loop
 class MyPointToPlane : public registration::TransformationEstimation {
 public:
@@ -214,6 +236,31 @@ int main() {
         auto none = geometry::PointCloud::CreateFromDepthImage(bad, k0);
         const size_t ns = strided->points_.size();
         std::printf("\"depth_strided\": %zu, \"depth_bad_empty\": %s, ", ns, none->IsEmpty() ? "true" : "false");
+    }
+    {   // RGB-D odometry between two rendered frames (odometry/odometry.cu)
+        const camera::PinholeCameraIntrinsic k0(320, 240, 262.5f, 262.5f, 159.5f, 119.5f);
+        const Matrix4f pose_b = Rigid(0.02f, 1, 2, 3, 0.02f, -0.02f, 0.01f);
+        geometry::RGBDImage target(RenderIntensity(k0, Matrix4f::Identity()), RenderDepth(k0, Matrix4f::Identity()));
+        geometry::RGBDImage source(RenderIntensity(k0, pose_b), RenderDepth(k0, pose_b));
+        bool ok;
+        Matrix4f T;
+        Eigen::Matrix6f info;
+        std::tie(ok, T, info) = odometry::ComputeRGBDOdometry(source, target, k0, Matrix4f::Identity(),
+                                                              odometry::RGBDOdometryJacobianFromHybridTerm(),
+                                                              odometry::OdometryOption({20, 10, 5}, 0.03f, 0.0f, 6.0f));
+        const float e_h = Fro(T, pose_b);
+        std::tie(ok, T, info) = odometry::ComputeRGBDOdometry(source, target, k0, Matrix4f::Identity(),
+                                                              odometry::RGBDOdometryJacobianFromColorTerm(),
+                                                              odometry::OdometryOption({20, 10, 5}, 0.03f, 0.0f, 6.0f));
+        geometry::Image small;
+        small.Prepare(8, 8, 1, 4);
+        bool bad_ok;
+        Matrix4f bad_T;
+        std::tie(bad_ok, bad_T, info) = odometry::ComputeRGBDOdometry(geometry::RGBDImage(small, small), target, k0);
+        const float motion = Fro(Matrix4f::Identity(), pose_b), e_c = Fro(T, pose_b);
+        std::printf("\"odometry_ok\": %s, \"odometry_hybrid_err\": %.3g, \"odometry_color_err\": %.3g, \"odometry_motion\": %.3g, "
+                    "\"odometry_mismatch_fails\": %s, ",
+                    ok ? "true" : "false", e_h, e_c, motion, (!bad_ok && bad_T.isIdentity()) ? "true" : "false");
     }
     {   // Kabsch golden shape (src/tests/registration/kabsch.cpp:35-55)
         std::vector<Vector3f> pts(20);

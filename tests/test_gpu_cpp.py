@@ -45,3 +45,7 @@ def test_cpp_surface_end_to_end(tmp_path):
     assert r["kinfu_points"] == [320 * 240, 160 * 120] and r["kinfu_normals"]
     assert r["depth_strided"] == 80 * 60 and r["depth_bad_empty"]
     assert "[PointCloud::CreateFromDepthImage] Unsupported image format." in out.stderr
+    # RGB-D odometry recovers most of the motion (hybrid term better than the colour term alone)
+    assert r["odometry_ok"] and r["odometry_hybrid_err"] < 0.15 * r["odometry_motion"], r
+    assert r["odometry_color_err"] < 0.6 * r["odometry_motion"] and r["odometry_mismatch_fails"], r
+    assert "[RGBDOdometry] Two RGBD pairs should be same in size." in out.stderr

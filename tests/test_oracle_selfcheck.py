@@ -229,3 +229,45 @@ def test_kinfu_pose_estimation_recovers_the_camera_motion():
     T = orc.kinfu_pose_estimation(np.eye(4, dtype=np.float32), frames, models, distance_threshold=0.03,
                                   icp_iterations=(10, 10, 10))
     assert np.linalg.norm(T - pose_b) < 2e-3, np.linalg.norm(T - pose_b)
+
+
+# --- RGB-D odometry (odometry/odometry.cu) -------------------------------------------------------
+def test_odometry_filters_and_correspondence_rule():
+    rng = np.random.default_rng(0)
+    img = rng.random((17, 23), dtype=np.float32)
+    g = orc.od_filter(img, 0)
+    pad = np.pad(img.astype(np.float64), 1, mode="edge")                       # clamp-to-edge
+    k = np.array([0.25, 0.5, 0.25])
+    ref = sum(k[j] * sum(k[i] * pad[j:j + 17, i:i + 23] for i in range(3)) for j in range(3))
+    np.testing.assert_allclose(g, ref, rtol=1e-6)
+    ramp = np.tile(np.arange(23, dtype=np.float32), (17, 1))                    # d/dx = 1: Sobel * 1/8
+    np.testing.assert_allclose(orc.od_filter(ramp, 1)[:, 1:-1] * 0.125, 1.0, rtol=1e-6)
+    assert np.abs(orc.od_filter(ramp, 2)).max() == 0.0
+    np.testing.assert_allclose(orc.od_downsample(img)[3, 4], img[6:8, 8:10].mean(), rtol=1e-6)
+    assert orc.od_downsample(img).shape == (8, 11)
+    # identity extrinsic: every valid pixel corresponds to itself; a NaN or a depth jump does not
+    d = np.full((12, 16), 2.0, np.float32)
+    d[3, 4] = np.nan
+    dt = d.copy()
+    dt[5, 6] = 2.5
+    dt[3, 4] = 2.0
+    c = orc.od_correspondence([[20, 0, 7.5], [0, 20, 5.5], [0, 0, 1]], np.eye(4), d, dt, 0.03)
+    assert len(c) == 12 * 16 - 2 and (c[:, 0] == c[:, 2]).all() and (c[:, 1] == c[:, 3]).all()
+    assert not ((c[:, 0] == 4) & (c[:, 1] == 3)).any() and not ((c[:, 0] == 6) & (c[:, 1] == 5)).any()
+
+
+@pytest.mark.parametrize("jac", [orc.OD_COLOR_TERM, orc.OD_HYBRID_TERM])
+def test_odometry_recovers_the_camera_motion(jac):
+    from conftest import render_rgbd, small_pose
+    K = [262.5, 262.5, 159.5, 119.5]
+    pose_b = small_pose(0.02, 0.03)
+    ca, da = render_rgbd(320, 240, K, np.eye(4))
+    cb, db = render_rgbd(320, 240, K, pose_b)
+    ok, T, info = orc.compute_rgbd_odometry(cb, db, ca, da, K, jacobian=jac, max_depth=6.0)
+    assert ok
+    motion = np.linalg.norm(np.eye(4) - pose_b)
+    assert np.linalg.norm(T - pose_b) < (0.1 if jac == orc.OD_HYBRID_TERM else 0.5) * motion
+    assert np.allclose(info, info.T) and (np.diag(info) > 1e4).all()
+    # no overlap in depth range: nothing corresponds, the "solution" of a zero system
+    ok2, T2, _ = orc.compute_rgbd_odometry(cb, db, ca, da, K, jacobian=jac, max_depth=0.1)
+    assert not np.isfinite(T2).all() or np.allclose(T2, np.eye(4))
