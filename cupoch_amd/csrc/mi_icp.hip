@@ -604,68 +604,6 @@ int check_ctx(mi_icp_ctx* c) {
 // ============================================================================
 // C ABI
 // ============================================================================
-// ---------------------------------------------------------------------------
-// odometry::ComputeRGBDOdometry (odometry/odometry.cu)
-namespace {
-
-struct OdCamera {
-    float k[9];  // row-major
-};
-
-void od_inverse3(const float* M, float* I) {  // Eigen's 3x3 inverse by cofactors, fp32
-    const float c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
-    const float det = M[0] * c00 + M[1] * c01 + M[2] * c02, id = 1.0f / det;
-    I[0] = c00 * id;
-    I[1] = (M[2] * M[7] - M[1] * M[8]) * id;
-    I[2] = (M[1] * M[5] - M[2] * M[4]) * id;
-    I[3] = c01 * id;
-    I[4] = (M[0] * M[8] - M[2] * M[6]) * id;
-    I[5] = (M[2] * M[3] - M[0] * M[5]) * id;
-    I[6] = c02 * id;
-    I[7] = (M[1] * M[6] - M[0] * M[7]) * id;
-    I[8] = (M[0] * M[4] - M[1] * M[3]) * id;
-}
-
-void od_mul3(const float* A, const float* B, float* C) {
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) C[r * 3 + c] = (A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c]) + A[r * 3 + 2] * B[6 + c];
-}
-
-// projection terms of ComputeCorrespondence (odometry.cu:225-229) + the Jacobians' camera terms
-void od_set_camera(OdArgs& a, const OdCamera& cam, const Mat4& E) {
-    float Kinv[9], R[9], KR[9];
-    od_inverse3(cam.k, Kinv);
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) R[r * 3 + c] = host::at(E, r, c);
-    od_mul3(cam.k, R, KR);
-    od_mul3(KR, Kinv, a.krk);
-    for (int r = 0; r < 3; ++r)
-        a.kt[r] = (cam.k[r * 3] * host::at(E, 0, 3) + cam.k[r * 3 + 1] * host::at(E, 1, 3)) + cam.k[r * 3 + 2] * host::at(E, 2, 3);
-    for (int i = 0; i < 9; ++i) a.e[i] = R[i];
-    for (int r = 0; r < 3; ++r) a.e[9 + r] = host::at(E, r, 3);
-    a.fx = cam.k[0];
-    a.fy = cam.k[4];
-    a.ox = cam.k[2];
-    a.oy = cam.k[5];
-    a.inv_fx = (float)(1.0 / (double)cam.k[0]);
-    a.inv_fy = (float)(1.0 / (double)cam.k[4]);
-}
-
-template <int MODE>
-int od_run(mi_icp_ctx* c, OdArgs& a, double* host32) {
-    HIPCHK(c, hipMemsetAsync(a.out, 0, 32 * sizeof(double), c->stream));
-    const int64_t n = (int64_t)a.w * a.h;
-    const int grid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + kOdThreads - 1) / kOdThreads));
-    od_accumulate<MODE><<<grid, kOdThreads, 0, c->stream>>>(a);
-    KCHK(c);
-    HIPCHK(c, hipMemcpyAsync(c->sys_host, a.out, 32 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::memcpy(host32, c->sys_host, 32 * sizeof(double));
-    return MI_ICP_OK;
-}
-
-}  // namespace
-
 extern "C" {
 
 const char* mi_icp_version(void) { return "mi_icp 0.1 (gfx950)"; }
@@ -1646,12 +1584,25 @@ int mi_icp_compute_rgbd_odometry(mi_icp_ctx* c, const float* source_color, const
             cam[l].k[8] = 1.0f;
         }
     }
+    // the running transformation and everything derived from it live on the device (OdState);
+    // the host enqueues the whole run and synchronises once, at the end
+    static_assert(sizeof(OdState) <= 64 * sizeof(float), "OdState is staged through the context's 64 pinned floats");
+    float* state_mem;
+    TRY(ensure(c, c->stage[5], sizeof(OdState) / sizeof(float) + 16, &state_mem));
+    OdState* state = reinterpret_cast<OdState*>(state_mem);
     const Mat4 init = load_T(odo_init);
+    OdState* hst = reinterpret_cast<OdState*>(c->f_host);
+    auto set_T = [&](const Mat4& T) -> int {
+        hst->T = T;
+        HIPCHK(c, hipMemcpyAsync(&state->T, &hst->T, sizeof(Mat4), hipMemcpyHostToDevice, c->stream));
+        return MI_ICP_OK;
+    };
+    HIPCHK(c, hipMemsetAsync(sums, 0, 32 * sizeof(double), c->stream));
     OdArgs a{};
     a.out = sums;
+    a.state = state;
     a.max_depth_diff = option->max_depth_diff;
-    double sys[32];
-    auto level_args = [&](int l, const Mat4& E) {
+    auto level_args = [&](int l) {
         a.depth_s = dep[0][l];
         a.depth_t = dep[1][l];
         a.color_s = col[0][l];
@@ -1662,15 +1613,18 @@ int mi_icp_compute_rgbd_odometry(mi_icp_ctx* c, const float* source_color, const
         a.dy_depth = grad[3][l];
         a.w = lw[l];
         a.h = lh[l];
-        od_set_camera(a, cam[l], E);
+    };
+    auto grid_for = [&](int l) {
+        const int64_t n = (int64_t)lw[l] * lh[l];
+        return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + kOdThreads - 1) / kOdThreads));
     };
     {   // NormalizeIntensity (:416-436) over the correspondences under odo_init
-        level_args(0, init);
-        TRY(od_run<kOdMeans>(c, a, sys));
-        const float nc = (float)sys[29];
-        const float mean_s = (float)sys[0] / nc, mean_t = (float)sys[1] / nc;
-        od_scale<<<blocks(n0), kOdThreads, 0, c->stream>>>(col[0][0], n0, (float)(0.5 / (double)mean_s));
-        od_scale<<<blocks(n0), kOdThreads, 0, c->stream>>>(col[1][0], n0, (float)(0.5 / (double)mean_t));
+        TRY(set_T(init));
+        od_step<<<1, 64, 0, c->stream>>>(state, sums, cam[0], 0);
+        level_args(0);
+        od_accumulate<kOdMeans><<<grid_for(0), kOdThreads, 0, c->stream>>>(a);
+        od_scale_by_mean<<<blocks(n0), kOdThreads, 0, c->stream>>>(col[0][0], n0, sums, 0);
+        od_scale_by_mean<<<blocks(n0), kOdThreads, 0, c->stream>>>(col[1][0], n0, sums, 1);
         KCHK(c);
     }
     // ---- pyramids (rgbdimage.cu:96-112, image_factory.cu:251-278): colour Gaussian3 + Downsample,
@@ -1692,36 +1646,42 @@ int mi_icp_compute_rgbd_odometry(mi_icp_ctx* c, const float* source_color, const
     }
     KCHK(c);
 
-    // ---- ComputeMultiscale (:708-764)
-    Mat4 T = init;
+    // ---- ComputeMultiscale (:708-764): one accumulate + one step launch per iteration
     {
         bool zero = true;
-        for (int i = 0; i < 16; ++i) zero = zero && (T.data()[i] == 0.0f);
-        if (zero) T = I4;
+        for (int i = 0; i < 16; ++i) zero = zero && (init.data()[i] == 0.0f);
+        TRY(set_T(zero ? I4 : init));
+        od_step<<<1, 64, 0, c->stream>>>(state, sums, cam[L - 1], 0);  // terms for the coarsest level; zeroes the sums
     }
-    bool ok = true;
-    for (int level = L - 1; level >= 0 && ok; --level) {
-        for (int iter = 0; iter < option->iterations[L - level - 1] && ok; ++iter) {
-            level_args(level, T);
-            if (jacobian == MI_ICP_ODOMETRY_COLOR_TERM) TRY(od_run<kOdColor>(c, a, sys));
-            else TRY(od_run<kOdHybrid>(c, a, sys));
-            Mat4 update;
-            ok = host::solve_system(sys, -1.0f, update);  // det_thresh default -1 (utility/eigen.h:84)
-            if (ok) T = host::mul4(update, T);
+    for (int level = L - 1; level >= 0; --level) {
+        level_args(level);
+        const int iters = option->iterations[L - level - 1];
+        for (int iter = 0; iter < iters; ++iter) {
+            if (jacobian == MI_ICP_ODOMETRY_COLOR_TERM) od_accumulate<kOdColor><<<grid_for(level), kOdThreads, 0, c->stream>>>(a);
+            else od_accumulate<kOdHybrid><<<grid_for(level), kOdThreads, 0, c->stream>>>(a);
+            // the next evaluation: this level again, the next finer one, or level 0 (information matrix)
+            const int next = (iter + 1 < iters) ? level : std::max(level - 1, 0);
+            od_step<<<1, 64, 0, c->stream>>>(state, sums, cam[next], 1);
         }
+        if (iters <= 0 && level > 0) od_step<<<1, 64, 0, c->stream>>>(state, sums, cam[level - 1], 0);
     }
-    if (ok) {
-        // CreateInformationMatrix (:349-394): I + sum G^T G over the final correspondences
-        level_args(0, T);
-        TRY(od_run<kOdInformation>(c, a, sys));
+    KCHK(c);
+    // CreateInformationMatrix (:349-394): I + sum G^T G over the final correspondences
+    level_args(0);
+    od_accumulate<kOdInformation><<<grid_for(0), kOdThreads, 0, c->stream>>>(a);
+    KCHK(c);
+    HIPCHK(c, hipMemcpyAsync(c->sys_host, sums, 32 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&hst->T, &state->T, sizeof(Mat4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
         int k = 0;
         for (int r = 0; r < 6; ++r)
             for (int q = r; q < 6; ++q, ++k) {
-                information36[r * 6 + q] += sys[k];
-                if (q != r) information36[q * 6 + r] += sys[k];
+                information36[r * 6 + q] += c->sys_host[k];
+                if (q != r) information36[q * 6 + r] += c->sys_host[k];
             }
-        std::memcpy(transformation16, T.data(), 16 * sizeof(float));
-        *success = 1;
+        std::memcpy(transformation16, hst->T.data(), 16 * sizeof(float));
+        *success = 1;  // without its determinant check the solver never reports failure (utility/eigen.cu:76-122)
     }
     return MI_ICP_OK;
 }

@@ -18,6 +18,7 @@
 // -ffp-contract=off), sums over pixels are fp64.
 #pragma once
 #include "device_utils.h"
+#include "host_solver.h"
 
 namespace mi {
 
@@ -65,11 +66,20 @@ __global__ __launch_bounds__(kOdThreads) void od_downsample(const float* __restr
     dst[idx] = (p[0] + p[1] + p[w] + p[w + 1]) / 4.0f;
 }
 
-// Image::LinearTransform(scale, 0) (image.cu:111-119)
-__global__ __launch_bounds__(kOdThreads) void od_scale(float* __restrict__ img, int64_t n, float scale) {
-    const int64_t idx = (int64_t)blockIdx.x * kOdThreads + threadIdx.x;
-    if (idx < n) img[idx] = scale * img[idx] + 0.0f;
-}
+// What changes from iteration to iteration lives in device memory: the running transformation
+// and the projection terms derived from it (written by od_step, read by od_accumulate), so that
+// the host can enqueue a whole multi-scale run without looking at intermediate results.
+struct OdState {
+    float krk[9];   // K R K^-1, row-major (ComputeCorrespondence, odometry.cu:225-229)
+    float kt[3];    // K t
+    float e[12];    // R (row-major 3x3) and t of the current extrinsic
+    float fx, fy, ox, oy, inv_fx, inv_fy;  // of the level the next evaluation runs on
+    host::Mat4 T;   // the running result (column-major)
+};
+
+struct OdCamera {
+    float k[9];  // row-major 3x3
+};
 
 struct OdArgs {
     const float* depth_s;
@@ -81,12 +91,9 @@ struct OdArgs {
     const float* dx_depth;
     const float* dy_depth;
     int w, h;
-    float krk[9];   // K R K^-1, row-major
-    float kt[3];    // K t
-    float e[12];    // R (row-major 3x3) and t of the current extrinsic
-    float fx, fy, ox, oy, inv_fx, inv_fy;
     float max_depth_diff;
-    double* out;    // 32 doubles, zeroed by the host: the layout of the ICP system (reduce.h)
+    const OdState* state;
+    double* out;    // 32 doubles, zero on entry (od_step leaves them so): the layout of the ICP system (reduce.h)
 };
 
 constexpr int kOdColor = 0, kOdHybrid = 1, kOdMeans = 2, kOdInformation = 3;
@@ -116,6 +123,7 @@ __global__ __launch_bounds__(kOdThreads) void od_accumulate(OdArgs a) {
 #pragma unroll
     for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
     double count = 0.0;
+    const OdState s = *a.state;  // wave-uniform: scalar loads
     const int64_t n = (int64_t)a.w * a.h;
     for (int64_t idx = (int64_t)blockIdx.x * kOdThreads + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * kOdThreads) {
         const int v_s = (int)(idx / a.w), u_s = (int)(idx % a.w);
@@ -124,8 +132,8 @@ __global__ __launch_bounds__(kOdThreads) void od_accumulate(OdArgs a) {
         float uv[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {  // d_s * KRK_inv * (u, v, 1) + Kt: the matrix is scaled first
-            const float m0 = d_s * a.krk[r * 3], m1 = d_s * a.krk[r * 3 + 1], m2 = d_s * a.krk[r * 3 + 2];
-            uv[r] = ((m0 * (float)u_s + m1 * (float)v_s) + m2 * 1.0f) + a.kt[r];
+            const float m0 = d_s * s.krk[r * 3], m1 = d_s * s.krk[r * 3 + 1], m2 = d_s * s.krk[r * 3 + 2];
+            uv[r] = ((m0 * (float)u_s + m1 * (float)v_s) + m2 * 1.0f) + s.kt[r];
         }
         const float tz = uv[2];
         const int u_t = (int)((double)(uv[0] / tz) + 0.5), v_t = (int)((double)(uv[1] / tz) + 0.5);
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(kOdThreads) void od_accumulate(OdArgs a) {
         }
         if (MODE == kOdInformation) {  // xyz of the TARGET pixel (ConvertDepthImageToXYZImage :273-330)
             const float z = d_t;
-            const float x = ((float)u_t - a.ox) * z * a.inv_fx, y = ((float)v_t - a.oy) * z * a.inv_fy;
+            const float x = ((float)u_t - s.ox) * z * s.inv_fx, y = ((float)v_t - s.oy) * z * s.inv_fy;
             const float g[3][6] = {{0.0f, z, -y, 1.0f, 0.0f, 0.0f}, {-z, 0.0f, x, 0.0f, 1.0f, 0.0f}, {y, -x, 0.0f, 0.0f, 0.0f, 1.0f}};
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -155,14 +163,14 @@ __global__ __launch_bounds__(kOdThreads) void od_accumulate(OdArgs a) {
         }
         // source point of the pixel, moved by the current extrinsic
         const float z = d_s;
-        const float p0 = ((float)u_s - a.ox) * z * a.inv_fx, p1 = ((float)v_s - a.oy) * z * a.inv_fy, p2 = z;
+        const float p0 = ((float)u_s - s.ox) * z * s.inv_fx, p1 = ((float)v_s - s.oy) * z * s.inv_fy, p2 = z;
         float pt[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) pt[r] = ((a.e[r * 3] * p0 + a.e[r * 3 + 1] * p1) + a.e[r * 3 + 2] * p2) + a.e[9 + r];
+        for (int r = 0; r < 3; ++r) pt[r] = ((s.e[r * 3] * p0 + s.e[r * 3 + 1] * p1) + s.e[r * 3 + 2] * p2) + s.e[9 + r];
         const float diff_photo = a.color_t[it] - a.color_s[idx];
         const float dIdx = 0.125f * a.dx_color[it], dIdy = 0.125f * a.dy_color[it];
         const float invz = (float)(1.0 / (double)pt[2]);
-        const float c0 = dIdx * a.fx * invz, c1 = dIdy * a.fy * invz;
+        const float c0 = dIdx * s.fx * invz, c1 = dIdy * s.fy * invz;
         const float c2 = -(c0 * pt[0] + c1 * pt[1]) * invz;
         float J[6];
         if (MODE == kOdColor) {
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(kOdThreads) void od_accumulate(OdArgs a) {
             if (dDdx != dDdx) dDdx = 0.0f;
             if (dDdy != dDdy) dDdy = 0.0f;
             const float diff_geo = d_t - pt[2];
-            const float d0 = dDdx * a.fx * invz, d1 = dDdy * a.fy * invz;
+            const float d0 = dDdx * s.fx * invz, d1 = dDdy * s.fy * invz;
             const float d2 = -(d0 * pt[0] + d1 * pt[1]) * invz;
             J[0] = sl_img * (-pt[2] * c1 + pt[1] * c2);
             J[1] = sl_img * (pt[2] * c0 - pt[0] * c2);
@@ -218,6 +226,80 @@ __global__ __launch_bounds__(kOdThreads) void od_accumulate(OdArgs a) {
         for (int p = 0; p < kOdThreads / 64; ++p) t += red[p][k];
         if (t != 0.0) atomicAdd(a.out + k, t);
     }
+}
+
+// Eigen's 3x3 inverse by cofactors and 3x3 product, fp32, row-major (K.inverse(), K * R * K_inv)
+__host__ __device__ inline void od_inverse3(const float* M, float* I) {
+    const float c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+    const float det = M[0] * c00 + M[1] * c01 + M[2] * c02, id = 1.0f / det;
+    I[0] = c00 * id;
+    I[1] = (M[2] * M[7] - M[1] * M[8]) * id;
+    I[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+    I[3] = c01 * id;
+    I[4] = (M[0] * M[8] - M[2] * M[6]) * id;
+    I[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+    I[6] = c02 * id;
+    I[7] = (M[1] * M[6] - M[0] * M[7]) * id;
+    I[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+}
+
+__host__ __device__ inline void od_mul3(const float* A, const float* B, float* C) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) C[r * 3 + c] = (A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c]) + A[r * 3 + 2] * B[6 + c];
+}
+
+// The step between two evaluations, one thread: (update != 0) solve the 6x6 system just
+// accumulated and compose it onto the running transformation (DoSingleIteration's tail,
+// odometry.cu:619-630, and ComputeMultiscale's `result_odo = curr_odo * result_odo`, :752);
+// then derive the projection terms for the NEXT evaluation, which runs with camera `cam`
+// (the same level, the next finer one, or level 0 for the information matrix), and zero
+// the accumulators.  The solver never reports failure without its determinant check
+// (utility/eigen.cu:76-122), so nothing here needs the host.
+__global__ __launch_bounds__(64) void od_step(OdState* st, double* sums, OdCamera cam, int update) {
+    __shared__ double sys[32];
+    if (threadIdx.x < 32) sys[threadIdx.x] = sums[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        host::Mat4 T = st->T;
+        if (update) {
+            host::Mat4 upd;
+            host::solve_system(sys, -1.0f, upd);
+            T = host::mul4(upd, T);
+            st->T = T;
+        }
+        float Kinv[9], R[9], KR[9], KRK[9];
+        od_inverse3(cam.k, Kinv);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) R[r * 3 + c] = host::at(T, r, c);
+        od_mul3(cam.k, R, KR);
+        od_mul3(KR, Kinv, KRK);
+        for (int i = 0; i < 9; ++i) {
+            st->krk[i] = KRK[i];
+            st->e[i] = R[i];
+        }
+        for (int r = 0; r < 3; ++r) {
+            st->kt[r] = (cam.k[r * 3] * host::at(T, 0, 3) + cam.k[r * 3 + 1] * host::at(T, 1, 3)) + cam.k[r * 3 + 2] * host::at(T, 2, 3);
+            st->e[9 + r] = host::at(T, r, 3);
+        }
+        st->fx = cam.k[0];
+        st->fy = cam.k[4];
+        st->ox = cam.k[2];
+        st->oy = cam.k[5];
+        st->inv_fx = (float)(1.0 / (double)cam.k[0]);
+        st->inv_fy = (float)(1.0 / (double)cam.k[4]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) sums[threadIdx.x] = 0.0;
+}
+
+// NormalizeIntensity's Image::LinearTransform(0.5 / mean, 0) (odometry.cu:431-435), the mean
+// taken from the kOdMeans sums on the device: which = 0 source, 1 target.
+__global__ __launch_bounds__(kOdThreads) void od_scale_by_mean(float* __restrict__ img, int64_t n,
+                                                               const double* __restrict__ sums, int which) {
+    const float mean = (float)sums[which] / (float)sums[29];
+    const float scale = (float)(0.5 / (double)mean);
+    const int64_t idx = (int64_t)blockIdx.x * kOdThreads + threadIdx.x;
+    if (idx < n) img[idx] = scale * img[idx] + 0.0f;
 }
 
 }  // namespace mi
