@@ -70,7 +70,8 @@ class Result(C.Structure):
 
 class OdometryOption(C.Structure):
     _fields_ = [("num_levels", C.c_int32), ("iterations", C.c_int32 * 8), ("max_depth_diff", C.c_float),
-                ("min_depth", C.c_float), ("max_depth", C.c_float)]
+                ("min_depth", C.c_float), ("max_depth", C.c_float), ("nu", C.c_float), ("sigma2_init", C.c_float),
+                ("inv_sigma_mat_diag", C.c_float * 6)]
 
 
 # name -> (restype, argtypes); must list every MI_ICP_API symbol of include/mi_icp.h
@@ -102,6 +103,7 @@ SIGNATURES = {
     "mi_icp_create_from_depth": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _F, _F, _F, _I, _I, _I, _I,
                                       _P, _P, _P, C.POINTER(_L), _I]),
     "mi_icp_compute_rgbd_odometry": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P, C.POINTER(_I), _P, _P, _I]),
+    "mi_icp_compute_weighted_rgbd_odometry": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, C.POINTER(_I), _P, _P, _P, _I]),
     "mi_icp_covariances_from_normals": (_I, [_P, _P, _L, _F, _P, _I]),
     "mi_icp_estimate_normals_knn": (_I, [_P, _P, _L, _I, _P, _I]),
     "mi_icp_estimate_normals_radius": (_I, [_P, _P, _L, _F, _I, _P, _I]),

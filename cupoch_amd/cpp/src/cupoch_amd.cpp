@@ -552,18 +552,17 @@ int KDTreeFlann::Search(const Eigen::Vector3f& query, const KDTreeSearchParam& p
 // ---------------------------------------------------------------- odometry
 namespace odometry {
 
-std::tuple<bool, Eigen::Matrix4f, Eigen::Matrix6f> ComputeRGBDOdometry(
-        const geometry::RGBDImage& source, const geometry::RGBDImage& target,
-        const camera::PinholeCameraIntrinsic& intrinsic, const Eigen::Matrix4f& odo_init,
-        const RGBDOdometryJacobian& jacobian_method, const OdometryOption& option) {
+static bool OdometryInputsOk(const geometry::RGBDImage& source, const geometry::RGBDImage& target) {
     auto is_float_image = [](const geometry::Image& im) { return im.num_of_channels_ == 1 && im.bytes_per_channel_ == 4; };
     const geometry::Image &sc = source.color_, &sd = source.depth_, &tc = target.color_, &td = target.depth_;
     const bool same = sc.width_ == tc.width_ && sc.height_ == tc.height_ && sd.width_ == td.width_ &&
                       sd.height_ == td.height_ && sc.width_ == sd.width_ && sc.height_ == sd.height_;
-    if (!same || !is_float_image(sc) || !is_float_image(sd) || !is_float_image(tc) || !is_float_image(td)) {
-        LogWarning("[RGBDOdometry] Two RGBD pairs should be same in size.");  // odometry.cu:845-851
-        return std::make_tuple(false, Eigen::Matrix4f::Identity(), Eigen::Matrix6f::Zero());
-    }
+    if (same && is_float_image(sc) && is_float_image(sd) && is_float_image(tc) && is_float_image(td)) return true;
+    LogWarning("[RGBDOdometry] Two RGBD pairs should be same in size.");  // odometry.cu:845-851
+    return false;
+}
+
+static mi_icp_odometry_option OdometryOptionC(const OdometryOption& option) {
     mi_icp_odometry_option opt = {};
     opt.num_levels = (int32_t)option.iteration_number_per_pyramid_level_.size();
     for (int i = 0; i < opt.num_levels && i < MI_ICP_ODOMETRY_MAX_LEVELS; ++i)
@@ -571,18 +570,59 @@ std::tuple<bool, Eigen::Matrix4f, Eigen::Matrix6f> ComputeRGBDOdometry(
     opt.max_depth_diff = option.max_depth_diff_;
     opt.min_depth = option.min_depth_;
     opt.max_depth = option.max_depth_;
+    opt.nu = option.nu_;
+    opt.sigma2_init = option.sigma2_init_;
+    for (int i = 0; i < 6; ++i) opt.inv_sigma_mat_diag[i] = option.inv_sigma_mat_diag_[i];
+    return opt;
+}
+
+static Eigen::Matrix6f Info6(const double* info) {
+    Eigen::Matrix6f I;
+    for (int r = 0; r < 6; ++r)
+        for (int c2 = 0; c2 < 6; ++c2) I(r, c2) = (float)info[r * 6 + c2];
+    return I;
+}
+
+std::tuple<bool, Eigen::Matrix4f, Eigen::Matrix6f> ComputeRGBDOdometry(
+        const geometry::RGBDImage& source, const geometry::RGBDImage& target,
+        const camera::PinholeCameraIntrinsic& intrinsic, const Eigen::Matrix4f& odo_init,
+        const RGBDOdometryJacobian& jacobian_method, const OdometryOption& option) {
+    if (!OdometryInputsOk(source, target))
+        return std::make_tuple(false, Eigen::Matrix4f::Identity(), Eigen::Matrix6f::Zero());
+    const mi_icp_odometry_option opt = OdometryOptionC(option);
     const float k4[4] = {intrinsic.fx_, intrinsic.fy_, intrinsic.cx_, intrinsic.cy_};
     int ok = 0;
     Eigen::Matrix4f T;
     double info[36];
-    Check(mi_icp_compute_rgbd_odometry(Engine(), (const float*)sc.data_.data(), (const float*)sd.data_.data(),
-                                       (const float*)tc.data_.data(), (const float*)td.data_.data(), sc.width_,
-                                       sc.height_, k4, odo_init.data(), (int)jacobian_method.jacobian_type_, &opt, &ok,
-                                       T.data(), info, MI_ICP_DEVICE));
-    Eigen::Matrix6f I;
-    for (int r = 0; r < 6; ++r)
-        for (int c2 = 0; c2 < 6; ++c2) I(r, c2) = (float)info[r * 6 + c2];
-    return std::make_tuple(ok != 0, T, I);
+    Check(mi_icp_compute_rgbd_odometry(Engine(), (const float*)source.color_.data_.data(),
+                                       (const float*)source.depth_.data_.data(),
+                                       (const float*)target.color_.data_.data(),
+                                       (const float*)target.depth_.data_.data(), source.color_.width_,
+                                       source.color_.height_, k4, odo_init.data(), (int)jacobian_method.jacobian_type_,
+                                       &opt, &ok, T.data(), info, MI_ICP_DEVICE));
+    return std::make_tuple(ok != 0, T, Info6(info));
+}
+
+std::tuple<bool, Eigen::Matrix4f, Eigen::Vector6f, Eigen::Matrix6f> ComputeWeightedRGBDOdometry(
+        const geometry::RGBDImage& source, const geometry::RGBDImage& target,
+        const camera::PinholeCameraIntrinsic& intrinsic, const Eigen::Matrix4f& odo_init,
+        const Eigen::Vector6f& prev_twist, const RGBDOdometryJacobian& /*always the hybrid term, odometry.cu:937-941*/,
+        const OdometryOption& option) {
+    if (!OdometryInputsOk(source, target))
+        return std::make_tuple(false, Eigen::Matrix4f::Identity(), Eigen::Vector6f::Zero(), Eigen::Matrix6f::Zero());
+    const mi_icp_odometry_option opt = OdometryOptionC(option);
+    const float k4[4] = {intrinsic.fx_, intrinsic.fy_, intrinsic.cx_, intrinsic.cy_};
+    int ok = 0;
+    Eigen::Matrix4f T;
+    Eigen::Vector6f twist;
+    double info[36];
+    Check(mi_icp_compute_weighted_rgbd_odometry(Engine(), (const float*)source.color_.data_.data(),
+                                                (const float*)source.depth_.data_.data(),
+                                                (const float*)target.color_.data_.data(),
+                                                (const float*)target.depth_.data_.data(), source.color_.width_,
+                                                source.color_.height_, k4, odo_init.data(), prev_twist.data(), &opt, &ok,
+                                                T.data(), twist.data(), info, MI_ICP_DEVICE));
+    return std::make_tuple(ok != 0, T, twist, Info6(info));
 }
 
 }  // namespace odometry

@@ -110,6 +110,7 @@ struct mi_icp_ctx {
     double* sys_host = nullptr;  // pinned, 32 doubles + spare
     float* f_host = nullptr;     // pinned, 16 floats
     uint32_t* u_host = nullptr;  // pinned, 4 words
+    void* od_host = nullptr;     // pinned OdState mirror (odometry), allocated on first use
 
     // ---- registration loop (device-resident, loop.h) ----
     DevBuf loop_dev, ticket;
@@ -651,6 +652,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
     if (c->cell_total_host) (void)hipHostFree(c->cell_total_host);
     if (c->f_host) (void)hipHostFree(c->f_host);
     if (c->u_host) (void)hipHostFree(c->u_host);
+    if (c->od_host) (void)hipHostFree(c->od_host);
     if (c->loop_host) (void)hipHostFree(c->loop_host);
     for (int k = 0; k < 2; ++k)
         for (int i = 0; i < mi_icp_ctx::kEvPairs; ++i)
@@ -1507,12 +1509,15 @@ int mi_icp_create_from_depth(mi_icp_ctx* c, const void* depth, int depth_type, c
 
 // ---------------------------------------------------------------------------
 // odometry::ComputeRGBDOdometry (odometry/odometry.cu); helpers above the extern "C" block
-int mi_icp_compute_rgbd_odometry(mi_icp_ctx* c, const float* source_color, const float* source_depth,
-                                 const float* target_color, const float* target_depth, int width, int height,
-                                 const float* intrinsic4, const float* odo_init, int jacobian,
-                                 const mi_icp_odometry_option* option, int* success, float* transformation16,
-                                 double* information36, int mem_kind) {
+static int rgbd_odometry_impl(mi_icp_ctx* c, const float* source_color, const float* source_depth,
+                              const float* target_color, const float* target_depth, int width, int height,
+                              const float* intrinsic4, const float* odo_init, int jacobian,
+                              const mi_icp_odometry_option* option, int* success, float* transformation16,
+                              double* information36, int mem_kind, bool weighted, const float* prev_twist6,
+                              float* twist6) {
     TRY(check_ctx(c));
+    if (twist6)
+        for (int i = 0; i < 6; ++i) twist6[i] = 0.0f;
     if (!success || !transformation16 || !information36 || !intrinsic4 || !option)
         return fail(c, MI_ICP_ERR_INVALID, "compute_rgbd_odometry: null argument");
     *success = 0;
@@ -1586,15 +1591,31 @@ int mi_icp_compute_rgbd_odometry(mi_icp_ctx* c, const float* source_color, const
     }
     // the running transformation and everything derived from it live on the device (OdState);
     // the host enqueues the whole run and synchronises once, at the end
-    static_assert(sizeof(OdState) <= 64 * sizeof(float), "OdState is staged through the context's 64 pinned floats");
     float* state_mem;
     TRY(ensure(c, c->stage[5], sizeof(OdState) / sizeof(float) + 16, &state_mem));
     OdState* state = reinterpret_cast<OdState*>(state_mem);
     const Mat4 init = load_T(odo_init);
-    OdState* hst = reinterpret_cast<OdState*>(c->f_host);
+    if (!c->od_host) HIPCHK(c, hipHostMalloc(&c->od_host, sizeof(OdState) + 64, hipHostMallocDefault));
+    OdState* hst = reinterpret_cast<OdState*>(c->od_host);
+    if (weighted) {  // the weighted variant's constants and its velocity, once
+        std::memset(hst, 0, sizeof(OdState));
+        hst->vel = I4;
+        hst->sigma2 = option->sigma2_init;
+        hst->nu = option->nu;
+        for (int i = 0; i < 6; ++i) {
+            hst->prev_twist[i] = prev_twist6 ? prev_twist6[i] : 0.0f;
+            hst->inv_sigma[i] = option->inv_sigma_mat_diag[i];
+        }
+        HIPCHK(c, hipMemcpyAsync(state, hst, sizeof(OdState), hipMemcpyHostToDevice, c->stream));
+    }
+    // (two pinned slots: an asynchronous copy reads its host source when it executes, so the second
+    // value must not overwrite the first one's source)
+    Mat4* t_slots[2] = {&hst->T, reinterpret_cast<Mat4*>(reinterpret_cast<char*>(c->od_host) + sizeof(OdState))};
+    int t_slot = 0;
     auto set_T = [&](const Mat4& T) -> int {
-        hst->T = T;
-        HIPCHK(c, hipMemcpyAsync(&state->T, &hst->T, sizeof(Mat4), hipMemcpyHostToDevice, c->stream));
+        Mat4* src = t_slots[t_slot++ & 1];
+        *src = T;
+        HIPCHK(c, hipMemcpyAsync(&state->T, src, sizeof(Mat4), hipMemcpyHostToDevice, c->stream));
         return MI_ICP_OK;
     };
     HIPCHK(c, hipMemsetAsync(sums, 0, 32 * sizeof(double), c->stream));
@@ -1657,10 +1678,17 @@ int mi_icp_compute_rgbd_odometry(mi_icp_ctx* c, const float* source_color, const
         level_args(level);
         const int iters = option->iterations[L - level - 1];
         for (int iter = 0; iter < iters; ++iter) {
-            if (jacobian == MI_ICP_ODOMETRY_COLOR_TERM) od_accumulate<kOdColor><<<grid_for(level), kOdThreads, 0, c->stream>>>(a);
-            else od_accumulate<kOdHybrid><<<grid_for(level), kOdThreads, 0, c->stream>>>(a);
             // the next evaluation: this level again, the next finer one, or level 0 (information matrix)
             const int next = (iter + 1 < iters) ? level : std::max(level - 1, 0);
+            if (weighted) {  // two passes: the weights' normalisation, then the weighted system
+                od_accumulate<kOdWeightSum><<<grid_for(level), kOdThreads, 0, c->stream>>>(a);
+                od_step<<<1, 64, 0, c->stream>>>(state, sums, cam[level], 3);
+                od_accumulate<kOdWeighted><<<grid_for(level), kOdThreads, 0, c->stream>>>(a);
+                od_step<<<1, 64, 0, c->stream>>>(state, sums, cam[next], 2);
+                continue;
+            }
+            if (jacobian == MI_ICP_ODOMETRY_COLOR_TERM) od_accumulate<kOdColor><<<grid_for(level), kOdThreads, 0, c->stream>>>(a);
+            else od_accumulate<kOdHybrid><<<grid_for(level), kOdThreads, 0, c->stream>>>(a);
             od_step<<<1, 64, 0, c->stream>>>(state, sums, cam[next], 1);
         }
         if (iters <= 0 && level > 0) od_step<<<1, 64, 0, c->stream>>>(state, sums, cam[level - 1], 0);
@@ -1672,7 +1700,9 @@ int mi_icp_compute_rgbd_odometry(mi_icp_ctx* c, const float* source_color, const
     KCHK(c);
     HIPCHK(c, hipMemcpyAsync(c->sys_host, sums, 32 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&hst->T, &state->T, sizeof(Mat4), hipMemcpyDeviceToHost, c->stream));
+    if (weighted) HIPCHK(c, hipMemcpyAsync(&hst->vel, &state->vel, sizeof(Mat4), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (weighted && twist6) od_matrix4_to_vector6(hst->vel, twist6);
     {
         int k = 0;
         for (int r = 0; r < 6; ++r)
@@ -1684,6 +1714,27 @@ int mi_icp_compute_rgbd_odometry(mi_icp_ctx* c, const float* source_color, const
         *success = 1;  // without its determinant check the solver never reports failure (utility/eigen.cu:76-122)
     }
     return MI_ICP_OK;
+}
+
+int mi_icp_compute_rgbd_odometry(mi_icp_ctx* c, const float* source_color, const float* source_depth,
+                                 const float* target_color, const float* target_depth, int width, int height,
+                                 const float* intrinsic4, const float* odo_init, int jacobian,
+                                 const mi_icp_odometry_option* option, int* success, float* transformation16,
+                                 double* information36, int mem_kind) {
+    return rgbd_odometry_impl(c, source_color, source_depth, target_color, target_depth, width, height, intrinsic4,
+                              odo_init, jacobian, option, success, transformation16, information36, mem_kind, false,
+                              nullptr, nullptr);
+}
+
+int mi_icp_compute_weighted_rgbd_odometry(mi_icp_ctx* c, const float* source_color, const float* source_depth,
+                                          const float* target_color, const float* target_depth, int width, int height,
+                                          const float* intrinsic4, const float* odo_init, const float* prev_twist6,
+                                          const mi_icp_odometry_option* option, int* success, float* transformation16,
+                                          float* twist6, double* information36, int mem_kind) {
+    if (!twist6) return c ? fail(c, MI_ICP_ERR_INVALID, "compute_weighted_rgbd_odometry: twist6 is null") : MI_ICP_ERR_INVALID;
+    return rgbd_odometry_impl(c, source_color, source_depth, target_color, target_depth, width, height, intrinsic4,
+                              odo_init, MI_ICP_ODOMETRY_HYBRID_TERM, option, success, transformation16, information36,
+                              mem_kind, true, prev_twist6, twist6);
 }
 
 static int estimate_normals_impl(mi_icp_ctx* c, const float* xyz, int64_t n, int knn, float r2,

@@ -75,6 +75,12 @@ struct OdState {
     float e[12];    // R (row-major 3x3) and t of the current extrinsic
     float fx, fy, ox, oy, inv_fx, inv_fy;  // of the level the next evaluation runs on
     host::Mat4 T;   // the running result (column-major)
+    // ComputeWeightedRGBDOdometry only (odometry.cu:633-706,766-831)
+    host::Mat4 vel;        // curr_vel: the product of this call's updates
+    float w_sum;           // sum of fw_reduce over the current correspondences
+    float sigma2;          // the t-distribution's scale, <- w_sum after every iteration
+    float nu;
+    float prev_twist[6], inv_sigma[6];
 };
 
 struct OdCamera {
@@ -96,7 +102,7 @@ struct OdArgs {
     double* out;    // 32 doubles, zero on entry (od_step leaves them so): the layout of the ICP system (reduce.h)
 };
 
-constexpr int kOdColor = 0, kOdHybrid = 1, kOdMeans = 2, kOdInformation = 3;
+constexpr int kOdColor = 0, kOdHybrid = 1, kOdMeans = 2, kOdInformation = 3, kOdWeightSum = 4, kOdWeighted = 5;
 
 __device__ __forceinline__ void od_accum_row(double* acc, const float* J, float r) {
     int k = 0;
@@ -118,7 +124,7 @@ __device__ __forceinline__ void od_accum_row(double* acc, const float* J, float 
 //   (CreateInformationMatrix :349-394; the host adds the identity).
 template <int MODE>
 __global__ __launch_bounds__(kOdThreads) void od_accumulate(OdArgs a) {
-    constexpr int kAcc = (MODE == kOdMeans) ? 2 : ((MODE == kOdInformation) ? 21 : 28);
+    constexpr int kAcc = (MODE == kOdMeans) ? 2 : ((MODE == kOdInformation) ? 21 : ((MODE == kOdWeightSum) ? 1 : 28));
     double acc[kAcc];
 #pragma unroll
     for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
@@ -190,20 +196,41 @@ __global__ __launch_bounds__(kOdThreads) void od_accumulate(OdArgs a) {
             const float diff_geo = d_t - pt[2];
             const float d0 = dDdx * s.fx * invz, d1 = dDdy * s.fy * invz;
             const float d2 = -(d0 * pt[0] + d1 * pt[1]) * invz;
+            const float r0 = sl_img * diff_photo, r1 = sl_dep * diff_geo;
+            if (MODE == kOdWeightSum) {
+                // weight_reduce_functor (:633-640) over the correspondence's r2 (eigen.inl:49-70)
+                const float r2 = r0 * r0 + r1 * r1;
+                acc[0] += (double)(float)((double)r2 * ((double)s.nu + 1.0) / (double)(s.nu + r2 / s.sigma2));
+                continue;
+            }
+            double wt = 1.0;
+            double one[28];
+            double* dst = acc;
+            if (MODE == kOdWeighted) {  // calc_weights_functor (:642-648): (nu + 1) / (nu + r2 / w_sum)
+                const float r2 = r0 * r0 + r1 * r1;
+                wt = (double)((s.nu + 1.0f) / (s.nu + r2 / s.w_sum));
+#pragma unroll
+                for (int k = 0; k < 28; ++k) one[k] = 0.0;
+                dst = one;
+            }
             J[0] = sl_img * (-pt[2] * c1 + pt[1] * c2);
             J[1] = sl_img * (pt[2] * c0 - pt[0] * c2);
             J[2] = sl_img * (-pt[1] * c0 + pt[0] * c1);
             J[3] = sl_img * c0;
             J[4] = sl_img * c1;
             J[5] = sl_img * c2;
-            od_accum_row(acc, J, sl_img * diff_photo);
+            od_accum_row(dst, J, r0);
             J[0] = sl_dep * ((-pt[2] * d1 + pt[1] * d2) - pt[1]);
             J[1] = sl_dep * ((pt[2] * d0 - pt[0] * d2) + pt[0]);
             J[2] = sl_dep * (-pt[1] * d0 + pt[0] * d1);
             J[3] = sl_dep * d0;
             J[4] = sl_dep * d1;
             J[5] = sl_dep * (d2 - 1.0f);
-            od_accum_row(acc, J, sl_dep * diff_geo);
+            od_accum_row(dst, J, r1);
+            if (MODE == kOdWeighted) {
+#pragma unroll
+                for (int k = 0; k < 28; ++k) acc[k] = __builtin_fma(wt, one[k], acc[k]);
+            }
         }
     }
     // block totals: DPP wave sums -> LDS -> one fp64 atomic per value
@@ -248,6 +275,44 @@ __host__ __device__ inline void od_mul3(const float* A, const float* B, float* C
         for (int c = 0; c < 3; ++c) C[r * 3 + c] = (A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c]) + A[r * 3 + 2] * B[6 + c];
 }
 
+// utility::TransformMatrix4fToVector6f (utility/eigen.cu:52-65): Eigen::Quaternionf of the rotation
+// block (trace / largest-diagonal branches), angle * axis, translation
+__host__ __device__ inline void od_matrix4_to_vector6(const host::Mat4& T, float* out) {
+    float m[3][3], q[4];  // q = x, y, z, w
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) m[r][c] = host::at(T, r, c);
+    const float tr = m[0][0] + m[1][1] + m[2][2];
+    if (tr > 0.0f) {
+        float s = sqrtf(tr + 1.0f);
+        q[3] = 0.5f * s;
+        s = 0.5f / s;
+        q[0] = (m[2][1] - m[1][2]) * s;
+        q[1] = (m[0][2] - m[2][0]) * s;
+        q[2] = (m[1][0] - m[0][1]) * s;
+    } else {
+        int i = 0;
+        if (m[1][1] > m[0][0]) i = 1;
+        if (m[2][2] > m[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        float s = sqrtf(m[i][i] - m[j][j] - m[k][k] + 1.0f);
+        q[i] = 0.5f * s;
+        s = 0.5f / s;
+        q[3] = (m[k][j] - m[j][k]) * s;
+        q[j] = (m[j][i] + m[i][j]) * s;
+        q[k] = (m[k][i] + m[i][k]) * s;
+    }
+    const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    float angle = 0.0f, axis[3] = {0.0f, 0.0f, 1.0f};
+    if (n > 0.0f) {
+        angle = (float)(2.0 * (double)atan2f(n, q[3]));
+        for (int a = 0; a < 3; ++a) axis[a] = q[a] / n;
+    }
+    for (int a = 0; a < 3; ++a) {
+        out[a] = angle * axis[a];
+        out[3 + a] = host::at(T, a, 3);
+    }
+}
+
 // The step between two evaluations, one thread: (update != 0) solve the 6x6 system just
 // accumulated and compose it onto the running transformation (DoSingleIteration's tail,
 // odometry.cu:619-630, and ComputeMultiscale's `result_odo = curr_odo * result_odo`, :752);
@@ -255,17 +320,32 @@ __host__ __device__ inline void od_mul3(const float* A, const float* B, float* C
 // (the same level, the next finer one, or level 0 for the information matrix), and zero
 // the accumulators.  The solver never reports failure without its determinant check
 // (utility/eigen.cu:76-122), so nothing here needs the host.
+// update: 0 derive the terms only, 1 plain iteration, 2 weighted iteration (the system gets the
+// motion prior first, the velocity and sigma2 are advanced; DoSingleIterationWeighted :690-705,
+// ComputeMultiscaleWeighted :806-818), 3 the weighted variant's half step: w_sum <- sums[0].
 __global__ __launch_bounds__(64) void od_step(OdState* st, double* sums, OdCamera cam, int update) {
     __shared__ double sys[32];
     if (threadIdx.x < 32) sys[threadIdx.x] = sums[threadIdx.x];
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && update == 3) st->w_sum = (float)sys[0];
+    if (threadIdx.x == 0 && update != 3) {
         host::Mat4 T = st->T;
+        if (update == 2) {
+            float cv[6];
+            od_matrix4_to_vector6(st->vel, cv);
+            const int diag[6] = {0, 6, 11, 15, 18, 20};  // JTJ(i,i) in the packed upper triangle
+            for (int a = 0; a < 6; ++a) {
+                sys[diag[a]] = (double)((float)sys[diag[a]] + st->inv_sigma[a]);
+                sys[21 + a] = (double)((float)sys[21 + a] - st->inv_sigma[a] * (st->prev_twist[a] - cv[a]));
+            }
+            st->sigma2 = st->w_sum;
+        }
         if (update) {
             host::Mat4 upd;
             host::solve_system(sys, -1.0f, upd);
             T = host::mul4(upd, T);
             st->T = T;
+            if (update == 2) st->vel = host::mul4(upd, st->vel);
         }
         float Kinv[9], R[9], KR[9], KRK[9];
         od_inverse3(cam.k, Kinv);

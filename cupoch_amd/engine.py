@@ -390,9 +390,11 @@ class Engine:
 
     def compute_rgbd_odometry(self, source_color, source_depth, target_color, target_depth, intrinsic4,
                               odo_init=None, jacobian=1, iterations=(20, 10, 5), max_depth_diff=0.03,
-                              min_depth=0.0, max_depth=4.0):
-        """odometry::ComputeRGBDOdometry (odometry/odometry.cu:833-943).  Images: [H, W] float32,
-        numpy or torch (all on the same side).  Returns (success, 4x4 transformation, 6x6 information)."""
+                              min_depth=0.0, max_depth=4.0, weighted=False, prev_twist=None, nu=5.0,
+                              sigma2_init=1.0, inv_sigma_mat_diag=None):
+        """odometry::ComputeRGBDOdometry / ComputeWeightedRGBDOdometry (odometry/odometry.cu:833-943).
+        Images: [H, W] float32, numpy or torch (all on the same side).  Returns (success, 4x4
+        transformation, 6x6 information), with weighted=True (success, transformation, twist, information)."""
         imgs = [source_color, source_depth, target_color, target_depth]
         on_dev = torch.is_tensor(imgs[0]) and imgs[0].is_cuda
         keep, ptrs = [], []
@@ -418,6 +420,9 @@ class Engine:
         for i, v in enumerate(list(iterations)[:8]):   # (more than 8 levels: the library reports it)
             opt.iterations[i] = int(v)
         opt.max_depth_diff, opt.min_depth, opt.max_depth = float(max_depth_diff), float(min_depth), float(max_depth)
+        opt.nu, opt.sigma2_init = float(nu), float(sigma2_init)
+        for i in range(6):
+            opt.inv_sigma_mat_diag[i] = 0.0 if inv_sigma_mat_diag is None else float(inv_sigma_mat_diag[i])
         K = (C.c_float * 4)(*[float(v) for v in intrinsic4])
         init = None
         if odo_init is not None:
@@ -425,6 +430,15 @@ class Engine:
         ok = C.c_int(0)
         T = np.empty(16, np.float32)
         info = np.empty(36, np.float64)
+        if weighted:
+            pt = (C.c_float * 6)(*([0.0] * 6 if prev_twist is None else [float(v) for v in prev_twist]))
+            tw = np.empty(6, np.float32)
+            self._chk(self._L.mi_icp_compute_weighted_rgbd_odometry(
+                self._ctx, ptrs[0], ptrs[1], ptrs[2], ptrs[3], int(shape[1]), int(shape[0]), K,
+                None if init is None else init.ctypes.data_as(C.c_void_p), pt, C.byref(opt), C.byref(ok),
+                T.ctypes.data_as(C.c_void_p), tw.ctypes.data_as(C.c_void_p), info.ctypes.data_as(C.c_void_p),
+                MI_ICP_DEVICE if on_dev else MI_ICP_HOST))
+            return bool(ok.value), T.reshape(4, 4).T.copy(), tw, info.reshape(6, 6).copy()
         self._chk(self._L.mi_icp_compute_rgbd_odometry(
             self._ctx, ptrs[0], ptrs[1], ptrs[2], ptrs[3], int(shape[1]), int(shape[0]), K,
             None if init is None else init.ctypes.data_as(C.c_void_p), int(jacobian), C.byref(opt), C.byref(ok),

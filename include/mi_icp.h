@@ -249,8 +249,7 @@ MI_ICP_API int mi_icp_create_from_depth(mi_icp_ctx* ctx, const void* depth, int 
  *   option           OdometryOption (odometry_option.h:30-62); iterations[] coarsest level
  *                    first, as iteration_number_per_pyramid_level_.
  * Outputs: *success (0: the reference's failure result -- identity transformation and
- * identity information), transformation16 column-major, information36 row-major.
- * Not provided: ComputeWeightedRGBDOdometry (the t-distribution weighted variant). */
+ * identity information), transformation16 column-major, information36 row-major. */
 #define MI_ICP_ODOMETRY_COLOR_TERM 0
 #define MI_ICP_ODOMETRY_HYBRID_TERM 1
 #define MI_ICP_ODOMETRY_MAX_LEVELS 8
@@ -260,6 +259,10 @@ typedef struct mi_icp_odometry_option {
     float max_depth_diff;                             /* 0.03 */
     float min_depth;                                  /* 0.0 */
     float max_depth;                                  /* 4.0 */
+    /* ComputeWeightedRGBDOdometry only */
+    float nu;                                         /* 5.0 */
+    float sigma2_init;                                /* 1.0 */
+    float inv_sigma_mat_diag[6];                      /* 0 */
 } mi_icp_odometry_option;
 MI_ICP_API int mi_icp_compute_rgbd_odometry(mi_icp_ctx* ctx, const float* source_color,
                                             const float* source_depth, const float* target_color,
@@ -268,6 +271,18 @@ MI_ICP_API int mi_icp_compute_rgbd_odometry(mi_icp_ctx* ctx, const float* source
                                             int jacobian, const mi_icp_odometry_option* option,
                                             int* success, float* transformation16,
                                             double* information36, int mem_kind);
+/* odometry::ComputeWeightedRGBDOdometry (odometry/odometry.cu:633-706,766-831,927-941): the same
+ * with t-distribution weights on the correspondences (always the hybrid term) and a motion prior
+ * inv_sigma_mat_diag . (prev_twist - velocity so far); twist6 receives the velocity of this call
+ * (angle * axis, translation: utility::TransformMatrix4fToVector6f).  prev_twist6 may be NULL (0). */
+MI_ICP_API int mi_icp_compute_weighted_rgbd_odometry(mi_icp_ctx* ctx, const float* source_color,
+                                                     const float* source_depth, const float* target_color,
+                                                     const float* target_depth, int width, int height,
+                                                     const float* intrinsic4, const float* odo_init,
+                                                     const float* prev_twist6,
+                                                     const mi_icp_odometry_option* option, int* success,
+                                                     float* transformation16, float* twist6,
+                                                     double* information36, int mem_kind);
 /* InitializePointCloudForGeneralizedICP's normals -> covariances
  * (registration/generalized_icp.cu:18-30,52-59). */
 MI_ICP_API int mi_icp_covariances_from_normals(mi_icp_ctx* ctx, const float* normals,

@@ -258,11 +258,60 @@ static void mul4(const float *A, const float *B, float *C) { /* column-major 4x4
  * cy; odo_init, trans_out: column-major 4x4; iterations[l]: coarsest level first
  * (iteration_number_per_pyramid_level_); info_out: row-major 6x6.  Returns is_success
  * (failure: identity transformation and identity information, :876-878). */
-ORACLE_API int oracle_od_compute(const float *src_color, const float *src_depth, const float *tgt_color,
-                                 const float *tgt_depth, int w, int h, const float *intrinsic4,
-                                 const float *odo_init, int hybrid, const int *iterations, int num_levels,
-                                 float max_depth_diff, float min_depth, float max_depth, float *trans_out,
-                                 double *info_out) {
+/* utility::TransformMatrix4fToVector6f (utility/eigen.cu:52-65): Eigen::Quaternionf from the
+ * rotation block (Eigen's trace / largest-diagonal branches), angle * axis, translation. */
+ORACLE_API void oracle_matrix4_to_vector6(const float *T, float *out) {
+    float m[3][3], q[4]; /* q = x, y, z, w */
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) m[r][c] = T[c * 4 + r];
+    float tr = m[0][0] + m[1][1] + m[2][2];
+    if (tr > 0.0f) {
+        float s = sqrtf(tr + 1.0f);
+        q[3] = 0.5f * s;
+        s = 0.5f / s;
+        q[0] = (m[2][1] - m[1][2]) * s;
+        q[1] = (m[0][2] - m[2][0]) * s;
+        q[2] = (m[1][0] - m[0][1]) * s;
+    } else {
+        int i = 0;
+        if (m[1][1] > m[0][0]) i = 1;
+        if (m[2][2] > m[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        float s = sqrtf(m[i][i] - m[j][j] - m[k][k] + 1.0f);
+        q[i] = 0.5f * s;
+        s = 0.5f / s;
+        q[3] = (m[k][j] - m[j][k]) * s;
+        q[j] = (m[j][i] + m[i][j]) * s;
+        q[k] = (m[k][i] + m[i][k]) * s;
+    }
+    const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    float angle = 0, axis[3] = {0, 0, 1.0f};
+    if (n > 0) {
+        angle = (float)(2.0 * atan2f(n, q[3]));
+        for (int a = 0; a < 3; ++a) axis[a] = q[a] / n;
+    }
+    for (int a = 0; a < 3; ++a) {
+        out[a] = angle * axis[a];
+        out[3 + a] = T[12 + a];
+    }
+}
+
+/* odometry::ComputeRGBDOdometry and ComputeWeightedRGBDOdometry (odometry.cu:498-528
+ * InitializeRGBDOdometry, :584-631 DoSingleIteration, :633-706 DoSingleIterationWeighted over
+ * utility/eigen.inl:147-195 ComputeWeightedJTJandJTr, :708-831 ComputeMultiscale[Weighted],
+ * :371-394 CreateInformationMatrix, :833-879 ComputeRGBDOdometryT).  color / depth: float images
+ * w x h; intrinsic4 = fx, fy, cx, cy; odo_init, trans_out: column-major 4x4; iterations[l]:
+ * coarsest level first (iteration_number_per_pyramid_level_); info_out: row-major 6x6.
+ * weighted != 0 (always the hybrid term, :937-941): the t-distribution weights -- w_sum = sum over
+ * correspondences of r2 (nu+1) / (nu + r2 / sigma2) with r2 the correspondence's squared residual,
+ * weight = (nu+1) / (nu + r2 / w_sum), sigma2 <- w_sum -- plus the motion prior
+ * inv_sigma_diag . (prev_twist - current velocity); twist_out = the velocity at the end.
+ * Returns is_success (failure: identity transformation and identity information, :876-878). */
+static int od_core(const float *src_color, const float *src_depth, const float *tgt_color, const float *tgt_depth,
+                   int w, int h, const float *intrinsic4, const float *odo_init, int hybrid, const int *iterations,
+                   int num_levels, float max_depth_diff, float min_depth, float max_depth, int weighted, float nu,
+                   float sigma2_init, const float *inv_sigma_diag, const float *prev_twist, float *trans_out,
+                   float *twist_out, double *info_out) {
     const size_t n0 = (size_t)w * h;
     float *col[2][8], *dep[2][8];
     int lw[8], lh[8];
@@ -321,6 +370,8 @@ ORACLE_API int oracle_od_compute(const float *src_color, const float *src_depth,
         }
     }
     int ok = 1;
+    float sigma2 = sigma2_init;
+    float vel[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; /* curr_vel (:785) */
     float Kl[8][9];
     for (int l = 0; l < num_levels; ++l) { /* CreateCameraMatrixPyramid (:332-347) */
         for (int i = 0; i < 9; ++i) Kl[l][i] = l == 0 ? K0[i] : (float)(0.5 * Kl[l - 1][i]);
@@ -342,16 +393,49 @@ ORACLE_API int oracle_od_compute(const float *src_color, const float *src_depth,
                     oracle_od_correspondence(Kl[level], T, dep[0][level], dep[1][level], W, H, max_depth_diff, corr);
             double sys[32];
             memset(sys, 0, sizeof(sys));
+            float w_sum = 0.0f;
+            if (weighted) { /* first pass: sum of fw_reduce over the correspondences' r2 */
+                double acc = 0.0;
+                for (int64_t i = 0; i < nc; ++i) {
+                    float J0[6], J1[6], r0, r1;
+                    oracle_od_jacobian(hybrid, (int)i, corr, col[0][level], col[1][level], dep[1][level], xyz, dxc,
+                                       dxd, dyc, dyd, W, Kl[level], T, J0, &r0, J1, &r1);
+                    const float r2 = r0 * r0 + r1 * r1;
+                    acc += (double)(float)(r2 * (nu + 1.0) / (nu + r2 / sigma2));
+                }
+                w_sum = (float)acc;
+            }
             for (int64_t i = 0; i < nc; ++i) {
                 float J0[6], J1[6], r0, r1;
                 oracle_od_jacobian(hybrid, (int)i, corr, col[0][level], col[1][level], dep[1][level], xyz, dxc, dxd,
                                    dyc, dyd, W, Kl[level], T, J0, &r0, J1, &r1);
-                accum(sys, J0, r0);
-                accum(sys, J1, r1);
+                if (!weighted) {
+                    accum(sys, J0, r0);
+                    accum(sys, J1, r1);
+                } else {
+                    const float r2 = r0 * r0 + r1 * r1;
+                    const double wt = (double)((nu + 1) / (nu + r2 / w_sum));
+                    double one[32];
+                    memset(one, 0, sizeof(one));
+                    accum(one, J0, r0);
+                    accum(one, J1, r1);
+                    for (int k = 0; k < 28; ++k) sys[k] += wt * one[k];
+                }
             }
             sys[29] = (double)nc;
+            if (weighted) {
+                float cv[6];
+                oracle_matrix4_to_vector6(vel, cv);
+                const int diag[6] = {0, 6, 11, 15, 18, 20}; /* positions of JTJ(i,i) in the packed upper triangle */
+                for (int a = 0; a < 6; ++a) {
+                    sys[diag[a]] = (double)((float)sys[diag[a]] + inv_sigma_diag[a]);
+                    sys[21 + a] = (double)((float)sys[21 + a] - inv_sigma_diag[a] * (prev_twist[a] - cv[a]));
+                }
+                sigma2 = w_sum;
+            }
             float upd[16];
             ok = oracle_solve_system(sys, -1.0f, upd); /* det_thresh default -1: always "solved" (utility/eigen.cu:76-122) */
+            if (ok && weighted) mul4(upd, vel, vel);
             if (ok) mul4(upd, T, T);
         }
         free(xyz);
@@ -363,6 +447,10 @@ ORACLE_API int oracle_od_compute(const float *src_color, const float *src_depth,
     memset(trans_out, 0, sizeof(float) * 16);
     trans_out[0] = trans_out[5] = trans_out[10] = trans_out[15] = 1.0f;
     for (int i = 0; i < 36; ++i) info_out[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    if (twist_out) {
+        for (int a = 0; a < 6; ++a) twist_out[a] = 0.0f;
+        if (ok && weighted) oracle_matrix4_to_vector6(vel, twist_out);
+    }
     if (ok) {
         memcpy(trans_out, T, sizeof(T));
         /* CreateInformationMatrix (:349-394): I + sum over correspondences of G^T G */
@@ -386,4 +474,24 @@ ORACLE_API int oracle_od_compute(const float *src_color, const float *src_depth,
         }
     free(corr);
     return ok;
+}
+
+ORACLE_API int oracle_od_compute(const float *src_color, const float *src_depth, const float *tgt_color,
+                                 const float *tgt_depth, int w, int h, const float *intrinsic4,
+                                 const float *odo_init, int hybrid, const int *iterations, int num_levels,
+                                 float max_depth_diff, float min_depth, float max_depth, float *trans_out,
+                                 double *info_out) {
+    return od_core(src_color, src_depth, tgt_color, tgt_depth, w, h, intrinsic4, odo_init, hybrid, iterations, num_levels,
+                   max_depth_diff, min_depth, max_depth, 0, 0.0f, 0.0f, NULL, NULL, trans_out, NULL, info_out);
+}
+
+ORACLE_API int oracle_od_compute_weighted(const float *src_color, const float *src_depth, const float *tgt_color,
+                                          const float *tgt_depth, int w, int h, const float *intrinsic4,
+                                          const float *odo_init, const float *prev_twist, const int *iterations,
+                                          int num_levels, float max_depth_diff, float min_depth, float max_depth,
+                                          float nu, float sigma2_init, const float *inv_sigma_diag, float *trans_out,
+                                          float *twist_out, double *info_out) {
+    return od_core(src_color, src_depth, tgt_color, tgt_depth, w, h, intrinsic4, odo_init, 1, iterations, num_levels,
+                   max_depth_diff, min_depth, max_depth, 1, nu, sigma2_init, inv_sigma_diag, prev_twist, trans_out,
+                   twist_out, info_out);
 }

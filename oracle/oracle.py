@@ -435,6 +435,32 @@ def compute_rgbd_odometry(src_color, src_depth, tgt_color, tgt_depth, intrinsic4
     return bool(ok), T.reshape(4, 4).T.copy(), info.reshape(6, 6).copy()
 
 
+def compute_weighted_rgbd_odometry(src_color, src_depth, tgt_color, tgt_depth, intrinsic4, odo_init=None,
+                                   prev_twist=None, iterations=(20, 10, 5), max_depth_diff=0.03, min_depth=0.0,
+                                   max_depth=4.0, nu=5.0, sigma2_init=1.0, inv_sigma_mat_diag=None):
+    """odometry::ComputeWeightedRGBDOdometry -> (success, transformation, twist (6), information)"""
+    sc, sd, tc, td = _f32(src_color), _f32(src_depth), _f32(tgt_color), _f32(tgt_depth)
+    h, w = sc.shape
+    init = np.eye(4, dtype=np.float32) if odo_init is None else odo_init
+    pt = _f32(np.zeros(6) if prev_twist is None else prev_twist)
+    isd = _f32(np.zeros(6) if inv_sigma_mat_diag is None else inv_sigma_mat_diag)
+    it = (C.c_int * len(iterations))(*[int(v) for v in iterations])
+    T, tw, info = np.empty(16, np.float32), np.empty(6, np.float32), np.empty(36, np.float64)
+    ok = lib().oracle_od_compute_weighted(
+        _p(sc), _p(sd), _p(tc), _p(td), C.c_int(w), C.c_int(h), _p(_f32(np.asarray(intrinsic4, np.float32))),
+        _p(_T_in(init)), _p(pt), it, C.c_int(len(iterations)), C.c_float(max_depth_diff), C.c_float(min_depth),
+        C.c_float(max_depth), C.c_float(nu), C.c_float(sigma2_init), _p(isd), _p(T), _p(tw),
+        info.ctypes.data_as(C.c_void_p))
+    return bool(ok), T.reshape(4, 4).T.copy(), tw.copy(), info.reshape(6, 6).copy()
+
+
+def matrix4_to_vector6(T):
+    """utility::TransformMatrix4fToVector6f"""
+    out = np.empty(6, np.float32)
+    lib().oracle_matrix4_to_vector6(_p(_T_in(T)), _p(out))
+    return out
+
+
 # ---------------------------------------------------------------------------
 # oracle/_ref : the reference's own code compiled where it lies (optional)
 # ---------------------------------------------------------------------------

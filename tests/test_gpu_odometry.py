@@ -83,3 +83,26 @@ def test_python_surface_and_errors(eng, frames):
         eng.compute_rgbd_odometry(cb, db, ca, da, K, None, 5)                      # unknown jacobian
     with pytest.raises(MiIcpError):
         eng.compute_rgbd_odometry(cb, db, ca, da, K, None, 1, iterations=(1,) * 9)  # too many levels
+
+
+def test_weighted_odometry_matches_oracle(eng, frames):
+    """ComputeWeightedRGBDOdometry: t-distribution weights, motion prior, the call's velocity as a twist"""
+    pose_b, ca, da, cb, db = frames
+    for kw in (dict(), dict(prev_twist=orc.matrix4_to_vector6(pose_b), inv_sigma_mat_diag=[500.0] * 6),
+               dict(nu=3.0, sigma2_init=0.5, iterations=(6, 4))):
+        it = kw.pop("iterations", (20, 10, 5))
+        ok, T, tw, info = eng.compute_rgbd_odometry(cb, db, ca, da, K, None, 1, it, 0.03, 0.0, 6.0, True,
+                                                    kw.get("prev_twist"), kw.get("nu", 5.0), kw.get("sigma2_init", 1.0),
+                                                    kw.get("inv_sigma_mat_diag"))
+        ok_r, T_r, tw_r, info_r = orc.compute_weighted_rgbd_odometry(cb, db, ca, da, K, iterations=it, max_depth=6.0, **kw)
+        assert ok and ok_r
+        assert np.linalg.norm(T - T_r) < 1e-4 and np.linalg.norm(tw - tw_r) < 1e-4
+        np.testing.assert_allclose(info, info_r, rtol=2e-3)
+        if it == (20, 10, 5):
+            assert np.linalg.norm(T - pose_b) < 0.1 * np.linalg.norm(np.eye(4) - pose_b)
+        np.testing.assert_allclose(tw, orc.matrix4_to_vector6(T), atol=1e-5)   # started from identity: velocity = result
+    from cupoch_amd import camera, geometry, odometry
+    ok, T, tw, info = odometry.compute_weighted_rgbd_odometry(geometry.RGBDImage(cb, db), geometry.RGBDImage(ca, da),
+                                                             camera.PinholeCameraIntrinsic(320, 240, *K),
+                                                             option=odometry.OdometryOption(max_depth=6.0))
+    assert ok and tw.shape == (6,) and np.linalg.norm(T - pose_b) < 0.1 * np.linalg.norm(np.eye(4) - pose_b)

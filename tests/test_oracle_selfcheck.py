@@ -271,3 +271,23 @@ def test_odometry_recovers_the_camera_motion(jac):
     # no overlap in depth range: nothing corresponds, the "solution" of a zero system
     ok2, T2, _ = orc.compute_rgbd_odometry(cb, db, ca, da, K, jacobian=jac, max_depth=0.1)
     assert not np.isfinite(T2).all() or np.allclose(T2, np.eye(4))
+
+
+def test_weighted_odometry_and_twist_conversion():
+    from conftest import render_rgbd, small_pose
+    x = np.array([0.1, -0.2, 0.05, 1, 2, 3], np.float32)
+    T = np.empty(16, np.float32)
+    orc.lib().oracle_vector6_to_matrix4(orc._p(x), orc._p(T))
+    np.testing.assert_allclose(orc.matrix4_to_vector6(T.reshape(4, 4).T), x, atol=1e-6)     # log(exp(x)) = x
+    np.testing.assert_array_equal(orc.matrix4_to_vector6(np.eye(4)), np.zeros(6, np.float32))
+    K = [262.5, 262.5, 159.5, 119.5]
+    pose_b = small_pose(0.02, 0.03)
+    ca, da = render_rgbd(320, 240, K, np.eye(4))
+    cb, db = render_rgbd(320, 240, K, pose_b)
+    ok, T, tw, info = orc.compute_weighted_rgbd_odometry(cb, db, ca, da, K, max_depth=6.0)
+    assert ok and np.linalg.norm(T - pose_b) < 0.1 * np.linalg.norm(np.eye(4) - pose_b)
+    np.testing.assert_allclose(tw, orc.matrix4_to_vector6(T), atol=1e-5)
+    # a strong prior on a wrong velocity pulls the result away from the data's optimum
+    ok, T2, _, _ = orc.compute_weighted_rgbd_odometry(cb, db, ca, da, K, max_depth=6.0, prev_twist=np.zeros(6),
+                                                      inv_sigma_mat_diag=[1e7] * 6)
+    assert np.linalg.norm(T2 - np.eye(4)) < np.linalg.norm(T - np.eye(4))
