@@ -125,6 +125,7 @@ SIGNATURES = {
     "mi_icp_debug_morton_order": (_I, [_P, _P, _L, _P]),
     "mi_icp_debug_nn_stats": (_I, [_P, _P, _F, _I, _P]),
     "mi_icp_debug_get_tree": (_I, [_P, C.POINTER(_L), _P, _P]),
+    "mi_icp_debug_drop_seeds": (_I, [_P]),
 }
 
 _lib = None

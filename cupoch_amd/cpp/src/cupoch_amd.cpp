@@ -5,6 +5,7 @@
 // (registration/registration.cu:106-172, transformation_estimation.cu,
 // generalized_icp.cu:37-61,185-198, geometry/pointcloud.cu:293-299,
 // down_sample.cu:170-273, estimate_normals.cu:82-127); no kernel lives here.
+#include <typeinfo>
 #include <hip/hip_runtime_api.h>
 
 #include <cstdio>
@@ -332,11 +333,13 @@ RegistrationResult EvaluateRegistration(const geometry::PointCloud& source, cons
     return MakeResult(r);
 }
 
+// exact type, not dynamic_cast: a user subclass of a built-in estimator may override
+// ComputeTransformation, and the reference always makes the virtual call (registration.cu:157)
 static bool IsBuiltin(const TransformationEstimation& e) {
-    return dynamic_cast<const TransformationEstimationPointToPoint*>(&e) ||
-           dynamic_cast<const TransformationEstimationPointToPlane*>(&e) ||
-           dynamic_cast<const TransformationEstimationSymmetricMethod*>(&e) ||
-           dynamic_cast<const TransformationEstimationForGeneralizedICP*>(&e);
+    const std::type_info& t = typeid(e);
+    return t == typeid(TransformationEstimationPointToPoint) || t == typeid(TransformationEstimationPointToPlane) ||
+           t == typeid(TransformationEstimationSymmetricMethod) ||
+           t == typeid(TransformationEstimationForGeneralizedICP);
 }
 
 RegistrationResult RegistrationICP(const geometry::PointCloud& source, const geometry::PointCloud& target,

@@ -123,6 +123,10 @@ struct mi_icp_ctx {
     ncclComm_t comm = nullptr;
     int nranks = 1;
 
+    // ---- private scratch context: PointCloud::EstimateNormals builds its own tree there, so
+    // that the target / source / loop state of THIS context survive the call ----
+    mi_icp_ctx* aux = nullptr;
+
     // ---- instrumentation ----
     bool profiling = false;
     static constexpr int kEvPairs = 16;   // per kind: one pair per launch of a chunk
@@ -422,6 +426,7 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
         fill_i32<<<blocks_for(c->ns), 256, 0, c->stream>>>(idx, c->ns, -1);
         KCHK(c);
         c->nn_valid = true;
+        c->n_user_pairs = -1;
         return MI_ICP_OK;
     }
     const uint32_t npackets = (uint32_t)((c->ns + 63) / 64);
@@ -638,6 +643,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->aux) mi_icp_destroy(c->aux);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     DevBuf* all[] = {&c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
                      &c->cell_gstart, &c->sx, &c->sy, &c->sz,
@@ -666,6 +672,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
 const char* mi_icp_last_error(const mi_icp_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 int mi_icp_set_stream(mi_icp_ctx* c, void* hip_stream) {
+    if (c && c->aux) c->aux->stream = (hipStream_t)hip_stream;
     TRY(check_ctx(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = (hipStream_t)hip_stream;
@@ -702,6 +709,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     c->inv_t_valid = false;
     c->nn_valid = false;
     c->n_user_pairs = -1;
+    c->loop_active = false;  // a stepping loop (icp_begin / icp_iterate) belongs to the clouds it started on
     c->t_has_nrm = normals != nullptr && n > 0;
     c->t_has_cov = covs != nullptr && n > 0;
     c->t_has_int = c->t_has_grad = false;
@@ -813,6 +821,7 @@ int mi_icp_set_source(mi_icp_ctx* c, const float* xyz, const float* normals, con
     c->inv_s_valid = false;
     c->nn_valid = false;
     c->n_user_pairs = -1;
+    c->loop_active = false;
     c->s_has_nrm = normals != nullptr && n > 0;
     c->s_has_cov = covs != nullptr && n > 0;
     c->s_has_int = false;
@@ -1743,20 +1752,31 @@ static int estimate_normals_impl(mi_icp_ctx* c, const float* xyz, int64_t n, int
     if (n < 0 || (n > 0 && (!xyz || !normals))) return fail(c, MI_ICP_ERR_INVALID, "estimate_normals: bad arguments");
     if (knn > kMaxKnn) return fail(c, MI_ICP_ERR_INVALID, "estimate_normals: more than %d neighbours are not supported", kMaxKnn);
     if (n == 0) return MI_ICP_OK;
-    // builds its own LBVH over the cloud: target slot is reused and invalidated afterwards
-    TRY(mi_icp_set_target(c, xyz, nullptr, nullptr, n, mem_kind));
-    float* dn = normals;
-    if (mem_kind == MI_ICP_HOST) TRY(ensure(c, c->stage[1], (size_t)n * 3, &dn));
-    const uint32_t nblocks = (uint32_t)((c->nleaf + kKnnLeavesPerBlock - 1) / kKnnLeavesPerBlock);
-    const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
-    knn_normals_kernel<0><<<grid, kKnnThreads, 0, c->stream>>>((const float*)c->nodes.p, (const float*)c->tblk.p,
-                                                               c->leaf_first, c->nts, c->nleaf, knn, r2, nblocks,
-                                                               dn, nullptr, nullptr);
-    KCHK(c);
-    if (mem_kind == MI_ICP_HOST) TRY(from_device(c, (const float*)dn, normals, (size_t)n * 3, mem_kind));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->nt = 0;  // the tree belonged to this call
-    c->t_has_nrm = c->t_has_cov = false;
+    // The cloud gets a tree of its own in a private scratch context: a registration in flight on
+    // this context (user estimators may call EstimateNormals between iterations) keeps its
+    // target, source, correspondences and loop state.
+    if (!c->aux) {
+        const int rc = mi_icp_create(c->device, &c->aux);
+        if (rc != MI_ICP_OK) return fail(c, rc, "estimate_normals: cannot create the scratch context");
+    }
+    mi_icp_ctx* a = c->aux;
+    a->stream = c->stream;
+    auto run = [&]() -> int {
+        TRY(mi_icp_set_target(a, xyz, nullptr, nullptr, n, mem_kind));
+        float* dn = normals;
+        if (mem_kind == MI_ICP_HOST) TRY(ensure(a, a->stage[1], (size_t)n * 3, &dn));
+        const uint32_t nblocks = (uint32_t)((a->nleaf + kKnnLeavesPerBlock - 1) / kKnnLeavesPerBlock);
+        const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
+        knn_normals_kernel<0><<<grid, kKnnThreads, 0, a->stream>>>((const float*)a->nodes.p, (const float*)a->tblk.p,
+                                                                   a->leaf_first, a->nts, a->nleaf, knn, r2, nblocks,
+                                                                   dn, nullptr, nullptr);
+        KCHK(a);
+        if (mem_kind == MI_ICP_HOST) TRY(from_device(a, (const float*)dn, normals, (size_t)n * 3, mem_kind));
+        HIPCHK(a, hipStreamSynchronize(a->stream));
+        return MI_ICP_OK;
+    };
+    const int rc = run();
+    if (rc != MI_ICP_OK) return fail(c, rc, "estimate_normals: %s", a->err.c_str());
     return MI_ICP_OK;
 }
 
@@ -1987,6 +2007,12 @@ int mi_icp_debug_nn_stats(mi_icp_ctx* c, const float* T, float radius, int use_s
     HIPCHK(c, hipStreamSynchronize(c->stream));
     collect_events(c);
     std::memcpy(out4, c->sys_host, 4 * sizeof(uint64_t));
+    return MI_ICP_OK;
+}
+
+int mi_icp_debug_drop_seeds(mi_icp_ctx* c) {
+    TRY(check_ctx(c));
+    c->nn_valid = false;
     return MI_ICP_OK;
 }
 

@@ -221,6 +221,10 @@ class Engine:
             stats.ctypes.data_as(C.c_void_p)))
         return idx, d2, stats
 
+    def drop_seeds(self):
+        """test hook (mi_icp_debug.h): the next search starts top-down, not from the previous matches"""
+        self._chk(self._L.mi_icp_debug_drop_seeds(self._ctx))
+
     def get_correspondences(self):
         cnt = C.c_int64(0)
         self._chk(self._L.mi_icp_get_correspondences(self._ctx, None, 0, C.byref(cnt), MI_ICP_HOST))
@@ -326,11 +330,11 @@ class Engine:
         geometry/pointcloud_factory.cu:286-376.  depth: [H, W] float32 or uint16; color: None,
         [H, W, 3] uint8 or [H, W] float32; numpy or torch (all on the same side).
         Returns (points, normals or None, colors or None)."""
-        on_dev = torch.is_tensor(depth) and depth.is_cuda
+        on_dev = _is_tensor(depth) and depth.is_cuda
         def prep(x, kinds):
             if x is None:
                 return None, None
-            if torch.is_tensor(x):
+            if _is_tensor(x):
                 if x.dtype not in kinds:
                     raise TypeError("unsupported image dtype %s" % x.dtype)
                 if x.is_cuda != on_dev:
@@ -341,7 +345,7 @@ class Engine:
                     raise ValueError("depth and color must live on the same side")
                 x = np.ascontiguousarray(x)
             return x, (C.c_void_p(x.data_ptr()) if on_dev else x.ctypes.data_as(C.c_void_p))
-        if torch.is_tensor(depth):
+        if _is_tensor(depth):
             dkinds, ckinds = (torch.float32, torch.uint16), (torch.uint8, torch.float32)
         else:
             dkinds = ckinds = None
@@ -396,10 +400,10 @@ class Engine:
         Images: [H, W] float32, numpy or torch (all on the same side).  Returns (success, 4x4
         transformation, 6x6 information), with weighted=True (success, transformation, twist, information)."""
         imgs = [source_color, source_depth, target_color, target_depth]
-        on_dev = torch.is_tensor(imgs[0]) and imgs[0].is_cuda
+        on_dev = _is_tensor(imgs[0]) and imgs[0].is_cuda
         keep, ptrs = [], []
         for x in imgs:
-            if torch.is_tensor(x):
+            if _is_tensor(x):
                 if x.is_cuda != on_dev or x.dtype != torch.float32:
                     raise TypeError("odometry images must be float32 and live on the same side")
                 x = x.contiguous() if on_dev else np.ascontiguousarray(x.numpy())
@@ -466,7 +470,6 @@ class Engine:
             out = np.empty((p.n, 3), np.float32)
             optr = out.ctypes.data_as(C.c_void_p)
         self._chk(self._L.mi_icp_estimate_normals_knn(self._ctx, p.ptr, p.n, int(knn), optr, p.kind))
-        self.n_target = 0
         return out
 
     def estimate_normals_radius(self, points, radius, max_nn=30):
@@ -479,7 +482,6 @@ class Engine:
             optr = out.ctypes.data_as(C.c_void_p)
         self._chk(self._L.mi_icp_estimate_normals_radius(self._ctx, p.ptr, p.n, float(radius),
                                                          int(max_nn), optr, p.kind))
-        self.n_target = 0
         return out
 
     # -- multi-GPU / instrumentation -------------------------------------------------------------

@@ -33,7 +33,7 @@ class KDTreeSearchParamKNN:
 class KDTreeSearchParamRadius:
     """knn::KDTreeSearchParamRadius (knn/kdtree_search_param.h:58-66)"""
 
-    def __init__(self, radius, max_nn=100):
+    def __init__(self, radius, max_nn):   # no default in the reference either
         self.radius = float(radius)
         self.max_nn = int(max_nn)
 

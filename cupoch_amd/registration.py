@@ -162,7 +162,7 @@ def registration_icp(source, target, max_correspondence_distance, init=None,
             and not target.has_normals()):
         print("[cupoch_amd] Error: TransformationEstimationPointToPlane and "
               "TransformationEstimationColoredICP require pre-computed target normal vectors.")
-    if isinstance(est, _BuiltinEstimation):
+    if _is_builtin(est):
         eng = get_engine()
         _load_clouds(eng, source, target)
         res = eng.registration_icp(est._est, max_correspondence_distance, init,
@@ -170,6 +170,14 @@ def registration_icp(source, target, max_correspondence_distance, init=None,
                                    getattr(est, "det_thresh", -1.0))
         return _result_from(eng, res)
     return _generic_icp(source, target, max_correspondence_distance, init, est, crit)
+
+
+def _is_builtin(est):
+    """The device-resident loop may replace the reference's loop only while the estimator's
+    ComputeTransformation is the built-in one: a user subclass that overrides it is called
+    every iteration, as the reference's virtual call would (registration.cu:157)."""
+    return (isinstance(est, _BuiltinEstimation)
+            and type(est).compute_transformation is _BuiltinEstimation.compute_transformation)
 
 
 def _generic_icp(source, target, max_dist, init, est, crit):

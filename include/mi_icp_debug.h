@@ -26,6 +26,10 @@ MI_ICP_API int mi_icp_debug_morton_order(mi_icp_ctx* ctx, const float* xyz, int6
  * use_seed != 0 seeds from the previous pass. */
 MI_ICP_API int mi_icp_debug_nn_stats(mi_icp_ctx* ctx, const float* T, float radius, int use_seed,
                                      uint64_t* out4);
+/* Forget the previous search result: the next nearest-neighbour pass starts top-down instead of
+ * from its predecessor's matches (tests compare the two; the results must be identical).  The
+ * context has no correspondence set until that pass has run. */
+MI_ICP_API int mi_icp_debug_drop_seeds(mi_icp_ctx* ctx);
 /* The target's tree as built by mi_icp_set_target, for invariant tests.  info5 = {slots
  * (padded sorted positions), leaves, leaf_first (id of the first leaf-level node), records,
  * points}.  records_out (records * 64 floats: 8 child boxes as 4 sibling pairs of 12,

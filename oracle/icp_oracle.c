@@ -393,6 +393,31 @@ ORACLE_API int64_t oracle_search_radius(const float *tgt, int64_t nt, const floa
     return c;
 }
 
+/* A tree kept across calls, for tests that query one large target many times
+ * (a 10M-point build takes seconds).  The handle borrows `tgt`: the caller keeps
+ * the array alive until oracle_tree_free. */
+ORACLE_API void *oracle_tree_create(const float *tgt, int64_t nt) {
+    return (void *)kd_build(tgt, (int)(nt > 0 ? nt : 0));
+}
+
+ORACLE_API int64_t oracle_tree_search_radius(const void *tree, const float *qry, int64_t nq,
+                                             float radius, int max_nn, int *idx, float *d2) {
+    const kd_tree *t = (const kd_tree *)tree;
+    if (!t || t->n <= 0 || nq <= 0 || max_nn < 0) return -1;
+    if (max_nn == 0) return 0;
+    return kd_search_all(t, qry, nq, max_nn, radius * radius, idx, d2);
+}
+
+ORACLE_API int64_t oracle_tree_search_knn(const void *tree, const float *qry, int64_t nq, int k,
+                                          int *idx, float *d2) {
+    const kd_tree *t = (const kd_tree *)tree;
+    if (!t || t->n <= 0 || nq <= 0 || k < 0) return -1;
+    if (k == 0) return 0;
+    return kd_search_all(t, qry, nq, k, INFINITY, idx, d2);
+}
+
+ORACLE_API void oracle_tree_free(void *tree) { kd_free((kd_tree *)tree); }
+
 /* Brute-force variant (O(nq*nt)), used to validate the kd-tree itself. */
 ORACLE_API int64_t oracle_search_bruteforce(const float *tgt, int64_t nt,
                                             const float *qry, int64_t nq, int k,
@@ -974,9 +999,17 @@ static inline void accum_row(double *sys, const float *J, float r) {
 ORACLE_API void oracle_compute_system(int est, const float *src, const float *src_nrm,
                                       const float *src_cov, const float *tgt,
                                       const float *tgt_nrm, const float *tgt_cov,
-                                      const int32_t *corres, int64_t c, double *sys) {
-    memset(sys, 0, 32 * sizeof(double));
-    for (int64_t k = 0; k < c; ++k) {
+                                      const int32_t *corres, int64_t c, double *sys_out) {
+    /* Summed in fixed chunks of 65536 correspondences (each chunk sequentially, the chunk
+     * totals in order), so that the result does not depend on the thread count. */
+    enum { CHUNK = 65536 };
+    const int64_t nchunk = (c + CHUNK - 1) / CHUNK;
+    double *part = (double *)calloc((size_t)(nchunk > 0 ? nchunk : 1) * 32, sizeof(double));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t ch = 0; ch < nchunk; ++ch) {
+    double *sys = part + ch * 32;
+    const int64_t k_end = (ch + 1) * CHUNK < c ? (ch + 1) * CHUNK : c;
+    for (int64_t k = ch * CHUNK; k < k_end; ++k) {
         const int i = corres[2 * k], j = corres[2 * k + 1];
         const float *vs = src + 3 * (int64_t)i;
         const float *vt = tgt + 3 * (int64_t)j;
@@ -1038,6 +1071,11 @@ ORACLE_API void oracle_compute_system(int est, const float *src, const float *sr
             sys[27] += (double)dist2f(vs, vt);
         }
     }
+    }
+    memset(sys_out, 0, 32 * sizeof(double));
+    for (int64_t ch = 0; ch < nchunk; ++ch)
+        for (int e = 0; e < 32; ++e) sys_out[e] += part[ch * 32 + e];
+    free(part);
 }
 
 /* Kabsch (kabsch.cu:42-120) from the accumulated sums.  The reference divides

@@ -52,6 +52,9 @@ def lib():
         _lib.oracle_create_from_depth.restype = C.c_int64
         _lib.oracle_od_correspondence.restype = C.c_int64
         _lib.oracle_compute_rmse.restype = C.c_float
+        _lib.oracle_tree_create.restype = C.c_void_p
+        _lib.oracle_tree_search_radius.restype = C.c_int64
+        _lib.oracle_tree_search_knn.restype = C.c_int64
     return _lib
 
 
@@ -117,6 +120,40 @@ def search_radius(tgt, qry, radius, max_nn):
     r = lib().oracle_search_radius(_p(tgt), C.c_int64(len(tgt)), _p(qry), C.c_int64(len(qry)),
                                    C.c_float(radius), C.c_int(max_nn), _p(idx), _p(d2))
     return int(r), idx, d2
+
+
+class Tree:
+    """The oracle's kd-tree over one target, kept across searches (large clouds)."""
+
+    def __init__(self, tgt):
+        self.tgt = _f32(tgt, (-1, 3))
+        self.h = C.c_void_p(lib().oracle_tree_create(_p(self.tgt), C.c_int64(len(self.tgt))))
+
+    def search_radius(self, qry, radius, max_nn=1):
+        qry = _f32(qry, (-1, 3))
+        idx = np.empty((len(qry), max(max_nn, 1)), np.int32)
+        d2 = np.empty((len(qry), max(max_nn, 1)), np.float32)
+        r = lib().oracle_tree_search_radius(self.h, _p(qry), C.c_int64(len(qry)), C.c_float(radius),
+                                            C.c_int(max_nn), _p(idx), _p(d2))
+        return int(r), idx, d2
+
+    def search_knn(self, qry, k):
+        qry = _f32(qry, (-1, 3))
+        idx = np.empty((len(qry), max(k, 1)), np.int32)
+        d2 = np.empty((len(qry), max(k, 1)), np.float32)
+        r = lib().oracle_tree_search_knn(self.h, _p(qry), C.c_int64(len(qry)), C.c_int(k), _p(idx), _p(d2))
+        return int(r), idx, d2
+
+    def close(self):
+        if self.h:
+            lib().oracle_tree_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def search_bruteforce(tgt, qry, k, radius=-1.0):

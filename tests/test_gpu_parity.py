@@ -209,10 +209,22 @@ def test_icp_final_transform_matches_oracle(eng, est, n):
     assert res.inlier_rmse == pytest.approx(ref.inlier_rmse, rel=1e-3, abs=1e-7)
     cor = eng.get_correspondences()
     assert (np.diff(cor[:, 0]) > 0).all()
-    # same sets up to the few points whose nearest neighbour flips on the last ulp of T
-    a = set(map(tuple, cor.tolist()))
-    b = set(map(tuple, ref.correspondence_set.tolist()))
-    assert len(a ^ b) <= max(4, len(b) // 500)
+    # The sets are equal except where the two final transforms (equal to ~1e-7: the engine applies
+    # the composed T to the pristine source, the reference transforms its copy incrementally) put a
+    # source point within rounding of a decision boundary -- and that is PROVEN pair by pair:
+    # a differing pair must be a near-tie between two target points, or sit on the radius.
+    a = dict(cor.tolist())
+    b = dict(ref.correspondence_set.tolist())
+    src64 = d["src"].astype(np.float64) @ T[:3, :3].astype(np.float64).T + T[:3, 3].astype(np.float64)
+    tgt64 = d["tgt"].astype(np.float64)
+    r2 = float(d["max_dist"]) ** 2
+    for i in set(a) | set(b):
+        ja, jb = a.get(i), b.get(i)
+        if ja == jb:
+            continue
+        da = ((src64[i] - tgt64[ja]) ** 2).sum() if ja is not None else r2
+        db = ((src64[i] - tgt64[jb]) ** 2).sum() if jb is not None else r2
+        assert abs(da - db) <= 1e-5 * max(da, db), "source %d: %s vs %s is not a near-tie" % (i, ja, jb)
 
 
 def test_icp_default_criteria_init_and_convergence(eng):
@@ -226,7 +238,7 @@ def test_icp_default_criteria_init_and_convergence(eng):
     T = np.array(res.transformation, np.float32).reshape(4, 4).T
     assert np.linalg.norm(T - ref.transformation) <= 1e-5
     assert np.linalg.norm(T - d["T_gt"]) <= 2e-5
-    assert res.iterations < 30 and abs(res.iterations - ref.iterations) <= 1    # converged, same place
+    assert res.iterations < 30 and res.iterations == ref.iterations            # converged at the same iteration
     ev = eng.evaluate_registration(d["max_dist"], T)
     oe = orc.evaluate_registration(d["src"], d["tgt"], d["max_dist"], T)
     assert ev.fitness == pytest.approx(oe.fitness, abs=1e-5) and ev.fitness > 0.999

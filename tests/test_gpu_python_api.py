@@ -117,6 +117,32 @@ def test_user_defined_estimators_go_through_the_generic_loop():
     assert np.linalg.norm(res2.transformation - o.transformation) <= 1e-5
 
 
+def test_subclass_of_a_builtin_estimator_that_overrides_compute_transformation_is_called():
+    """the fused device loop may only replace the reference loop for the built-in
+    ComputeTransformation; an override must be called every iteration (registration.cu:157)."""
+    cph, d, source, target = clouds(20000, seed=5)
+    calls = []
+
+    class Counting(cph.registration.TransformationEstimationPointToPlane):
+        def compute_transformation(self, s, t, c):
+            calls.append(len(np.asarray(c)))
+            return super().compute_transformation(s, t, c)
+
+    res = cph.registration.registration_icp(source, target, d["max_dist"], np.eye(4, dtype=np.float32),
+                                            Counting(-1.0), cph.registration.ICPConvergenceCriteria(max_iteration=6))
+    assert len(calls) >= 2 and np.linalg.norm(res.transformation - d["T_gt"]) < 1e-4
+    # and a user estimator that calls estimate_normals (which used to wipe the engine's target)
+    class Renormalising(cph.registration.TransformationEstimationPointToPlane):
+        def compute_transformation(self, s, t, c):
+            tmp = cph.geometry.PointCloud(np.asarray(s.points.cpu())[:2000])
+            tmp.estimate_normals(cph.geometry.KDTreeSearchParamKNN(10))
+            return super().compute_transformation(s, t, c)
+
+    res2 = cph.registration.registration_icp(source, target, d["max_dist"], np.eye(4, dtype=np.float32),
+                                             Renormalising(-1.0), cph.registration.ICPConvergenceCriteria(max_iteration=6))
+    assert res2.fitness > 0.999 and np.linalg.norm(res2.transformation - res.transformation) < 1e-6
+
+
 def test_pointcloud_members_and_dlpack_bridge(tmp_path):
     cph, d, source, target = clouds(20000, seed=2)
     T = d["T_gt"]

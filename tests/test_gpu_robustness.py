@@ -205,3 +205,38 @@ def test_normals_and_correspondences_on_the_padded_layout(eng):
     sys_g = eng.compute_system(PT2PL, T)
     sys_o = orc.compute_system(PT2PL, orc.transform_points(T, src), tgt, cor[::2], tgt_nrm=nrm_o)
     assert np.abs(sys_g[:30] - sys_o[:30]).max() <= 1e-9 * max(np.abs(sys_o[:27]).max(), 1.0)
+
+
+def test_estimate_normals_leaves_a_registration_in_flight_alone(eng):
+    """EstimateNormals builds its tree in a private scratch context; target, source,
+    correspondences and the stepping loop's state of the calling context survive it."""
+    from conftest import make_pair
+    d = make_pair(40000, seed=31, noise=0.05)
+    eng.set_target(d["tgt"], d["tgt_nrm"])
+    eng.set_source(d["src"])
+    eng.icp_begin(PT2PL, d["max_dist"], None, -1.0)
+    eng.icp_iterate(2)
+    other = np.random.default_rng(0).random((5000, 3), dtype=np.float32)
+    n1 = eng.estimate_normals_knn(other, 10)
+    n2 = eng.estimate_normals_radius(other, 0.2, 30)
+    assert np.isfinite(n1).all() and np.isfinite(n2).all()
+    res = eng.icp_iterate(4)
+    cor = eng.get_correspondences()
+    eng.set_target(d["tgt"], d["tgt_nrm"])
+    eng.set_source(d["src"])
+    eng.icp_begin(PT2PL, d["max_dist"], None, -1.0)
+    ref = eng.icp_iterate(6)
+    np.testing.assert_array_equal(np.array(res.transformation), np.array(ref.transformation))
+    assert res.fitness == ref.fitness and res.iterations == ref.iterations == 6
+    np.testing.assert_array_equal(cor, eng.get_correspondences())
+    # a new cloud ends a stepping loop: iterate() is then a no-op on stale state
+    eng.set_source(d["src"][:1000])
+    out = eng.icp_iterate(3)
+    assert out.iterations == 6 and eng.evaluate_registration(d["max_dist"]).n_correspondences <= 1000
+    # search against an empty target forgets an explicit correspondence set
+    eng.set_target(d["tgt"])
+    eng.set_source(d["src"])
+    eng.set_correspondences(np.array([[0, 1], [2, 3]], np.int32))
+    eng.set_target(np.zeros((0, 3), np.float32))
+    eng.search_radius_1nn(1.0)
+    assert len(eng.get_correspondences()) == 0

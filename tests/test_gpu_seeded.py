@@ -1,0 +1,135 @@
+"""GPU: the SEEDED correspondence search (what every ICP iteration after the first runs) must
+return exactly what an unseeded search and the oracle return, after the transform changed by a
+lot or by an ulp, on uniform / clustered / surface data, before and after the loop's
+match-order re-sort of the source.  Bit-exact d2; an index may differ only on an exact tie.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+P2P, PT2PL = 1, 2
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from cupoch_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rigid(angle, axis, t):
+    axis = np.asarray(axis, np.float64)
+    axis /= np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    T = np.eye(4)
+    T[:3, :3] = np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
+    T[:3, 3] = t
+    return T.astype(np.float32)
+
+
+def cloud(kind, n, rng):
+    if kind == "uniform":
+        return rng.random((n, 3), dtype=np.float32)
+    if kind == "clustered":          # blobs whose densities differ by three orders of magnitude
+        k = 12
+        centres = rng.random((k, 3))
+        sig = 10.0 ** rng.uniform(-3.5, -1.0, k)
+        which = rng.integers(0, k, n)
+        return (centres[which] + rng.standard_normal((n, 3)) * sig[which, None]).astype(np.float32)
+    if kind == "surface":            # a thin sheet: leaves are flat, regions are slabs
+        uv = rng.random((n, 2))
+        z = 0.15 * np.sin(5 * uv[:, 0]) * np.cos(4 * uv[:, 1]) + rng.standard_normal(n) * 2e-4
+        return np.stack([uv[:, 0], uv[:, 1], z], 1).astype(np.float32)
+    raise ValueError(kind)
+
+
+def compare(idx, d2, q, tgt, tree, radius):
+    _, oi, od = tree.search_radius(q, radius, 1)
+    oi, od = oi[:, 0], od[:, 0]
+    assert np.array_equal(idx < 0, oi < 0), "hit/miss pattern differs"
+    hit = oi >= 0
+    assert np.array_equal(d2[hit], od[hit]), "d2 not bit-exact"
+    diff = np.flatnonzero(idx != oi)
+    if len(diff):
+        dd = q[diff] - tgt[idx[diff]]
+        alt = (dd[:, 2] * dd[:, 2] + (dd[:, 1] * dd[:, 1] + dd[:, 0] * dd[:, 0])).astype(np.float32)
+        assert np.array_equal(alt, od[diff]), "index mismatch that is not an exact tie"
+    return int(hit.sum())
+
+
+@pytest.mark.parametrize("kind", ["uniform", "clustered", "surface"])
+@pytest.mark.parametrize("noise", [0.0, 0.2])
+def test_seeded_search_equals_oracle_after_the_transform_changed(eng, kind, noise):
+    n = 200_000
+    rng = np.random.default_rng({"uniform": 10, "clustered": 20, "surface": 30}[kind] + int(noise * 10))
+    tgt = cloud(kind, n, rng)
+    spacing = n ** (-1.0 / 3.0) if kind != "surface" else n ** (-0.5)
+    T0 = rigid(0.02, [1, 2, 3], [0.004, -0.003, 0.002])
+    take = rng.permutation(n)[: int(0.7 * n)]          # partial overlap, source order incoherent
+    src = orc.transform_points(np.linalg.inv(T0).astype(np.float32), tgt[take])
+    src = (src + rng.standard_normal(src.shape).astype(np.float32) * np.float32(noise * spacing)).astype(np.float32)
+    radius = 3.0 * spacing
+    tree = orc.Tree(tgt)
+    eng.set_target(cuda(tgt))
+    eng.set_source(cuda(src))
+
+    def check(T, seeded_hits=None):
+        idx, d2, st = eng.search_radius_1nn(radius, T)
+        q = src if T is None else orc.transform_points(T, src)
+        h = compare(idx, d2, q, tgt, tree, radius)
+        assert st[0] == h
+        return idx, d2
+
+    # before any re-sort: unseeded, then seeded under other transforms
+    check(None)
+    check(T0)                                              # far from the identity result's matches
+    step = rigid(1e-7, [0, 1, 0], [1e-8, 0, 0])
+    check((step @ T0).astype(np.float32))                   # ~1 ulp away
+    # the loop's state: first pass under a poor initial guess + match-order re-sort
+    init = rigid(0.012, [1, 2, 3], [0.002, -0.001, 0.001])
+    eng.icp_begin(P2P, radius, init, -1.0)
+    a_idx, a_d2 = check(T0)                                 # large step from `init`
+    check((step @ T0).astype(np.float32))
+    far = rigid(0.05, [3, -1, 2], [0.01, 0.01, -0.02])
+    b_idx, b_d2 = check(far)                                # seeds mostly useless
+    # unseeded from scratch under the same transform: identical arrays
+    eng.drop_seeds()
+    u_idx, u_d2 = check(far)
+    assert np.array_equal(b_d2, u_d2)
+    ne = b_idx != u_idx
+    assert not ne.any() or np.array_equal(b_d2[ne], u_d2[ne])
+    # a few real iterations, then a search under the loop's own transform and under T0 again
+    res = eng.icp_iterate(3)
+    T = np.array(res.transformation, np.float32).reshape(4, 4).T
+    check(T)
+    c_idx, c_d2 = check(T0)
+    assert np.array_equal(a_d2, c_d2)
+    tree.close()
+
+
+def test_seeded_search_tiny_radius_and_all_misses(eng):
+    rng = np.random.default_rng(3)
+    n = 150_000
+    tgt = cloud("uniform", n, rng)
+    src = (tgt[rng.permutation(n)[:100_000]] + rng.standard_normal((100_000, 3)).astype(np.float32) *
+           np.float32(0.3 * n ** (-1 / 3))).astype(np.float32)
+    tree = orc.Tree(tgt)
+    eng.set_target(tgt)
+    eng.set_source(src)
+    r_small = 0.3 * n ** (-1 / 3)
+    eng.icp_begin(P2P, 2.0 * n ** (-1 / 3), None, -1.0)     # seeds from a WIDER search than the next one
+    for radius, T in ((r_small, None), (r_small, rigid(0.01, [1, 0, 0], [0.001, 0, 0])),
+                      (1e-6, None), (5.0 * n ** (-1 / 3), rigid(0.3, [0, 0, 1], [0.2, 0, 0]))):
+        idx, d2, st = eng.search_radius_1nn(radius, T)
+        q = src if T is None else orc.transform_points(T, src)
+        h = compare(idx, d2, q, tgt, tree, radius)
+        assert st[0] == h
+    tree.close()
