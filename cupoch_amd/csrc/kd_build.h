@@ -28,7 +28,20 @@ struct GroupBuildArgs {
     float4* tnrm;             // [ngroups * 4096] or null
     float* tcov;              // [ngroups * 4096 * 9] or null
     float* records;
+    float* lreg;              // [ngroups * 512][8] leaf regions (below)
 };
+
+// LEAF REGIONS.  Every leaf (8 slots) also gets its kd cell -- the box that is free of points
+// of ANY other leaf -- as {lo.xyz, delta | hi.xyz, -}: the seeded search (nn_search.h) evaluates a
+// query's previous match's leaf first, and a query whose search cube lies inside that leaf's
+// region is finished without touching the tree.  The 64-slot nodes' regions come out of
+// kd_sort_levels (kd_refine.h, SAFE); the last three splits are replayed here from the leaf
+// boxes: a half's region is its parent's, cut along the split axis at the exact extreme of the
+// sibling half.  Cutting along ANY axis at the sibling's exact extreme keeps the defining
+// property (every sibling point lies on or beyond the new face), so the axis is simply
+// recomputed as the longest axis of the parent's box -- the rule the sort used.
+// delta (float 3) is the reach of the leaf's neighbour list (leaf_links.h); 0: none.
+
 
 __global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) {
     __shared__ KdShared s;
@@ -124,6 +137,49 @@ __global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) 
     // that it may be used to end a search early (traverse.h).  A cell that needed several
     // groups has no such regions: its groups are not separated by a split.
     const uint32_t own_flag = (s_src[2] == 1u) ? 1u : 0u;
+    if (a.lreg && tid < kKdChunks) {
+        float reg[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};  // invalid: nothing is inside
+        if (own_flag) {
+#pragma unroll
+            for (int e = 0; e < 6; ++e) reg[e] = s.safe[e * 64 + (tid >> 3)];
+#pragma unroll
+            for (int lev = 2; lev >= 0; --lev) {
+                const int h = tid >> lev, sib = h ^ 1;
+                const int p0 = (h >> 1) << (lev + 1), s0 = sib << lev;
+                float pmn[3] = {INFINITY, INFINITY, INFINITY}, pmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+                float smn[3] = {INFINITY, INFINITY, INFINITY}, smx[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (int c = 0; c < (2 << lev); ++c) {
+                    const bool in_sib = (p0 + c) >= s0 && (p0 + c) < s0 + (1 << lev);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const float lo = s.bb[d * kKdChunks + p0 + c], hi = s.bb[(3 + d) * kKdChunks + p0 + c];
+                        pmn[d] = fminf(pmn[d], lo);
+                        pmx[d] = fmaxf(pmx[d], hi);
+                        if (in_sib) {
+                            smn[d] = fminf(smn[d], lo);
+                            smx[d] = fmaxf(smx[d], hi);
+                        }
+                    }
+                }
+                int ax = 0;
+                float e = pmx[0] - pmn[0];
+                if (pmx[1] - pmn[1] > e) {
+                    e = pmx[1] - pmn[1];
+                    ax = 1;
+                }
+                if (pmx[2] - pmn[2] > e) ax = 2;
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    if (d == ax) {
+                        if ((h & 1) == 0) reg[3 + d] = fminf(reg[3 + d], smn[d]);
+                        else reg[d] = fmaxf(reg[d], smx[d]);
+                    }
+            }
+        }
+        float4* out = reinterpret_cast<float4*>(a.lreg + ((size_t)g * kKdChunks + (size_t)tid) * kLeafRegFloats);
+        out[0] = make_float4(reg[0], reg[1], reg[2], 0.0f);
+        out[1] = make_float4(reg[3], reg[4], reg[5], 0.0f);
+    }
     // level j: 512 >> 3j boxes; box t of level j is node (leaf_first >> 3(j-1)) + g*(64 >> 3(j-1)) + t
     // for j >= 1, and leaf g*512 + t (child of node leaf_first + (g*512 + t)/8) for j = 0
     for (int j = 0; j < 4; ++j) {

@@ -85,7 +85,7 @@ struct mi_icp_ctx {
     int64_t nts = 0;  // sorted positions of the target incl. padding slots (kd_cells.h)
     uint32_t leaf_first = 1, nrecords = 0;  // 8-ary tree: first last-level node id, record count
     bool t_has_nrm = false, t_has_cov = false, t_has_int = false, t_has_grad = false;
-    DevBuf tblk, tnrm, tcov, tgrad, nodes, inv_t;
+    DevBuf tblk, tnrm, tcov, tgrad, nodes, inv_t, tlreg;
     DevBuf cell_planes, cell_samples, cell_cstart, cell_gstart;
     uint32_t* cell_total_host = nullptr;  // pinned
     bool inv_t_valid = false;
@@ -435,7 +435,7 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
     const Xform X = make_xform(T);
     EvTimer t(c, 0, loop != nullptr);
 #define MI_NN_ARGS (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns, \
-                   (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, X, loop, r2, nblocks, idx, d2, stats
+                   (const float*)c->nodes.p, (const float*)c->tblk.p, (const float*)c->tlreg.p, c->leaf_first, X, loop, r2, nblocks, idx, d2, stats
     const bool use_seed = seed && c->nn_valid;
     if (stats) {
         if (use_seed) nn_packet_kernel<true, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
@@ -645,7 +645,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->aux) mi_icp_destroy(c->aux);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    DevBuf* all[] = {&c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
+    DevBuf* all[] = {&c->tlreg, &c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
                      &c->cell_gstart, &c->sx, &c->sy, &c->sz,
                      &c->sperm, &c->snrm, &c->scov, &c->nn_idx, &c->nn_d2, &c->inv_s,
                      &c->user_pairs, &c->keys0, &c->keys1, &c->vals0, &c->vals1, &c->hist,
@@ -755,6 +755,8 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     float* nodes;
     TRY(ensure(c, c->tblk, (size_t)nleaf * kLeafFloats, &tblk));
     TRY(ensure(c, c->nodes, (size_t)nrecords * kRecordFloats, &nodes));
+    float* lreg;
+    TRY(ensure(c, c->tlreg, (size_t)nleaf * kLeafRegFloats, &lreg));
     if (d_nrm) TRY(ensure(c, c->tnrm, (size_t)nts, &tnrm));
     if (d_cov) TRY(ensure(c, c->tcov, (size_t)nts * 9, &tcov));
     uint32_t first, used;  // the level whose nodes' boxes still have to be formed from their records
@@ -763,6 +765,9 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     if (no_cells) {
         // own boxes / flags of the leaf-level records stay zero: no early stop on a Morton-run tree
         HIPCHK(c, hipMemsetAsync(nodes, 0, (size_t)nrecords * kRecordFloats * sizeof(float), c->stream));
+        // no leaf regions either (+inf: no cube is inside)
+        fill_i32<<<blocks_for((int64_t)nleaf * kLeafRegFloats), 256, 0, c->stream>>>((int32_t*)lreg, (int64_t)nleaf * kLeafRegFloats, 0x7f800000);
+        KCHK(c);
         const int nslots = (int)used_last * 8;
         build_leaves<<<blocks_for(nslots), 256, 0, c->stream>>>(order, d_pts, d_nrm, d_cov, nts, nleaf, nslots,
                                                                 leaf_first, tblk, tnrm, tcov, nodes);
@@ -786,6 +791,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
         ga.tnrm = tnrm;
         ga.tcov = tcov;
         ga.records = nodes;
+        ga.lreg = lreg;
         kd_build_groups<<<(unsigned)lay.ngroups, kKdThreads, 0, c->stream>>>(ga);
         KCHK(c);
         first = leaf_first >> 9;  // the groups' own boxes sit in the records of this level
@@ -2007,6 +2013,15 @@ int mi_icp_debug_nn_stats(mi_icp_ctx* c, const float* T, float radius, int use_s
     HIPCHK(c, hipStreamSynchronize(c->stream));
     collect_events(c);
     std::memcpy(out4, c->sys_host, 4 * sizeof(uint64_t));
+    return MI_ICP_OK;
+}
+
+int mi_icp_debug_get_leaf_regions(mi_icp_ctx* c, float* regions_out) {
+    TRY(check_ctx(c));
+    if (!regions_out || c->nt <= 0) return fail(c, MI_ICP_ERR_INVALID, "debug_get_leaf_regions: no target / bad arguments");
+    HIPCHK(c, hipMemcpyAsync(regions_out, c->tlreg.p, (size_t)c->nleaf * kLeafRegFloats * sizeof(float),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return MI_ICP_OK;
 }
 

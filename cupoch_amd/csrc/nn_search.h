@@ -98,7 +98,7 @@ template <bool SEED, bool STATS>
 __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_packet_kernel(
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
         int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
-        uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, uint32_t nblocks, int32_t* __restrict__ nn_idx,
+        const float* __restrict__ lreg_g, uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, uint32_t nblocks, int32_t* __restrict__ nn_idx,
         float* __restrict__ nn_d2, unsigned long long* __restrict__ stats) {
     __shared__ PacketShared s_pk[kNNPacketsPerBlock];
     uint32_t logical;
@@ -120,29 +120,65 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     int32_t bidx = -1;
 
     uint32_t my_node = 0u;  // leaf-level node of the lane's previous match (traverse_seeded), 0: none
+    uint32_t seed_leaf = 0xffffffffu;
+    bool retired = !valid;  // this lane's search is complete
+    Cube cube;
     if (SEED) {
-        // last iteration's match bounds this one's search radius, and its leaf-level node is
-        // where this lane's search starts (taken from the raw index: the first record's fetch
-        // does not wait for the gather below)
+        // The previous iteration's match: its whole LEAF is evaluated right here (one 128-B line,
+        // the same the old single-point gather touched), which gives the search radius -- and if
+        // the resulting cube lies inside that leaf's REGION (kd_build.h: free of points of any
+        // other leaf) the lane is finished before the tree is touched.  A converged iteration
+        // is therefore one streaming pass: query + previous match in, leaf line + region in,
+        // match + distance out.
         const int32_t j = valid ? nn_idx[i] : -1;
         if (j >= 0) {
-            my_node = leaf_first + ((uint32_t)j >> 6);
-            const float* line = tblk_g + (int64_t)(j >> 3) * kLeafFloats + (j & 7);
-            const float d2 = sq3(qx - line[0], qy - line[8], qz - line[16]);
-            if (d2 < best) {
-                best = d2;
-                bidx = j;
+            const uint32_t L = (uint32_t)j >> 3;
+            seed_leaf = L;
+            my_node = leaf_first + (L >> 3);
+            const float4* line = reinterpret_cast<const float4*>(tblk_g + (size_t)L * kLeafFloats);
+            const float4* rg = reinterpret_cast<const float4*>(lreg_g + (size_t)L * kLeafRegFloats);
+            const float4 x0 = line[0], x1 = line[1], y0 = line[2], y1 = line[3], z0 = line[4], z1 = line[5];
+            const float4 g0 = rg[0], g1 = rg[1];
+            const float px[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            const float py[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+            const float pz[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+            float d[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = sq3(qx - px[k], qy - py[k], qz - pz[k]);
+            const float m = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+            if (m < best) {  // strict radius test (also drops NaN); lowest slot among equals
+                int k = 7;
+                k = (d[6] == m) ? 6 : k;
+                k = (d[5] == m) ? 5 : k;
+                k = (d[4] == m) ? 4 : k;
+                k = (d[3] == m) ? 3 : k;
+                k = (d[2] == m) ? 2 : k;
+                k = (d[1] == m) ? 1 : k;
+                k = (d[0] == m) ? 0 : k;
+                best = m;
+                bidx = (int32_t)(L * (uint32_t)kLeaf + (uint32_t)k);
             }
+            set_cube(cube, qx, qy, qz, best);
+            // every point of another leaf lies on or beyond a face of the region, i.e. at
+            // L-infinity distance >= rb > sqrt(best) from the query: it cannot improve the match
+            if (g0.x <= cube.lox && g0.y <= cube.loy && g0.z <= cube.loz && g1.x >= cube.hix && g1.y >= cube.hiy &&
+                g1.z >= cube.hiz)
+                retired = true;
+        } else {
+            set_cube(cube, qx, qy, qz, best);
         }
+    } else {
+        set_cube(cube, qx, qy, qz, best);  // invalid lanes: best = -1 -> empty cube
     }
-    Cube cube;
-    set_cube(cube, qx, qy, qz, best);  // invalid lanes: best = -1 -> empty cube
+    if (retired) {  // an empty cube takes no part in box tests
+        cube.lox = cube.loy = cube.loz = INFINITY;
+        cube.hix = cube.hiy = cube.hiz = -INFINITY;
+    }
     // the lane's running result lives in LDS, where any lane may improve it
     sh.best[lane] = ((unsigned long long)__float_as_uint(fmaxf(best, 0.0f)) << 32) | (unsigned long long)(uint32_t)bidx;
     __builtin_amdgcn_wave_barrier();
 
     uint32_t queued = 0u, batches = 0u;  // wave-uniform
-    bool retired = !valid;               // traverse_seeded: this lane's search is complete
     constexpr uint32_t kNoItem = 0xffffffffu;
     uint32_t held = kNoItem;             // this lane's one pending leaf while no lane has had a second
     bool spilled = false;                // wave-uniform: the held items have moved into the LDS queue
@@ -162,6 +198,8 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
         take_results();
     };
     auto on_leaf_record = [&](uint32_t lbase, uint32_t vm, uint32_t hit) {
+        // the lane's seed leaf has been evaluated in the prologue
+        if (SEED && (seed_leaf & ~7u) == lbase) vm &= ~(1u << (seed_leaf & 7u));
         // The steady state of a converged loop: every lane overlaps ONE leaf in the whole walk
         // (its match's).  A lane's first item therefore stays in a register; only when some
         // lane gets a second one do the held items move into the LDS queue (below), where items
@@ -204,8 +242,9 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
             drain(queued, 64u);
         }
     };
-    const uint32_t steps = SEED ? traverse_seeded(records_g, leaf_first, my_node, cube, retired, on_leaf_record)
-                                : traverse_from(records_g, leaf_first, 1u, cube, on_leaf_record);
+    uint32_t steps = 0u;
+    if (!SEED) steps = traverse_from(records_g, leaf_first, 1u, cube, on_leaf_record);
+    else if (__ballot(!retired) != 0ull) steps = traverse_seeded(records_g, leaf_first, my_node, cube, retired, on_leaf_record);
     if (!spilled) {  // one item per lane at most: each lane evaluates its own
         if (__ballot(held != kNoItem) != 0ull) {
             if (STATS) ++batches;

@@ -38,6 +38,10 @@ MI_ICP_API int mi_icp_debug_drop_seeds(mi_icp_ctx* ctx);
  * sizes only. */
 MI_ICP_API int mi_icp_debug_get_tree(mi_icp_ctx* ctx, int64_t* info5, float* records_out,
                                      float* leaf_lines_out);
+/* Per leaf (mi_icp_debug_get_tree's info5[1] leaves) 8 floats: region lo.xyz, reach of the
+ * leaf's neighbour list, region hi.xyz, unused.  The region is free of points of any other
+ * leaf (an invalid one is +inf / -inf: nothing is inside). */
+MI_ICP_API int mi_icp_debug_get_leaf_regions(mi_icp_ctx* ctx, float* regions_out);
 #ifdef __cplusplus
 }
 #endif

@@ -94,7 +94,31 @@ def check_tree(eng, pts, expect_all_flagged):
         span *= 8
     if expect_all_flagged:
         assert flagged == total
+    check_leaf_regions(eng, nleaf, xyz, finite)
     return flagged, total
+
+
+def check_leaf_regions(eng, nleaf, xyz, finite):
+    """A LEAF's region (mi_icp_debug_get_leaf_regions: what finishes a seeded query without a tree
+    walk, nn_search.h) holds no point of any other leaf strictly inside; invalid ones are empty."""
+    reg = np.empty((nleaf, 8), np.float32)
+    eng._chk(eng._L.mi_icp_debug_get_leaf_regions(eng._ctx, reg.ctypes.data_as(C.c_void_p)))
+    lo, hi = reg[:, 0:3], reg[:, 4:7]
+    valid = (lo <= hi).all(1)
+    leaf_of = np.arange(len(xyz)) // 8
+    pts, owner = xyz[finite], leaf_of[finite]
+    order = np.random.default_rng(5).permutation(np.flatnonzero(valid))[:400]
+    for L in order:
+        inside = ((pts > lo[L]) & (pts < hi[L])).all(1)
+        assert not (inside & (owner != L)).any(), (int(L), int((inside & (owner != L)).sum()))
+    # own points: inside the closed region except near-ties at a median
+    own_ok = own_n = 0
+    for L in order[:200]:
+        mine = pts[owner == L]
+        own_n += len(mine)
+        own_ok += int(((mine >= lo[L]) & (mine <= hi[L])).all(1).sum())
+    assert own_n == 0 or own_ok >= 0.98 * own_n
+    return int(valid.sum())
 
 
 def test_regions_uniform_cloud(eng):
