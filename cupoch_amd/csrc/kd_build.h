@@ -40,7 +40,7 @@ struct GroupBuildArgs {
 // sibling half.  Cutting along ANY axis at the sibling's exact extreme keeps the defining
 // property (every sibling point lies on or beyond the new face), so the axis is simply
 // recomputed as the longest axis of the parent's box -- the rule the sort used.
-// delta (float 3) is the reach of the leaf's neighbour list (leaf_links.h); 0: none.
+// Float 3 is the REACH of the leaf's neighbour list (leaf_links.h); 0: none.
 
 
 __global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) {
@@ -176,9 +176,26 @@ __global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) 
                     }
             }
         }
+        // float 7: the bound the neighbour-list build starts from (leaf_links.h) -- a quarter of the
+        // leaf-level node's largest extent, i.e. about one point spacing on volumetric data
+        float delta0 = 0.0f;
+        if (own_flag) {
+            const int n0 = tid & ~7;
+            float ext = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float mn = INFINITY, mx = -INFINITY;
+                for (int c = 0; c < 8; ++c) {
+                    mn = fminf(mn, s.bb[d * kKdChunks + n0 + c]);
+                    mx = fmaxf(mx, s.bb[(3 + d) * kKdChunks + n0 + c]);
+                }
+                ext = fmaxf(ext, mx - mn);
+            }
+            delta0 = (ext > 0.0f && ext < INFINITY) ? 0.25f * ext : 0.0f;
+        }
         float4* out = reinterpret_cast<float4*>(a.lreg + ((size_t)g * kKdChunks + (size_t)tid) * kLeafRegFloats);
         out[0] = make_float4(reg[0], reg[1], reg[2], 0.0f);
-        out[1] = make_float4(reg[3], reg[4], reg[5], 0.0f);
+        out[1] = make_float4(reg[3], reg[4], reg[5], delta0);
     }
     // level j: 512 >> 3j boxes; box t of level j is node (leaf_first >> 3(j-1)) + g*(64 >> 3(j-1)) + t
     // for j >= 1, and leaf g*512 + t (child of node leaf_first + (g*512 + t)/8) for j = 0

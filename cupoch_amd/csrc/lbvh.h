@@ -251,6 +251,15 @@ __global__ __launch_bounds__(256) void build_level(float* __restrict__ records, 
     store_box(records, id, mn, mx);
 }
 
+// leaf regions of a tree that has none (Morton-run fallback): nothing is inside, no neighbour list
+__global__ __launch_bounds__(256) void fill_invalid_leaf_regions(float* __restrict__ lreg, int nleaf) {
+    const int L = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (L >= nleaf) return;
+    float4* out = reinterpret_cast<float4*>(lreg + (size_t)L * kLeafRegFloats);
+    out[0] = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);
+    out[1] = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
+}
+
 // ---- source: Morton-ordered SoA copy ---------------------------------------
 __global__ __launch_bounds__(256) void gather_source(
         const uint32_t* __restrict__ order, const float* __restrict__ pts,

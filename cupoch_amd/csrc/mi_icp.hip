@@ -30,6 +30,7 @@
 #include "kd_refine.h"
 #include "knn_normals.h"
 #include "lbvh.h"
+#include "leaf_links.h"
 #include "loop.h"
 #include "nn_search.h"
 #include "odometry.h"
@@ -85,10 +86,11 @@ struct mi_icp_ctx {
     int64_t nts = 0;  // sorted positions of the target incl. padding slots (kd_cells.h)
     uint32_t leaf_first = 1, nrecords = 0;  // 8-ary tree: first last-level node id, record count
     bool t_has_nrm = false, t_has_cov = false, t_has_int = false, t_has_grad = false;
-    DevBuf tblk, tnrm, tcov, tgrad, nodes, inv_t, tlreg;
+    DevBuf tblk, tnrm, tcov, tgrad, nodes, inv_t, tlreg, tlinks;
     DevBuf cell_planes, cell_samples, cell_cstart, cell_gstart;
     uint32_t* cell_total_host = nullptr;  // pinned
     bool inv_t_valid = false;
+    bool links_ready = false, links_allowed = false;  // leaf_links.h
 
     // ---- source (Morton order) ----
     int64_t ns = 0, ns_global = 0;
@@ -416,6 +418,26 @@ void collect_pooled(mi_icp_ctx* c, int executed) {
     }
 }
 
+// Every leaf's neighbour list (leaf_links.h): what lets a seeded query whose cube pokes out of its
+// leaf's region finish without a tree walk.  Built once per target, by the first search that can
+// use it (one-shot searches, k-NN and normal estimation never pay for it).
+int ensure_links(mi_icp_ctx* c) {
+    if (c->links_ready || c->nt <= 0) return MI_ICP_OK;
+    static const bool no_links = std::getenv("MI_ICP_NO_LINKS") != nullptr;  // A/B switch
+    uint2* links;
+    TRY(ensure(c, c->tlinks, (size_t)c->nleaf * kLinkSlots, &links));
+    if (c->links_allowed && !no_links) {
+        const uint32_t lblocks = (uint32_t)((c->nleaf + 63) / 64);
+        leaf_links_kernel<<<((lblocks + 7u) / 8u) * 8u, 64, 0, c->stream>>>(
+                (const float*)c->nodes.p, c->leaf_first, c->nleaf, lblocks, (float*)c->tlreg.p, links);
+        KCHK(c);
+    } else {
+        HIPCHK(c, hipMemsetAsync(links, 0xff, (size_t)c->nleaf * kLinkSlots * sizeof(uint2), c->stream));
+    }
+    c->links_ready = true;
+    return MI_ICP_OK;
+}
+
 // ---- nearest-neighbour pass --------------------------------------------------
 int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long long* stats = nullptr,
               const DevLoop* loop = nullptr) {
@@ -433,10 +455,11 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
     const uint32_t nblocks = (npackets + kNNPacketsPerBlock - 1) / kNNPacketsPerBlock;
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
     const Xform X = make_xform(T);
+    const bool use_seed = seed && c->nn_valid;
+    if (use_seed) TRY(ensure_links(c));
     EvTimer t(c, 0, loop != nullptr);
 #define MI_NN_ARGS (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns, \
-                   (const float*)c->nodes.p, (const float*)c->tblk.p, (const float*)c->tlreg.p, c->leaf_first, X, loop, r2, nblocks, idx, d2, stats
-    const bool use_seed = seed && c->nn_valid;
+                   (const float*)c->nodes.p, (const float*)c->tblk.p, (const float*)c->tlreg.p, (const uint2*)c->tlinks.p, c->leaf_first, X, loop, r2, nblocks, idx, d2, stats
     if (stats) {
         if (use_seed) nn_packet_kernel<true, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
         else nn_packet_kernel<false, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
@@ -645,7 +668,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->aux) mi_icp_destroy(c->aux);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    DevBuf* all[] = {&c->tlreg, &c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
+    DevBuf* all[] = {&c->tlreg, &c->tlinks, &c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
                      &c->cell_gstart, &c->sx, &c->sy, &c->sz,
                      &c->sperm, &c->snrm, &c->scov, &c->nn_idx, &c->nn_d2, &c->inv_s,
                      &c->user_pairs, &c->keys0, &c->keys1, &c->vals0, &c->vals1, &c->hist,
@@ -765,8 +788,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     if (no_cells) {
         // own boxes / flags of the leaf-level records stay zero: no early stop on a Morton-run tree
         HIPCHK(c, hipMemsetAsync(nodes, 0, (size_t)nrecords * kRecordFloats * sizeof(float), c->stream));
-        // no leaf regions either (+inf: no cube is inside)
-        fill_i32<<<blocks_for((int64_t)nleaf * kLeafRegFloats), 256, 0, c->stream>>>((int32_t*)lreg, (int64_t)nleaf * kLeafRegFloats, 0x7f800000);
+        fill_invalid_leaf_regions<<<blocks_for(nleaf), 256, 0, c->stream>>>(lreg, nleaf);  // no leaf regions either
         KCHK(c);
         const int nslots = (int)used_last * 8;
         build_leaves<<<blocks_for(nslots), 256, 0, c->stream>>>(order, d_pts, d_nrm, d_cov, nts, nleaf, nslots,
@@ -805,6 +827,8 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
         KCHK(c);
         used = (used + 7u) / 8u;
     }
+    c->links_ready = false;  // the leaves' neighbour lists are built by the first seeded search (launch_nn)
+    c->links_allowed = !no_cells && (uint32_t)nleaf <= kLinkIdMask;
     c->nt = n;
     c->nts = nts;
     c->nleaf = nleaf;
@@ -2020,6 +2044,16 @@ int mi_icp_debug_get_leaf_regions(mi_icp_ctx* c, float* regions_out) {
     TRY(check_ctx(c));
     if (!regions_out || c->nt <= 0) return fail(c, MI_ICP_ERR_INVALID, "debug_get_leaf_regions: no target / bad arguments");
     HIPCHK(c, hipMemcpyAsync(regions_out, c->tlreg.p, (size_t)c->nleaf * kLeafRegFloats * sizeof(float),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MI_ICP_OK;
+}
+
+int mi_icp_debug_get_leaf_links(mi_icp_ctx* c, uint32_t* links_out) {
+    TRY(check_ctx(c));
+    if (!links_out || c->nt <= 0) return fail(c, MI_ICP_ERR_INVALID, "debug_get_leaf_links: no target / bad arguments");
+    TRY(ensure_links(c));
+    HIPCHK(c, hipMemcpyAsync(links_out, c->tlinks.p, (size_t)c->nleaf * kLinkSlots * sizeof(uint2),
                              hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MI_ICP_OK;

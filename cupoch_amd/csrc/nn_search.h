@@ -38,6 +38,7 @@ constexpr int kNNPacketsPerBlock = kNNThreads / 64;
 // result goes back with an LDS atomic min on (d2 bits << 32 | slot) -- d2 >= 0, so the
 // integer order is the float order and equal distances resolve to the lowest slot.
 constexpr int kItemQueue = 64 + 8 * 64;  // a drain leaves < 64 behind, one record adds <= 512
+constexpr int kLinkSlotsNN = 32;         // entries per leaf neighbour list (leaf_links.h: kLinkSlots)
 
 struct PacketShared {
     unsigned long long best[64];  // per lane: d2 bits << 32 | slot
@@ -98,7 +99,7 @@ template <bool SEED, bool STATS>
 __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_packet_kernel(
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
         int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
-        const float* __restrict__ lreg_g, uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, uint32_t nblocks, int32_t* __restrict__ nn_idx,
+        const float* __restrict__ lreg_g, const uint2* __restrict__ links_g, uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, uint32_t nblocks, int32_t* __restrict__ nn_idx,
         float* __restrict__ nn_d2, unsigned long long* __restrict__ stats) {
     __shared__ PacketShared s_pk[kNNPacketsPerBlock];
     uint32_t logical;
@@ -122,6 +123,9 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     uint32_t my_node = 0u;  // leaf-level node of the lane's previous match (traverse_seeded), 0: none
     uint32_t seed_leaf = 0xffffffffu;
     bool retired = !valid;  // this lane's search is complete
+    bool linked = false;    // ... will be once the neighbour list of its seed leaf has been scanned
+    float over = 0.0f;      // overhang of the cube beyond the seed leaf's region
+    uint32_t faces = 0u;    // faces it pokes through
     Cube cube;
     if (SEED) {
         // The previous iteration's match: its whole LEAF is evaluated right here (one 128-B line,
@@ -162,8 +166,19 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
             // every point of another leaf lies on or beyond a face of the region, i.e. at
             // L-infinity distance >= rb > sqrt(best) from the query: it cannot improve the match
             if (g0.x <= cube.lox && g0.y <= cube.loy && g0.z <= cube.loz && g1.x >= cube.hix && g1.y >= cube.hiy &&
-                g1.z >= cube.hiz)
+                g1.z >= cube.hiz) {
                 retired = true;
+            } else {
+                // The cube pokes out of the region: by how much (L-infinity overhang), and through which
+                // faces.  Below the REACH of the leaf's neighbour list (leaf_links.h) the list names
+                // every leaf the cube can touch outside its own.
+                const float ux = cube.hix - g1.x, uy = cube.hiy - g1.y, uz = cube.hiz - g1.z;
+                const float lx = g0.x - cube.lox, ly = g0.y - cube.loy, lz = g0.z - cube.loz;
+                over = fmaxf(fmaxf(fmaxf(ux, lx), fmaxf(uy, ly)), fmaxf(uz, lz)) * 1.000001f;
+                faces = (ux > 0.0f ? 1u : 0u) | (lx > 0.0f ? 2u : 0u) | (uy > 0.0f ? 4u : 0u) | (ly > 0.0f ? 8u : 0u) |
+                        (uz > 0.0f ? 16u : 0u) | (lz > 0.0f ? 32u : 0u);
+                linked = over < g0.w;  // (NaN from inf - inf: false)
+            }
         } else {
             set_cube(cube, qx, qy, qz, best);
         }
@@ -242,6 +257,48 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
             drain(queued, 64u);
         }
     };
+    if (SEED && __ballot(linked) != 0ull) {
+        // ---- neighbour lists: lane-private scans of the seed leaves' lists (the 8 or so lanes that
+        // share a seed leaf read the same 32-byte pieces).  Entries come sorted by distance, so a
+        // lane stops at the first one beyond its overhang; an entry whose box lies beyond a face
+        // the cube does not poke through cannot overlap it.  What passes is queued as a
+        // (lane, leaf) item like any leaf the tree walk would have found.
+        const uint4* lk = reinterpret_cast<const uint4*>(links_g + (size_t)(linked ? seed_leaf : 0u) * kLinkSlotsNN);
+        bool scanning = linked;
+        spilled = true;
+        for (int k4 = 0; k4 < kLinkSlotsNN / 4; ++k4) {
+            if (__ballot(scanning) == 0ull) break;
+            uint4 e0 = make_uint4(0u, 0x7f800000u, 0u, 0x7f800000u), e1 = e0;
+            if (scanning) {
+                e0 = lk[2 * k4];
+                e1 = lk[2 * k4 + 1];
+            }
+            const uint32_t ids[4] = {e0.x, e0.z, e1.x, e1.z};
+            const uint32_t dw[4] = {e0.y, e0.w, e1.y, e1.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                scanning = scanning && (__uint_as_float(dw[u] & ~63u) <= over);
+                const bool push = scanning && ((dw[u] & 63u & ~faces) == 0u);
+                const uint64_t m = __ballot(push);
+                if (push) {
+                    const uint32_t pos = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    sh.queue[pos] = ((uint32_t)lane << 26) | ids[u];
+                }
+                queued += (uint32_t)__popcll(m);
+            }
+            __builtin_amdgcn_wave_barrier();
+            while (queued >= 64u) {
+                queued -= 64u;
+                drain(queued, 64u);
+            }
+        }
+        if (linked) {  // everything this lane can still find is in the queue
+            retired = true;
+            cube.lox = cube.loy = cube.loz = INFINITY;
+            cube.hix = cube.hiy = cube.hiz = -INFINITY;
+        }
+    }
     uint32_t steps = 0u;
     if (!SEED) steps = traverse_from(records_g, leaf_first, 1u, cube, on_leaf_record);
     else if (__ballot(!retired) != 0ull) steps = traverse_seeded(records_g, leaf_first, my_node, cube, retired, on_leaf_record);

@@ -41,6 +41,8 @@
 // them into the wave-uniform hit mask.
 // The exact fp32 d2 comparison happens only on leaf points.
 #pragma once
+#include <type_traits>
+
 #include "device_utils.h"
 
 namespace mi {
@@ -190,8 +192,9 @@ __device__ __forceinline__ uint32_t traverse_from(const float* records_g, uint32
     typedef const __attribute__((address_space(4))) char* cchar_p;
     const cchar_p base = (cchar_p)(uintptr_t)records_g;
     uint32_t id = __builtin_amdgcn_readfirstlane(start), steps = 0u;
-    // off = record_index(id) - id of id's level: -1 at the root, (8^k - 1)/7 - 8^k at the leaf level
-    int32_t off = (id == 1u) ? -1 : (int32_t)(full_levels_below(leaf_first) - leaf_first);
+    // off = record_index(id) - id of id's level: -1 at the root, (8^k - 1)/7 - 8^k at level k
+    const uint32_t start_h = 1u << (31 - __builtin_clz(id));
+    int32_t off = (int32_t)(full_levels_below(start_h) - start_h);
     uint32_t top = id;      // the subtree being completed
     int32_t top_off = off;
     uint32_t skip = 8u;     // child of `top` that is already done (8: none)
@@ -244,7 +247,11 @@ __device__ __forceinline__ uint32_t traverse_from(const float* records_g, uint32
                 continue;
             }
         } else if (hit) {
-            leaf_rec((id - leaf_first) * 8u, vm, hit);
+            // (a callback that takes a fourth argument also gets the record's 8 child boxes)
+            if constexpr (std::is_invocable_v<LeafRecFn&, uint32_t, uint32_t, uint32_t, const float(&)[48]>)
+                leaf_rec((id - leaf_first) * 8u, vm, hit, w);
+            else
+                leaf_rec((id - leaf_first) * 8u, vm, hit);
         }
         if (pend != 0ull) {
             const uint32_t z = (uint32_t)__builtin_ctzll(pend);  // lowest pending sibling, 8 bits per level

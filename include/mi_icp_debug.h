@@ -42,6 +42,12 @@ MI_ICP_API int mi_icp_debug_get_tree(mi_icp_ctx* ctx, int64_t* info5, float* rec
  * leaf's neighbour list, region hi.xyz, unused.  The region is free of points of any other
  * leaf (an invalid one is +inf / -inf: nothing is inside). */
 MI_ICP_API int mi_icp_debug_get_leaf_regions(mi_icp_ctx* ctx, float* regions_out);
+/* Per leaf 32 entries of 2 words (builds the lists if no seeded search has yet): leaf id, fp32
+ * bits of the L-infinity distance between that leaf's bounding box and this leaf's region with the
+ * 6 low mantissa bits replaced by the direction mask (bit 2a: beyond the upper face of axis a,
+ * 2a+1: beyond the lower one); ascending in distance; unused entries 0xffffffff / +inf.  Call
+ * mi_icp_debug_get_leaf_regions afterwards for the lists' reach (float 3). */
+MI_ICP_API int mi_icp_debug_get_leaf_links(mi_icp_ctx* ctx, uint32_t* links_out);
 #ifdef __cplusplus
 }
 #endif

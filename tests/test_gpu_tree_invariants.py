@@ -95,7 +95,50 @@ def check_tree(eng, pts, expect_all_flagged):
     if expect_all_flagged:
         assert flagged == total
     check_leaf_regions(eng, nleaf, xyz, finite)
+    check_leaf_links(eng, nleaf, xyz, finite)
     return flagged, total
+
+
+def check_leaf_links(eng, nleaf, xyz, finite):
+    """The neighbour lists (leaf_links.h): for a leaf with region R and list reach d, EVERY other
+    leaf whose bounding box is nearer than d to R (L-infinity, box to box) is in the list; the
+    stored distances never exceed the true ones, the direction masks are true, the order ascends."""
+    links = np.empty((nleaf, 32, 2), np.uint32)
+    eng._chk(eng._L.mi_icp_debug_get_leaf_links(eng._ctx, links.ctypes.data_as(C.c_void_p)))
+    reg = np.empty((nleaf, 8), np.float32)
+    eng._chk(eng._L.mi_icp_debug_get_leaf_regions(eng._ctx, reg.ctypes.data_as(C.c_void_p)))
+    lo, hi, reach = reg[:, 0:3].astype(np.float64), reg[:, 4:7].astype(np.float64), reg[:, 3]
+    p = np.where(finite[:, None], xyz, np.nan).reshape(nleaf, 8, 3)
+    with np.errstate(all="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            bmin, bmax = np.nanmin(p, 1).astype(np.float64), np.nanmax(p, 1).astype(np.float64)   # NaN rows: empty leaves
+    nonempty = np.isfinite(bmin).all(1)
+    have = np.flatnonzero(reach > 0)
+    if os.environ.get("MI_ICP_NO_CELLS") is not None or os.environ.get("MI_ICP_NO_LINKS") is not None:
+        assert len(have) == 0
+        return 0
+    for L in np.random.default_rng(6).permutation(have)[:300]:
+        with np.errstate(invalid="ignore"):
+            gaps = np.concatenate([bmin - hi[L], lo[L] - bmax], 1)            # [ux uy uz lx ly lz] per leaf
+        dist = np.maximum(np.nan_to_num(gaps, nan=-np.inf).max(1), 0.0)
+        others = nonempty.copy()
+        others[L] = False
+        near = set(np.flatnonzero(others & (dist < float(reach[L]))).tolist())
+        ids, dw = links[L, :, 0], links[L, :, 1]
+        used = ids != 0xffffffff
+        listed = set(ids[used].tolist())
+        assert near <= listed, (int(L), sorted(near - listed)[:5], float(reach[L]))
+        assert L not in listed
+        d_stored = (dw & ~np.uint32(63)).view(np.float32)
+        assert np.isinf(d_stored[~used]).all() and (np.diff(d_stored[used]) >= 0).all()
+        for j, ds, m in zip(ids[used], d_stored[used], dw[used] & 63):
+            assert ds <= dist[j] * (1 + 1e-6) + 1e-30 and ds >= dist[j] * (1 - 1e-5) - 1e-30, (int(L), int(j), ds, dist[j])
+            g = gaps[j]
+            want = sum(((g[a] >= 0) << (2 * a)) | ((g[3 + a] >= 0) << (2 * a + 1)) for a in range(3))
+            assert int(m) == int(want), (int(L), int(j), int(m), int(want))
+    return len(have)
 
 
 def check_leaf_regions(eng, nleaf, xyz, finite):
