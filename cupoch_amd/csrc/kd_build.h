@@ -29,6 +29,7 @@ struct GroupBuildArgs {
     float* tcov;              // [ngroups * 4096 * 9] or null
     float* records;
     float* lreg;              // [ngroups * 512][8] leaf regions (below)
+    float link_delta;         // start bound of the neighbour lists as a fraction of the leaf-level node's extent
 };
 
 // LEAF REGIONS.  Every leaf (8 slots) also gets its kd cell -- the box that is free of points
@@ -43,7 +44,8 @@ struct GroupBuildArgs {
 // Float 3 is the REACH of the leaf's neighbour list (leaf_links.h); 0: none.
 
 
-__global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) {
+// (two 1024-thread workgroups per CU = 8 waves per SIMD: at most 64 VGPRs)
+__global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void kd_build_groups(GroupBuildArgs a) {
     __shared__ KdShared s;
     __shared__ uint32_t s_src[3];  // first sorted position, number of points of this group, groups of its cell
     __shared__ float s_region[6];
@@ -142,42 +144,38 @@ __global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) 
         if (own_flag) {
 #pragma unroll
             for (int e = 0; e < 6; ++e) reg[e] = s.safe[e * 64 + (tid >> 3)];
-#pragma unroll
-            for (int lev = 2; lev >= 0; --lev) {
+            for (int lev = 2; lev >= 0; --lev) {  // (not unrolled: registers are scarce here)
                 const int h = tid >> lev, sib = h ^ 1;
                 const int p0 = (h >> 1) << (lev + 1), s0 = sib << lev;
-                float pmn[3] = {INFINITY, INFINITY, INFINITY}, pmx[3] = {-INFINITY, -INFINITY, -INFINITY};
-                float smn[3] = {INFINITY, INFINITY, INFINITY}, smx[3] = {-INFINITY, -INFINITY, -INFINITY};
-                for (int c = 0; c < (2 << lev); ++c) {
-                    const bool in_sib = (p0 + c) >= s0 && (p0 + c) < s0 + (1 << lev);
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        const float lo = s.bb[d * kKdChunks + p0 + c], hi = s.bb[(3 + d) * kKdChunks + p0 + c];
-                        pmn[d] = fminf(pmn[d], lo);
-                        pmx[d] = fmaxf(pmx[d], hi);
-                        if (in_sib) {
-                            smn[d] = fminf(smn[d], lo);
-                            smx[d] = fmaxf(smx[d], hi);
-                        }
+                // the parent's longest axis: the axis the sort split it along
+                int ax = 0;
+                float e = -INFINITY;
+                for (int d = 0; d < 3; ++d) {
+                    float mn = INFINITY, mx = -INFINITY;
+                    for (int c = 0; c < (2 << lev); ++c) {
+                        mn = fminf(mn, s.bb[d * kKdChunks + p0 + c]);
+                        mx = fmaxf(mx, s.bb[(3 + d) * kKdChunks + p0 + c]);
+                    }
+                    if (d == 0 || mx - mn > e) {
+                        e = mx - mn;
+                        ax = d;
                     }
                 }
-                int ax = 0;
-                float e = pmx[0] - pmn[0];
-                if (pmx[1] - pmn[1] > e) {
-                    e = pmx[1] - pmn[1];
-                    ax = 1;
-                }
-                if (pmx[2] - pmn[2] > e) ax = 2;
+                // the sibling half's exact extreme along it
+                const bool lower = (h & 1) == 0;
+                float ext = lower ? INFINITY : -INFINITY;
+                for (int c = 0; c < (1 << lev); ++c)
+                    ext = lower ? fminf(ext, s.bb[ax * kKdChunks + s0 + c]) : fmaxf(ext, s.bb[(3 + ax) * kKdChunks + s0 + c]);
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
                     if (d == ax) {
-                        if ((h & 1) == 0) reg[3 + d] = fminf(reg[3 + d], smn[d]);
-                        else reg[d] = fmaxf(reg[d], smx[d]);
+                        if (lower) reg[3 + d] = fminf(reg[3 + d], ext);
+                        else reg[d] = fmaxf(reg[d], ext);
                     }
             }
         }
-        // float 7: the bound the neighbour-list build starts from (leaf_links.h) -- a quarter of the
-        // leaf-level node's largest extent, i.e. about one point spacing on volumetric data
+        // float 7: the bound the neighbour-list build starts from (leaf_links.h) -- a.link_delta (a
+        // quarter) of the leaf-level node's largest extent, i.e. about one point spacing on volumetric data
         float delta0 = 0.0f;
         if (own_flag) {
             const int n0 = tid & ~7;
@@ -191,7 +189,7 @@ __global__ __launch_bounds__(kKdThreads) void kd_build_groups(GroupBuildArgs a) 
                 }
                 ext = fmaxf(ext, mx - mn);
             }
-            delta0 = (ext > 0.0f && ext < INFINITY) ? 0.25f * ext : 0.0f;
+            delta0 = (ext > 0.0f && ext < INFINITY) ? ext * a.link_delta : 0.0f;
         }
         float4* out = reinterpret_cast<float4*>(a.lreg + ((size_t)g * kKdChunks + (size_t)tid) * kLeafRegFloats);
         out[0] = make_float4(reg[0], reg[1], reg[2], 0.0f);

@@ -20,30 +20,42 @@
 // overhang: two integer/float tests per entry instead of six compares on 24 bytes of box.
 // Unused entries: id 0xffffffff, distance +inf.
 //
-// Built by one wave per 64 consecutive leaves with the packet walk of traverse.h: lane = leaf,
-// search cube = R grown by the lane's current bound (starts at lreg[7] = a quarter of the
-// leaf-level node's extent, shrinks to the 32nd-nearest distance once the list is full), the
-// walk starts at the node that holds the 64 leaves and climbs until every lane's cube is inside
-// a completed subtree's region.  Candidate lists live in LDS columns exactly like the k-NN
-// search's (knn_normals.h: knn_offer), "distance" being the box distance.
+// Built in two launches.  leaf_links_collect: one wave per 64 consecutive leaves with the packet
+// walk of traverse.h -- lane = leaf, search cube = R grown by the lane's bound (lreg[7] = a quarter
+// of the leaf-level node's extent, about one point spacing on volumetric data), the walk starts
+// at the node that holds the 64 leaves and climbs until every lane's cube is inside a completed
+// subtree's region; what a lane accepts is appended to its row of the list array right away (no
+// LDS, so the walk -- a chain of dependent record fetches -- runs at full occupancy).  A row of
+// 64 candidates that fills up stops accepting and its bound drops to the nearest box it turned
+// away (rare).  leaf_links_select then sorts every row by distance in registers, keeps the 32
+// nearest and sets the reach: the 33rd-nearest distance, or the bound when there is none.
 #pragma once
 #include "device_utils.h"
-#include "knn_normals.h"
 #include "nn_search.h"
 #include "traverse.h"
 
 namespace mi {
 
-constexpr int kLinkSlots = kMaxKnn;           // 32 entries of 8 bytes per leaf
+constexpr int kLinkSlots = 32;                // entries of 8 bytes per leaf
 static_assert(kLinkSlots == kLinkSlotsNN, "nn_search.h scans kLinkSlotsNN entries");
 constexpr uint32_t kLinkIdMask = 0x3ffffffu;  // leaf ids fit 26 bits (the item queue's limit, nn_search.h)
 constexpr float kLinkShrink = 0.999999f;      // reach is reported a little short, the overhang a little long
 
-__global__ __launch_bounds__(64) void leaf_links_kernel(const float* __restrict__ records_g, uint32_t leaf_first,
-                                                        int nleaf, uint32_t nblocks, float* __restrict__ lreg,
-                                                        uint2* __restrict__ links) {
-    __shared__ float s_d[kLinkSlots * 64];
-    __shared__ int32_t s_id[kLinkSlots * 64];
+// Storage: tiles of 64 consecutive leaves.  Collected candidates -- up to kLinkCand per leaf -- go to a
+// scratch tile, candidate t of leaf L at link_temp_index (slot-major inside the tile: the
+// selection's loads are coalesced).  The finished tile (16 KB) is chunk-major -- the 32-byte chunk
+// k (entries 4k .. 4k+3) of leaf L at ((L / 64 * 8 + k) * 64 + L % 64) * 32 bytes -- so that a
+// search packet, whose lanes' seed leaves are consecutive, reads consecutive chunks.
+constexpr int kLinkCand = 64;
+__host__ __device__ __forceinline__ size_t link_temp_index(uint32_t L, int t) {  // in uint2
+    return ((size_t)(L >> 6) * kLinkCand + (size_t)t) * 64u + (L & 63u);
+}
+
+// lreg[L][3] <- bound, lreg[L][7] <- number of candidates (as an integer's bits), cand[L][0..count) unsorted;
+// candidate = {leaf id | direction mask << 26, distance bits}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void leaf_links_collect(
+        const float* __restrict__ records_g, uint32_t leaf_first, int nleaf, uint32_t nblocks,
+        float* __restrict__ lreg, uint2* __restrict__ cand) {
     uint32_t logical;
     if (!xcd_remap(nblocks, logical)) return;
     const int lane = lane_id();
@@ -57,91 +69,125 @@ __global__ __launch_bounds__(64) void leaf_links_kernel(const float* __restrict_
     }
     const float delta0 = g1.w;
     const bool usable = valid && g0.x <= g1.x && g0.y <= g1.y && g0.z <= g1.z && delta0 > 0.0f && delta0 < INFINITY;
-    KnnState st;
-    st.init(usable ? delta0 : -1.0f);
-    Cube cube;
-    auto grow = [&](float reach) {  // R grown by `reach` on every side (infinite faces stay infinite)
-        const float r = reach * 1.000001f;
-        cube.lox = widen_down(g0.x - r);
-        cube.loy = widen_down(g0.y - r);
-        cube.loz = widen_down(g0.z - r);
-        cube.hix = widen_up(g1.x + r);
-        cube.hiy = widen_up(g1.y + r);
-        cube.hiz = widen_up(g1.z + r);
-    };
-    if (usable) {
-        grow(delta0);
-    } else {
-        cube.lox = cube.loy = cube.loz = INFINITY;
-        cube.hix = cube.hiy = cube.hiz = -INFINITY;
-    }
-    // the node that holds this packet's 64 leaves: 8 leaf-level nodes = one node of the level above
-    const uint32_t start = (leaf_first >= 8u) ? ((leaf_first >> 3) + logical) : 1u;
-    traverse_from(records_g, leaf_first, start, cube,
-                  [&](uint32_t lbase, uint32_t vm, uint32_t hit, const float(&w)[48]) {
-                      bool shrunk = false;
-#pragma unroll
-                      for (int c = 0; c < 8; ++c) {
-                          if (!((hit >> c) & 1u)) continue;  // wave-uniform
-                          const float* b = w + (c >> 1) * kPairStride + (c & 1);
-                          const uint32_t leaf = lbase + (uint32_t)c;
-                          const bool mine = ((vm >> c) & 1u) != 0u && leaf != L;
-                          // gaps between the box [b0,b2,b4 .. b6,b8,b10] and R along each axis and side
-                          const float ux = b[0] - g1.x, uy = b[2] - g1.y, uz = b[4] - g1.z;   // box beyond the upper faces
-                          const float lx = g0.x - b[6], ly = g0.y - b[8], lz = g0.z - b[10];  // box beyond the lower faces
-                          const float dist = fmaxf(fmaxf(fmaxf(ux, lx), fmaxf(uy, ly)), fmaxf(fmaxf(uz, lz), 0.0f));
-                          const uint32_t dir = (ux >= 0.0f ? 1u : 0u) | (lx >= 0.0f ? 2u : 0u) | (uy >= 0.0f ? 4u : 0u) |
-                                               (ly >= 0.0f ? 8u : 0u) | (uz >= 0.0f ? 16u : 0u) | (lz >= 0.0f ? 32u : 0u);
-                          shrunk |= knn_offer(s_d, s_id, lane, kLinkSlots, st, mine ? dist : INFINITY,
-                                              (int32_t)(leaf | (dir << 26)));
-                      }
-                      if (shrunk) grow(st.worst);
-                  });
-    if (!valid) return;
-    // ---- sort by distance (ties: leaf id) in registers: one 64-bit key per entry, distance bits
-    // (>= 0, so their integer order is the float order) above the leaf id; unused slots last
-    unsigned long long key[kLinkSlots];
-#pragma unroll
-    for (int t = 0; t < kLinkSlots; ++t) {
-        key[t] = ~0ull;
-        if (t < st.count) {
-            const uint32_t pid = (uint32_t)s_id[t * 64 + lane];
-            // direction mask rides in the distance's 6 low mantissa bits (the distance is rounded down)
-            const uint32_t dw = (__float_as_uint(s_d[t * 64 + lane]) & ~63u) | (pid >> 26);
-            key[t] = ((unsigned long long)dw << 32) | (unsigned long long)(pid & kLinkIdMask);
+    float bound = usable ? delta0 : -1.0f;  // strict acceptance limit
+    int count = 0;
+    if (__ballot(usable) != 0ull) {  // (a packet of padding leaves -- the tail of every group -- has nothing to do)
+        Cube cube;
+        auto grow = [&](float reach) {  // R grown by `reach` on every side (infinite faces stay infinite)
+            const float r = reach * 1.000001f;
+            cube.lox = widen_down(g0.x - r);
+            cube.loy = widen_down(g0.y - r);
+            cube.loz = widen_down(g0.z - r);
+            cube.hix = widen_up(g1.x + r);
+            cube.hiy = widen_up(g1.y + r);
+            cube.hiz = widen_up(g1.z + r);
+        };
+        if (usable) {
+            grow(delta0);
+        } else {
+            cube.lox = cube.loy = cube.loz = INFINITY;
+            cube.hix = cube.hiy = cube.hiz = -INFINITY;
         }
-    }
+        // the node that holds this packet's 64 leaves: 8 leaf-level nodes = one node of the level above
+        const uint32_t start = (leaf_first >= 8u) ? ((leaf_first >> 3) + logical) : 1u;
+        traverse_from(records_g, leaf_first, start, cube,
+                      [&](uint32_t lbase, uint32_t vm, uint32_t hit, const float(&w)[48]) {
 #pragma unroll
-    for (int kk = 2; kk <= kLinkSlots; kk <<= 1)
+                          for (int c = 0; c < 8; ++c) {
+                              if (!((hit >> c) & 1u)) continue;  // wave-uniform
+                              const float* b = w + (c >> 1) * kPairStride + (c & 1);
+                              const uint32_t leaf = lbase + (uint32_t)c;
+                              // gaps between the box [b0,b2,b4 .. b6,b8,b10] and R along each axis and side
+                              const float ux = b[0] - g1.x, uy = b[2] - g1.y, uz = b[4] - g1.z;   // beyond the upper faces
+                              const float lx = g0.x - b[6], ly = g0.y - b[8], lz = g0.z - b[10];  // beyond the lower faces
+                              const float dist = fmaxf(fmaxf(fmaxf(ux, lx), fmaxf(uy, ly)), fmaxf(fmaxf(uz, lz), 0.0f));
+                              if (((vm >> c) & 1u) != 0u && leaf != L && dist < bound) {
+                                  if (count < kLinkCand) {
+                                      const uint32_t dir = (ux >= 0.0f ? 1u : 0u) | (lx >= 0.0f ? 2u : 0u) |
+                                                           (uy >= 0.0f ? 4u : 0u) | (ly >= 0.0f ? 8u : 0u) |
+                                                           (uz >= 0.0f ? 16u : 0u) | (lz >= 0.0f ? 32u : 0u);
+                                      cand[link_temp_index(L, count)] = make_uint2(leaf | (dir << 26), __float_as_uint(dist));
+                                      ++count;
+                                  } else {  // full: turned away, and nothing this far is promised any more
+                                      bound = dist;
+                                      grow(bound);
+                                  }
+                              }
+                          }
+                      });
+    }
+    if (!valid) return;
+    lreg[(size_t)L * kLeafRegFloats + 3] = usable ? bound : 0.0f;
+    lreg[(size_t)L * kLeafRegFloats + 7] = __int_as_float(count);
+}
+
+// Bitonic sort of N 32-bit keys held in registers (ascending)
+template <int N>
+__device__ __forceinline__ void sort_keys(uint32_t (&key)[N]) {
+#pragma unroll
+    for (int kk = 2; kk <= N; kk <<= 1)
 #pragma unroll
         for (int jj = kk >> 1; jj > 0; jj >>= 1)
 #pragma unroll
-            for (int t = 0; t < kLinkSlots; ++t) {
+            for (int t = 0; t < N; ++t) {
                 const int l = t ^ jj;
                 if (l > t) {
-                    const unsigned long long a = key[t], b = key[l];
-                    const unsigned long long mn = a < b ? a : b, mx = a < b ? b : a;
+                    const uint32_t mn = min(key[t], key[l]), mx = max(key[t], key[l]);
                     const bool asc = (t & kk) == 0;
                     key[t] = asc ? mn : mx;
                     key[l] = asc ? mx : mn;
                 }
             }
-    uint4* out = reinterpret_cast<uint4*>(links + (size_t)L * kLinkSlots);
+}
+
+// One wave per tile, lane = leaf: the 32 nearest candidates ascending in distance (unused entries
+// 0xffffffff / +inf) into the finished tile, and the list's reach into lreg[L][3].
+// Sort key = the distance's bits (>= 0: integer order = float order) with the 6 low mantissa bits
+// replaced by the candidate's slot; the final entry carries the direction mask in those bits
+// instead (both round the distance DOWN, the conservative side).
+template <int N>
+__device__ __forceinline__ void links_select(const uint2* __restrict__ cand, uint32_t L, int count, uint32_t lane,
+                                             uint4* __restrict__ tile, float bound, float* __restrict__ reach_out) {
+    uint32_t key[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        const uint32_t d = cand[link_temp_index(L, t)].y;  // (slots past `count` hold stale bytes: masked)
+        key[t] = (t < count) ? ((d & ~63u) | (uint32_t)t) : 0xffffffffu;
+    }
+    sort_keys<N>(key);
 #pragma unroll
     for (int t = 0; t < kLinkSlots; t += 2) {
         uint32_t e[4];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const bool have = key[t + u] != ~0ull;
-            e[2 * u] = have ? (uint32_t)key[t + u] : 0xffffffffu;
-            e[2 * u + 1] = have ? (uint32_t)(key[t + u] >> 32) : 0x7f800000u;
+            const bool have = key[t + u] != 0xffffffffu;
+            const uint32_t pid = cand[link_temp_index(L, have ? (int)(key[t + u] & 63u) : 0)].x;
+            e[2 * u] = have ? (pid & kLinkIdMask) : 0xffffffffu;
+            e[2 * u + 1] = have ? ((key[t + u] & ~63u) | (pid >> 26)) : 0x7f800000u;
         }
-        out[t >> 1] = make_uint4(e[0], e[1], e[2], e[3]);
+        // chunk t/4 of this leaf, its first or second half
+        tile[((size_t)(t >> 2) * 64u + lane) * 2u + ((t >> 1) & 1)] = make_uint4(e[0], e[1], e[2], e[3]);
     }
-    // complete for every distance below: the 32nd-nearest when the list is full, the start bound otherwise
+    // complete below: the nearest candidate that was left out, or the collection's bound
+    float reach = bound;
+    if (N > kLinkSlots) {
+        if (key[N > kLinkSlots ? kLinkSlots : 0] != 0xffffffffu)
+            reach = fminf(reach, __uint_as_float(key[N > kLinkSlots ? kLinkSlots : 0] & ~63u));
+    }
+    *reach_out = reach * kLinkShrink;
+}
+
+__global__ __launch_bounds__(64) void leaf_links_select(float* __restrict__ lreg, int nleaf,
+                                                        const uint2* __restrict__ cand, uint2* __restrict__ links) {
+    const uint32_t L = blockIdx.x * 64u + threadIdx.x;
+    const bool valid = L < (uint32_t)nleaf;
+    const int count = valid ? __float_as_int(lreg[(size_t)L * kLeafRegFloats + 7]) : 0;
+    const float bound = valid ? lreg[(size_t)L * kLeafRegFloats + 3] : 0.0f;
+    uint4* tile = reinterpret_cast<uint4*>(links) + (size_t)blockIdx.x * (kLinkSlots / 4) * 64u * 2u;
     float reach = 0.0f;
-    if (usable) reach = ((st.count >= kLinkSlots) ? st.worst : delta0) * kLinkShrink;
-    lreg[(size_t)L * kLeafRegFloats + 3] = reach;
+    if (__ballot(count > kLinkSlots) != 0ull) links_select<kLinkCand>(cand, L, count, threadIdx.x, tile, bound, &reach);
+    else links_select<kLinkSlots>(cand, L, count, threadIdx.x, tile, bound, &reach);
+    if (valid) lreg[(size_t)L * kLeafRegFloats + 3] = reach;
 }
 
 }  // namespace mi

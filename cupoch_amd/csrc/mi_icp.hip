@@ -86,11 +86,15 @@ struct mi_icp_ctx {
     int64_t nts = 0;  // sorted positions of the target incl. padding slots (kd_cells.h)
     uint32_t leaf_first = 1, nrecords = 0;  // 8-ary tree: first last-level node id, record count
     bool t_has_nrm = false, t_has_cov = false, t_has_int = false, t_has_grad = false;
-    DevBuf tblk, tnrm, tcov, tgrad, nodes, inv_t, tlreg, tlinks;
+    DevBuf tblk, tnrm, tcov, tgrad, nodes, inv_t, tlreg, tlinks, tlinks_tmp;
     DevBuf cell_planes, cell_samples, cell_cstart, cell_gstart;
     uint32_t* cell_total_host = nullptr;  // pinned
     bool inv_t_valid = false;
     bool links_ready = false, links_allowed = false;  // leaf_links.h
+    // the neighbour lists are built on a private stream, next to the loop's first (unseeded) pass
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_links = nullptr;
+    bool links_inflight = false;
 
     // ---- source (Morton order) ----
     int64_t ns = 0, ns_global = 0;
@@ -421,20 +425,62 @@ void collect_pooled(mi_icp_ctx* c, int executed) {
 // Every leaf's neighbour list (leaf_links.h): what lets a seeded query whose cube pokes out of its
 // leaf's region finish without a tree walk.  Built once per target, by the first search that can
 // use it (one-shot searches, k-NN and normal estimation never pay for it).
-int ensure_links(mi_icp_ctx* c) {
-    if (c->links_ready || c->nt <= 0) return MI_ICP_OK;
+int build_links(mi_icp_ctx* c, hipStream_t st) {
     static const bool no_links = std::getenv("MI_ICP_NO_LINKS") != nullptr;  // A/B switch
     uint2* links;
-    TRY(ensure(c, c->tlinks, (size_t)c->nleaf * kLinkSlots, &links));
+    const size_t ntiles = ((size_t)c->nleaf + 63) / 64;
+    TRY(ensure(c, c->tlinks, ntiles * 64 * kLinkSlots, &links));
     if (c->links_allowed && !no_links) {
-        const uint32_t lblocks = (uint32_t)((c->nleaf + 63) / 64);
-        leaf_links_kernel<<<((lblocks + 7u) / 8u) * 8u, 64, 0, c->stream>>>(
-                (const float*)c->nodes.p, c->leaf_first, c->nleaf, lblocks, (float*)c->tlreg.p, links);
+        uint2* cand;  // scratch: up to 64 candidates per leaf
+        TRY(ensure(c, c->tlinks_tmp, ntiles * 64 * kLinkCand, &cand));
+        const uint32_t lblocks = (uint32_t)ntiles;
+        leaf_links_collect<<<((lblocks + 7u) / 8u) * 8u, 64, 0, st>>>(
+                (const float*)c->nodes.p, c->leaf_first, c->nleaf, lblocks, (float*)c->tlreg.p, cand);
+        KCHK(c);
+        leaf_links_select<<<(unsigned)ntiles, 64, 0, st>>>((float*)c->tlreg.p, c->nleaf, cand, links);
         KCHK(c);
     } else {
-        HIPCHK(c, hipMemsetAsync(links, 0xff, (size_t)c->nleaf * kLinkSlots * sizeof(uint2), c->stream));
+        HIPCHK(c, hipMemsetAsync(links, 0xff, ntiles * 64 * kLinkSlots * sizeof(uint2), st));
     }
+    return MI_ICP_OK;
+}
+
+// The lists must be complete before the next kernel on the context's stream reads them.
+int ensure_links(mi_icp_ctx* c) {
+    if (c->nt <= 0) return MI_ICP_OK;
+    if (c->links_inflight) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_links, 0));
+        c->links_inflight = false;
+        c->links_ready = true;
+    }
+    if (c->links_ready) return MI_ICP_OK;
+    TRY(build_links(c, c->stream));
     c->links_ready = true;
+    return MI_ICP_OK;
+}
+
+// Start the build on the private stream (behind everything enqueued on the context's stream so
+// far): the registration loop calls this before its first, unseeded pass, which does not read
+// the lists -- the two run side by side.
+int start_links_async(mi_icp_ctx* c) {
+    static const bool sync_links = std::getenv("MI_ICP_LINKS_SYNC") != nullptr;  // A/B switch
+    if (c->nt <= 0 || c->links_ready || c->links_inflight || sync_links) return MI_ICP_OK;
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    TRY(build_links(c, c->side));
+    HIPCHK(c, hipEventRecord(c->ev_links, c->side));
+    c->links_inflight = true;
+    return MI_ICP_OK;
+}
+
+// A new target: nothing of the old one may still be read or written by the private stream.
+int drain_links(mi_icp_ctx* c) {
+    if (c->links_inflight) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_links, 0));
+        HIPCHK(c, hipStreamSynchronize(c->side));
+        c->links_inflight = false;
+    }
+    c->links_ready = false;
     return MI_ICP_OK;
 }
 
@@ -651,6 +697,9 @@ int mi_icp_create(int device, mi_icp_ctx** out) {
               hipHostMalloc((void**)&c->u_host, 16 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&c->loop_host, sizeof(DevLoop), hipHostMallocDefault) == hipSuccess;
     for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_links, hipEventDisableTiming) == hipSuccess;
     for (int k = 0; k < 2 && ok; ++k)
         for (int i = 0; i < mi_icp_ctx::kEvPairs && ok; ++i)
             ok = hipEventCreate(&c->evp[k][i][0]) == hipSuccess && hipEventCreate(&c->evp[k][i][1]) == hipSuccess;
@@ -667,8 +716,14 @@ void mi_icp_destroy(mi_icp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->aux) mi_icp_destroy(c->aux);
+    if (c->side) {
+        (void)hipStreamSynchronize(c->side);
+        (void)hipStreamDestroy(c->side);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_links) (void)hipEventDestroy(c->ev_links);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    DevBuf* all[] = {&c->tlreg, &c->tlinks, &c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
+    DevBuf* all[] = {&c->tlreg, &c->tlinks, &c->tlinks_tmp, &c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
                      &c->cell_gstart, &c->sx, &c->sy, &c->sz,
                      &c->sperm, &c->snrm, &c->scov, &c->nn_idx, &c->nn_d2, &c->inv_s,
                      &c->user_pairs, &c->keys0, &c->keys1, &c->vals0, &c->vals1, &c->hist,
@@ -728,6 +783,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
                       int64_t n, int mem_kind) {
     TRY(check_ctx(c));
     if (n < 0 || n > 0x7fffff00ll || (n > 0 && !xyz)) return fail(c, MI_ICP_ERR_INVALID, "set_target: bad size/pointer");
+    TRY(drain_links(c));
     c->nt = 0;
     c->inv_t_valid = false;
     c->nn_valid = false;
@@ -814,6 +870,8 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
         ga.tcov = tcov;
         ga.records = nodes;
         ga.lreg = lreg;
+        static const float link_delta = [] { const char* e = std::getenv("MI_ICP_LINK_DELTA"); const float v = e ? (float)std::atof(e) : 0.0f; return v > 0.0f ? v : 0.25f; }();
+        ga.link_delta = link_delta;
         kd_build_groups<<<(unsigned)lay.ngroups, kKdThreads, 0, c->stream>>>(ga);
         KCHK(c);
         first = leaf_first >> 9;  // the groups' own boxes sit in the records of this level
@@ -827,7 +885,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
         KCHK(c);
         used = (used + 7u) / 8u;
     }
-    c->links_ready = false;  // the leaves' neighbour lists are built by the first seeded search (launch_nn)
+    c->links_ready = false;  // the leaves' neighbour lists are built by the registration loop / the first seeded search
     c->links_allowed = !no_cells && (uint32_t)nleaf <= kLinkIdMask;
     c->nt = n;
     c->nts = nts;
@@ -1228,6 +1286,7 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
     TRY(ensure(c, c->loop_dev, 1, &d));
     HIPCHK(c, hipMemcpyAsync(d, &L, sizeof(DevLoop), hipMemcpyHostToDevice, c->stream));
     c->loop_active = true;
+    TRY(start_links_async(c));  // (the first pass below is unseeded and does not read them)
     TRY(loop_enqueue_evaluation(c, false));
     // from here on the packets follow the target's order (pays for itself in ~4 iterations)
     static const bool no_resort = std::getenv("MI_ICP_NO_RESORT") != nullptr;  // A/B switch for tuning
@@ -2053,9 +2112,16 @@ int mi_icp_debug_get_leaf_links(mi_icp_ctx* c, uint32_t* links_out) {
     TRY(check_ctx(c));
     if (!links_out || c->nt <= 0) return fail(c, MI_ICP_ERR_INVALID, "debug_get_leaf_links: no target / bad arguments");
     TRY(ensure_links(c));
-    HIPCHK(c, hipMemcpyAsync(links_out, c->tlinks.p, (size_t)c->nleaf * kLinkSlots * sizeof(uint2),
-                             hipMemcpyDeviceToHost, c->stream));
+    // device layout: tiles of 64 leaves, 32-byte chunks (4 entries) chunk-major -> rows per leaf
+    const size_t ntiles = ((size_t)c->nleaf + 63) / 64;
+    std::vector<uint32_t> raw(ntiles * 64 * kLinkSlots * 2);
+    HIPCHK(c, hipMemcpyAsync(raw.data(), c->tlinks.p, raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int64_t L = 0; L < c->nleaf; ++L)
+        for (int k = 0; k < kLinkSlots / 4; ++k)
+            std::memcpy(links_out + ((size_t)L * kLinkSlots + (size_t)k * 4) * 2,
+                        raw.data() + (((size_t)(L >> 6) * (kLinkSlots / 4) + (size_t)k) * 64 + (size_t)(L & 63)) * 8,
+                        8 * sizeof(uint32_t));
     return MI_ICP_OK;
 }
 

@@ -263,15 +263,17 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
         // lane stops at the first one beyond its overhang; an entry whose box lies beyond a face
         // the cube does not poke through cannot overlap it.  What passes is queued as a
         // (lane, leaf) item like any leaf the tree walk would have found.
-        const uint4* lk = reinterpret_cast<const uint4*>(links_g + (size_t)(linked ? seed_leaf : 0u) * kLinkSlotsNN);
+        // chunk k4 of leaf L: 32 bytes at ((L / 64 * 8 + k4) * 64 + L % 64) * 32 (leaf_links.h)
+        const uint32_t sl = linked ? seed_leaf : 0u;
+        const uint4* lk = reinterpret_cast<const uint4*>(links_g) + ((size_t)(sl >> 6) * (kLinkSlotsNN / 4) * 64u + (sl & 63u)) * 2u;
         bool scanning = linked;
         spilled = true;
         for (int k4 = 0; k4 < kLinkSlotsNN / 4; ++k4) {
             if (__ballot(scanning) == 0ull) break;
             uint4 e0 = make_uint4(0u, 0x7f800000u, 0u, 0x7f800000u), e1 = e0;
             if (scanning) {
-                e0 = lk[2 * k4];
-                e1 = lk[2 * k4 + 1];
+                e0 = lk[(size_t)k4 * 128u];
+                e1 = lk[(size_t)k4 * 128u + 1u];
             }
             const uint32_t ids[4] = {e0.x, e0.z, e1.x, e1.z};
             const uint32_t dw[4] = {e0.y, e0.w, e1.y, e1.w};
