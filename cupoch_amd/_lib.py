@@ -117,6 +117,7 @@ SIGNATURES = {
     "mi_icp_comm_init": (_I, [_P, _P, _I, _I]),
     "mi_icp_comm_destroy": (_I, [_P]),
     "mi_icp_set_global_source_count": (_I, [_P, _L]),
+    "mi_icp_spatial_order": (_I, [_P, _P, _L, _P, _I]),
     "mi_icp_set_profiling": (_I, [_P, _I]),
     "mi_icp_get_profile": (_I, [_P, _P]),
     # include/mi_icp_debug.h (test-only)

@@ -2073,16 +2073,23 @@ int mi_icp_debug_exclusive_scan(mi_icp_ctx* c, const uint32_t* in, uint32_t* out
     return MI_ICP_OK;
 }
 
-int mi_icp_debug_morton_order(mi_icp_ctx* c, const float* xyz, int64_t n, uint32_t* order_out) {
+int mi_icp_spatial_order(mi_icp_ctx* c, const float* xyz, int64_t n, uint32_t* order_out, int mem_kind) {
     TRY(check_ctx(c));
-    if (n <= 0 || !xyz || !order_out) return fail(c, MI_ICP_ERR_INVALID, "debug_morton_order: bad arguments");
+    if (n < 0 || n > 0x7fffff00ll || (n > 0 && (!xyz || !order_out)))
+        return fail(c, MI_ICP_ERR_INVALID, "spatial_order: bad arguments");
+    if (n == 0) return MI_ICP_OK;
     const float* d_pts;
-    TRY(to_device(c, xyz, (size_t)n * 3, MI_ICP_HOST, c->stage[0], &d_pts));
+    TRY(to_device(c, xyz, (size_t)n * 3, mem_kind, c->stage[0], &d_pts));
     const uint32_t* order;
     TRY(morton_order(c, d_pts, n, &order, false));
-    HIPCHK(c, hipMemcpyAsync(order_out, order, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    TRY(from_device(c, order, order_out, (size_t)n, mem_kind));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MI_ICP_OK;
+}
+
+int mi_icp_debug_morton_order(mi_icp_ctx* c, const float* xyz, int64_t n, uint32_t* order_out) {
+    if (n <= 0) return fail(c, MI_ICP_ERR_INVALID, "debug_morton_order: bad arguments");
+    return mi_icp_spatial_order(c, xyz, n, order_out, MI_ICP_HOST);
 }
 
 int mi_icp_debug_nn_stats(mi_icp_ctx* c, const float* T, float radius, int use_seed, uint64_t* out4) {

@@ -113,3 +113,66 @@ def allreduce_system(sys32):
         t = t.to(torch.device("cuda", torch.cuda.current_device()))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()
+
+
+class HostDrivenLoop:
+    """The registration loop driven from the host, one rank of a sharded run: search + reduction on
+    this rank's shard (HIP kernels), torch.distributed all-reduce of the 32 doubles (any backend:
+    gloo between processes that share one GPU, nccl = RCCL between GPUs), the 6x6 solve on the
+    host, identical on every rank.  One host round trip per iteration -- the fallback for when the
+    in-library RCCL communicator (init_engine_comm: all-reduce and step stay on the device) is
+    not available, and the form the two-processes-on-one-GPU test drives.
+
+    Same stepping interface as Engine.icp_begin / icp_iterate."""
+
+    def __init__(self, engine, est, max_distance, n_source_total, det_thresh=-1.0, init=None, world=None):
+        import torch.distributed as dist
+        self.eng, self.est, self.max_distance = engine, int(est), float(max_distance)
+        self.det_thresh = float(det_thresh)
+        self.n_total = int(n_source_total)
+        self.world = (dist.get_world_size() if dist.is_initialized() else 1) if world is None else int(world)
+        self.T = np.eye(4, dtype=np.float32) if init is None else np.asarray(init, np.float32).copy()
+        self.fitness = self.inlier_rmse = 0.0
+        self.iterations = 0
+        engine.set_global_source_count(self.n_total)
+
+    def _evaluate(self):
+        """correspondences under self.T; the job's fitness / rmse from the summed statistics"""
+        self.eng.evaluate_registration(self.max_distance, self.T)
+        sys32 = self.eng.compute_system(self.est, self.T)
+        if self.world > 1:
+            sys32 = allreduce_system(sys32)
+        cnt = sys32[29]
+        self.fitness = float(np.float32(cnt) / np.float32(self.n_total)) if cnt > 0 and self.n_total > 0 else 0.0
+        self.inlier_rmse = float(np.sqrt(np.float32(sys32[28]) / np.float32(cnt))) if cnt > 0 else 0.0
+        return sys32
+
+    def begin(self):
+        self.sys32 = self._evaluate()
+        return self
+
+    def iterate(self, k=1):
+        from .engine import kabsch_from_sums, solve_system
+        for _ in range(int(k)):
+            if self.est == 1:                                  # point-to-point: Kabsch from the sums
+                upd = kabsch_from_sums(self.sys32, self.n_total)
+            else:
+                ok, upd = solve_system(self.sys32, self.det_thresh)
+                if self.est == 3 and ok:                        # symmetric: the half rotation applied twice
+                    full = np.eye(4, dtype=np.float32)
+                    full[:3, :3] = (upd[:3, :3].astype(np.float64) @ upd[:3, :3].astype(np.float64)).astype(np.float32)
+                    full[:3, 3] = upd[:3, 3]
+                    upd = full
+            self.T = (upd @ self.T).astype(np.float32)
+            self.iterations += 1
+            self.sys32 = self._evaluate()
+        return self
+
+
+def device_shard_source(engine, points, rank, world):
+    """Original indices (ascending) of rank's spatial shard, cut from the Morton order the ENGINE
+    computes on the device (no host sort of the whole cloud on every rank).  points: (n, 3)
+    numpy array or torch tensor on the engine's device; returns an int64 numpy array."""
+    order = engine.morton_order(points)
+    lo, hi = shard_bounds(len(order), rank, world)
+    return np.sort(order[lo:hi].astype(np.int64))

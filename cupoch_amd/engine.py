@@ -204,6 +204,20 @@ class Engine:
                                                           C.byref(res)))
         return res
 
+    def morton_order(self, points):
+        """order[s] = original index of the s-th point of the engine's spatial (Morton) order;
+        numpy int64.  points: numpy or a torch tensor on the engine's device (sorted there)."""
+        p = _Buf(points, np.float32, 3, self.device)
+        if p.n == 0:
+            return np.zeros(0, np.int64)
+        if p.kind == MI_ICP_DEVICE:
+            out = torch.empty(p.n, dtype=torch.int32, device=p.keep.device)
+            self._chk(self._L.mi_icp_spatial_order(self._ctx, p.ptr, p.n, C.c_void_p(out.data_ptr()), p.kind))
+            return out.cpu().numpy().view(np.uint32).astype(np.int64)
+        out = np.empty(p.n, np.uint32)
+        self._chk(self._L.mi_icp_spatial_order(self._ctx, p.ptr, p.n, out.ctypes.data_as(C.c_void_p), p.kind))
+        return out.astype(np.int64)
+
     def set_global_source_count(self, n_total):
         self._chk(self._L.mi_icp_set_global_source_count(self._ctx, int(n_total)))
 

@@ -353,6 +353,12 @@ MI_ICP_API int mi_icp_comm_init(mi_icp_ctx* ctx, const char* id128, int nranks, 
 MI_ICP_API int mi_icp_comm_destroy(mi_icp_ctx* ctx);
 /* total source size over all ranks (fitness denominator, registration.cu:76) */
 MI_ICP_API int mi_icp_set_global_source_count(mi_icp_ctx* ctx, int64_t n_total);
+/* The order in which a source cloud is cut into per-rank shards: order_out[s] = original index
+ * of the s-th point along the engine's space-filling (Morton) order, so that rank r of R takes
+ * order_out[r*n/R .. (r+1)*n/R) -- one compact region of the target tree per GPU.  Computed on
+ * the device (bounds, keys, radix sort); xyz and order_out on the side named by mem_kind. */
+MI_ICP_API int mi_icp_spatial_order(mi_icp_ctx* ctx, const float* xyz, int64_t n, uint32_t* order_out,
+                                    int mem_kind);
 
 /* ---- instrumentation ----------------------------------------------------
  * enable != 0: every nearest-neighbour and reduction launch is bracketed by

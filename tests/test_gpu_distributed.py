@@ -1,0 +1,107 @@
+"""GPU: the N > 1 path on the HIP kernels.
+
+Two PROCESSES share GPU 0, each holds the full target and its Morton-contiguous shard of the
+source (cut from the order the engine computes on the device), every iteration all-reduces the
+32 doubles over torch.distributed (gloo here -- RCCL cannot put two ranks on one device) and
+solves the same 6x6: final transformation, statistics and the gathered correspondence set must
+equal the single-process run.  Plus the in-library RCCL all-reduce on a one-rank communicator."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT, make_pair
+
+pytestmark = pytest.mark.gpu
+PT2PL = 2
+N, ITER = 60000, 8
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from cupoch_amd import distributed as D
+    from cupoch_amd.engine import Engine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    d = make_pair(N, seed=13, noise=0.03)
+    eng = Engine(0)
+    src_dev = torch.from_numpy(d["src"]).cuda()
+    mine = D.device_shard_source(eng, src_dev, rank, world)          # Morton order computed on the device
+    box = d["src"][mine]
+    assert np.prod(box.max(0) - box.min(0)) < 0.8                      # a spatial shard, not a random half
+    eng.set_target(torch.from_numpy(d["tgt"]).cuda(), torch.from_numpy(d["tgt_nrm"]).cuda())
+    eng.set_source(src_dev[torch.from_numpy(mine).cuda()])
+    loop = D.HostDrivenLoop(eng, PT2PL, d["max_dist"], N).begin()
+    loop.iterate(ITER)
+    allc = D.gather_correspondences(eng.get_correspondences(), mine)
+    np.save(os.path.join(out_dir, "T_%d.npy" % rank), loop.T)
+    np.save(os.path.join(out_dir, "stat_%d.npy" % rank), np.array([loop.fitness, loop.inlier_rmse]))
+    np.save(os.path.join(out_dir, "corr_%d.npy" % rank), allc)
+    np.save(os.path.join(out_dir, "idx_%d.npy" % rank), mine)
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_on_one_gpu_equal_the_single_process_run(tmp_path):
+    from cupoch_amd import distributed as D
+    from cupoch_amd.engine import Engine
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    d = make_pair(N, seed=13, noise=0.03)
+    eng = Engine(0)
+    eng.set_target(d["tgt"], d["tgt_nrm"])
+    eng.set_source(d["src"])
+    # the same host-driven arithmetic on one rank ...
+    one = D.HostDrivenLoop(eng, PT2PL, d["max_dist"], N, world=1).begin()
+    one.iterate(ITER)
+    cor1 = eng.get_correspondences()
+    # ... and the device-resident loop
+    res = eng.registration_icp(PT2PL, d["max_dist"], None, 0.0, 0.0, ITER, -1.0)
+    Tdev = np.array(res.transformation, np.float32).reshape(4, 4).T
+    T0, T1 = np.load(tmp_path / "T_0.npy"), np.load(tmp_path / "T_1.npy")
+    np.testing.assert_array_equal(T0, T1)                                  # all ranks take identical steps
+    assert np.linalg.norm(T0 - one.T) <= 1e-6 and np.linalg.norm(T0 - Tdev) <= 1e-6
+    s0 = np.load(tmp_path / "stat_0.npy")
+    assert s0[0] == pytest.approx(one.fitness, abs=1e-6) and s0[1] == pytest.approx(one.inlier_rmse, rel=1e-5)
+    assert s0[0] == pytest.approx(res.fitness, abs=1e-6)
+    c0, c1 = np.load(tmp_path / "corr_0.npy"), np.load(tmp_path / "corr_1.npy")
+    np.testing.assert_array_equal(c0, c1)
+    np.testing.assert_array_equal(c0, cor1)                                 # = the single-process set, same order
+    i0, i1 = np.load(tmp_path / "idx_0.npy"), np.load(tmp_path / "idx_1.npy")
+    assert len(np.intersect1d(i0, i1)) == 0 and len(i0) + len(i1) == N
+    eng.close()
+
+
+def test_in_library_rccl_allreduce_on_a_one_rank_communicator():
+    """mi_icp_comm_init + the per-iteration ncclAllReduce(double, 32) on the engine's stream: with a
+    single rank the sum is the identity, so the loop must return exactly what it returns without."""
+    from cupoch_amd.engine import Engine, comm_unique_id
+    d = make_pair(40000, seed=5, noise=0.02)
+    eng = Engine(0)
+    eng.set_target(d["tgt"], d["tgt_nrm"])
+    eng.set_source(d["src"])
+    ref = eng.registration_icp(PT2PL, d["max_dist"], None, 0.0, 0.0, 6, -1.0)
+    eng.comm_init(comm_unique_id(), 1, 0)
+    eng.set_global_source_count(len(d["src"]))
+    got = eng.registration_icp(PT2PL, d["max_dist"], None, 0.0, 0.0, 6, -1.0)
+    np.testing.assert_array_equal(np.array(got.transformation), np.array(ref.transformation))
+    assert got.fitness == ref.fitness and got.inlier_rmse == ref.inlier_rmse
+    eng.comm_destroy()
+    eng.close()
