@@ -1,7 +1,7 @@
 // cupoch/knn/kdtree_flann.h (reference: knn/kdtree_flann.h:43-124, .inl:46-144, .cu:34-79)
 // Same class and method names; the index behind it is the engine's kd tree
 // (mi_icp_set_target / mi_icp_search_knn), one engine context per KDTreeFlann.
-// At most 32 neighbours per query (the reference allows NUM_MAX_NN = 100).
+// Up to knn::NUM_MAX_NN = 100 neighbours per query, as the reference.
 #pragma once
 #include <memory>
 

@@ -26,7 +26,7 @@ public:
 
 class KDTreeSearchParamRadius : public KDTreeSearchParam {
 public:
-    KDTreeSearchParamRadius(float radius, int max_nn = NUM_MAX_NN)
+    KDTreeSearchParamRadius(float radius, int max_nn)
         : KDTreeSearchParam(SearchType::Radius), radius_(radius), max_nn_(max_nn) {}
     float radius_;
     int max_nn_;

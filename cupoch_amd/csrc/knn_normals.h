@@ -28,30 +28,39 @@
 
 namespace mi {
 
-constexpr int kMaxKnn = 32;
+// Candidate lists come in two capacities: 32 slots (two waves per workgroup, 16 KB of LDS per
+// wave: every caller on the ICP path -- normals with 30, GICP 20, colour gradients 30) and 104 slots
+// for anything up to knn::NUM_MAX_NN = 100 (knn/kdtree_search_param.h:26; one wave per workgroup,
+// 52 KB of LDS: three workgroups per CU -- slower per query, same results).
+constexpr int kMaxKnn = 32;       // capacity of the small instantiation
+constexpr int kMaxKnnBig = 104;   // ... of the big one (a multiple of 8: the maxima are tracked per group of 8)
+constexpr int kKnnLimit = 100;    // NUM_MAX_NN: the most neighbours a search may ask for
+__host__ __device__ constexpr int knn_waves(int kcap) { return kcap <= kMaxKnn ? 2 : 1; }
 constexpr int kKnnThreads = 128;
 constexpr int kKnnWaves = kKnnThreads / 64;
 constexpr int kKnnLeavesPerBlock = kKnnWaves * 8;
 constexpr int kKnnSeedBefore = 4, kKnnSeedAfter = 12;  // leaves around the packet's first leaf
 
-struct KnnState {
+template <int KCAP>
+struct KnnStateT {
     float worst;  // current bound: +inf (or the search radius) until k candidates are held
     int count;
     int worst_pos;
     // the largest distance (and its slot) within each group of 8 candidate slots
-    float gmax[kMaxKnn / 8];
-    int gpos[kMaxKnn / 8];
+    float gmax[KCAP / 8];
+    int gpos[KCAP / 8];
     __device__ __forceinline__ void init(float bound) {
         worst = bound;
         count = 0;
         worst_pos = 0;
 #pragma unroll
-        for (int g = 0; g < kMaxKnn / 8; ++g) {
+        for (int g = 0; g < KCAP / 8; ++g) {
             gmax[g] = -1.0f;  // below every d2
             gpos[g] = g * 8;
         }
     }
 };
+typedef KnnStateT<kMaxKnn> KnnState;
 
 // Offer candidate (d2, j) to this lane's list of the k nearest (LDS columns kd2 / kidx, slot
 // t of lane l at [t * 64 + l]).  A full list replaces its largest entry; the new largest is
@@ -59,9 +68,10 @@ struct KnnState {
 // are compared in registers -- instead of re-reading all 32 slots (which cost 32 LDS reads +
 // ~130 VALU per accepted candidate, and the wave executes this path whenever ANY lane
 // accepts).  Ties resolve to the lowest slot either way, so the results are unchanged.
-__device__ __forceinline__ bool knn_offer(float* kd2, int32_t* kidx, int lane, int k, KnnState& s,
+template <int KCAP>
+__device__ __forceinline__ bool knn_offer(float* kd2, int32_t* kidx, int lane, int k, KnnStateT<KCAP>& s,
                                           float d2, int32_t j) {
-    constexpr int kGroups = kMaxKnn / 8;
+    constexpr int kGroups = KCAP / 8;
     bool shrunk = false;
     if (d2 < s.worst) {
         const int pos = s.worst_pos;
@@ -117,14 +127,15 @@ __device__ __forceinline__ bool knn_offer(float* kd2, int32_t* kidx, int lane, i
 // OUT 0: normals_out[orig] (3 floats).  OUT 1: tgrad[sorted] (float4, w = 0) and, when
 // not null, normals_out[orig] receives the gradient for inspection; tnrm = sorted target
 // normals with the intensity in .w.
-template <int OUT>
-__global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
+template <int OUT, int KCAP = kMaxKnn>
+__global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_normals_kernel(
         const float* __restrict__ records_g, const float* __restrict__ tblk_g, uint32_t leaf_first, int64_t n,
         int nleaf,
         int k, float r2, uint32_t nblocks, float* __restrict__ normals_out,
         const float4* __restrict__ tnrm, float4* __restrict__ tgrad) {
-    __shared__ float s_d2[kKnnWaves][kMaxKnn * 64];
-    __shared__ int32_t s_idx[kKnnWaves][kMaxKnn * 64];
+    constexpr int kWaves = knn_waves(KCAP);
+    __shared__ float s_d2[kWaves][KCAP * 64];
+    __shared__ int32_t s_idx[kWaves][KCAP * 64];
     uint32_t logical;
     if (!xcd_remap(nblocks, logical)) return;
     const cfloat_p tblk = (cfloat_p)(uintptr_t)tblk_g;
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
     float* kd2 = s_d2[wid];
     int32_t* kidx = s_idx[wid];
 
-    const int pkt = (int)logical * kKnnWaves + wid;
+    const int pkt = (int)logical * kWaves + wid;
     const int leaf0 = pkt * 8;
     if (leaf0 >= nleaf) return;  // whole wave out of range (no block barriers below)
     const int64_t i = (int64_t)pkt * 64 + lane;
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
         orig = __float_as_int(line[24]);
     }
     const bool valid = orig >= 0;
-    KnnState st;
+    KnnStateT<KCAP> st;
     // r2 = +inf: plain k-NN; finite: the k nearest with d2 < r2 (KDTreeSearchParamRadius)
     st.init((valid && k > 0) ? r2 : -1.0f);
 
@@ -294,20 +305,22 @@ __global__ __launch_bounds__(kKnnThreads) void knn_normals_kernel(
 // need not be near any particular leaf), and at the end every lane sorts its candidates in
 // registers -- a 32-input bitonic network on (d2, original index) -- and writes its row
 // [k] of indices / squared distances, padded with -1 / +inf, at the query's ORIGINAL index.
-__global__ __launch_bounds__(kKnnThreads) void knn_search_kernel(
+template <int KCAP = kMaxKnn>
+__global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
         const float* __restrict__ records_g, const float* __restrict__ tblk_g, uint32_t leaf_first,
         const float* __restrict__ qx_g, const float* __restrict__ qy_g, const float* __restrict__ qz_g,
         const int32_t* __restrict__ qperm, int nq, int nleaf, int k, float r2, uint32_t nblocks,
         int32_t* __restrict__ idx_out, float* __restrict__ d2_out, unsigned long long* __restrict__ found) {
-    __shared__ float s_d2[kKnnWaves][kMaxKnn * 64];
-    __shared__ int32_t s_idx[kKnnWaves][kMaxKnn * 64];
+    constexpr int kWaves = knn_waves(KCAP);
+    __shared__ float s_d2[kWaves][KCAP * 64];
+    __shared__ int32_t s_idx[kWaves][KCAP * 64];
     uint32_t logical;
     if (!xcd_remap(nblocks, logical)) return;
     const cfloat_p tblk = (cfloat_p)(uintptr_t)tblk_g;
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
     float* kd2 = s_d2[wid];
     int32_t* kidx = s_idx[wid];
-    const int64_t i = ((int64_t)logical * kKnnWaves + wid) * 64 + lane;
+    const int64_t i = ((int64_t)logical * kWaves + wid) * 64 + lane;
     if (i - lane >= nq) return;  // whole wave out of range (no block barriers below)
     const bool valid = i < nq;
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_search_kernel(
         qy = qy_g[i];
         qz = qz_g[i];
     }
-    KnnState st;
+    KnnStateT<KCAP> st;
     st.init((valid && k > 0) ? r2 : -1.0f);  // r2 = +inf: plain k-NN
 
     // ---- A: a first bound.  A plain k-NN query starts with an infinite search cube, and a
@@ -427,6 +440,35 @@ __global__ __launch_bounds__(kKnnThreads) void knn_search_kernel(
         if (shrunk) set_cube(cube, qx, qy, qz, st.worst);
     });
     if (!valid) return;
+    const int64_t row = (int64_t)qperm[i] * k;
+    if constexpr (KCAP > kMaxKnn) {
+        // ---- the big lists are sorted where they are: original indices first, then a lane-private
+        // insertion sort of its LDS column by (d2, original index)
+        for (int t = 0; t < st.count; ++t) {
+            const int32_t j = kidx[t * 64 + lane];
+            kidx[t * 64 + lane] = __float_as_int(tblk_g[(int64_t)(j >> 3) * kLeafFloats + 24 + (j & 7)]);
+        }
+        for (int a = 1; a < st.count; ++a) {
+            const float dv = kd2[a * 64 + lane];
+            const int32_t iv = kidx[a * 64 + lane];
+            int b = a - 1;
+            while (b >= 0) {
+                const float db = kd2[b * 64 + lane];
+                const int32_t ib = kidx[b * 64 + lane];
+                if (!(db > dv || (db == dv && ib > iv))) break;
+                kd2[(b + 1) * 64 + lane] = db;
+                kidx[(b + 1) * 64 + lane] = ib;
+                --b;
+            }
+            kd2[(b + 1) * 64 + lane] = dv;
+            kidx[(b + 1) * 64 + lane] = iv;
+        }
+        for (int t = 0; t < k; ++t) {
+            const bool have = t < st.count;
+            idx_out[row + t] = have ? kidx[t * 64 + lane] : -1;
+            d2_out[row + t] = have ? kd2[t * 64 + lane] : INFINITY;
+        }
+    } else {
     // ---- sort (d2, original index) ascending in registers, unused slots last
     float v[kMaxKnn];
     int32_t p[kMaxKnn];
@@ -460,7 +502,6 @@ __global__ __launch_bounds__(kKnnThreads) void knn_search_kernel(
                     }
                 }
             }
-    const int64_t row = (int64_t)qperm[i] * k;
 #pragma unroll
     for (int t = 0; t < kMaxKnn; ++t)
         if (t < k) {
@@ -468,6 +509,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_search_kernel(
             idx_out[row + t] = have ? p[t] : -1;
             d2_out[row + t] = have ? v[t] : INFINITY;
         }
+    }
     if (found) atomicAdd(found, (unsigned long long)st.count);
 }
 

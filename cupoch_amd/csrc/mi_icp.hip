@@ -1839,7 +1839,7 @@ static int estimate_normals_impl(mi_icp_ctx* c, const float* xyz, int64_t n, int
                                  float* normals, int mem_kind) {
     TRY(check_ctx(c));
     if (n < 0 || (n > 0 && (!xyz || !normals))) return fail(c, MI_ICP_ERR_INVALID, "estimate_normals: bad arguments");
-    if (knn > kMaxKnn) return fail(c, MI_ICP_ERR_INVALID, "estimate_normals: more than %d neighbours are not supported", kMaxKnn);
+    if (knn > kKnnLimit) return fail(c, MI_ICP_ERR_INVALID, "estimate_normals: more than %d neighbours (knn::NUM_MAX_NN) are not supported", kKnnLimit);
     if (n == 0) return MI_ICP_OK;
     // The cloud gets a tree of its own in a private scratch context: a registration in flight on
     // this context (user estimators may call EstimateNormals between iterations) keeps its
@@ -1854,11 +1854,18 @@ static int estimate_normals_impl(mi_icp_ctx* c, const float* xyz, int64_t n, int
         TRY(mi_icp_set_target(a, xyz, nullptr, nullptr, n, mem_kind));
         float* dn = normals;
         if (mem_kind == MI_ICP_HOST) TRY(ensure(a, a->stage[1], (size_t)n * 3, &dn));
-        const uint32_t nblocks = (uint32_t)((a->nleaf + kKnnLeavesPerBlock - 1) / kKnnLeavesPerBlock);
+        // (lists of up to 32 neighbours: two waves per workgroup; up to NUM_MAX_NN = 100: one)
+        const int waves = knn_waves(knn <= kMaxKnn ? kMaxKnn : kMaxKnnBig);
+        const uint32_t nblocks = (uint32_t)((a->nleaf + waves * 8 - 1) / (waves * 8));
         const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
-        knn_normals_kernel<0><<<grid, kKnnThreads, 0, a->stream>>>((const float*)a->nodes.p, (const float*)a->tblk.p,
-                                                                   a->leaf_first, a->nts, a->nleaf, knn, r2, nblocks,
-                                                                   dn, nullptr, nullptr);
+        if (knn <= kMaxKnn)
+            knn_normals_kernel<0, kMaxKnn><<<grid, waves * 64, 0, a->stream>>>(
+                    (const float*)a->nodes.p, (const float*)a->tblk.p, a->leaf_first, a->nts, a->nleaf, knn, r2, nblocks,
+                    dn, nullptr, nullptr);
+        else
+            knn_normals_kernel<0, kMaxKnnBig><<<grid, waves * 64, 0, a->stream>>>(
+                    (const float*)a->nodes.p, (const float*)a->tblk.p, a->leaf_first, a->nts, a->nleaf, knn, r2, nblocks,
+                    dn, nullptr, nullptr);
         KCHK(a);
         if (mem_kind == MI_ICP_HOST) TRY(from_device(a, (const float*)dn, normals, (size_t)n * 3, mem_kind));
         HIPCHK(a, hipStreamSynchronize(a->stream));
@@ -1887,7 +1894,7 @@ int mi_icp_search_knn(mi_icp_ctx* c, const float* queries, int64_t nq, int knn, 
     if (found) *found = 0;
     if (nq < 0 || knn < 0 || (nq > 0 && (!queries || !idx_out || !d2_out)))
         return fail(c, MI_ICP_ERR_INVALID, "search_knn: bad arguments");
-    if (knn > kMaxKnn) return fail(c, MI_ICP_ERR_INVALID, "search_knn: more than %d neighbours are not supported", kMaxKnn);
+    if (knn > kKnnLimit) return fail(c, MI_ICP_ERR_INVALID, "search_knn: more than %d neighbours (knn::NUM_MAX_NN) are not supported", kKnnLimit);
     if (c->nt <= 0) return fail(c, MI_ICP_ERR_STATE, "search_knn: no target cloud (mi_icp_set_target)");
     if (nq == 0 || knn == 0) return MI_ICP_OK;
     // the queries are staged exactly like an ICP source (Morton-ordered SoA + permutation)
@@ -1902,12 +1909,15 @@ int mi_icp_search_knn(mi_icp_ctx* c, const float* queries, int64_t nq, int knn, 
     TRY(ensure(c, c->flags, 8, (unsigned long long**)&cnt));
     HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(unsigned long long), c->stream));
     const uint32_t npackets = (uint32_t)((nq + 63) / 64);
-    const uint32_t nblocks = (npackets + kKnnWaves - 1) / kKnnWaves;
+    const int waves = knn_waves(knn <= kMaxKnn ? kMaxKnn : kMaxKnnBig);
+    const uint32_t nblocks = (npackets + waves - 1) / waves;
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
-    knn_search_kernel<<<grid, kKnnThreads, 0, c->stream>>>(
-            (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, (const float*)c->sx.p,
-            (const float*)c->sy.p, (const float*)c->sz.p, (const int32_t*)c->sperm.p, (int)nq, c->nleaf, knn,
-            radius > 0.0f ? radius * radius : INFINITY, nblocks, d_idx, d_d2, cnt);
+#define MI_KNN_ARGS (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, (const float*)c->sx.p, \
+                    (const float*)c->sy.p, (const float*)c->sz.p, (const int32_t*)c->sperm.p, (int)nq, c->nleaf, knn, \
+                    radius > 0.0f ? radius * radius : INFINITY, nblocks, d_idx, d_d2, cnt
+    if (knn <= kMaxKnn) knn_search_kernel<kMaxKnn><<<grid, waves * 64, 0, c->stream>>>(MI_KNN_ARGS);
+    else knn_search_kernel<kMaxKnnBig><<<grid, waves * 64, 0, c->stream>>>(MI_KNN_ARGS);
+#undef MI_KNN_ARGS
     KCHK(c);
     if (mem_kind == MI_ICP_HOST) {
         TRY(from_device(c, (const int32_t*)d_idx, idx_out, (size_t)nq * knn, mem_kind));
@@ -1963,18 +1973,24 @@ int mi_icp_compute_color_gradients(mi_icp_ctx* c, float radius, int max_nn, floa
     if (c->nt <= 0) return MI_ICP_OK;
     if (!c->t_has_nrm || !c->t_has_int)
         return fail(c, MI_ICP_ERR_STATE, "compute_color_gradients: the target needs normals and colours");
-    if (max_nn > kMaxKnn)
-        return fail(c, MI_ICP_ERR_INVALID, "compute_color_gradients: more than %d neighbours are not supported", kMaxKnn);
+    if (max_nn > kKnnLimit)
+        return fail(c, MI_ICP_ERR_INVALID, "compute_color_gradients: more than %d neighbours (knn::NUM_MAX_NN) are not supported", kKnnLimit);
     const int64_t n = c->nt;
     float4* tgrad;
     TRY(ensure(c, c->tgrad, (size_t)c->nts, &tgrad));
     float* dg = gradients_out;
     if (gradients_out && mem_kind == MI_ICP_HOST) TRY(ensure(c, c->stage[1], (size_t)n * 3, &dg));
-    const uint32_t nblocks = (uint32_t)((c->nleaf + kKnnLeavesPerBlock - 1) / kKnnLeavesPerBlock);
+    const int waves = knn_waves(max_nn <= kMaxKnn ? kMaxKnn : kMaxKnnBig);
+    const uint32_t nblocks = (uint32_t)((c->nleaf + waves * 8 - 1) / (waves * 8));
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
-    knn_normals_kernel<1><<<grid, kKnnThreads, 0, c->stream>>>(
-            (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, c->nts, c->nleaf, max_nn,
-            radius * radius, nblocks, dg, (const float4*)c->tnrm.p, tgrad);
+    if (max_nn <= kMaxKnn)
+        knn_normals_kernel<1, kMaxKnn><<<grid, waves * 64, 0, c->stream>>>(
+                (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, c->nts, c->nleaf, max_nn,
+                radius * radius, nblocks, dg, (const float4*)c->tnrm.p, tgrad);
+    else
+        knn_normals_kernel<1, kMaxKnnBig><<<grid, waves * 64, 0, c->stream>>>(
+                (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, c->nts, c->nleaf, max_nn,
+                radius * radius, nblocks, dg, (const float4*)c->tnrm.p, tgrad);
     KCHK(c);
     c->t_has_grad = true;
     if (gradients_out) {

@@ -41,7 +41,7 @@ class KDTreeSearchParamRadius:
 class KDTreeFlann:
     """knn::KDTreeFlann (knn/kdtree_flann.h:43-124; python surface
     cupoch_pybind/geometry/kdtree_flann.cpp:88-141).  Owns its own engine context, i.e. its
-    own tree; at most 32 neighbours per query."""
+    own tree; at most knn::NUM_MAX_NN = 100 neighbours per query."""
 
     def __init__(self, geometry=None):
         self._eng = None

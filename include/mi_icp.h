@@ -289,11 +289,12 @@ MI_ICP_API int mi_icp_covariances_from_normals(mi_icp_ctx* ctx, const float* nor
                                                int64_t n, float epsilon, float* covs,
                                                int mem_kind);
 /* PointCloud::EstimateNormals(KDTreeSearchParamKNN(knn))
- * (geometry/estimate_normals.cu:82-127), knn <= 64. */
+ * (geometry/estimate_normals.cu:82-127), knn <= 100 (knn::NUM_MAX_NN,
+ * knn/kdtree_search_param.h:26; lists of up to 32 neighbours take the faster kernel). */
 MI_ICP_API int mi_icp_estimate_normals_knn(mi_icp_ctx* ctx, const float* xyz, int64_t n,
                                            int knn, float* normals, int mem_kind);
 /* PointCloud::EstimateNormals(KDTreeSearchParamRadius(radius, max_nn)): the max_nn
- * (<= 32) nearest points with d2 < radius^2, as KDTreeFlann::SearchRadius
+ * (<= 100) nearest points with d2 < radius^2, as KDTreeFlann::SearchRadius
  * feeds it (geometry/estimate_normals.cu:93-101, knn/kdtree_flann.inl:96-122);
  * fewer than 3 neighbours -> (0,0,1). */
 MI_ICP_API int mi_icp_estimate_normals_radius(mi_icp_ctx* ctx, const float* xyz, int64_t n,
@@ -303,7 +304,7 @@ MI_ICP_API int mi_icp_estimate_normals_radius(mi_icp_ctx* ctx, const float* xyz,
 /* ---- knn::KDTreeFlann as a search object (knn/kdtree_flann.h:43-124) ---------
  * SearchKNN / SearchRadius (knn/kdtree_flann.inl:46-122) of arbitrary queries
  * float[nq][3] against the cloud given to mi_icp_set_target: per query the knn
- * (<= 32) nearest target points -- with d2 < radius^2 when radius > 0, i.e.
+ * (<= 100 = knn::NUM_MAX_NN) nearest target points -- with d2 < radius^2 when radius > 0, i.e.
  * SearchRadius(radius, max_nn = knn) -- ascending in distance (ties ascending in
  * index).  idx_out / d2_out are [nq][knn] row-major in the caller's query order,
  * original target indices, padded with -1 / +inf.  *found (optional) = number of
@@ -327,7 +328,7 @@ MI_ICP_API int mi_icp_set_source_colors(mi_icp_ctx* ctx, const float* rgb, int m
  * MI_ICP_EST_COLORED evaluation. */
 MI_ICP_API int mi_icp_set_lambda_geometric(mi_icp_ctx* ctx, float lambda_geometric);
 /* InitializePointCloudForColoredICP (colored_icp.cu:108-148): per target point
- * the intensity gradient in the tangent plane over the max_nn (<= 32) nearest
+ * the intensity gradient in the tangent plane over the max_nn (<= 100) nearest
  * points within `radius` (the nearest -- the point itself -- excluded; fewer
  * than 4 others -> 0).  Kept on the device for MI_ICP_EST_COLORED;
  * gradients_out (float[nt][3], target's original order) may be NULL. */

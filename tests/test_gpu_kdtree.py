@@ -1,5 +1,5 @@
-"""GPU: knn::KDTreeFlann as a search object (SearchKNN / SearchRadius with up to 32
-neighbours): the reference's own golden vectors (src/tests/knn/kdtree_flann.cpp:47-135)
+"""GPU: knn::KDTreeFlann as a search object (SearchKNN / SearchRadius with up to
+knn::NUM_MAX_NN = 100 neighbours): the reference's own golden vectors (src/tests/knn/kdtree_flann.cpp:47-135)
 and the oracle's exact k-NN on random data, through the C ABI, the Python class and
 batches of queries."""
 import numpy as np
@@ -61,7 +61,8 @@ def rows_equal_up_to_ties(idx, d2, oi, od, tgt, qry):
 
 
 @pytest.mark.parametrize("nt,nq,k", [(1, 5, 3), (7, 100, 8), (100, 1, 30), (5000, 3000, 1), (5000, 3000, 17),
-                                     (200000, 50000, 32), (200000, 50000, 20)])
+                                     (200000, 50000, 32), (200000, 50000, 20),
+                                     (50, 40, 100), (3000, 2000, 33), (100000, 20000, 64), (100000, 20000, 100)])
 def test_search_knn_matches_oracle(eng, nt, nq, k):
     rng = np.random.default_rng(nt * 31 + nq + k)
     tgt = rng.random((nt, 3), dtype=np.float32)
@@ -75,7 +76,7 @@ def test_search_knn_matches_oracle(eng, nt, nq, k):
     assert np.all(np.diff(np.where(np.isfinite(d2), d2, np.float32(3e38)), axis=1) >= 0)
 
 
-@pytest.mark.parametrize("radius,max_nn", [(0.01, 10), (0.03, 32), (0.1, 5), (1e-4, 8)])
+@pytest.mark.parametrize("radius,max_nn", [(0.01, 10), (0.03, 32), (0.1, 5), (1e-4, 8), (0.05, 100), (0.03, 50)])
 def test_search_radius_matches_oracle(eng, radius, max_nn):
     rng = np.random.default_rng(int(radius * 1e5) + max_nn)
     tgt = rng.random((120000, 3), dtype=np.float32)
@@ -93,7 +94,7 @@ def test_errors_and_limits(eng):
     from cupoch_amd.engine import MiIcpError
     eng.set_target(np.random.default_rng(0).random((100, 3), dtype=np.float32))
     with pytest.raises(MiIcpError):
-        eng.search_knn(np.zeros((4, 3), np.float32), 33)
+        eng.search_knn(np.zeros((4, 3), np.float32), 101)                  # knn::NUM_MAX_NN = 100
     found, idx, d2 = eng.search_knn(np.zeros((0, 3), np.float32), 5)
     assert found == 0 and idx.shape == (0, 5)
     # duplicates in the target: ties come out ascending in index

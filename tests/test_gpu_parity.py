@@ -362,3 +362,41 @@ def test_estimate_normals_golden_and_oracle(eng, golden):
         dots = np.abs((got * ref).sum(1))
         assert (dots > 1 - 1e-3).mean() > agree, (radius, (dots > 1 - 1e-3).mean())
     assert fallback.any() and not fallback.all()
+
+
+def test_estimate_normals_disagreements_are_explained(eng):
+    """the normals agree with the oracle's only statistically (fp32 raw-moment
+    covariances, estimate_normals.cu:38-64).  This pins WHY: the neighbour sets themselves are
+    identical (bit-exact distances; indices up to ties at the k-th distance), every normal --
+    the engine's and the oracle's -- matches the fp64 normal of its own neighbour set wherever the
+    covariance's smallest eigenvalue is well separated, and every engine/oracle disagreement sits
+    on a differing set or a near-degenerate covariance."""
+    rng = np.random.default_rng(12)
+    n, k = 30000, 30
+    pts = rng.random((n, 3), dtype=np.float32)
+    pts[:, 2] = 0.2 * np.sin(3 * pts[:, 0]) + 0.0005 * rng.standard_normal(n).astype(np.float32)
+    got = eng.estimate_normals_knn(cuda(pts), k).cpu().numpy()
+    ref = orc.estimate_normals_knn(pts, k)
+    eng.set_target(pts)
+    found, idx, d2 = eng.search_knn(pts, k)
+    _, oi, od = orc.search_knn(pts, pts, k)
+    assert found == n * k and np.array_equal(d2, od)                       # distances bit for bit
+    sets_equal = (np.sort(idx, 1) == np.sort(oi, 1)).all(1)
+    assert sets_equal.mean() > 0.999                                        # (ties at the k-th distance only)
+    P = pts[idx].astype(np.float64)
+    C = np.einsum("nki,nkj->nij", P, P) / k - np.einsum("ni,nj->nij", P.mean(1), P.mean(1))
+    w, v = np.linalg.eigh(C)
+    n64 = v[:, :, 0]
+    sep = (w[:, 1] - w[:, 0]) / np.maximum(w[:, 2], 1e-300)                # separation of the smallest eigenvalue
+    well = sep > 0.02
+    assert well.mean() > 0.9
+    dg, dr = np.abs((got * n64).sum(1)), np.abs((ref * n64).sum(1))
+    assert (dg[well & sets_equal] > 1 - 1e-4).all() and (dr[well & sets_equal] > 1 - 1e-4).all()
+    bad = np.abs((got * ref).sum(1)) < 1 - 1e-4
+    assert not (bad & well & sets_equal).any(), int((bad & well & sets_equal).sum())
+    # up to NUM_MAX_NN = 100 neighbours (the big candidate lists): same statement of agreement
+    for kk in (64, 100):
+        g2 = eng.estimate_normals_knn(cuda(pts), kk).cpu().numpy()
+        r2 = orc.estimate_normals_knn(pts, kk)
+        dots = np.abs((g2 * r2).sum(1))
+        assert (dots > 1 - 1e-4).mean() > 0.995 and np.median(1 - dots) < 1e-6
