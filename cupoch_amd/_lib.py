@@ -99,6 +99,8 @@ SIGNATURES = {
     "mi_icp_icp_begin": (_I, [_P, _I, _F, _P, _F, C.POINTER(Result)]),
     "mi_icp_icp_iterate": (_I, [_P, _I, C.POINTER(Result)]),
     "mi_icp_transform": (_I, [_P, _P, _P, _P, _P, _L, _I]),
+    "mi_icp_compute_bounds": (_I, [_P, _P, _L, _I, _P, _P, _P]),
+    "mi_icp_affine": (_I, [_P, _P, _F, _I, _P, _P, _P, _P, _P, _L, _I]),
     "mi_icp_voxel_downsample": (_I, [_P, _P, _P, _P, _L, _F, _P, _P, _P, C.POINTER(_L), _I]),
     "mi_icp_create_from_depth": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _F, _F, _F, _I, _I, _I, _I,
                                       _P, _P, _P, C.POINTER(_L), _I]),

@@ -3,6 +3,7 @@
 // geometry/geometry.h).  Same public members and layouts; the operations run
 // HIP kernels through libmi_icp.so's C ABI (include/mi_icp.h).
 #pragma once
+#include <cmath>
 #include <memory>
 
 #include "cupoch/camera/pinhole_camera_intrinsic.h"
@@ -16,7 +17,7 @@ namespace geometry {
 
 class Geometry {
 public:
-    enum class GeometryType { Unspecified = 0, PointCloud = 1 };
+    enum class GeometryType { Unspecified = 0, PointCloud = 1, AxisAlignedBoundingBox = 13 };  // geometry.h:37-68
     virtual ~Geometry() {}
     GeometryType GetGeometryType() const { return type_; }
     int Dimension() const { return dimension_; }
@@ -31,11 +32,80 @@ private:
     int dimension_;
 };
 
-class PointCloud : public Geometry {
+class AxisAlignedBoundingBox3;
+
+/// geometry/geometry_base.h:33-90 with VectorT = Vector3f, MatrixT = Matrix3f, TransformT = Matrix4f
+class GeometryBase3D : public Geometry {
+protected:
+    GeometryBase3D(GeometryType type) : Geometry(type, 3) {}
+
 public:
-    PointCloud() : Geometry(GeometryType::PointCloud, 3) {}
+    GeometryBase3D& Clear() override = 0;
+    bool IsEmpty() const override = 0;
+    virtual Eigen::Vector3f GetMinBound() const = 0;
+    virtual Eigen::Vector3f GetMaxBound() const = 0;
+    virtual Eigen::Vector3f GetCenter() const = 0;
+    virtual AxisAlignedBoundingBox3 GetAxisAlignedBoundingBox() const = 0;
+    virtual GeometryBase3D& Transform(const Eigen::Matrix4f& transformation) = 0;
+    virtual GeometryBase3D& Translate(const Eigen::Vector3f& translation, bool relative = true) = 0;
+    virtual GeometryBase3D& Scale(const float scale, bool center = true) = 0;
+    virtual GeometryBase3D& Rotate(const Eigen::Matrix3f& R, bool center = true) = 0;
+};
+
+/// geometry::AxisAlignedBoundingBox<3> (geometry/boundingvolume.h:121-230): the value
+/// PointCloud::GetAxisAlignedBoundingBox hands out -- bounds, centre, extent, volume and the
+/// GeometryBase3D moves of a box (geometry/boundingvolume.cu; Rotate is not defined for an
+/// axis-aligned box and logs an error there as here).
+class AxisAlignedBoundingBox3 : public GeometryBase3D {
+public:
+    AxisAlignedBoundingBox3()
+        : GeometryBase3D(GeometryType::AxisAlignedBoundingBox),
+          min_bound_(Eigen::Vector3f::Zero()), max_bound_(Eigen::Vector3f::Zero()), color_(Eigen::Vector3f::Zero()) {}
+    AxisAlignedBoundingBox3(const Eigen::Vector3f& min_bound, const Eigen::Vector3f& max_bound)
+        : GeometryBase3D(GeometryType::AxisAlignedBoundingBox),
+          min_bound_(min_bound), max_bound_(max_bound), color_(Eigen::Vector3f::Zero()) {}
+    AxisAlignedBoundingBox3& Clear() override {
+        min_bound_ = max_bound_ = Eigen::Vector3f::Zero();
+        return *this;
+    }
+    bool IsEmpty() const override { return Volume() <= 0; }
+    Eigen::Vector3f GetMinBound() const override { return min_bound_; }
+    Eigen::Vector3f GetMaxBound() const override { return max_bound_; }
+    Eigen::Vector3f GetCenter() const override { return (min_bound_ + max_bound_) * 0.5f; }
+    AxisAlignedBoundingBox3 GetAxisAlignedBoundingBox() const override;
+    AxisAlignedBoundingBox3& Transform(const Eigen::Matrix4f& transformation) override;
+    AxisAlignedBoundingBox3& Translate(const Eigen::Vector3f& translation, bool relative = true) override;
+    AxisAlignedBoundingBox3& Scale(const float scale, bool center = true) override;
+    AxisAlignedBoundingBox3& Rotate(const Eigen::Matrix3f& R, bool center = true) override;
+    Eigen::Vector3f GetExtent() const { return max_bound_ - min_bound_; }
+    Eigen::Vector3f GetHalfExtent() const { return GetExtent() * 0.5f; }
+    float GetMaxExtent() const {
+        const Eigen::Vector3f e = GetExtent();
+        return std::fmax(e[0], std::fmax(e[1], e[2]));
+    }
+    float Volume() const {
+        const Eigen::Vector3f e = GetExtent();
+        return e[0] * e[1] * e[2];
+    }
+
+public:
+    Eigen::Vector3f min_bound_, max_bound_, color_;
+};
+template <int Dim>
+struct AxisAlignedBoundingBoxOf;
+template <>
+struct AxisAlignedBoundingBoxOf<3> {
+    typedef AxisAlignedBoundingBox3 type;
+};
+/// the reference spells the 3-D box AxisAlignedBoundingBox<3>
+template <int Dim>
+using AxisAlignedBoundingBox = typename AxisAlignedBoundingBoxOf<Dim>::type;
+
+class PointCloud : public GeometryBase3D {
+public:
+    PointCloud() : GeometryBase3D(GeometryType::PointCloud) {}
     PointCloud(const thrust::host_vector<Eigen::Vector3f>& points)
-        : Geometry(GeometryType::PointCloud, 3), points_(points) {}
+        : GeometryBase3D(GeometryType::PointCloud), points_(points) {}
     PointCloud(const PointCloud& other) = default;
     PointCloud& operator=(const PointCloud& other) = default;
     ~PointCloud() override {}
@@ -60,14 +130,21 @@ public:
     bool HasColors() const { return !points_.empty() && colors_.size() == points_.size(); }
     bool HasCovariances() const { return !points_.empty() && covariances_.size() == points_.size(); }
 
-    Eigen::Vector3f GetMinBound() const;
-    Eigen::Vector3f GetMaxBound() const;
+    /// pointcloud.cu:205-219 (device reductions; zero vectors for an empty cloud)
+    Eigen::Vector3f GetMinBound() const override;
+    Eigen::Vector3f GetMaxBound() const override;
+    Eigen::Vector3f GetCenter() const override;
+    AxisAlignedBoundingBox3 GetAxisAlignedBoundingBox() const override;
+    /// pointcloud.cu:225-242
+    PointCloud& Translate(const Eigen::Vector3f& translation, bool relative = true) override;
+    PointCloud& Scale(const float scale, bool center = true) override;
+    PointCloud& Rotate(const Eigen::Matrix3f& R, bool center = true) override;
 
     /// pointcloud.cu:293-299
-    PointCloud& Transform(const Eigen::Matrix4f& transformation);
+    PointCloud& Transform(const Eigen::Matrix4f& transformation) override;
     /// down_sample.cu:170-273
     std::shared_ptr<PointCloud> VoxelDownSample(float voxel_size) const;
-    /// estimate_normals.cu:82-127 (KNN search parameter; knn <= 32)
+    /// estimate_normals.cu:82-127 (KNN or radius search parameter; up to knn::NUM_MAX_NN neighbours)
     bool EstimateNormals(const knn::KDTreeSearchParam& search_param = knn::KDTreeSearchParamKNN());
 
     /// pointcloud_factory.cu:329-351 (float or uint16 depth)

@@ -49,6 +49,11 @@ struct Matrix {
     }
     Matrix operator+(const Matrix& o) const { Matrix m; for (int i = 0; i < R * C; ++i) m.v[i] = v[i] + o.v[i]; return m; }
     Matrix operator-(const Matrix& o) const { Matrix m; for (int i = 0; i < R * C; ++i) m.v[i] = v[i] - o.v[i]; return m; }
+    Matrix& operator+=(const Matrix& o) { for (int i = 0; i < R * C; ++i) v[i] += o.v[i]; return *this; }
+    Matrix& operator-=(const Matrix& o) { for (int i = 0; i < R * C; ++i) v[i] -= o.v[i]; return *this; }
+    Matrix operator*(T k) const { Matrix m; for (int i = 0; i < R * C; ++i) m.v[i] = v[i] * k; return m; }
+    Matrix& operator*=(T k) { for (int i = 0; i < R * C; ++i) v[i] *= k; return *this; }
+    friend Matrix operator*(T k, const Matrix& a) { return a * k; }
     bool operator==(const Matrix& o) const { return std::memcmp(v, o.v, sizeof(v)) == 0; }
     T norm() const { T s = T(0); for (int i = 0; i < R * C; ++i) s += v[i] * v[i]; return std::sqrt(s); }
     // MatrixBase::isIdentity with the scalar's dummy precision (1e-5 for float)

@@ -207,16 +207,94 @@ bool PointCloud::EstimateNormals(const knn::KDTreeSearchParam& search_param) {
     }
 }
 
-static Eigen::Vector3f Bound(const utility::device_vector<Eigen::Vector3f>& pts, bool want_max) {
-    const auto h = pts.to_host();
-    if (h.empty()) return Eigen::Vector3f::Zero();
-    Eigen::Vector3f b = h[0];
-    for (const auto& p : h)
-        for (int d = 0; d < 3; ++d) b[d] = want_max ? std::fmax(b[d], p[d]) : std::fmin(b[d], p[d]);
+// GeometryBase3D on a cloud (pointcloud.cu:205-242): device reductions / one in-place kernel each
+static void Bounds(const utility::device_vector<Eigen::Vector3f>& pts, Eigen::Vector3f* mn, Eigen::Vector3f* mx,
+                   Eigen::Vector3f* center) {
+    Check(mi_icp_compute_bounds(Engine(), Ptr(pts), (int64_t)pts.size(), MI_ICP_DEVICE, mn ? mn->data() : nullptr,
+                                mx ? mx->data() : nullptr, center ? center->data() : nullptr));
+}
+Eigen::Vector3f PointCloud::GetMinBound() const {
+    Eigen::Vector3f b;
+    Bounds(points_, &b, nullptr, nullptr);
     return b;
 }
-Eigen::Vector3f PointCloud::GetMinBound() const { return Bound(points_, false); }
-Eigen::Vector3f PointCloud::GetMaxBound() const { return Bound(points_, true); }
+Eigen::Vector3f PointCloud::GetMaxBound() const {
+    Eigen::Vector3f b;
+    Bounds(points_, nullptr, &b, nullptr);
+    return b;
+}
+Eigen::Vector3f PointCloud::GetCenter() const {
+    Eigen::Vector3f b;
+    Bounds(points_, nullptr, nullptr, &b);
+    return b;
+}
+AxisAlignedBoundingBox3 PointCloud::GetAxisAlignedBoundingBox() const {  // AxisAlignedBoundingBox<3>::CreateFromPoints
+    Eigen::Vector3f mn, mx;
+    Bounds(points_, &mn, &mx, nullptr);
+    return AxisAlignedBoundingBox3(mn, mx);
+}
+PointCloud& PointCloud::Translate(const Eigen::Vector3f& translation, bool relative) {
+    Eigen::Vector3f t = translation;
+    if (!relative) t -= GetCenter();                       // geometry_utils.cu:155-158
+    Check(mi_icp_affine(Engine(), nullptr, 0.0f, 0, nullptr, t.data(), points_.empty() ? nullptr : points_.data()->data(),
+                        nullptr, nullptr, (int64_t)points_.size(), MI_ICP_DEVICE));
+    return *this;
+}
+PointCloud& PointCloud::Scale(const float scale, bool center) {
+    Eigen::Vector3f c = Eigen::Vector3f::Zero();
+    const bool use_c = center && !points_.empty();          // geometry_utils.cu:170-173
+    if (use_c) c = GetCenter();
+    Check(mi_icp_affine(Engine(), nullptr, scale, 1, use_c ? c.data() : nullptr, nullptr,
+                        points_.empty() ? nullptr : points_.data()->data(), nullptr, nullptr, (int64_t)points_.size(),
+                        MI_ICP_DEVICE));
+    return *this;
+}
+PointCloud& PointCloud::Rotate(const Eigen::Matrix3f& R, bool center) {
+    Eigen::Vector3f c = Eigen::Vector3f::Zero();
+    const bool use_c = center && !points_.empty();          // geometry_utils.cu:211-214
+    if (use_c) c = GetCenter();
+    const size_t n = points_.size();
+    Check(mi_icp_affine(Engine(), R.data(), 0.0f, 0, use_c ? c.data() : nullptr, nullptr,
+                        n ? points_.data()->data() : nullptr, normals_.size() == n && n ? normals_.data()->data() : nullptr,
+                        covariances_.size() == n && n ? covariances_.data()->data() : nullptr, (int64_t)n,
+                        MI_ICP_DEVICE));
+    return *this;
+}
+
+// geometry::AxisAlignedBoundingBox<3> (geometry/boundingvolume.cu:300-354)
+AxisAlignedBoundingBox3 AxisAlignedBoundingBox3::GetAxisAlignedBoundingBox() const { return *this; }
+AxisAlignedBoundingBox3& AxisAlignedBoundingBox3::Transform(const Eigen::Matrix4f&) {
+    LogError("A general transform of a AxisAlignedBoundingBox would not be axis aligned anymore, convert it to a "
+             "OrientedBoundingBox first");
+    return *this;
+}
+AxisAlignedBoundingBox3& AxisAlignedBoundingBox3::Translate(const Eigen::Vector3f& translation, bool relative) {
+    if (relative) {
+        min_bound_ += translation;
+        max_bound_ += translation;
+    } else {
+        const Eigen::Vector3f half_extent = GetHalfExtent();
+        min_bound_ = translation - half_extent;
+        max_bound_ = translation + half_extent;
+    }
+    return *this;
+}
+AxisAlignedBoundingBox3& AxisAlignedBoundingBox3::Scale(const float scale, bool center) {
+    if (center) {
+        const Eigen::Vector3f c = GetCenter();
+        min_bound_ = c + scale * (min_bound_ - c);
+        max_bound_ = c + scale * (max_bound_ - c);
+    } else {
+        min_bound_ *= scale;
+        max_bound_ *= scale;
+    }
+    return *this;
+}
+AxisAlignedBoundingBox3& AxisAlignedBoundingBox3::Rotate(const Eigen::Matrix3f&, bool) {
+    LogError("A rotation of a AxisAlignedBoundingBox would not be axis aligned anymore, convert it to an "
+             "OrientedBoundingBox first");
+    return *this;
+}
 
 static std::shared_ptr<PointCloud> FromDepth(const Image& depth, const Image* color, int color_type,
                                              const camera::PinholeCameraIntrinsic& intrinsic,

@@ -47,6 +47,107 @@ __global__ __launch_bounds__(256) void transform_cloud(Xform T, float* __restric
     }
 }
 
+// ---- GeometryBase3D::Translate / Scale / Rotate (geometry/geometry_utils.cu:150-270) ---------
+// p <- (R (p - c)) * s + c + t, in the reference functors' order of operations: Translate is
+// pt += t, Scale (pt - c) * s + c, Rotate R (pt - c) + c (the terms a call does not use are
+// the exact identities 0 / 1 / I and drop out bit for bit); normals <- R n; covariances <-
+// R C R^T.  R row-major 3x3.
+struct Affine {
+    float r[9];
+    float c[3], t[3];
+    float s;
+    int use_r, use_s, use_c, use_t;
+};
+
+__global__ __launch_bounds__(256) void affine_cloud(Affine A, float* __restrict__ pts, float* __restrict__ nrm,
+                                                    float* __restrict__ cov, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (pts) {
+        float v[3] = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
+        if (A.use_c) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) v[d] -= A.c[d];
+        }
+        if (A.use_r) {
+            const float x = v[0], y = v[1], z = v[2];
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                v[d] = __builtin_fmaf(A.r[d * 3 + 2], z, __builtin_fmaf(A.r[d * 3 + 1], y, A.r[d * 3] * x));
+        }
+        if (A.use_s) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) v[d] *= A.s;
+        }
+        if (A.use_c) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) v[d] += A.c[d];
+        }
+        if (A.use_t) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) v[d] += A.t[d];
+        }
+        pts[i * 3] = v[0];
+        pts[i * 3 + 1] = v[1];
+        pts[i * 3 + 2] = v[2];
+    }
+    if (nrm && A.use_r) {
+        const float x = nrm[i * 3], y = nrm[i * 3 + 1], z = nrm[i * 3 + 2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            nrm[i * 3 + d] = __builtin_fmaf(A.r[d * 3 + 2], z, __builtin_fmaf(A.r[d * 3 + 1], y, A.r[d * 3] * x));
+    }
+    if (cov && A.use_r) {
+        float C[9], RC[3][3];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) C[e] = cov[i * 9 + e];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                RC[r][c] = __builtin_fmaf(A.r[r * 3 + 2], C[c * 3 + 2],
+                                          __builtin_fmaf(A.r[r * 3 + 1], C[c * 3 + 1], A.r[r * 3] * C[c * 3]));
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                cov[i * 9 + c * 3 + r] = __builtin_fmaf(RC[r][2], A.r[c * 3 + 2],
+                                                        __builtin_fmaf(RC[r][1], A.r[c * 3 + 1], RC[r][0] * A.r[c * 3]));
+    }
+}
+
+// ---- utility::ComputeCenter (utility/eigen.inl:223-232): per-block fp64 sums, one more block totals them
+constexpr int kCenterBlocks = 512;
+__global__ __launch_bounds__(256) void center_partial(const float* __restrict__ pts, int64_t n,
+                                                      double* __restrict__ partial /*[blocks][4]*/) {
+    __shared__ double red[4][3];
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) s[d] += (double)pts[i * 3 + d];
+    }
+    const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const double v = wave_sum(s[d]);
+        if (lane == kWaveSumLane) red[wid][d] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int d = (int)threadIdx.x;
+        partial[blockIdx.x * 4 + d] = ((red[0][d] + red[1][d]) + red[2][d]) + red[3][d];
+    }
+}
+
+// out[7..9] = sum / n as floats (out = the bounds record: min[3], max[3], extent, center[3])
+__global__ void center_final(const double* __restrict__ partial, int nblocks, int64_t n, float* __restrict__ out) {
+    const int d = (int)threadIdx.x;
+    if (d >= 3) return;
+    double t = 0.0;
+    for (int b = 0; b < nblocks; ++b) t += partial[b * 4 + d];
+    out[7 + d] = (n > 0) ? (float)(t / (double)n) : 0.0f;
+}
+
 // ---- GICP: covariance from a normal, C = Rx diag(eps,1,1) Rx^T ----------------
 __global__ __launch_bounds__(256) void cov_from_normals(const float* __restrict__ nrm, int64_t n,
                                                         float eps, float* __restrict__ cov) {

@@ -1369,6 +1369,76 @@ int mi_icp_transform(mi_icp_ctx* c, const float* T, float* xyz, float* normals, 
     return MI_ICP_OK;
 }
 
+// GeometryBase3D::GetMinBound / GetMaxBound / GetCenter (geometry/pointcloud.cu:205-215)
+int mi_icp_compute_bounds(mi_icp_ctx* c, const float* xyz, int64_t n, int mem_kind, float* min3, float* max3,
+                          float* center3) {
+    TRY(check_ctx(c));
+    if (n < 0 || (n > 0 && !xyz)) return fail(c, MI_ICP_ERR_INVALID, "compute_bounds: bad size/pointer");
+    const float zero[3] = {0.0f, 0.0f, 0.0f};
+    if (n == 0) {  // the reference returns zero vectors for an empty cloud
+        if (min3) std::memcpy(min3, zero, sizeof(zero));
+        if (max3) std::memcpy(max3, zero, sizeof(zero));
+        if (center3) std::memcpy(center3, zero, sizeof(zero));
+        return MI_ICP_OK;
+    }
+    const float* d_pts;
+    TRY(to_device(c, xyz, (size_t)n * 3, mem_kind, c->stage[0], &d_pts));
+    float* bnd;
+    TRY(compute_bounds(c, d_pts, n, &bnd));  // min[3], max[3], extent
+    float* rec;
+    TRY(ensure(c, c->flags, 16, &rec));
+    HIPCHK(c, hipMemcpyAsync(rec, bnd, 7 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    if (center3) {
+        double* part;
+        TRY(ensure(c, c->partial, (size_t)kReduceBlocks * kSysSize, &part));
+        const int blocks = (int)std::min<int64_t>(kCenterBlocks, blocks_for(n));
+        center_partial<<<blocks, 256, 0, c->stream>>>(d_pts, n, part);
+        KCHK(c);
+        center_final<<<1, 64, 0, c->stream>>>(part, blocks, n, rec);
+        KCHK(c);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->f_host, rec, 10 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (min3) std::memcpy(min3, c->f_host, 3 * sizeof(float));
+    if (max3) std::memcpy(max3, c->f_host + 3, 3 * sizeof(float));
+    if (center3) std::memcpy(center3, c->f_host + 7, 3 * sizeof(float));
+    return MI_ICP_OK;
+}
+
+// GeometryBase3D::Translate / Scale / Rotate (geometry/pointcloud.cu:225-242)
+int mi_icp_affine(mi_icp_ctx* c, const float* R9, float scale, int use_scale, const float* center3,
+                  const float* translate3, float* xyz, float* normals, float* covs, int64_t n, int mem_kind) {
+    TRY(check_ctx(c));
+    if (n < 0) return fail(c, MI_ICP_ERR_INVALID, "affine: negative size");
+    if (n == 0 || (!xyz && !normals && !covs)) return MI_ICP_OK;
+    Affine A;
+    std::memset(&A, 0, sizeof(A));
+    A.use_r = R9 != nullptr;
+    A.use_s = use_scale != 0;
+    A.use_c = center3 != nullptr;
+    A.use_t = translate3 != nullptr;
+    A.s = scale;
+    if (R9)   // column-major (Eigen::Matrix3f::data()) -> row-major
+        for (int r = 0; r < 3; ++r)
+            for (int q = 0; q < 3; ++q) A.r[r * 3 + q] = R9[q * 3 + r];
+    if (center3) std::memcpy(A.c, center3, sizeof(A.c));
+    if (translate3) std::memcpy(A.t, translate3, sizeof(A.t));
+    const float *dp, *dn, *dc;
+    TRY(to_device(c, (const float*)xyz, (size_t)n * 3, mem_kind, c->stage[0], &dp));
+    TRY(to_device(c, (const float*)normals, (size_t)n * 3, mem_kind, c->stage[1], &dn));
+    TRY(to_device(c, (const float*)covs, (size_t)n * 9, mem_kind, c->stage[2], &dc));
+    affine_cloud<<<blocks_for(n), 256, 0, c->stream>>>(A, const_cast<float*>(dp), const_cast<float*>(dn),
+                                                        const_cast<float*>(dc), n);
+    KCHK(c);
+    if (mem_kind == MI_ICP_HOST) {
+        TRY(from_device(c, dp, xyz, (size_t)n * 3, mem_kind));
+        TRY(from_device(c, dn, normals, (size_t)n * 3, mem_kind));
+        TRY(from_device(c, dc, covs, (size_t)n * 9, mem_kind));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return MI_ICP_OK;
+}
+
 int mi_icp_covariances_from_normals(mi_icp_ctx* c, const float* normals, int64_t n, float epsilon,
                                     float* covs, int mem_kind) {
     TRY(check_ctx(c));

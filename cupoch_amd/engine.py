@@ -316,6 +316,33 @@ class Engine:
         self._chk(self._L.mi_icp_transform(self._ctx, tp, p.ptr, n.ptr, c.ptr, cnt, kind))
         return p.keep, n.keep, _cov_out(c.keep)
 
+    def compute_bounds(self, points):
+        """(min_bound, max_bound, center) of a cloud as float32 numpy vectors
+        (GeometryBase3D::GetMinBound / GetMaxBound / GetCenter); zeros for an empty cloud."""
+        p = _Buf(points, np.float32, 3, self.device)
+        out = np.zeros((3, 3), np.float32)
+        ptr = lambda r: out[r].ctypes.data_as(C.c_void_p)
+        self._chk(self._L.mi_icp_compute_bounds(self._ctx, p.ptr, p.n, p.kind, ptr(0), ptr(1), ptr(2)))
+        return out[0].copy(), out[1].copy(), out[2].copy()
+
+    def affine(self, points=None, normals=None, covariances=None, R=None, scale=None, center=None, translate=None):
+        """GeometryBase3D::Translate / Scale / Rotate: p <- (R (p - center)) * scale + center + translate,
+        normals <- R n, covariances <- R C R^T.  In place on torch CUDA tensors; numpy inputs are left
+        untouched and moved copies are returned, as Engine.transform."""
+        p = _Buf(points, np.float32, 3, self.device, copy=True)
+        n = _Buf(normals, np.float32, 3, self.device, copy=True)
+        c = _Buf(_cov_in(covariances), np.float32, 9, self.device, copy=True)
+        kind = self._same_kind(p, n, c)
+        cnt = max(p.n, n.n, c.n)
+        vec = lambda v: None if v is None else np.ascontiguousarray(np.asarray(v, np.float32).reshape(3))
+        Rc = None if R is None else np.ascontiguousarray(np.asarray(R, np.float32).reshape(3, 3).T)   # column-major
+        cv, tv = vec(center), vec(translate)
+        ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        self._chk(self._L.mi_icp_affine(self._ctx, ptr(Rc), float(scale if scale is not None else 1.0),
+                                        0 if scale is None else 1, ptr(cv), ptr(tv), p.ptr, n.ptr, c.ptr, cnt, kind))
+        self.synchronize()
+        return p.keep, n.keep, _cov_out(c.keep)
+
     def voxel_downsample(self, points, voxel_size, normals=None, colors=None):
         p = _Buf(points, np.float32, 3, self.device)
         n = _Buf(normals, np.float32, 3, self.device)

@@ -89,6 +89,43 @@ class KDTreeFlann:
         return self.search_knn_vector_3f(query, search_param.knn)
 
 
+class AxisAlignedBoundingBox:
+    """geometry::AxisAlignedBoundingBox<3> (geometry/boundingvolume.h:121-230) as far as the
+    ICP path's PointCloud hands it out: bounds, extent, centre, volume."""
+
+    def __init__(self, min_bound=(0, 0, 0), max_bound=(0, 0, 0)):
+        self.min_bound = np.asarray(min_bound, np.float32).reshape(3).copy()
+        self.max_bound = np.asarray(max_bound, np.float32).reshape(3).copy()
+        self.color = np.zeros(3, np.float32)
+
+    def get_min_bound(self):
+        return self.min_bound
+
+    def get_max_bound(self):
+        return self.max_bound
+
+    def get_center(self):
+        return ((self.min_bound + self.max_bound) * np.float32(0.5)).astype(np.float32)
+
+    def get_extent(self):
+        return self.max_bound - self.min_bound
+
+    def get_half_extent(self):
+        return self.get_extent() * np.float32(0.5)
+
+    def get_max_extent(self):
+        return float(self.get_extent().max())
+
+    def volume(self):
+        return float(np.prod(self.get_extent()))
+
+    def is_empty(self):
+        return self.volume() <= 0
+
+    def __repr__(self):
+        return "geometry::AxisAlignedBoundingBox with min_bound %s and max_bound %s" % (self.min_bound, self.max_bound)
+
+
 class PointCloud:
     def __init__(self, points=None):
         self._points = utility.Vector3fVector() if points is None else _v3(points)
@@ -158,6 +195,47 @@ class PointCloud:
         return out
 
     # PointCloud::Transform (pointcloud.cu:293-299) ------------------------------------------
+    # GeometryBase3D (geometry/geometry_base.h:44-90, geometry/pointcloud.cu:205-242) ---------------
+    def _bounds(self):
+        return get_engine(self._points.tensor.device.index if self._points.tensor.is_cuda else None) \
+            .compute_bounds(self._points.tensor)
+
+    def get_min_bound(self):
+        return self._bounds()[0]
+
+    def get_max_bound(self):
+        return self._bounds()[1]
+
+    def get_center(self):
+        return self._bounds()[2]
+
+    def get_axis_aligned_bounding_box(self):
+        mn, mx, _ = self._bounds()
+        return AxisAlignedBoundingBox(mn, mx)
+
+    def _affine(self, with_attributes, **kw):
+        eng = get_engine(self._points.tensor.device.index if self._points.tensor.is_cuda else None)
+        n = self._normals.tensor if with_attributes and self._normals is not None and len(self._normals) else None
+        c = self._covariances.tensor if with_attributes and self._covariances is not None and len(self._covariances) else None
+        _, _, c_new = eng.affine(self._points.tensor, n, c, **kw)
+        if c_new is not None:
+            self._covariances.tensor = c_new
+        return self
+
+    def translate(self, translation, relative=True):
+        t = np.asarray(translation, np.float32).reshape(3)
+        if not relative:
+            t = (t - self.get_center()).astype(np.float32)
+        return self._affine(False, translate=t)
+
+    def scale(self, scale, center=True):
+        c = self.get_center() if center and len(self._points) else None
+        return self._affine(False, scale=float(scale), center=c)
+
+    def rotate(self, R, center=True):
+        c = self.get_center() if center and len(self._points) else None
+        return self._affine(True, R=np.asarray(R, np.float32).reshape(3, 3), center=c)
+
     def transform(self, transformation):
         eng = get_engine(self._points.tensor.device.index)
         n = self._normals.tensor if self._normals is not None and len(self._normals) else None

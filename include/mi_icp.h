@@ -196,6 +196,25 @@ MI_ICP_API int mi_icp_icp_iterate(mi_icp_ctx* ctx, int n_iterations, mi_icp_resu
  * caller's arrays; any of the three may be NULL. */
 MI_ICP_API int mi_icp_transform(mi_icp_ctx* ctx, const float* T, float* xyz, float* normals,
                                 float* covs, int64_t n, int mem_kind);
+/* GeometryBase3D::GetMinBound / GetMaxBound / GetCenter of a cloud (geometry/geometry_base.h:47-52,
+ * geometry/pointcloud.cu:205-215; utility::ComputeMinBound / ComputeMaxBound / ComputeCenter,
+ * utility/eigen.inl:208-232).  Any of the outputs (host float[3]) may be NULL; an empty cloud
+ * gives zero vectors.  The centre is the fp64 sum divided by n, rounded once (the reference
+ * sums in fp32). */
+MI_ICP_API int mi_icp_compute_bounds(mi_icp_ctx* ctx, const float* xyz, int64_t n, int mem_kind,
+                                     float* min3, float* max3, float* center3);
+/* GeometryBase3D::Translate / Scale / Rotate (geometry/geometry_base.h:58-90,
+ * geometry/pointcloud.cu:225-242, geometry_utils.cu:150-270), in place:
+ *   points  <- (R (p - center)) * scale + center + translate
+ *   normals <- R n          covariances <- R C R^T           (only when R9 is given)
+ * with exactly the reference functors' operations for the terms present: R9 (column-major 3x3,
+ * Eigen::Matrix3f::data()), center3, translate3 may be NULL, use_scale = 0 skips the scaling.
+ *   Translate(t, relative)  = affine(NULL, 0, 0, NULL, relative ? t : t - GetCenter(), points)
+ *   Scale(s, center)        = affine(NULL, s, 1, center ? GetCenter() : NULL, NULL, points)
+ *   Rotate(R, center)       = affine(R, 0, 0, center ? GetCenter() : NULL, NULL, points, normals, covs) */
+MI_ICP_API int mi_icp_affine(mi_icp_ctx* ctx, const float* R9, float scale, int use_scale,
+                             const float* center3, const float* translate3, float* xyz, float* normals,
+                             float* covs, int64_t n, int mem_kind);
 /* PointCloud::VoxelDownSample (geometry/down_sample.cu:170-273): outputs in
  * lexicographic voxel order; out arrays must hold n entries; *m receives the
  * voxel count (0 for voxel_size <= 0 or a too-small voxel, as the reference

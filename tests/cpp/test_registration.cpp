@@ -281,7 +281,49 @@ int main() {
         std::printf("\"voxel_zero_empty\": %s, ", empty->IsEmpty() ? "true" : "false");
         geometry::PointCloud q(tgt);
         q.EstimateNormals(knn::KDTreeSearchParamKNN(20));
-        std::printf("\"has_normals\": %s", q.HasNormals() ? "true" : "false");
+        std::printf("\"has_normals\": %s, ", q.HasNormals() ? "true" : "false");
+    }
+    {   // GeometryBase3D on a cloud, through the base-class interface (geometry_base.h:44-90)
+        geometry::PointCloud p = target;
+        geometry::GeometryBase3D& g = p;
+        Vector3f mn(1e9f, 1e9f, 1e9f), mx(-1e9f, -1e9f, -1e9f);
+        double cs[3] = {0, 0, 0};
+        for (int i = 0; i < n; ++i)
+            for (int d = 0; d < 3; ++d) {
+                mn[d] = std::fmin(mn[d], tgt[i][d]);
+                mx[d] = std::fmax(mx[d], tgt[i][d]);
+                cs[d] += tgt[i][d];
+            }
+        const Vector3f c0((float)(cs[0] / n), (float)(cs[1] / n), (float)(cs[2] / n));
+        const bool bounds_ok = g.GetMinBound() == mn && g.GetMaxBound() == mx && (g.GetCenter() - c0).norm() < 1e-6f;
+        const geometry::AxisAlignedBoundingBox<3> box = g.GetAxisAlignedBoundingBox();
+        const bool box_ok = box.GetMinBound() == mn && box.GetMaxBound() == mx &&
+                            std::fabs(box.Volume() - (mx[0] - mn[0]) * (mx[1] - mn[1]) * (mx[2] - mn[2])) < 1e-6f;
+        g.Translate(Vector3f(1.0f, -2.0f, 0.5f));                       // relative
+        const bool tr_ok = (g.GetCenter() - (c0 + Vector3f(1.0f, -2.0f, 0.5f))).norm() < 2e-6f;
+        g.Translate(Vector3f(0.0f, 0.0f, 0.0f), false);                 // centre moved TO the origin
+        const bool tr_abs_ok = g.GetCenter().norm() < 2e-6f;
+        g.Scale(2.0f);                                                  // about the centre
+        const Vector3f ext = g.GetMaxBound() - g.GetMinBound();
+        const bool sc_ok = (ext - 2.0f * (mx - mn)).norm() < 1e-5f && g.GetCenter().norm() < 4e-6f;
+        const Matrix4f R4 = Rigid(0.7f, 1, 1, 0, 0, 0, 0);
+        Eigen::Matrix3f R;
+        for (int r2 = 0; r2 < 3; ++r2) for (int q2 = 0; q2 < 3; ++q2) R(r2, q2) = R4(r2, q2);
+        g.Rotate(R, false);
+        auto pr = p.GetPoints();
+        auto nr = p.GetNormals();
+        double worst = 0, worst_n = 0;
+        for (int i = 0; i < n; i += 97) {
+            const Vector3f want = R * ((tgt[i] - c0) * 2.0f);
+            worst = std::fmax(worst, (pr[i] - want).norm());
+            worst_n = std::fmax(worst_n, (nr[i] - R * nrm[i]).norm());
+        }
+        std::printf("\"base3d_bounds\": %s, \"base3d_box\": %s, \"base3d_translate\": %s, \"base3d_translate_abs\": %s, "
+                    "\"base3d_scale\": %s, \"base3d_rotate_err\": %.3g, \"base3d_rotate_normals_err\": %.3g, "
+                    "\"base3d_empty_center_zero\": %s",
+                    bounds_ok ? "true" : "false", box_ok ? "true" : "false", tr_ok ? "true" : "false",
+                    tr_abs_ok ? "true" : "false", sc_ok ? "true" : "false", worst, worst_n,
+                    geometry::PointCloud().GetCenter().norm() == 0.0f ? "true" : "false");
     }
     std::printf("}\n");
     return 0;

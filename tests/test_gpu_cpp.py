@@ -40,6 +40,11 @@ def test_cpp_surface_end_to_end(tmp_path):
     assert r["colored_no_colors_is_identity"]
     assert 1000 < r["voxels"] <= 9261 and r["voxel_normals_unit"] and r["voxel_zero_empty"] and r["has_normals"]
     assert "require pre-computed target normal vectors" in out.stderr      # LogError path
+    # GeometryBase3D virtuals on the cloud, called through the base class
+    for k in ("base3d_bounds", "base3d_box", "base3d_translate", "base3d_translate_abs", "base3d_scale",
+              "base3d_empty_center_zero"):
+        assert r[k], k
+    assert r["base3d_rotate_err"] < 1e-5 and r["base3d_rotate_normals_err"] < 1e-6, r
     # depth frames -> cloud pyramids -> kinfu::PoseEstimation recovers the camera motion
     assert r["kinfu_ok"] and r["kinfu_err"] < 2e-3, r["kinfu_err"]
     assert r["kinfu_points"] == [320 * 240, 160 * 120] and r["kinfu_normals"]

@@ -168,6 +168,38 @@ def test_pointcloud_members_and_dlpack_bridge(tmp_path):
         np.testing.assert_array_equal(np.asarray(back.normals.cpu()), d["tgt_nrm"])
 
 
+def test_geometry_base_3d_members_of_the_cloud():
+    """get_min_bound / get_max_bound / get_center / get_axis_aligned_bounding_box / translate / scale /
+    rotate (geometry_base.h:44-90; geometry_utils.cu:150-270) against numpy in the functors' order."""
+    cph, d, source, target = clouds(30000, seed=4)
+    P, Nn = d["tgt"], d["tgt_nrm"]
+    np.testing.assert_array_equal(target.get_min_bound(), P.min(0))
+    np.testing.assert_array_equal(target.get_max_bound(), P.max(0))
+    c = target.get_center()
+    np.testing.assert_allclose(c, P.astype(np.float64).mean(0), atol=1e-7)
+    box = target.get_axis_aligned_bounding_box()
+    np.testing.assert_array_equal(box.get_extent(), P.max(0) - P.min(0))
+    assert box.volume() == pytest.approx(float(np.prod(P.max(0) - P.min(0))))
+    t = np.array([0.5, -1.0, 2.0], np.float32)
+    moved = target.clone().translate(t)
+    np.testing.assert_array_equal(np.asarray(moved.points.cpu()), P + t)                      # pt += t, exactly
+    moved = target.clone().translate(t, relative=False)
+    np.testing.assert_allclose(moved.get_center(), t, atol=3e-7)
+    sc = target.clone().scale(3.0)
+    np.testing.assert_array_equal(np.asarray(sc.points.cpu()), (P - c) * np.float32(3.0) + c)   # (pt - c) * s + c
+    sc0 = target.clone().scale(3.0, center=False)
+    np.testing.assert_array_equal(np.asarray(sc0.points.cpu()), P * np.float32(3.0))
+    a = 0.4
+    R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+    rot = target.clone().rotate(R)
+    want = (P - c).astype(np.float64) @ R.astype(np.float64).T + c
+    np.testing.assert_allclose(np.asarray(rot.points.cpu()), want, atol=2e-7)
+    np.testing.assert_allclose(np.asarray(rot.normals.cpu()), Nn.astype(np.float64) @ R.astype(np.float64).T, atol=2e-7)
+    np.testing.assert_allclose(rot.get_center(), c, atol=3e-7)                                 # rotation about the centre
+    empty = cph.geometry.PointCloud()
+    assert not empty.get_center().any() and not empty.get_min_bound().any()
+
+
 def test_error_conventions_of_the_reference():
     cph, d, source, target = clouds(5000, seed=6)
     bare = cph.geometry.PointCloud(d["tgt"])
