@@ -94,6 +94,8 @@ SIGNATURES = {
     "mi_icp_solve_system": (_I, [_P, _F, _P]),
     "mi_icp_kabsch_from_sums": (_I, [_P, _L, _P]),
     "mi_icp_vector6_to_matrix4": (None, [_P, _P]),
+    "mi_icp_lzf_decompress": (_L, [_P, _L, _P, _L]),
+    "mi_icp_lzf_compress": (_L, [_P, _L, _P, _L]),
     "mi_icp_evaluate_registration": (_I, [_P, _F, _P, C.POINTER(Result)]),
     "mi_icp_registration_icp": (_I, [_P, _I, _F, _P, C.POINTER(Params), C.POINTER(Result)]),
     "mi_icp_icp_begin": (_I, [_P, _I, _F, _P, _F, C.POINTER(Result)]),

@@ -30,6 +30,7 @@
 #include "kd_refine.h"
 #include "knn_normals.h"
 #include "lbvh.h"
+#include "lzf.h"
 #include "leaf_links.h"
 #include "loop.h"
 #include "nn_search.h"
@@ -1121,6 +1122,16 @@ int mi_icp_solve_system(const double* sys32, float det_thresh, float* T16) {
     const bool ok = host::solve_system(sys32, det_thresh, T);
     std::memcpy(T16, T.data(), sizeof(float) * 16);
     return ok ? 1 : 0;
+}
+
+int64_t mi_icp_lzf_decompress(const void* in, int64_t in_len, void* out, int64_t out_capacity) {
+    if (!in || !out || in_len < 0 || out_capacity < 0) return 0;
+    return (int64_t)lzf::decompress((const uint8_t*)in, (size_t)in_len, (uint8_t*)out, (size_t)out_capacity);
+}
+
+int64_t mi_icp_lzf_compress(const void* in, int64_t in_len, void* out, int64_t out_capacity) {
+    if (!in || !out || in_len < 0 || out_capacity < 0) return 0;
+    return (int64_t)lzf::compress((const uint8_t*)in, (size_t)in_len, (uint8_t*)out, (size_t)out_capacity);
 }
 
 int mi_icp_kabsch_from_sums(const double* sys32, int64_t n_model, float* T16) {

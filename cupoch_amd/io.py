@@ -8,6 +8,29 @@ utility.Vector3fVector / Engine.set_*."""
 import numpy as np
 
 
+def lzf_decompress(data, out_size):
+    """The LZF stream of PCD's binary_compressed (host helper of the C ABI: mi_icp_lzf_decompress)."""
+    import ctypes as C
+    from . import _lib
+    src = bytes(data)
+    out = C.create_string_buffer(max(int(out_size), 1))
+    got = _lib.load().mi_icp_lzf_decompress(src, len(src), out, int(out_size))
+    if got != out_size:
+        raise ValueError("PCD: corrupt LZF stream (%d of %d bytes)" % (got, out_size))
+    return out.raw[:out_size]
+
+
+def lzf_compress(data):
+    import ctypes as C
+    from . import _lib
+    src = bytes(data)
+    out = C.create_string_buffer(2 * len(src) + 16)
+    got = _lib.load().mi_icp_lzf_compress(src, len(src), out, len(out))
+    if got <= 0 and len(src):
+        raise ValueError("LZF compression failed")
+    return out.raw[:got]
+
+
 def read_pcd_arrays(path):
     """Returns dict(points (n,3) f32, normals (n,3) f32 or None, colors (n,3) f32 in [0,1] or None)."""
     with open(path, "rb") as f:
@@ -39,8 +62,22 @@ def read_pcd_arrays(path):
             rec = np.frombuffer(f.read(n * dt.itemsize), dtype=dt, count=n)
         elif mode == "ascii":
             rec = np.loadtxt(f, dtype=dt, max_rows=n, ndmin=1)
+        elif mode == "binary_compressed":
+            # uint32 compressed size, uint32 uncompressed size, an LZF stream whose payload is
+            # FIELD-major: all x, then all y, ... (file_pcd.cu:455-520)
+            csize, usize = np.frombuffer(f.read(8), "<u4")
+            if int(usize) != n * dt.itemsize:
+                raise ValueError("PCD: binary_compressed payload of %d bytes for %d records of %d" % (usize, n, dt.itemsize))
+            raw = lzf_decompress(f.read(int(csize)), int(usize))
+            rec = np.zeros(n, dt)
+            pos = 0
+            for name in dt.names:
+                sub = dt.fields[name][0]
+                nbytes = sub.itemsize * n
+                rec[name] = np.frombuffer(raw, dtype=sub, count=n, offset=pos)
+                pos += nbytes
         else:
-            raise ValueError("PCD: DATA %s is not supported (binary_compressed needs lzf)" % mode)
+            raise ValueError("PCD: unknown DATA mode %r" % mode)
 
     def cols(names):
         if not all(k in rec.dtype.names for k in names):
@@ -178,8 +215,9 @@ def write_ply_arrays(path, points, normals=None, colors=None, ascii=False):
             f.write(rec.tobytes())
 
 
-def write_pcd_arrays(path, points, normals=None, colors=None):
-    """Binary PCD v0.7 with the fields PCL / cupoch write: x y z [normal_x normal_y normal_z] [rgb]."""
+def write_pcd_arrays(path, points, normals=None, colors=None, ascii=False, compressed=False):
+    """PCD v0.7 with the fields PCL / cupoch write: x y z [normal_x normal_y normal_z] [rgb];
+    DATA binary, ascii or binary_compressed (file_pcd.cu:628-700)."""
     pts = np.asarray(points, np.float32).reshape(-1, 3)
     fields = ["x", "y", "z"]
     cols = [pts]
@@ -195,10 +233,20 @@ def write_pcd_arrays(path, points, normals=None, colors=None):
     n, k = data.shape
     head = ["# .PCD v0.7 - Point Cloud Data file format", "VERSION 0.7", "FIELDS " + " ".join(fields),
             "SIZE " + " ".join(["4"] * k), "TYPE " + " ".join(["F"] * k), "COUNT " + " ".join(["1"] * k),
-            "WIDTH %d" % n, "HEIGHT 1", "VIEWPOINT 0 0 0 1 0 0 0", "POINTS %d" % n, "DATA binary"]
+            "WIDTH %d" % n, "HEIGHT 1", "VIEWPOINT 0 0 0 1 0 0 0", "POINTS %d" % n,
+            "DATA " + ("ascii" if ascii else ("binary_compressed" if compressed else "binary"))]
     with open(path, "wb") as f:
         f.write(("\n".join(head) + "\n").encode("ascii"))
-        f.write(data.tobytes())
+        if ascii:
+            for row in data:
+                f.write((" ".join("%.10g" % v for v in row) + "\n").encode("ascii"))
+        elif compressed:
+            payload = np.ascontiguousarray(data.T).tobytes()          # field-major
+            comp = lzf_compress(payload)
+            f.write(np.array([len(comp), len(payload)], "<u4").tobytes())
+            f.write(comp)
+        else:
+            f.write(data.tobytes())
 
 
 def read_point_cloud_arrays(path):
@@ -210,8 +258,8 @@ def read_point_cloud_arrays(path):
     raise ValueError("read_point_cloud: unsupported extension .%s (pcd and ply are)" % ext)
 
 
-def write_point_cloud(path, pointcloud, write_ascii=False):
-    """cupoch.io.write_point_cloud for .pcd / .ply"""
+def write_point_cloud(path, pointcloud, write_ascii=False, compressed=False):
+    """cupoch.io.write_point_cloud for .pcd / .ply (pointcloud_io.h:70-75: write_ascii, compressed)"""
     def host(v):
         return None if v is None or len(v) == 0 else np.asarray(v.cpu())
     pts = host(pointcloud.points)
@@ -221,7 +269,7 @@ def write_point_cloud(path, pointcloud, write_ascii=False):
     if ext == "ply":
         write_ply_arrays(path, pts, nrm, col, ascii=write_ascii)
     elif ext == "pcd":
-        write_pcd_arrays(path, pts, nrm, col)
+        write_pcd_arrays(path, pts, nrm, col, ascii=write_ascii, compressed=compressed)
     else:
         raise ValueError("write_point_cloud: unsupported extension .%s" % ext)
     return True

@@ -169,6 +169,12 @@ MI_ICP_API int mi_icp_solve_system(const double* sys32, float det_thresh, float*
 MI_ICP_API int mi_icp_kabsch_from_sums(const double* sys32, int64_t n_model, float* T16);
 MI_ICP_API void mi_icp_vector6_to_matrix4(const float* x6, float* T16);
 
+/* host-only: the LZF byte format of PCD's "DATA binary_compressed" (io/file_format/file_pcd.cu:218,461,690
+ * call liblzf's lzf_decompress / lzf_compress).  Return the number of bytes produced, 0 on a
+ * corrupt stream or when out_capacity is too small (compress: 2 x in_len always suffices). */
+MI_ICP_API int64_t mi_icp_lzf_decompress(const void* in, int64_t in_len, void* out, int64_t out_capacity);
+MI_ICP_API int64_t mi_icp_lzf_compress(const void* in, int64_t in_len, void* out, int64_t out_capacity);
+
 /* ---- the registration loop ---------------------------------------------
  * registration::EvaluateRegistration (registration.cu:106-119) and
  * registration::RegistrationICP (registration.cu:121-172) with the built-in

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "cupoch/cupoch.h"
@@ -90,7 +91,8 @@ public:
     mutable int calls = 0;
 };
 
-int main() {
+int main(int argc, char** argv) {
+    const std::string io_dir = argc > 1 ? argv[1] : "/tmp";
     const int n = 50000;
     std::mt19937 rng(7);
     std::uniform_real_distribution<float> U(0.0f, 1.0f);
@@ -324,6 +326,59 @@ int main() {
                     bounds_ok ? "true" : "false", box_ok ? "true" : "false", tr_ok ? "true" : "false",
                     tr_abs_ok ? "true" : "false", sc_ok ? "true" : "false", worst, worst_n,
                     geometry::PointCloud().GetCenter().norm() == 0.0f ? "true" : "false");
+    }
+    {   // io::WritePointCloud / ReadPointCloud (pointcloud_io.h): PCD ascii / binary / binary_compressed, PLY ascii / binary
+        geometry::PointCloud pc(std::vector<Vector3f>(tgt.begin(), tgt.begin() + 5000));
+        pc.SetNormals(std::vector<Vector3f>(nrm.begin(), nrm.begin() + 5000));
+        std::vector<Vector3f> col(5000);
+        for (int i = 0; i < 5000; ++i) col[i] = Vector3f((float)(i % 256) / 255.0f, (float)((i / 7) % 256) / 255.0f, (float)((i / 3) % 256) / 255.0f);
+        pc.SetColors(col);
+        struct Case { const char* file; bool ascii, comp; float tol; } cases[] = {
+                {"cpp_bin.pcd", false, false, 0.0f}, {"cpp_ascii.pcd", true, false, 1e-6f}, {"cpp_comp.pcd", false, true, 0.0f},
+                {"cpp_bin.ply", false, false, 0.0f}, {"cpp_ascii.ply", true, false, 0.0f}};
+        bool all_ok = true;
+        std::printf(", \"io\": {");
+        for (const auto& cs : cases) {
+            const std::string path = io_dir + "/" + cs.file;
+            const bool w = io::WritePointCloud(path, pc, cs.ascii, cs.comp);
+            geometry::PointCloud back;
+            const bool r = io::ReadPointCloud(path, back);
+            double worst = 1e9;
+            if (w && r && back.points_.size() == 5000 && back.HasNormals() && back.HasColors()) {
+                worst = 0;
+                auto bp = back.GetPoints(), bn = back.GetNormals(), bc = back.GetColors();
+                for (int i = 0; i < 5000; ++i) {
+                    worst = std::fmax(worst, (bp[i] - tgt[i]).norm() / std::fmax(1e-9f, tgt[i].norm()));
+                    worst = std::fmax(worst, (bn[i] - nrm[i]).norm());
+                    worst = std::fmax(worst, (bc[i] - col[i]).norm());
+                }
+            }
+            all_ok = all_ok && worst <= cs.tol + 1e-12;
+            std::printf("\"%s\": %.3g, ", cs.file, worst);
+        }
+        // files written by the Python side (tests/test_gpu_cpp.py) before this program started
+        double py_sum = 0;
+        int py_n = 0;
+        for (const char* f : {"py_comp.pcd", "py_bin.ply"}) {
+            auto q = io::CreatePointCloudFromFile(io_dir + "/" + f);
+            py_n += (int)q->points_.size() + (q->HasNormals() ? 1 : 0);
+            for (const auto& v : q->GetPoints()) py_sum += (double)v[0] + 2.0 * (double)v[1] + 3.0 * (double)v[2];
+        }
+        // NaN / inf points are dropped on reading (pointcloud_io.cpp:92-95); unknown extension fails
+        {
+            FILE* f = std::fopen((io_dir + "/nan.pcd").c_str(), "w");
+            std::fprintf(f, "VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 4\nHEIGHT 1\nPOINTS 4\nDATA ascii\n"
+                            "1 2 3\nnan 0 0\n4 5 6\ninf 1 1\n");
+            std::fclose(f);
+        }
+        geometry::PointCloud nanpc, raw;
+        io::ReadPointCloud(io_dir + "/nan.pcd", nanpc);
+        io::ReadPointCloud(io_dir + "/nan.pcd", raw, "auto", false, false);
+        geometry::PointCloud none;
+        const bool bad = io::ReadPointCloud(io_dir + "/cloud.xyz123", none) || io::WritePointCloud(io_dir + "/cloud.xyz123", pc);
+        std::printf("\"all_ok\": %s, \"py_points\": %d, \"py_checksum\": %.17g, \"nan_removed\": %zu, \"nan_kept\": %zu, "
+                    "\"unknown_ext_fails\": %s}",
+                    all_ok ? "true" : "false", py_n, py_sum, nanpc.points_.size(), raw.points_.size(), bad ? "false" : "true");
     }
     std::printf("}\n");
     return 0;

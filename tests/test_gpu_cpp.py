@@ -23,7 +23,15 @@ def test_cpp_surface_end_to_end(tmp_path):
                            "-I/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "test_registration.cpp"),
                            "-o", exe, "-L" + libdir, "-lcupoch_amd", "-lmi_icp", "-L/opt/rocm/lib",
                            "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    # files the C++ readers must understand: written by the Python mirror
+    import numpy as np
+    from cupoch_amd.io import read_point_cloud_arrays, write_pcd_arrays, write_ply_arrays
+    rng = np.random.default_rng(3)
+    py_pts = rng.random((3000, 3), dtype=np.float32)
+    py_nrm = rng.standard_normal((3000, 3)).astype(np.float32)
+    write_pcd_arrays(str(tmp_path / "py_comp.pcd"), py_pts, py_nrm, None, compressed=True)
+    write_ply_arrays(str(tmp_path / "py_bin.ply"), py_pts * 2, None, None)
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads(out.stdout.strip().splitlines()[-1])
     assert r["roundtrip_max"] < 1e-6
@@ -45,6 +53,25 @@ def test_cpp_surface_end_to_end(tmp_path):
               "base3d_empty_center_zero"):
         assert r[k], k
     assert r["base3d_rotate_err"] < 1e-5 and r["base3d_rotate_normals_err"] < 1e-6, r
+    # io::ReadPointCloud / WritePointCloud: every PCD / PLY flavour round-trips in C++ (binary flavours bit for bit),
+    # C++ reads what Python wrote, Python reads what C++ wrote
+    io = r["io"]
+    assert io["all_ok"], io
+    assert io["py_points"] == 3000 + 1 + 3000
+    w = np.array([1.0, 2.0, 3.0])
+    assert io["py_checksum"] == pytest.approx(float((py_pts.astype(np.float64) @ w).sum() * 3), rel=1e-9)
+    assert io["nan_removed"] == 2 and io["nan_kept"] == 4 and io["unknown_ext_fails"]
+    first = None
+    for name in ("cpp_bin.pcd", "cpp_comp.pcd", "cpp_ascii.pcd", "cpp_bin.ply", "cpp_ascii.ply"):
+        a = read_point_cloud_arrays(str(tmp_path / name))
+        assert a["points"].shape == (5000, 3) and a["normals"].shape == (5000, 3) and a["colors"].shape == (5000, 3)
+        if first is None:
+            first = a
+        tol = 1e-6 if "ascii.pcd" in name else 0
+        np.testing.assert_allclose(a["points"], first["points"], rtol=tol)
+        np.testing.assert_allclose(a["normals"], first["normals"], rtol=tol, atol=tol)
+        np.testing.assert_allclose(a["colors"], first["colors"], atol=1e-6)
+    assert "unknown file extension" in out.stderr
     # depth frames -> cloud pyramids -> kinfu::PoseEstimation recovers the camera motion
     assert r["kinfu_ok"] and r["kinfu_err"] < 2e-3, r["kinfu_err"]
     assert r["kinfu_points"] == [320 * 240, 160 * 120] and r["kinfu_normals"]

@@ -45,6 +45,49 @@ def test_pcd_reader_roundtrip(tmp_path):
     assert a["normals"] is None and a["colors"] is None
 
 
+def test_lzf_format_vectors_and_roundtrip():
+    """PCD's binary_compressed carries an LZF stream (mi_icp_lzf_*, host helpers of the C ABI).  liblzf is
+    an absent third-party dependency of the reference, so the decoder is pinned on streams written out
+    by hand from the published format: literal runs (ctrl < 32: ctrl + 1 bytes follow) and back
+    references (len = (ctrl >> 5) + 2, 7 -> + next byte; distance = ((ctrl & 31) << 8 | next) + 1)."""
+    from cupoch_amd.io import lzf_compress, lzf_decompress
+    # "abc" literal, then 6 bytes from 3 back (overlapping copy): abcabcabc
+    assert lzf_decompress(bytes([2]) + b"abc" + bytes([(6 - 2) << 5, 3 - 1]), 9) == b"abcabcabc"
+    # long match: 1 literal 'x', then 40 bytes from 1 back: ctrl = 7 << 5, extension byte = 40 - 2 - 7
+    assert lzf_decompress(bytes([0]) + b"x" + bytes([7 << 5, 40 - 2 - 7, 0]), 41) == b"x" * 41
+    # distance with a high part: 300 literals (10 runs of <= 32), then 5 bytes from 300 back
+    lit = bytes(range(256)) + bytes(range(44))
+    runs = b"".join(bytes([len(lit[i:i + 32]) - 1]) + lit[i:i + 32] for i in range(0, 300, 32))
+    assert lzf_decompress(runs + bytes([((5 - 2) << 5) | ((300 - 1) >> 8), (300 - 1) & 255]), 305) == lit + lit[:5]
+    with pytest.raises(ValueError):
+        lzf_decompress(bytes([(3 << 5), 9]), 5)                       # reference before the start of the output
+    rng = np.random.default_rng(0)
+    for data in (b"", b"a", bytes(rng.integers(0, 256, 10000, dtype=np.uint8)),          # incompressible
+                 np.repeat(rng.random(500, dtype=np.float32), 7).tobytes(),              # repetitive floats
+                 bytes(100000), (b"0123456789" * 3000)):
+        comp = lzf_compress(data)
+        assert lzf_decompress(comp, len(data)) == data
+        if len(data) > 20000:
+            assert len(comp) < len(data) // 4
+
+
+@pytest.mark.parametrize("mode", ["binary", "ascii", "binary_compressed"])
+def test_pcd_writer_reader_roundtrip_all_data_modes(tmp_path, mode):
+    from cupoch_amd.io import read_pcd_arrays, write_pcd_arrays
+    rng = np.random.default_rng(1)
+    pts = (rng.random((777, 3), dtype=np.float32) * 10 - 5).astype(np.float32)
+    nrm = rng.standard_normal((777, 3)).astype(np.float32)
+    col = (rng.integers(0, 256, (777, 3)) / 255.0).astype(np.float32)
+    p = str(tmp_path / "c.pcd")
+    write_pcd_arrays(p, pts, nrm, col, ascii=(mode == "ascii"), compressed=(mode == "binary_compressed"))
+    assert ("DATA " + mode).encode() in open(p, "rb").read(400)
+    a = read_pcd_arrays(p)
+    tol = 0 if mode != "ascii" else 1e-6           # %.10g
+    np.testing.assert_allclose(a["points"], pts, rtol=tol, atol=0)
+    np.testing.assert_allclose(a["normals"], nrm, rtol=tol, atol=0)
+    np.testing.assert_allclose(a["colors"], col, atol=1e-6)
+
+
 def test_oracle_icp_on_real_scan():
     """The example flow of examples/python/basic/icp_registration.py (threshold 0.02,
     point-to-plane) on the reference's sample scan against a moved copy of itself."""
