@@ -26,6 +26,7 @@ struct GroupBuildArgs {
     uint32_t leaf_first;      // id of the first leaf-level node (8^k >= 64 * ngroups)
     float* tblk;              // [ngroups * 512] leaf lines
     float4* tnrm;             // [ngroups * 4096] or null
+    float* trec;              // [ngroups * 4096][6] {x, y, z, nx, ny, nz} or null: what the point-to-plane reduction gathers
     float* tcov;              // [ngroups * 4096 * 9] or null
     float* records;
     float* lreg;              // [ngroups * 512][8] leaf regions (below)
@@ -104,9 +105,20 @@ __global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_eu(8, 8
         line[8] = s.cy[li];
         line[16] = s.cz[li];
         line[24] = __int_as_float((int)o);
-        if (a.tnrm)
-            a.tnrm[slot0 + p] = real ? make_float4(a.nrm[o * 3], a.nrm[o * 3 + 1], a.nrm[o * 3 + 2], 0.0f)
-                                     : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (a.tnrm) {
+            const float4 n4 = real ? make_float4(a.nrm[o * 3], a.nrm[o * 3 + 1], a.nrm[o * 3 + 2], 0.0f)
+                                   : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            a.tnrm[slot0 + p] = n4;
+            if (a.trec) {
+                float* r = a.trec + (slot0 + p) * 6;
+                r[0] = s.cx[li];
+                r[1] = s.cy[li];
+                r[2] = s.cz[li];
+                r[3] = n4.x;
+                r[4] = n4.y;
+                r[5] = n4.z;
+            }
+        }
         if (a.tcov) {
 #pragma unroll
             for (int e = 0; e < 9; ++e) a.tcov[(slot0 + p) * 9 + e] = real ? a.cov[o * 9 + e] : 0.0f;

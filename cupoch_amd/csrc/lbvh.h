@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void build_leaves(
         const uint32_t* __restrict__ order, const float* __restrict__ pts,
         const float* __restrict__ nrm, const float* __restrict__ cov, int64_t n, int nleaf, int nslots,
         uint32_t leaf_first, float* __restrict__ tblk, float4* __restrict__ tnrm,
-        float* __restrict__ tcov, float* __restrict__ records) {
+        float* __restrict__ tcov, float* __restrict__ records, float* __restrict__ trec) {
     const int L = (int)(blockIdx.x * 256 + threadIdx.x);
     if (L >= nslots) return;
     float mn[3] = {INFINITY, INFINITY, INFINITY};
@@ -175,9 +175,17 @@ __global__ __launch_bounds__(256) void build_leaves(
                     mn[d] = fminf(mn[d], p[d]);
                     mx[d] = fmaxf(mx[d], p[d]);
                 }
-                if (nrm)
+                if (nrm) {
                     tnrm[s] = make_float4(nrm[(int64_t)o * 3], nrm[(int64_t)o * 3 + 1],
                                           nrm[(int64_t)o * 3 + 2], 0.0f);
+                    if (trec) {
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            trec[s * 6 + d] = p[d];
+                            trec[s * 6 + 3 + d] = nrm[(int64_t)o * 3 + d];
+                        }
+                    }
+                }
                 if (cov) {
 #pragma unroll
                     for (int e = 0; e < 9; ++e) tcov[s * 9 + e] = cov[(int64_t)o * 9 + e];

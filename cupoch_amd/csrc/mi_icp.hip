@@ -86,8 +86,8 @@ struct mi_icp_ctx {
     int nleaf = 0;
     int64_t nts = 0;  // sorted positions of the target incl. padding slots (kd_cells.h)
     uint32_t leaf_first = 1, nrecords = 0;  // 8-ary tree: first last-level node id, record count
-    bool t_has_nrm = false, t_has_cov = false, t_has_int = false, t_has_grad = false;
-    DevBuf tblk, tnrm, tcov, tgrad, nodes, inv_t, tlreg, tlinks, tlinks_tmp;
+    bool t_has_nrm = false, t_has_cov = false, t_has_int = false, t_has_grad = false, t_has_rec = false;
+    DevBuf tblk, tnrm, trec, tcov, tgrad, nodes, inv_t, tlreg, tlinks, tlinks_tmp;
     DevBuf cell_planes, cell_samples, cell_cstart, cell_gstart;
     uint32_t* cell_total_host = nullptr;  // pinned
     bool inv_t_valid = false;
@@ -589,6 +589,7 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, const DevLoop
     a.scov = (const float*)c->scov.p;
     a.tblk = (const float*)c->tblk.p;
     a.tnrm = (const float4*)c->tnrm.p;
+    a.trec = c->t_has_rec ? (const float*)c->trec.p : nullptr;
     a.tcov = (const float*)c->tcov.p;
     a.tgrad = (const float4*)c->tgrad.p;
     a.sint = (const float*)c->sint.p;
@@ -618,6 +619,16 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, const DevLoop
     if (!estimator_ready(c, est)) {
         est = kEstP2P;
         mode = 1;
+    }
+    static const bool no_fast_reduce = std::getenv("MI_ICP_NO_FAST_REDUCE") != nullptr;  // A/B switch
+    if (est == kEstPt2Pl && mode == 0 && !a.pairs && a.trec && a.count > 0 && !no_fast_reduce) {
+        // four elements in flight per thread; at most 512 blocks (2 per CU): measured best on the 10M bench
+        // (256 / 512 / 1024 / 2048 blocks: 0.090 / 0.079 / 0.080 / 0.091 ms, scripts/gpu_reduce_sweep.sh)
+        const int g2 = std::min(grid, 512);
+        EvTimer t(c, 1, loop != nullptr);
+        reduce_pt2pl_kernel<4><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys);
+        KCHK(c);
+        return MI_ICP_OK;
     }
     {
         EvTimer t(c, 1, loop != nullptr);
@@ -724,7 +735,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_links) (void)hipEventDestroy(c->ev_links);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    DevBuf* all[] = {&c->tlreg, &c->tlinks, &c->tlinks_tmp, &c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
+    DevBuf* all[] = {&c->trec, &c->tlreg, &c->tlinks, &c->tlinks_tmp, &c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
                      &c->cell_gstart, &c->sx, &c->sy, &c->sz,
                      &c->sperm, &c->snrm, &c->scov, &c->nn_idx, &c->nn_d2, &c->inv_s,
                      &c->user_pairs, &c->keys0, &c->keys1, &c->vals0, &c->vals1, &c->hist,
@@ -793,6 +804,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     c->t_has_nrm = normals != nullptr && n > 0;
     c->t_has_cov = covs != nullptr && n > 0;
     c->t_has_int = c->t_has_grad = false;
+    c->t_has_rec = false;
     if (n == 0) return MI_ICP_OK;
     hipEvent_t e0 = c->ev[2], e1 = c->ev[3];
     if (c->profiling) {
@@ -837,7 +849,11 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     TRY(ensure(c, c->nodes, (size_t)nrecords * kRecordFloats, &nodes));
     float* lreg;
     TRY(ensure(c, c->tlreg, (size_t)nleaf * kLeafRegFloats, &lreg));
+    float* trec = nullptr;
+    static const bool no_trec = std::getenv("MI_ICP_NO_TREC") != nullptr;  // A/B switch
     if (d_nrm) TRY(ensure(c, c->tnrm, (size_t)nts, &tnrm));
+    if (d_nrm && !no_trec) TRY(ensure(c, c->trec, (size_t)nts * 6, &trec));
+    c->t_has_rec = trec != nullptr;
     if (d_cov) TRY(ensure(c, c->tcov, (size_t)nts * 9, &tcov));
     uint32_t first, used;  // the level whose nodes' boxes still have to be formed from their records
     // nodes above the groups are kd subtrees -- disjoint boxes -- when every cell has exactly one group
@@ -849,7 +865,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
         KCHK(c);
         const int nslots = (int)used_last * 8;
         build_leaves<<<blocks_for(nslots), 256, 0, c->stream>>>(order, d_pts, d_nrm, d_cov, nts, nleaf, nslots,
-                                                                leaf_first, tblk, tnrm, tcov, nodes);
+                                                                leaf_first, tblk, tnrm, tcov, nodes, trec);
         KCHK(c);
         first = leaf_first;
         used = used_last;
@@ -868,6 +884,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
         ga.leaf_first = leaf_first;
         ga.tblk = tblk;
         ga.tnrm = tnrm;
+        ga.trec = trec;
         ga.tcov = tcov;
         ga.records = nodes;
         ga.lreg = lreg;

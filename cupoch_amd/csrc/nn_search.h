@@ -104,18 +104,26 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     __shared__ PacketShared s_pk[kNNPacketsPerBlock];
     uint32_t logical;
     if (!xcd_remap(nblocks, logical)) return;
+    PacketShared& sh = s_pk[threadIdx.x >> 6];
+    const int lane = lane_id();
+    const int64_t i = ((int64_t)logical * kNNPacketsPerBlock + (threadIdx.x >> 6)) * 64 + lane;
+    const bool valid = i < ns;
+    // Everything this lane needs from global memory that does not depend on anything else is
+    // requested FIRST, branch-free (lanes past the end re-read element 0), so that these loads,
+    // the scalar loads of the loop state below and -- seeded -- the previous match travel together:
+    // a wave's life is a chain of memory round trips, and each one taken out of it counts.
+    const int64_t ic = valid ? i : 0;
+    int32_t seed_j = -1;
+    if (SEED) seed_j = nn_idx[ic];
+    const float rx = sx[ic], ry = sy[ic], rz = sz[ic];
     Xform T = Tv;
     if (loop) {
         if (loop->done) return;
         T = loop->X;
     }
-    PacketShared& sh = s_pk[threadIdx.x >> 6];
-    const int lane = lane_id();
-
-    const int64_t i = ((int64_t)logical * kNNPacketsPerBlock + (threadIdx.x >> 6)) * 64 + lane;
-    const bool valid = i < ns;
+    if (!valid) seed_j = -1;
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
-    if (valid) xform_point(T, sx[i], sy[i], sz[i], qx, qy, qz);
+    if (valid) xform_point(T, rx, ry, rz, qx, qy, qz);
     // invalid lanes: best = -1 is below every d2 and yields an empty search cube
     float best = valid ? r2 : -1.0f;
     int32_t bidx = -1;
@@ -134,15 +142,17 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
         // other leaf) the lane is finished before the tree is touched.  A converged iteration
         // is therefore one streaming pass: query + previous match in, leaf line + region in,
         // match + distance out.
-        const int32_t j = valid ? nn_idx[i] : -1;
+        const int32_t j = seed_j;
+        // (lanes without a previous match read leaf 0: no branch between the index and its loads)
+        const uint32_t Lc = (j >= 0) ? ((uint32_t)j >> 3) : 0u;
+        const float4* line = reinterpret_cast<const float4*>(tblk_g + (size_t)Lc * kLeafFloats);
+        const float4* rg = reinterpret_cast<const float4*>(lreg_g + (size_t)Lc * kLeafRegFloats);
+        const float4 x0 = line[0], x1 = line[1], y0 = line[2], y1 = line[3], z0 = line[4], z1 = line[5];
+        const float4 g0 = rg[0], g1 = rg[1];
         if (j >= 0) {
-            const uint32_t L = (uint32_t)j >> 3;
+            const uint32_t L = Lc;
             seed_leaf = L;
             my_node = leaf_first + (L >> 3);
-            const float4* line = reinterpret_cast<const float4*>(tblk_g + (size_t)L * kLeafFloats);
-            const float4* rg = reinterpret_cast<const float4*>(lreg_g + (size_t)L * kLeafRegFloats);
-            const float4 x0 = line[0], x1 = line[1], y0 = line[2], y1 = line[3], z0 = line[4], z1 = line[5];
-            const float4 g0 = rg[0], g1 = rg[1];
             const float px[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
             const float py[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
             const float pz[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};

@@ -57,6 +57,10 @@ __device__ __forceinline__ void accum_row(double* acc, const float* J, float r) 
     acc[27] = __builtin_fma((double)r, (double)r, acc[27]);
 }
 
+struct __attribute__((packed, aligned(4))) F3 {  // 12 bytes at 4-byte alignment: one global_load_dwordx3
+    float x, y, z;
+};
+
 struct ReduceArgs {
     const float* sx;
     const float* sy;
@@ -65,6 +69,7 @@ struct ReduceArgs {
     const float* scov;    // sorted source covariances (GICP)
     const float* tblk;    // target leaf lines
     const float4* tnrm;   // sorted target normals; .w = target intensity when colours are set
+    const float* trec;    // [slot][6] {x, y, z, nx, ny, nz}: point-to-plane gathers one 24-byte record (or null)
     const float4* tgrad;  // sorted target colour gradients (colored ICP)
     const float* sint;    // sorted source intensities (colored ICP)
     float sqrt_lambda_geometric, sqrt_lambda_photometric;
@@ -76,6 +81,79 @@ struct ReduceArgs {
     int ns, nt;
     int64_t count;          // ns, or number of pairs
 };
+
+// The block-level end of a reduction: `acc[k]` (k < 30) holds this thread's sums.  Wave sums on
+// the DPP network -> LDS -> this block's row of `partial`; the LAST block to arrive (agent-scope
+// release -> ticket -> acquire) totals the rows in a fixed order into out32, so the result is
+// bitwise reproducible; the ticket is the only atomic.
+__device__ __forceinline__ void block_finish(const double* acc, double* __restrict__ partial,
+                                             uint32_t* __restrict__ ticket, double* __restrict__ out32) {
+    __shared__ double red[kReduceThreads / 32][kSysSize];
+    __shared__ uint32_t s_last;
+    const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
+#pragma unroll
+    for (int k = 0; k < 30; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == kWaveSumLane) red[wid][k] = v;
+    }
+    if (lane == kWaveSumLane) {
+        red[wid][30] = 0.0;
+        red[wid][31] = 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x < kSysSize) {
+        const int k = (int)threadIdx.x;
+        // ---- hand-off to the finishing block (cdna_hip_programming.md section 6, Guideline 16; MI355X_MICROARCH.md,
+        // "publish" rows): the row is stored WRITE-THROUGH (agent-scope relaxed atomic store = global_store ... sc1),
+        // drained with vmcnt(0), and only then is the ticket taken.  The first version used plain stores +
+        // fence(release, "agent"): that fence is a buffer_wbl2 -- a write-back of the whole XCD's L2 per block,
+        // and those serialise: ~50 ns per block of the grid, 50 us of a 115-us launch with 1024 blocks.
+        __hip_atomic_store(&partial[(int64_t)blockIdx.x * kSysSize + k],
+                           ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    {   // fixed-order total of the per-block partials (independent of which block finishes)
+        const int k = (int)(threadIdx.x & 31u), part = (int)(threadIdx.x >> 5);
+        constexpr int kParts = kReduceThreads / 32;
+        // 16 independent accumulators keep 16 loads in flight: the partials were written by
+        // other CUs / XCDs, every load is a ~1 us miss, and a single dependent chain made this
+        // phase cost 20 us.  The association order is fixed, so the sum is reproducible.
+        const int nb = (int)gridDim.x;
+        const double* pk = partial + k;
+        constexpr int kU = 16;
+        double acc16[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) acc16[u] = 0.0;
+        int b = part;
+        for (; b + (kU - 1) * kParts < nb; b += kU * kParts) {
+#pragma unroll
+            for (int u = 0; u < kU; ++u) acc16[u] += pk[(int64_t)(b + u * kParts) * kSysSize];
+        }
+        for (; b < nb; b += kParts) acc16[0] += pk[(int64_t)b * kSysSize];
+#pragma unroll
+        for (int w = kU / 2; w > 0; w >>= 1)
+#pragma unroll
+            for (int u = 0; u < w; ++u) acc16[u] += acc16[u + w];
+        red[part][k] = acc16[0];
+        __syncthreads();
+        if (threadIdx.x < kSysSize) {
+            double t = 0.0;
+#pragma unroll
+            for (int p = 0; p < kParts; ++p) t += red[p][k];
+            out32[k] = t;
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // MODE 0: accumulate the linear system; MODE 1: accumulate only the
 // estimator's ComputeRMSE error into acc[27] (+ [28],[29]).
@@ -111,19 +189,38 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_kernel(ReduceArgs a, Xf
             j = a.nn_idx[k];
         }
         if (j < 0) continue;
-        float vs[3], vt[3];
+        float vs[3], vt[3], nt_rec[3] = {0.0f, 0.0f, 0.0f};
         xform_point(T, a.sx[i], a.sy[i], a.sz[i], vs[0], vs[1], vs[2]);
-        const float* line = a.tblk + (int64_t)(j >> 3) * kLeafFloats + (j & 7);
-        vt[0] = line[0];
-        vt[1] = line[8];
-        vt[2] = line[16];
+        if (EST == kEstPt2Pl && a.trec) {
+            // point and normal of the match in ONE 24-byte record (two 12-byte loads): the leaf line
+            // costs 16 bytes per slot for the 12 used, the float4 normal another 16 -- a quarter of
+            // this kernel's traffic that nothing reads
+            const F3* r = reinterpret_cast<const F3*>(a.trec + (int64_t)j * 6);
+            const F3 p3 = r[0], n3 = r[1];
+            vt[0] = p3.x;
+            vt[1] = p3.y;
+            vt[2] = p3.z;
+            nt_rec[0] = n3.x;
+            nt_rec[1] = n3.y;
+            nt_rec[2] = n3.z;
+        } else {
+            const float* line = a.tblk + (int64_t)(j >> 3) * kLeafFloats + (j & 7);
+            vt[0] = line[0];
+            vt[1] = line[8];
+            vt[2] = line[16];
+        }
         const float d[3] = {vs[0] - vt[0], vs[1] - vt[1], vs[2] - vt[2]};
         acc[28] += (double)sq3(d[0], d[1], d[2]);
         acc[29] += 1.0;
 
         if (EST == kEstPt2Pl) {
-            const float4 n4 = a.tnrm[j];
-            const float nt[3] = {n4.x, n4.y, n4.z};
+            float nt[3] = {nt_rec[0], nt_rec[1], nt_rec[2]};
+            if (!a.trec) {
+                const float4 n4 = a.tnrm[j];
+                nt[0] = n4.x;
+                nt[1] = n4.y;
+                nt[2] = n4.z;
+            }
             const float r = dot3(d, nt);
             if (MODE == 0) {
                 float J[6];
@@ -244,69 +341,80 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_kernel(ReduceArgs a, Xf
         }
     }
 
-    __shared__ double red[kReduceThreads / 32][kSysSize];
-    __shared__ uint32_t s_last;
-    const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
+    block_finish(acc, partial, ticket, out32);
+}
+
+// Point-to-plane, nearest-neighbour correspondences, 24-byte target records: the loop that runs in
+// every iteration of the headline workload, written for memory-level parallelism.  reduce_kernel's
+// generic loop takes two DEPENDENT round trips per element (match index, then the gather) with
+// nothing else in flight -- 38 elements per thread at 10M points, i.e. the kernel's whole duration
+// was 76 serial memory latencies.  Here kU elements per thread travel together: their coalesced
+// loads (index + source point) are issued back to back, then their gathers, then the arithmetic;
+// no branch sits between a load and its use (lanes past the end re-read element 0, unmatched points
+// re-read slot 0; both are masked out of the sums).  Same per-element arithmetic and the same
+// per-thread summation order as reduce_kernel<point-to-plane, 0> with the same grid.
+template <int kU>
+__global__ __launch_bounds__(kReduceThreads) void reduce_pt2pl_kernel(ReduceArgs a, Xform Tv,
+                                                                      const DevLoop* __restrict__ loop,
+                                                                      double* __restrict__ partial,
+                                                                      uint32_t* __restrict__ ticket,
+                                                                      double* __restrict__ out32) {
+    const int64_t stride = (int64_t)gridDim.x * kReduceThreads;
+    const int64_t k0 = (int64_t)blockIdx.x * kReduceThreads + threadIdx.x;
+    // the first batch is requested before the loop state is even looked at
+    int32_t j[kU];
+    float px[kU], py[kU], pz[kU];
+    auto fetch = [&](int64_t kb) {
 #pragma unroll
-    for (int k = 0; k < 30; ++k) {
-        const double v = wave_sum(acc[k]);
-        if (lane == kWaveSumLane) red[wid][k] = v;
-    }
-    if (lane == kWaveSumLane) {
-        red[wid][30] = 0.0;
-        red[wid][31] = 0.0;
-    }
-    __syncthreads();
-    if (threadIdx.x < kSysSize) {
-        const int k = (int)threadIdx.x;
-        partial[(int64_t)blockIdx.x * kSysSize + k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
-    }
-    // ---- hand-off to the finishing block: agent-scope release -> ticket -> acquire
-    // (cdna_hip_programming.md section 6, Guideline 16)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == gridDim.x - 1u) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-    {   // fixed-order total of the per-block partials (independent of which block finishes)
-        const int k = (int)(threadIdx.x & 31u), part = (int)(threadIdx.x >> 5);
-        constexpr int kParts = kReduceThreads / 32;
-        // 16 independent accumulators keep 16 loads in flight: the partials were written by
-        // other CUs / XCDs, every load is a ~1 us miss, and a single dependent chain made this
-        // phase cost 20 us.  The association order is fixed, so the sum is reproducible.
-        const int nb = (int)gridDim.x;
-        const double* pk = partial + k;
-        constexpr int kU = 16;
-        double acc16[kU];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) acc16[u] = 0.0;
-        int b = part;
-        for (; b + (kU - 1) * kParts < nb; b += kU * kParts) {
-#pragma unroll
-            for (int u = 0; u < kU; ++u) acc16[u] += pk[(int64_t)(b + u * kParts) * kSysSize];
+        for (int u = 0; u < kU; ++u) {
+            const int64_t k = kb + (int64_t)u * stride;
+            const int64_t kc = (k < a.count) ? k : 0;
+            j[u] = a.nn_idx[kc];
+            px[u] = a.sx[kc];
+            py[u] = a.sy[kc];
+            pz[u] = a.sz[kc];
         }
-        for (; b < nb; b += kParts) acc16[0] += pk[(int64_t)b * kSysSize];
-#pragma unroll
-        for (int w = kU / 2; w > 0; w >>= 1)
-#pragma unroll
-            for (int u = 0; u < w; ++u) acc16[u] += acc16[u + w];
-        red[part][k] = acc16[0];
-        __syncthreads();
-        if (threadIdx.x < kSysSize) {
-            double t = 0.0;
-#pragma unroll
-            for (int p = 0; p < kParts; ++p) t += red[p][k];
-            out32[k] = t;
-        }
-        if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    fetch(k0);
+    Xform T = Tv;
+    if (loop) {
+        if (loop->done) return;
+        T = loop->X;
     }
+    double acc[30];
+#pragma unroll
+    for (int k = 0; k < 30; ++k) acc[k] = 0.0;
+    for (int64_t kb = k0; kb < a.count; kb += stride * kU) {
+        F3 tp[kU], tn[kU];
+        bool have[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            have[u] = (kb + (int64_t)u * stride) < a.count && j[u] >= 0;
+            const F3* r = reinterpret_cast<const F3*>(a.trec + (int64_t)(have[u] ? j[u] : 0) * 6);
+            tp[u] = r[0];
+            tn[u] = r[1];
+        }
+        float vs[kU][3];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) xform_point(T, px[u], py[u], pz[u], vs[u][0], vs[u][1], vs[u][2]);
+        fetch(kb + stride * kU);  // the next batch's coalesced loads overlap this batch's arithmetic
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            if (!have[u]) continue;
+            const float nt[3] = {tn[u].x, tn[u].y, tn[u].z};
+            const float d[3] = {vs[u][0] - tp[u].x, vs[u][1] - tp[u].y, vs[u][2] - tp[u].z};
+            acc[28] += (double)sq3(d[0], d[1], d[2]);
+            acc[29] += 1.0;
+            const float r = dot3(d, nt);
+            float J[6];
+            cross3(vs[u], nt, J);
+            J[3] = nt[0];
+            J[4] = nt[1];
+            J[5] = nt[2];
+            accum_row(acc, J, r);
+        }
+    }
+    block_finish(acc, partial, ticket, out32);
 }
 
 }  // namespace mi
