@@ -223,12 +223,11 @@ def main():
 
     # det_thresh <= 0: at this size the fp32 determinant of JtJ overflows and the
     # reference's default check would reject every solve
-    # N == 1: per-kernel HIP events run INSIDE the timed region (they cost ~4 us per
-    # launch, 1.6 % at 10M).  N > 1: the timed region runs without them -- at 1/8 of the
-    # work they would be 10 % of a step -- and the kernel averages come from a second
-    # pass of the same K steps right after.
-    in_region_events = world == 1 and os.environ.get("MI_ICP_BENCH_NO_EVENTS") != "1"
-    eng.set_profiling(in_region_events)
+    # The timed windows run WITHOUT per-kernel HIP events (two event pairs per iteration cost
+    # ~12 us of a 0.18-ms step at N = 1 and far more of a sharded one); the kernels' average
+    # durations come from one further window of the same K steps, bracketed by events on the
+    # engine's stream, right after.
+    eng.set_profiling(False)
 
     if host_allreduce:
         import ctypes as C
@@ -249,8 +248,6 @@ def main():
     else:
         eng.icp_begin(_lib.EST_POINT_TO_PLANE, max_dist, None, -1.0)
         eng.icp_iterate(args.warmup)
-    prof0 = eng.get_profile()
-
     windows = []
     for _ in range(max(1, args.repeats)):
         if world > 1:
@@ -268,12 +265,15 @@ def main():
             w = float(t.item())
         windows.append(w)
     elapsed = float(np.median(windows))
+    eng.set_profiling(True)
+    prof0 = eng.get_profile()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.icp_iterate(args.steps)
+    torch.cuda.synchronize()
+    profiled_window = time.perf_counter() - t0
     prof1 = eng.get_profile()
-    if not in_region_events:
-        eng.set_profiling(True)
-        prof0 = eng.get_profile()
-        eng.icp_iterate(args.steps)
-        prof1 = eng.get_profile()
+    eng.set_profiling(False)
 
     T = np.array(res.transformation, np.float32).reshape(4, 4).T
     err = float(np.linalg.norm(T - T_gt))
@@ -331,6 +331,9 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_ms_avg": round(nn_ms, 4), "reduce_ms_avg": round(red_ms, 4),
+                         "kernel_ms_source": "HIP events on the engine's stream around every search / reduction launch "
+                                             "of one further window of the same %d steps (%.4f ms per step with the events; "
+                                             "the timed windows run without them)" % (args.steps, profiled_window / args.steps * 1e3),
                          # a whole iteration moves 60 N_s + 20 N_t algorithmic bytes
                          "iteration": {"algorithmic_bytes": 60.0 * n + 20.0 * nt,
                                        "achieved": round((60.0 * n + 20.0 * nt) * args.steps / elapsed / 1e9, 2),

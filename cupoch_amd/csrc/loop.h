@@ -78,17 +78,17 @@ __host__ __device__ inline void stats_from_system(const double* sys, int64_t n_s
 // evaluation, and -- unless finished -- the next update (registration.cu:157-160).
 // resume > 0 instead re-opens a finished loop for `resume` more updates (stepping API):
 // no statistics / test, just the update from the system of the last evaluation.
-__global__ __launch_bounds__(64) void loop_step_kernel(DevLoop* st_g, const double* __restrict__ sys_in,
-                                                       int resume) {
-    // the state is staged through LDS: one coalesced read, one thread of scalar work at
-    // LDS latency, one coalesced write (a thread poking at global memory field by field
-    // took 13 us; this takes ~3)
-    __shared__ DevLoop st_s;
+// One workgroup (any size >= 32): the state is staged through LDS -- one coalesced read, one thread
+// of scalar work at LDS latency, one coalesced write (a thread poking at global memory field by
+// field took 13 us; this takes ~3).  sys_in may have been written by this very block just before
+// (behind a __syncthreads()), or by an earlier kernel.
+__device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys_in, int resume, DevLoop& st_s) {
     constexpr int kWords = (int)(sizeof(DevLoop) / 4);
     static_assert(sizeof(DevLoop) % 4 == 0, "DevLoop is copied word by word");
+    const int nth = (int)blockDim.x;
     uint32_t* dst = reinterpret_cast<uint32_t*>(&st_s);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(st_g);
-    for (int i = (int)threadIdx.x; i < kWords; i += 64) dst[i] = src[i];
+    for (int i = (int)threadIdx.x; i < kWords; i += nth) dst[i] = src[i];
     __syncthreads();
     if (resume <= 0 && st_s.done) return;  // uniform: every thread reads the same flag
     if (threadIdx.x < 32 && resume <= 0) st_s.sys[threadIdx.x] = sys_in[threadIdx.x];
@@ -129,7 +129,13 @@ __global__ __launch_bounds__(64) void loop_step_kernel(DevLoop* st_g, const doub
     }
     __syncthreads();
     uint32_t* out = reinterpret_cast<uint32_t*>(st_g);
-    for (int i = (int)threadIdx.x; i < kWords; i += 64) out[i] = dst[i];
+    for (int i = (int)threadIdx.x; i < kWords; i += nth) out[i] = dst[i];
+}
+
+__global__ __launch_bounds__(64) void loop_step_kernel(DevLoop* st_g, const double* __restrict__ sys_in,
+                                                       int resume) {
+    __shared__ DevLoop st_s;
+    loop_step_block(st_g, sys_in, resume, st_s);
 }
 
 }  // namespace mi

@@ -490,6 +490,8 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
               const DevLoop* loop = nullptr) {
     if (c->ns <= 0) return MI_ICP_OK;
     int32_t* idx = (int32_t*)c->nn_idx.p;
+    // (inside the registration loop the distances are not stored: nothing reads them there, and every
+    // entry point that hands distances out runs its own search first)
     float* d2 = (float*)c->nn_d2.p;
     if (c->nt <= 0) {
         fill_i32<<<blocks_for(c->ns), 256, 0, c->stream>>>(idx, c->ns, -1);
@@ -506,7 +508,7 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
     if (use_seed) TRY(ensure_links(c));
     EvTimer t(c, 0, loop != nullptr);
 #define MI_NN_ARGS (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns, \
-                   (const float*)c->nodes.p, (const float*)c->tblk.p, (const float*)c->tlreg.p, (const uint2*)c->tlinks.p, c->leaf_first, X, loop, r2, nblocks, idx, d2, stats
+                   (const float*)c->nodes.p, (const float*)c->tblk.p, (const float*)c->tlreg.p, (const uint2*)c->tlinks.p, c->leaf_first, X, loop, r2, nblocks, idx, (loop ? nullptr : d2), stats
     if (stats) {
         if (use_seed) nn_packet_kernel<true, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
         else nn_packet_kernel<false, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
@@ -571,7 +573,11 @@ bool estimator_ready(const mi_icp_ctx* c, int est) {
 
 // Accumulate sys[32] on the device (into c->sys_dev) for the current correspondences.
 // When the estimator's inputs are missing only the statistics ([28], [29]) are formed.
-int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, const DevLoop* loop = nullptr) {
+// fuse_step: the loop's step may ride in the reduction's finishing block (reduce.h STEP; single GPU only);
+// *stepped tells whether it did
+int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, DevLoop* loop = nullptr, bool fuse_step = false,
+                  bool* stepped = nullptr) {
+    if (stepped) *stepped = false;
     double *partial, *sys;
     uint32_t* ticket;
     TRY(ensure(c, c->partial, (size_t)kReduceBlocks * kSysSize, &partial));
@@ -625,8 +631,14 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, const DevLoop
         // four elements in flight per thread; at most 512 blocks (2 per CU): measured best on the 10M bench
         // (256 / 512 / 1024 / 2048 blocks: 0.090 / 0.079 / 0.080 / 0.091 ms, scripts/gpu_reduce_sweep.sh)
         const int g2 = std::min(grid, 512);
+        static const bool no_fused_step = std::getenv("MI_ICP_NO_FUSED_STEP") != nullptr;  // A/B switch
         EvTimer t(c, 1, loop != nullptr);
-        reduce_pt2pl_kernel<4><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys);
+        if (fuse_step && loop && !c->comm && !no_fused_step) {
+            reduce_pt2pl_kernel<4, true><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys);
+            if (stepped) *stepped = true;
+        } else {
+            reduce_pt2pl_kernel<4, false><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys);
+        }
         KCHK(c);
         return MI_ICP_OK;
     }
@@ -1261,7 +1273,9 @@ static int loop_enqueue_evaluation(mi_icp_ctx* c, bool seed) {
     DevLoop* d = (DevLoop*)c->loop_dev.p;
     const Mat4 I = host::identity4();
     TRY(launch_nn(c, I, c->loop_r2, seed, nullptr, d));
-    TRY(launch_reduce(c, c->loop_est, 0, I, d));
+    bool stepped = false;
+    TRY(launch_reduce(c, c->loop_est, 0, I, d, true, &stepped));
+    if (stepped) return MI_ICP_OK;  // (single GPU, point-to-plane: the reduction's last block took the step)
     TRY(allreduce_system(c));
     loop_step_kernel<<<1, 64, 0, c->stream>>>(d, (const double*)c->sys_dev.p, 0);
     KCHK(c);

@@ -325,8 +325,11 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     }
 
     if (valid) {
-        nn_idx[i] = bidx;
-        nn_d2[i] = (bidx >= 0) ? best : INFINITY;
+        // a converged iteration changes (almost) no match: the store is skipped where nothing changed.
+        // nn_d2 == nullptr: the caller has no use for the distances (the registration loop: the
+        // reduction recomputes them from the points) -- together a fifth of this kernel's traffic
+        if (!SEED || bidx != seed_j) nn_idx[i] = bidx;
+        if (nn_d2) nn_d2[i] = (bidx >= 0) ? best : INFINITY;
     }
     if (STATS && lane == 0) {  // traversal census for tuning (mi_icp_debug_nn_stats)
         atomicAdd(stats + 0, (unsigned long long)steps);

@@ -86,7 +86,8 @@ struct ReduceArgs {
 // the DPP network -> LDS -> this block's row of `partial`; the LAST block to arrive (agent-scope
 // release -> ticket -> acquire) totals the rows in a fixed order into out32, so the result is
 // bitwise reproducible; the ticket is the only atomic.
-__device__ __forceinline__ void block_finish(const double* acc, double* __restrict__ partial,
+// Returns true (to every thread of the block) in the block that wrote out32.
+__device__ __forceinline__ bool block_finish(const double* acc, double* __restrict__ partial,
                                              uint32_t* __restrict__ ticket, double* __restrict__ out32) {
     __shared__ double red[kReduceThreads / 32][kSysSize];
     __shared__ uint32_t s_last;
@@ -118,7 +119,7 @@ __device__ __forceinline__ void block_finish(const double* acc, double* __restri
         s_last = (t == gridDim.x - 1u) ? 1u : 0u;
     }
     __syncthreads();
-    if (!s_last) return;
+    if (!s_last) return false;
     if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     {   // fixed-order total of the per-block partials (independent of which block finishes)
@@ -153,6 +154,7 @@ __device__ __forceinline__ void block_finish(const double* acc, double* __restri
         }
         if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    return true;
 }
 
 // MODE 0: accumulate the linear system; MODE 1: accumulate only the
@@ -353,9 +355,15 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_kernel(ReduceArgs a, Xf
 // no branch sits between a load and its use (lanes past the end re-read element 0, unmatched points
 // re-read slot 0; both are masked out of the sums).  Same per-element arithmetic and the same
 // per-thread summation order as reduce_kernel<point-to-plane, 0> with the same grid.
-template <int kU>
+//
+// STEP (single-GPU loops): the finishing block also takes the loop's step -- statistics, convergence
+// test, 6x6 solve, T <- dT * T (loop.h: loop_step_body) -- instead of a launch of its own: one kernel
+// boundary and ~8 us less per iteration.  With the all-reduce between reduction and step (N > 1) the
+// step stays a kernel.  (On reduce_kernel this was tried and dropped in round 1: the solver's
+// registers cost it an occupancy step; this kernel runs two blocks per CU and has them to spare.)
+template <int kU, bool STEP>
 __global__ __launch_bounds__(kReduceThreads) void reduce_pt2pl_kernel(ReduceArgs a, Xform Tv,
-                                                                      const DevLoop* __restrict__ loop,
+                                                                      DevLoop* __restrict__ loop,
                                                                       double* __restrict__ partial,
                                                                       uint32_t* __restrict__ ticket,
                                                                       double* __restrict__ out32) {
@@ -414,7 +422,12 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_pt2pl_kernel(ReduceArgs
             accum_row(acc, J, r);
         }
     }
-    block_finish(acc, partial, ticket, out32);
+    const bool last = block_finish(acc, partial, ticket, out32);
+    if (STEP && last) {
+        __syncthreads();  // out32 has been written by this block's first 32 threads
+        __shared__ DevLoop st_s;
+        loop_step_block(loop, out32, 0, st_s);
+    }
 }
 
 }  // namespace mi
