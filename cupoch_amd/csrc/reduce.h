@@ -178,21 +178,47 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_kernel(ReduceArgs a, Xf
     for (int k = 0; k < 30; ++k) acc[k] = 0.0;
 
     const int64_t stride = (int64_t)gridDim.x * kReduceThreads;
-    for (int64_t k = (int64_t)blockIdx.x * kReduceThreads + threadIdx.x; k < a.count; k += stride) {
+    const int64_t k0 = (int64_t)blockIdx.x * kReduceThreads + threadIdx.x;
+    // Nearest-neighbour correspondences: the match and the source point of the NEXT element are
+    // requested before this element's gathers go out, so that an element costs one dependent round
+    // trip instead of two (branch-free: past the end element 0 is re-read and never used).
+    int32_t nj = -1;
+    float npx = 0.0f, npy = 0.0f, npz = 0.0f;
+    if (!a.pairs && a.count > 0) {
+        const int64_t kc = (k0 < a.count) ? k0 : 0;
+        nj = a.nn_idx[kc];
+        npx = a.sx[kc];
+        npy = a.sy[kc];
+        npz = a.sz[kc];
+    }
+    for (int64_t k = k0; k < a.count; k += stride) {
         int64_t i;
         int32_t j;
+        float spx, spy, spz;
         if (a.pairs) {
             const int32_t pi = a.pairs[2 * k], pj = a.pairs[2 * k + 1];
             if ((uint32_t)pi >= (uint32_t)a.ns || (uint32_t)pj >= (uint32_t)a.nt) continue;
             i = a.inv_s[pi];
             j = a.inv_t[pj];
+            if (j < 0) continue;
+            spx = a.sx[i];
+            spy = a.sy[i];
+            spz = a.sz[i];
         } else {
             i = k;
-            j = a.nn_idx[k];
+            j = nj;
+            spx = npx;
+            spy = npy;
+            spz = npz;
+            const int64_t kc = (k + stride < a.count) ? k + stride : 0;
+            nj = a.nn_idx[kc];
+            npx = a.sx[kc];
+            npy = a.sy[kc];
+            npz = a.sz[kc];
         }
         if (j < 0) continue;
         float vs[3], vt[3], nt_rec[3] = {0.0f, 0.0f, 0.0f};
-        xform_point(T, a.sx[i], a.sy[i], a.sz[i], vs[0], vs[1], vs[2]);
+        xform_point(T, spx, spy, spz, vs[0], vs[1], vs[2]);
         if (EST == kEstPt2Pl && a.trec) {
             // point and normal of the match in ONE 24-byte record (two 12-byte loads): the leaf line
             // costs 16 bytes per slot for the 12 used, the float4 normal another 16 -- a quarter of
