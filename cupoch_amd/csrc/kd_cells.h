@@ -70,10 +70,11 @@ __device__ __forceinline__ uint32_t descend_cell(const float2* __restrict__ plan
     return node - (1u << levels);
 }
 
-// keys[i] = cell of point i, vals[i] = i
+// keys[i] = cell of point i, vals[i] = i  (K: width of the sort keys, primitives.h)
+template <typename K>
 __global__ __launch_bounds__(256) void cells_assign(const float* __restrict__ pts, int64_t n,
                                                     const float2* __restrict__ planes, int levels,
-                                                    uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                    K* __restrict__ keys, uint32_t* __restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     keys[i] = descend_cell(planes, levels, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]);
@@ -82,7 +83,8 @@ __global__ __launch_bounds__(256) void cells_assign(const float* __restrict__ pt
 
 // cstart[c] = first sorted position with key >= c, for c in [0, ncells]  (cstart[ncells] = n).
 // The thread at every key change writes the cells in the gap; no atomics, no pre-fill.
-__global__ __launch_bounds__(256) void cells_starts(const uint64_t* __restrict__ keys, int64_t n, int ncells,
+template <typename K>
+__global__ __launch_bounds__(256) void cells_starts(const K* __restrict__ keys, int64_t n, int ncells,
                                                     uint32_t* __restrict__ cstart) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;

@@ -96,9 +96,11 @@ __device__ __forceinline__ uint64_t spread3(uint32_t v) {  // 21 bits -> every t
 }
 
 // key = interleave(qx,qy,qz), q = cell of a cubic 2^bits grid over the bounds
+// (K = uint32_t when 3 * bits <= 32: the narrow sort, primitives.h)
+template <typename K>
 __global__ __launch_bounds__(256) void morton_keys(const float* __restrict__ pts, int n,
                                                    const float* __restrict__ bounds, int bits,
-                                                   uint64_t* __restrict__ keys,
+                                                   K* __restrict__ keys,
                                                    uint32_t* __restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void morton_keys(const float* __restrict__ pts
         f = fminf(fmaxf(f, 0.0f), top);  // NaN -> 0
         q[d] = (uint32_t)f;
     }
-    keys[i] = (spread3(q[0]) << 2) | (spread3(q[1]) << 1) | spread3(q[2]);
+    keys[i] = (K)((spread3(q[0]) << 2) | (spread3(q[1]) << 1) | spread3(q[2]));
     vals[i] = (uint32_t)i;
 }
 
@@ -297,13 +299,13 @@ __global__ __launch_bounds__(256) void gather_source(
 // to search for as long as the clouds stay roughly where they are (ICP iterations).
 __global__ __launch_bounds__(256) void match_order_keys(const int32_t* __restrict__ nn_idx, int ns,
                                                         uint32_t unmatched_key,
-                                                        uint64_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ keys,
                                                         uint32_t* __restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= ns) return;
     const int32_t j = nn_idx[i];
     // unmatched points keep their order at the end
-    keys[i] = (j < 0) ? (uint64_t)unmatched_key : (uint64_t)((uint32_t)j >> 3);
+    keys[i] = (j < 0) ? unmatched_key : ((uint32_t)j >> 3);
     vals[i] = (uint32_t)i;
 }
 

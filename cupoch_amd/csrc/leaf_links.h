@@ -145,29 +145,47 @@ __device__ __forceinline__ void sort_keys(uint32_t (&key)[N]) {
 // Sort key = the distance's bits (>= 0: integer order = float order) with the 6 low mantissa bits
 // replaced by the candidate's slot; the final entry carries the direction mask in those bits
 // instead (both round the distance DOWN, the conservative side).
+// The candidates' ids wait in LDS ([slot][lane]: the winners' gather is bank-conflict free) and the
+// finished tile is put together there as well, then copied out 1 KB per store instruction.  (Gathering
+// the ids from global memory moved a whole line per 4 bytes -- 5 GB per 10M-point target -- and the
+// entries went out as half-written lines: 0.5 ms instead of 0.2.)
 template <int N>
 __device__ __forceinline__ void links_select(const uint2* __restrict__ cand, uint32_t L, int count, uint32_t lane,
-                                             uint4* __restrict__ tile, float bound, float* __restrict__ reach_out) {
+                                             uint32_t* __restrict__ lds, uint4* __restrict__ tile, float bound,
+                                             float* __restrict__ reach_out) {
     uint32_t key[N];
+    {
+        uint2 c[N];  // all N loads first, in one go (one at a time they are N serial round trips)
 #pragma unroll
-    for (int t = 0; t < N; ++t) {
-        const uint32_t d = cand[link_temp_index(L, t)].y;  // (slots past `count` hold stale bytes: masked)
-        key[t] = (t < count) ? ((d & ~63u) | (uint32_t)t) : 0xffffffffu;
+        for (int t = 0; t < N; ++t) c[t] = cand[link_temp_index(L, t)];  // (slots past `count` hold stale bytes: masked below)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            lds[t * 64 + (int)lane] = c[t].x;
+            key[t] = (t < count) ? ((c[t].y & ~63u) | (uint32_t)t) : 0xffffffffu;
+        }
     }
     sort_keys<N>(key);
+    uint32_t pid[kLinkSlots];
+#pragma unroll
+    for (int t = 0; t < kLinkSlots; ++t) pid[t] = lds[(int)(key[t] & 63u) * 64 + (int)lane];  // (unused: any slot)
+    __builtin_amdgcn_wave_barrier();  // (one wave: every read of the ids is issued before the entries overwrite them)
+    uint4* stage = reinterpret_cast<uint4*>(lds);
 #pragma unroll
     for (int t = 0; t < kLinkSlots; t += 2) {
         uint32_t e[4];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const bool have = key[t + u] != 0xffffffffu;
-            const uint32_t pid = cand[link_temp_index(L, have ? (int)(key[t + u] & 63u) : 0)].x;
-            e[2 * u] = have ? (pid & kLinkIdMask) : 0xffffffffu;
-            e[2 * u + 1] = have ? ((key[t + u] & ~63u) | (pid >> 26)) : 0x7f800000u;
+            e[2 * u] = have ? (pid[t + u] & kLinkIdMask) : 0xffffffffu;
+            e[2 * u + 1] = have ? ((key[t + u] & ~63u) | (pid[t + u] >> 26)) : 0x7f800000u;
         }
         // chunk t/4 of this leaf, its first or second half
-        tile[((size_t)(t >> 2) * 64u + lane) * 2u + ((t >> 1) & 1)] = make_uint4(e[0], e[1], e[2], e[3]);
+        stage[((t >> 2) * 64 + (int)lane) * 2 + ((t >> 1) & 1)] = make_uint4(e[0], e[1], e[2], e[3]);
     }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < kLinkSlots / 2; ++r) tile[r * 64 + (int)lane] = stage[r * 64 + (int)lane];
     // complete below: the nearest candidate that was left out, or the collection's bound
     float reach = bound;
     if (N > kLinkSlots) {
@@ -179,14 +197,15 @@ __device__ __forceinline__ void links_select(const uint2* __restrict__ cand, uin
 
 __global__ __launch_bounds__(64) void leaf_links_select(float* __restrict__ lreg, int nleaf,
                                                         const uint2* __restrict__ cand, uint2* __restrict__ links) {
+    __shared__ alignas(16) uint32_t s_ids[kLinkCand * 64];  // 16 KB: the candidates' ids, then the finished tile
     const uint32_t L = blockIdx.x * 64u + threadIdx.x;
     const bool valid = L < (uint32_t)nleaf;
     const int count = valid ? __float_as_int(lreg[(size_t)L * kLeafRegFloats + 7]) : 0;
     const float bound = valid ? lreg[(size_t)L * kLeafRegFloats + 3] : 0.0f;
     uint4* tile = reinterpret_cast<uint4*>(links) + (size_t)blockIdx.x * (kLinkSlots / 4) * 64u * 2u;
     float reach = 0.0f;
-    if (__ballot(count > kLinkSlots) != 0ull) links_select<kLinkCand>(cand, L, count, threadIdx.x, tile, bound, &reach);
-    else links_select<kLinkSlots>(cand, L, count, threadIdx.x, tile, bound, &reach);
+    if (__ballot(count > kLinkSlots) != 0ull) links_select<kLinkCand>(cand, L, count, threadIdx.x, s_ids, tile, bound, &reach);
+    else links_select<kLinkSlots>(cand, L, count, threadIdx.x, s_ids, tile, bound, &reach);
     if (valid) lreg[(size_t)L * kLeafRegFloats + 3] = reach;
 }
 

@@ -96,6 +96,8 @@ struct mi_icp_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_links = nullptr;
     bool links_inflight = false;
+    int last_search_kind = -1;  // mi_icp_debug.h
+    bool ran_loop = false;  // a context that has registered before builds the lists right behind the tree
 
     // ---- source (Morton order) ----
     int64_t ns = 0, ns_global = 0;
@@ -238,12 +240,16 @@ Mat4 load_T(const float* T) {
 }
 
 // Morton grid: 2^bits cells per axis, ~4 per mean point spacing -- fine enough that almost every
-// point has a cell of its own (ties keep the input order), and every 8 key bits saved is a radix
-// pass less (10M points: 30-bit keys, 4 passes; 100k points: 24 bits, 3 passes)
+// point has a cell of its own (ties keep the input order).  Every 8 key bits are a radix pass, so the
+// grid is coarsened to the pass boundary below as long as that leaves >= 1 cell per mean spacing:
+// packets of 64 consecutive points stay as compact (10M points: 24-bit keys, 3 passes instead of 4).
 int morton_bits_for(int64_t n) {
     int lg = 0;
     while ((1ll << lg) < n) ++lg;
-    return std::min(21, std::max(6, (lg + 2) / 3 + 2));
+    const int per_axis = (lg + 2) / 3;
+    const int fine = std::min(21, std::max(6, per_axis + 2));
+    const int coarse = (((3 * fine + 7) / 8 - 1) * 8) / 3;
+    return coarse >= std::max(6, per_axis) ? coarse : fine;
 }
 
 // bounds (min/max/extent) of an AoS cloud into c->bounds (8 floats, device)
@@ -287,9 +293,16 @@ int morton_order(mi_icp_ctx* c, const float* pts, int64_t n, const uint32_t** or
     SortBuffers sb;
     TRY(sort_buffers(c, n, &sb));
     const int bits = grid_bounds ? grid_bits : morton_bits_for(n);
-    morton_keys<<<blocks_for(n), 256, 0, c->stream>>>(pts, (int)n, bnd, bits, sb.keys[0], sb.vals[0]);
-    KCHK(c);
-    const int cur = radix_sort_pairs(c->stream, sb, n, 3 * bits);
+    int cur;
+    if (3 * bits <= 32) {  // narrow keys: a third less traffic per pass
+        morton_keys<uint32_t><<<blocks_for(n), 256, 0, c->stream>>>(pts, (int)n, bnd, bits, (uint32_t*)sb.keys[0], sb.vals[0]);
+        KCHK(c);
+        cur = radix_sort_pairs32(c->stream, sb, n, 3 * bits);
+    } else {
+        morton_keys<uint64_t><<<blocks_for(n), 256, 0, c->stream>>>(pts, (int)n, bnd, bits, sb.keys[0], sb.vals[0]);
+        KCHK(c);
+        cur = radix_sort_pairs(c->stream, sb, n, 3 * bits);
+    }
     KCHK(c);
     if (!kd_refine) {
         *order = sb.vals[cur];
@@ -335,7 +348,7 @@ int kd_cell_layout(mi_icp_ctx* c, const float* pts, int64_t n, CellLayout* out) 
         for (int st = 0; st < stages; ++st) {
             const int levels = (st == 0) ? d - kCellStageLevels * (stages - 1) : kCellStageLevels;
             if (base > 0) {  // samples grouped by their depth-`base` cell
-                cells_assign<<<blocks_for(S), 256, 0, c->stream>>>(samp, S, planes, base, sb.keys[0], sb.vals[0]);
+                cells_assign<uint64_t><<<blocks_for(S), 256, 0, c->stream>>>(samp, S, planes, base, sb.keys[0], sb.vals[0]);
                 KCHK(c);
                 cur = radix_sort_pairs(c->stream, sb, S, base);
                 KCHK(c);
@@ -348,11 +361,11 @@ int kd_cell_layout(mi_icp_ctx* c, const float* pts, int64_t n, CellLayout* out) 
     uint32_t *cstart, *gstart;
     TRY(ensure(c, c->cell_cstart, (size_t)ncells + 2, &cstart));
     TRY(ensure(c, c->cell_gstart, (size_t)ncells, &gstart));
-    cells_assign<<<blocks_for(n), 256, 0, c->stream>>>(pts, n, planes, d, sb.keys[0], sb.vals[0]);
+    cells_assign<uint32_t><<<blocks_for(n), 256, 0, c->stream>>>(pts, n, planes, d, (uint32_t*)sb.keys[0], sb.vals[0]);
     KCHK(c);
-    const int cur = radix_sort_pairs(c->stream, sb, n, d);
+    const int cur = radix_sort_pairs32(c->stream, sb, n, d);  // (cell ids: narrow keys)
     KCHK(c);
-    cells_starts<<<blocks_for(n), 256, 0, c->stream>>>(sb.keys[cur], n, ncells, cstart);
+    cells_starts<uint32_t><<<blocks_for(n), 256, 0, c->stream>>>((const uint32_t*)sb.keys[cur], n, ncells, cstart);
     KCHK(c);
     cells_layout<<<1, 1024, 0, c->stream>>>(cstart, ncells, gstart, cstart + ncells + 1);
     KCHK(c);
@@ -486,6 +499,12 @@ int drain_links(mi_icp_ctx* c) {
 }
 
 // ---- nearest-neighbour pass --------------------------------------------------
+// sources of at least this many points make their own seeds for a first pass (tuning knob MI_ICP_COARSE_MIN)
+static int64_t coarse_first_min() {
+    static const int64_t v = [] { const char* s = std::getenv("MI_ICP_COARSE_MIN"); return s ? std::atoll(s) : (int64_t)1 << 16; }();
+    return v;
+}
+
 int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long long* stats = nullptr,
               const DevLoop* loop = nullptr) {
     if (c->ns <= 0) return MI_ICP_OK;
@@ -500,23 +519,42 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
         c->n_user_pairs = -1;
         return MI_ICP_OK;
     }
-    const uint32_t npackets = (uint32_t)((c->ns + 63) / 64);
-    const uint32_t nblocks = (npackets + kNNPacketsPerBlock - 1) / kNNPacketsPerBlock;
-    const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
     const Xform X = make_xform(T);
     const bool use_seed = seed && c->nn_valid;
     if (use_seed) TRY(ensure_links(c));
     EvTimer t(c, 0, loop != nullptr);
-#define MI_NN_ARGS (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns, \
-                   (const float*)c->nodes.p, (const float*)c->tblk.p, (const float*)c->tlreg.p, (const uint2*)c->tlinks.p, c->leaf_first, X, loop, r2, nblocks, idx, (loop ? nullptr : d2), stats
-    if (stats) {
-        if (use_seed) nn_packet_kernel<true, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
-        else nn_packet_kernel<false, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
-    } else {
-        if (use_seed) nn_packet_kernel<true, false><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
-        else nn_packet_kernel<false, false><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
-    }
+    const uint2* links = (const uint2*)c->tlinks.p;
+    bool self_seeded = false;
+    static const bool no_coarse = std::getenv("MI_ICP_NO_COARSE_FIRST") != nullptr;  // A/B switch
+    auto launch = [&](bool seeded, const float* sx, const float* sy, const float* sz, int64_t ns, int32_t* out_idx,
+                      float* out_d2) {
+        const uint32_t npackets = (uint32_t)((ns + 63) / 64);
+        const uint32_t nblocks = (npackets + kNNPacketsPerBlock - 1) / kNNPacketsPerBlock;
+        const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
+#define MI_NN_ARGS sx, sy, sz, (int)ns, (const float*)c->nodes.p, (const float*)c->tblk.p, (const float*)c->tlreg.p, \
+                   links, c->leaf_first, X, loop, r2, nblocks, out_idx, out_d2, stats
+        if (stats) {
+            if (seeded) nn_packet_kernel<true, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
+            else nn_packet_kernel<false, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
+        } else {
+            if (seeded) nn_packet_kernel<true, false><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
+            else nn_packet_kernel<false, false><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
+        }
 #undef MI_NN_ARGS
+    };
+    if (!use_seed && !stats && !no_coarse && c->links_ready && !c->links_inflight && c->ns >= coarse_first_min()) {
+        // No previous matches, but the leaves' neighbour lists are there: every query takes the leaf a
+        // greedy descent lands in as its seed (nn_search.h: locate_leaves) and the seeded search does the rest.
+        locate_leaves<<<blocks_for(c->ns), 256, 0, c->stream>>>((const float*)c->sx.p, (const float*)c->sy.p,
+                                                                (const float*)c->sz.p, (int)c->ns,
+                                                                (const float*)c->nodes.p, c->leaf_first,
+                                                                (uint32_t)c->nleaf, X, loop, idx);
+        KCHK(c);
+        self_seeded = true;
+    }
+    c->last_search_kind = use_seed ? 1 : (self_seeded ? 2 : 0);
+    launch(use_seed || self_seeded, (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, c->ns, idx,
+           loop ? nullptr : d2);
     KCHK(c);
     c->nn_valid = true;
     c->n_user_pairs = -1;
@@ -721,7 +759,10 @@ int mi_icp_create(int device, mi_icp_ctx** out) {
               hipHostMalloc((void**)&c->u_host, 16 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&c->loop_host, sizeof(DevLoop), hipHostMallocDefault) == hipSuccess;
     for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
+    // (lowest priority: the neighbour-list build fills what the context's own stream leaves idle)
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    ok = ok && hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_least) == hipSuccess &&
          hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&c->ev_links, hipEventDisableTiming) == hipSuccess;
     for (int k = 0; k < 2 && ok; ++k)
@@ -922,6 +963,9 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     c->nleaf = nleaf;
     c->leaf_first = leaf_first;
     c->nrecords = nrecords;
+    // A context that has run a registration loop will run another: the lists are started now, on the
+    // private stream, next to the staging of the source (its first pass then has them, see loop_begin).
+    if (c->ran_loop && c->links_allowed) TRY(start_links_async(c));
     if (c->profiling) {
         (void)hipEventRecord(e1, c->stream);
         (void)hipStreamSynchronize(c->stream);
@@ -1214,9 +1258,9 @@ static int resort_source_by_match(mi_icp_ctx* c) {
     int bits = 1;
     while (bits < 32 && (1ull << bits) <= (uint64_t)c->nleaf) ++bits;
     match_order_keys<<<blocks_for(n), 256, 0, c->stream>>>((const int32_t*)c->nn_idx.p, (int)n, (uint32_t)c->nleaf,
-                                                           sb.keys[0], sb.vals[0]);
+                                                           (uint32_t*)sb.keys[0], sb.vals[0]);
     KCHK(c);
-    const uint32_t* ord = sb.vals[radix_sort_pairs(c->stream, sb, n, bits)];
+    const uint32_t* ord = sb.vals[radix_sort_pairs32(c->stream, sb, n, bits)];
     KCHK(c);
     SourceArrays in, out;
     in.sx = (float*)c->sx.p; in.sy = (float*)c->sy.p; in.sz = (float*)c->sz.p;
@@ -1328,7 +1372,12 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
     TRY(ensure(c, c->loop_dev, 1, &d));
     HIPCHK(c, hipMemcpyAsync(d, &L, sizeof(DevLoop), hipMemcpyHostToDevice, c->stream));
     c->loop_active = true;
-    TRY(start_links_async(c));  // (the first pass below is unseeded and does not read them)
+    // The first pass has no previous matches.  With the neighbour lists at hand (started by set_target)
+    // it makes its own seeds (launch_nn: locate_leaves); otherwise it walks the tree from the root while
+    // the lists are built next to it on the private stream.
+    c->ran_loop = true;
+    if (c->links_ready || c->links_inflight) TRY(ensure_links(c));
+    else TRY(start_links_async(c));
     TRY(loop_enqueue_evaluation(c, false));
     // from here on the packets follow the target's order (pays for itself in ~4 iterations)
     static const bool no_resort = std::getenv("MI_ICP_NO_RESORT") != nullptr;  // A/B switch for tuning
@@ -2259,6 +2308,8 @@ int mi_icp_debug_get_leaf_links(mi_icp_ctx* c, uint32_t* links_out) {
                         8 * sizeof(uint32_t));
     return MI_ICP_OK;
 }
+
+int mi_icp_debug_last_search_kind(const mi_icp_ctx* c) { return c ? c->last_search_kind : -1; }
 
 int mi_icp_debug_drop_seeds(mi_icp_ctx* c) {
     TRY(check_ctx(c));

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
                 over = fmaxf(fmaxf(fmaxf(ux, lx), fmaxf(uy, ly)), fmaxf(uz, lz)) * 1.000001f;
                 faces = (ux > 0.0f ? 1u : 0u) | (lx > 0.0f ? 2u : 0u) | (uy > 0.0f ? 4u : 0u) | (ly > 0.0f ? 8u : 0u) |
                         (uz > 0.0f ? 16u : 0u) | (lz > 0.0f ? 32u : 0u);
-                linked = over < g0.w;  // (NaN from inf - inf: false)
+                linked = links_g != nullptr && over < g0.w;  // (NaN from inf - inf: false; no lists (yet): walk)
             }
         } else {
             set_cube(cube, qx, qy, qz, best);
@@ -345,6 +345,82 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
 
 // dense per-source arrays in ORIGINAL source order with ORIGINAL target indices
 // (KDTreeFlann::SearchRadius outputs, knn/kdtree_flann.inl:96-122)
+// The first pass of a registration loop has no previous matches to start from.  It makes its own:
+// every query walks down the tree on its own, at each record into the child whose box is nearest
+// (inside: distance 0), and takes the leaf it arrives at as its seed.  No backtracking, so the leaf
+// is only near the true match -- the seeded search above turns it into the exact answer through
+// that leaf's region and neighbour list.  Consecutive queries are spatial neighbours (the source is
+// staged in Morton order): the upper records are the same for a whole wave, the lower ones shared
+// by many lanes, so the 12 vector loads per level mostly hit the same few lines.
+// (While a wave's lanes still agree on the node -- the upper levels -- its record comes through the
+// scalar unit, one round trip for the wave; the 12 vector loads of a divergent level cost the texture
+// path 16 cycles each whatever the addresses: 0.48 ms for 10M queries when every level went that way.)
+__device__ __forceinline__ uint32_t nearest_child(const float (&w)[48], float qx, float qy, float qz) {
+    float best = INFINITY;
+    uint32_t c = 0u;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float* b = w + p * kPairStride;  // {Amin.x,Bmin.x, Amin.y,Bmin.y, Amin.z,Bmin.z, Amax.x,Bmax.x, ...}
+        const float ax = fmaxf(fmaxf(b[0] - qx, qx - b[6]), 0.0f), bx = fmaxf(fmaxf(b[1] - qx, qx - b[7]), 0.0f);
+        const float ay = fmaxf(fmaxf(b[2] - qy, qy - b[8]), 0.0f), by = fmaxf(fmaxf(b[3] - qy, qy - b[9]), 0.0f);
+        const float az = fmaxf(fmaxf(b[4] - qz, qz - b[10]), 0.0f), bz = fmaxf(fmaxf(b[5] - qz, qz - b[11]), 0.0f);
+        const float da = ax * ax + ay * ay + az * az, db = bx * bx + by * by + bz * bz;  // empty child: +inf
+        if (da < best) { best = da; c = 2u * (uint32_t)p; }
+        if (db < best) { best = db; c = 2u * (uint32_t)p + 1u; }
+    }
+    return c;
+}
+
+__global__ __launch_bounds__(256) void locate_leaves(const float* __restrict__ sx, const float* __restrict__ sy,
+                                                     const float* __restrict__ sz, int ns,
+                                                     const float* __restrict__ records_g, uint32_t leaf_first,
+                                                     uint32_t nleaf, Xform Tv, const DevLoop* __restrict__ loop,
+                                                     int32_t* __restrict__ nn_idx) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int ic = min(i, ns - 1);  // (lanes past the end walk along: the wave stays whole for the scalar path)
+    Xform T = Tv;
+    if (loop) {
+        if (loop->done) return;
+        T = loop->X;
+    }
+    float qx, qy, qz;
+    xform_point(T, sx[ic], sy[ic], sz[ic], qx, qy, qz);
+    typedef const __attribute__((address_space(4))) char* cchar_p;
+    const cchar_p sbase = (cchar_p)(uintptr_t)records_g;
+    uint32_t id = 1u, c = 0u;
+    bool uniform = true;
+    for (;;) {
+        float w[48];
+        const uint32_t uid = __builtin_amdgcn_readfirstlane(id);
+        uniform = uniform && __ballot(id != uid) == 0ull;
+        if (uniform) {
+            const cf16_p rec = (cf16_p)(sbase + ((size_t)record_index(uid) << 8));
+            const f16v r0 = rec[0], r1 = rec[1], r2 = rec[2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                w[e] = r0[e];
+                w[16 + e] = r1[e];
+                w[32 + e] = r2[e];
+            }
+        } else {
+            const float4* rec = reinterpret_cast<const float4*>(records_g + (size_t)record_index(id) * kRecordFloats);
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                const float4 v = rec[e];
+                w[4 * e] = v.x;
+                w[4 * e + 1] = v.y;
+                w[4 * e + 2] = v.z;
+                w[4 * e + 3] = v.w;
+            }
+        }
+        c = nearest_child(w, qx, qy, qz);
+        if (id >= leaf_first) break;  // (all ids of a wave sit on the same level)
+        id = 8u * id + c;
+    }
+    const uint32_t leaf = min(8u * (id - leaf_first) + c, nleaf - 1u);
+    if (i < ns) nn_idx[i] = (int32_t)(leaf * (uint32_t)kLeaf);
+}
+
 __global__ __launch_bounds__(256) void export_dense(const int32_t* __restrict__ nn_idx,
                                                     const float* __restrict__ nn_d2,
                                                     const int32_t* __restrict__ sperm,

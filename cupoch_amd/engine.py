@@ -239,6 +239,10 @@ class Engine:
         """test hook (mi_icp_debug.h): the next search starts top-down, not from the previous matches"""
         self._chk(self._L.mi_icp_debug_drop_seeds(self._ctx))
 
+    def last_search_kind(self):
+        """test hook: 0 = the last search started at the root, 1 = from the previous matches, 2 = from its own seeds"""
+        return int(self._L.mi_icp_debug_last_search_kind(self._ctx))
+
     def get_correspondences(self):
         cnt = C.c_int64(0)
         self._chk(self._L.mi_icp_get_correspondences(self._ctx, None, 0, C.byref(cnt), MI_ICP_HOST))

@@ -30,6 +30,11 @@ MI_ICP_API int mi_icp_debug_nn_stats(mi_icp_ctx* ctx, const float* T, float radi
  * from its predecessor's matches (tests compare the two; the results must be identical).  The
  * context has no correspondence set until that pass has run. */
 MI_ICP_API int mi_icp_debug_drop_seeds(mi_icp_ctx* ctx);
+/* How the last nearest-neighbour pass started: 0 = from the root (no previous matches), 1 = from the
+ * previous pass's matches, 2 = from seeds it made itself (a greedy descent per query; what a registration
+ * loop's first pass does when the target's neighbour lists were built ahead, mi_icp_set_target on a
+ * context that has registered before), -1 = no pass yet. */
+MI_ICP_API int mi_icp_debug_last_search_kind(const mi_icp_ctx* ctx);
 /* The target's tree as built by mi_icp_set_target, for invariant tests.  info5 = {slots
  * (padded sorted positions), leaves, leaf_first (id of the first leaf-level node), records,
  * points}.  records_out (records * 64 floats: 8 child boxes as 4 sibling pairs of 12,

@@ -133,3 +133,51 @@ def test_seeded_search_tiny_radius_and_all_misses(eng):
         h = compare(idx, d2, q, tgt, tree, radius)
         assert st[0] == h
     tree.close()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "clustered", "surface"])
+def test_first_pass_from_its_own_seeds_equals_the_walk_from_the_root(kind):
+    """A context that has registered before builds the leaves' neighbour lists right behind the tree
+    and its loops' FIRST pass starts every query from the leaf a greedy descent lands in (launch_nn:
+    locate_leaves) instead of walking the tree from the root.  Same correspondences, bit for bit,
+    as a fresh context's first pass (from the root) and as the oracle -- under a poor initial guess,
+    with partial overlap and noise."""
+    from cupoch_amd.engine import Engine
+    n = 160_000
+    rng = np.random.default_rng({"uniform": 41, "clustered": 42, "surface": 43}[kind])
+    tgt = cloud(kind, n, rng)
+    spacing = n ** (-1.0 / 3.0) if kind != "surface" else n ** (-0.5)
+    take = rng.permutation(n)[: int(0.8 * n)]
+    src = (tgt[take] + rng.standard_normal((len(take), 3)).astype(np.float32) * np.float32(0.2 * spacing)).astype(np.float32)
+    init = rigid(0.015, [1, -2, 1], [0.003, 0.002, -0.002])
+    radius = 3.0 * spacing
+    tree = orc.Tree(tgt)
+    _, oi, od = tree.search_radius(orc.transform_points(init, src), radius, 1)
+    tree.close()
+    oi = oi[:, 0]
+    got = {}
+    for name in ("fresh", "warm"):
+        e = Engine(0)
+        if name == "warm":                                   # one registration on other clouds first
+            e.set_target(tgt[:70_000])
+            e.set_source(src[:70_000])
+            e.icp_begin(P2P, radius, None, -1.0)
+        e.set_target(cuda(tgt))
+        e.set_source(cuda(src))
+        res = e.icp_begin(P2P, radius, init, -1.0)
+        assert e.last_search_kind() == (2 if name == "warm" else 0)
+        corr = e.get_correspondences()
+        dense = np.full(len(src), -1, np.int32)
+        dense[corr[:, 0]] = corr[:, 1]
+        got[name] = (dense, res.fitness, res.inlier_rmse)
+        e.close()
+    for name, (dense, fit, rmse) in got.items():
+        assert np.array_equal(dense < 0, oi < 0), name
+        ne = np.flatnonzero(dense != oi)
+        if len(ne):                                          # only exact ties may differ
+            q = orc.transform_points(init, src)[ne]
+            dd = q - tgt[dense[ne]]
+            alt = (dd[:, 2] * dd[:, 2] + (dd[:, 1] * dd[:, 1] + dd[:, 0] * dd[:, 0])).astype(np.float32)
+            assert np.array_equal(alt, od[ne, 0]), name
+    assert np.array_equal(got["fresh"][0], got["warm"][0])
+    assert got["fresh"][1] == got["warm"][1] and got["fresh"][2] == pytest.approx(got["warm"][2], rel=1e-6)
