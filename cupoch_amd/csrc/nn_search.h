@@ -106,13 +106,13 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     if (!xcd_remap(nblocks, logical)) return;
     PacketShared& sh = s_pk[threadIdx.x >> 6];
     const int lane = lane_id();
-    const int64_t i = ((int64_t)logical * kNNPacketsPerBlock + (threadIdx.x >> 6)) * 64 + lane;
+    const int i = (int)((logical * (uint32_t)kNNPacketsPerBlock + (threadIdx.x >> 6)) * 64u) + lane;  // (ns < 2^31)
     const bool valid = i < ns;
     // Everything this lane needs from global memory that does not depend on anything else is
     // requested FIRST, branch-free (lanes past the end re-read element 0), so that these loads,
     // the scalar loads of the loop state below and -- seeded -- the previous match travel together:
     // a wave's life is a chain of memory round trips, and each one taken out of it counts.
-    const int64_t ic = valid ? i : 0;
+    const int ic = valid ? i : 0;
     int32_t seed_j = -1;
     if (SEED) seed_j = nn_idx[ic];
     const float rx = sx[ic], ry = sy[ic], rz = sz[ic];
@@ -172,13 +172,21 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
                 best = m;
                 bidx = (int32_t)(L * (uint32_t)kLeaf + (uint32_t)k);
             }
-            set_cube(cube, qx, qy, qz, best);
-            // every point of another leaf lies on or beyond a face of the region, i.e. at
-            // L-infinity distance >= rb > sqrt(best) from the query: it cannot improve the match
-            if (g0.x <= cube.lox && g0.y <= cube.loy && g0.z <= cube.loz && g1.x >= cube.hix && g1.y >= cube.hiy &&
-                g1.z >= cube.hiz) {
+            // Every point of another leaf lies on or beyond a face of the region.  If every face is at
+            // least rb = sqrt(best) * (1 + 2^-21) away from the query -- the differences below round to
+            // nearest (relative error 2^-24), the hardware square root is good to an ulp, which leaves a
+            // margin of ~7e-7 -- such a point's computed d2 exceeds `best`: it cannot improve the match,
+            // the lane is finished.  (The search cube itself, twenty instructions, is only formed for
+            // the lanes that go on.)
+            const float rb = __builtin_amdgcn_sqrtf(best) * 1.0000005f;
+            const float inside = fminf(fminf(fminf(qx - g0.x, qy - g0.y), fminf(qz - g0.z, g1.x - qx)),
+                                       fminf(g1.y - qy, g1.z - qz));
+            if (inside >= rb) {  // (NaN anywhere: not finished)
                 retired = true;
+                cube.lox = cube.loy = cube.loz = INFINITY;
+                cube.hix = cube.hiy = cube.hiz = -INFINITY;
             } else {
+                set_cube(cube, qx, qy, qz, best);
                 // The cube pokes out of the region: by how much (L-infinity overhang), and through which
                 // faces.  Below the REACH of the leaf's neighbour list (leaf_links.h) the list names
                 // every leaf the cube can touch outside its own.
