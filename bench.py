@@ -102,7 +102,7 @@ def cpu_baseline(src, tgt, nrm, max_dist, n_total, engine_nn=None):
 
 def secondary(eng, src, tgt, nrm, d_tgt, d_nrm, d_src, max_dist, n, torch, _lib):
     """What the headline does not show (each a median of 3): noisy / partially overlapping source,
-    cold whole call, unseeded first pass, build times.  Leaves the engine loaded with (tgt, src)."""
+    cold whole call, first pass (no previous matches), build times.  Leaves the engine loaded with (tgt, src)."""
     med = lambda xs: float(np.median(xs))
     out = {}
     # -- cold call: tree build + source staging + 30 iterations, inputs resident on the device
@@ -120,7 +120,7 @@ def secondary(eng, src, tgt, nrm, d_tgt, d_nrm, d_src, max_dist, n, torch, _lib)
     out["cold_30_iteration_call_ms"] = round(med(tc) * 1e3, 3)
     out["build_ms_target"] = round(med(tt) * 1e3, 3)
     out["build_ms_source"] = round(med(ts) * 1e3, 3)
-    # -- the unseeded first pass (what every new pair of clouds pays once)
+    # -- a pass without previous matches (what every new pair of clouds pays once)
     eng.set_profiling(True)
     fp = []
     for _ in range(3):
@@ -130,6 +130,10 @@ def secondary(eng, src, tgt, nrm, d_tgt, d_nrm, d_src, max_dist, n, torch, _lib)
         p1 = eng.get_profile()
         fp.append(p1["nn_ms"] - p0["nn_ms"])
     out["first_pass_ms"] = round(med(fp), 4)
+    # 2: every query started from the leaf a greedy descent put it in (the target's neighbour lists exist),
+    # 0: the packets walked the tree from the root (a context's very first registration)
+    out["first_pass_kind"] = {0: "from the root", 1: "seeded", 2: "own seeds (greedy descent) + seeded search"}.get(
+        eng.last_search_kind(), "?")
     # -- the same loop on data that looks like a sensor's: a random 60 % of the target as the source,
     # Gaussian noise of 0.15 mean spacings per coordinate (scripts/measure_noisy.py)
     rng = np.random.default_rng(5)

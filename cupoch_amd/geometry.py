@@ -65,7 +65,7 @@ class KDTreeFlann:
                                     else queries.tensor, knn)
 
     def search_radius(self, queries, radius, max_nn):
-        if self._n == 0:
+        if self._n == 0 or not radius > 0.0:   # (a non-positive radius holds no neighbours; the engine reads 0 as "unbounded")
             return -1, None, None
         return self._eng.search_knn(_v3(queries).tensor if not isinstance(queries, utility.Vector3fVector)
                                     else queries.tensor, max_nn, radius)
@@ -80,6 +80,8 @@ class KDTreeFlann:
     def search_radius_vector_3f(self, query, radius, max_nn):
         if self._n == 0:
             raise RuntimeError("search_radius_vector_3f() error!")
+        if not radius > 0.0:
+            return 0, [], []
         k, idx, d2 = self._eng.search_knn(np.asarray(query, np.float32).reshape(1, 3), max_nn, radius)
         return k, list(idx[0, :k]), list(d2[0, :k])
 
