@@ -194,7 +194,8 @@ def main():
     src, tgt, nrm, T_gt, max_dist = synth(n)
     eng = Engine(local)
     if world > 1:
-        mine = D.shard_source(src, rank, world)
+        # the rank's Morton-contiguous shard, cut from the order the engine computes on the device
+        mine = D.device_shard_source(eng, torch.from_numpy(src).cuda(), rank, world)
         src_local = np.ascontiguousarray(src[mine])
     else:
         src_local = src
@@ -208,17 +209,45 @@ def main():
     eng.synchronize()
     build_ms = (time.perf_counter() - t0) * 1e3
     host_allreduce = False
+    begun = False
     if world > 1:
-        try:
-            D.init_engine_comm(eng, n)
-        except Exception as e:   # noqa: BLE001 -- keep the scaling run alive, say what happened
+        # The exchange, best first: the node's shared-memory mailbox (the kernels exchange the 32 sums
+        # themselves, csrc/mailbox.h), the in-library ncclAllReduce, a host-driven loop over
+        # torch.distributed.  A way counts only if the warm-up iterations ran on EVERY rank.
+        for attempt in ("mailbox", "rccl"):
+            ok, why = 1, ""
+            try:
+                if attempt == "rccl":
+                    os.environ["MI_ICP_NO_MAILBOX"] = "1"
+                D.init_engine_comm(eng, n)
+                eng.set_profiling(False)
+                eng.icp_begin(_lib.EST_POINT_TO_PLANE, max_dist, None, -1.0)
+                eng.icp_iterate(args.warmup)
+            except Exception as e:   # noqa: BLE001 -- keep the scaling run alive, say what happened
+                ok, why = 0, str(e)
+            t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 1:
+                begun = True
+                break
+            if rank == 0:
+                print("bench: exchange via %s unavailable (%s)" % (attempt, why or "failed on another rank"), file=sys.stderr)
+            try:
+                eng.comm_destroy()
+            except Exception:   # noqa: BLE001
+                pass
+        if not begun:
             host_allreduce = True
             eng.set_global_source_count(n)
             if rank == 0:
-                print("bench: in-library RCCL communicator unavailable (%s); falling back to a host-driven "
-                      "loop with torch.distributed all-reduce" % e, file=sys.stderr)
+                print("bench: falling back to a host-driven loop with torch.distributed all-reduce", file=sys.stderr)
     elif os.environ.get("MI_ICP_BENCH_HOST_LOOP") == "1":
         host_allreduce = True      # exercises the fallback loop on one rank
+    elif os.environ.get("MI_ICP_FORCE_COMM") == "2":
+        # single-rank mailbox: the exchange's fixed cost (post, poll, read back through host memory) on a 1-GPU box
+        os.environ["MI_ICP_MAILBOX_SOLO"] = "1"
+        eng.comm_init_local("bench_solo_%d" % os.getpid(), 1, 0)
+        eng.set_global_source_count(n)
     elif os.environ.get("MI_ICP_FORCE_COMM") == "1":
         # single-rank communicator: exercises the RCCL all-reduce path on a 1-GPU box
         from cupoch_amd.engine import comm_unique_id
@@ -249,7 +278,7 @@ def main():
 
         eng.icp_iterate = _Stepper().iterate           # same call shape below
         eng.icp_iterate(args.warmup)
-    else:
+    elif not begun:
         eng.icp_begin(_lib.EST_POINT_TO_PLANE, max_dist, None, -1.0)
         eng.icp_iterate(args.warmup)
     windows = []
@@ -323,7 +352,9 @@ def main():
                                    "clouds (BASELINE.md section 3)" % (_fmt(n), _fmt(n)),
                        "points": n, "max_correspondence_distance": max_dist, "det_thresh": -1.0,
                        "parallelism": ("source sharded x%d, target+tree replicated, %s all-reduce of 32 f64/iter"
-                                       % (world, "host-driven torch.distributed" if host_allreduce else "in-library RCCL"))
+                                       % (world, "host-driven torch.distributed" if host_allreduce else
+                                          ("shared-memory mailbox (inside the reduction kernel), no collective launch:"
+                                           if eng.comm_kind() == 2 else "in-library RCCL")))
                        if world > 1 else "single GPU",
                        "accumulate": "f64", "build_ms": round(build_ms, 2),
                        "final_fitness": round(float(res.fitness), 6),

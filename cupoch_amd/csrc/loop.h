@@ -12,6 +12,7 @@
 #pragma once
 #include "device_utils.h"
 #include "host_solver.h"
+#include "mailbox.h"
 
 namespace mi {
 
@@ -28,7 +29,7 @@ struct DevLoop {
     float fitness, rmse, prev_fitness, prev_rmse;
     int64_t n_source_global;
     int32_t ready;       // estimator inputs present (normals / covariances)
-    int32_t pad_;
+    int32_t error;       // != 0: the ranks' exchange failed (mailbox.h); the loop is finished, its result void
     host::Mat4 T;        // reported transformation (column-major)
     host::Mat4 A;        // applied transformation (differs from T only by an ~identity init)
     double sys[32];      // the reduced (and all-reduced) system of the last evaluation
@@ -109,7 +110,7 @@ __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys
             if (st->have_prev && fabsf(st->prev_fitness - fit) < st->rel_fitness &&
                 fabsf(st->prev_rmse - rmse) < st->rel_rmse)
                 finished = true;
-            if (st->iterations >= st->max_iterations) finished = true;
+            if (st->iterations >= st->max_iterations || st->error) finished = true;
             if (finished) {
                 st->done = 1;
                 update_now = false;
@@ -132,9 +133,19 @@ __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys
     for (int i = (int)threadIdx.x; i < kWords; i += nth) out[i] = dst[i];
 }
 
-__global__ __launch_bounds__(64) void loop_step_kernel(DevLoop* st_g, const double* __restrict__ sys_in,
-                                                       int resume) {
+// The ranks' exchange (mailbox.h) in front of the step, for a block that already holds this rank's
+// sums in sys (global memory, written before a barrier or by an earlier kernel).  A finished loop
+// exchanges nothing -- on every rank alike, the flag derives from the all-reduced sums.
+__device__ __forceinline__ void loop_exchange(DevLoop* st_g, const MailArgs& mail, double* sys) {
+    __shared__ uint32_t s_mail[2];
+    if (mail.box == nullptr || st_g->done) return;  // (uniform)
+    if (!mail_allreduce(mail, sys, s_mail) && threadIdx.x == 0) st_g->error = 1;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void loop_step_kernel(DevLoop* st_g, double* sys_in, int resume, MailArgs mail) {
     __shared__ DevLoop st_s;
+    if (resume <= 0) loop_exchange(st_g, mail, sys_in);
     loop_step_block(st_g, sys_in, resume, st_s);
 }
 

@@ -7,6 +7,10 @@
 // per iteration, one 256-byte D2H copy, the 6x6 solve on the host, and the new
 // 4x4 passed back as a kernel argument.  Nothing is allocated inside the loop.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -15,8 +19,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
+#include <cctype>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mi_icp.h"
@@ -130,7 +137,13 @@ struct mi_icp_ctx {
 
     // ---- multi-GPU ----
     ncclComm_t comm = nullptr;
-    int nranks = 1;
+    int nranks = 1, rank = 0;
+    // the node's mailbox (mailbox.h): POSIX shared memory registered with HIP, or null
+    MailBox* mail_host = nullptr;
+    MailBox* mail_dev = nullptr;
+    size_t mail_bytes = 0;
+    std::string mail_name;
+    DevBuf mail_state;  // [0]: this rank's exchange counter, [1]: error flag of the one-shot exchange
 
     // ---- private scratch context: PointCloud::EstimateNormals builds its own tree there, so
     // that the target / source / loop state of THIS context survive the call ----
@@ -593,6 +606,8 @@ static int reduce_elems_per_thread() {
     return v;
 }
 
+MailArgs mail_args(const mi_icp_ctx* c);  // (below, with the communicator code)
+
 bool known_estimator(int est) {
     return est == kEstP2P || est == kEstPt2Pl || est == kEstSym || est == kEstColored || est == kEstGICP;
 }
@@ -667,15 +682,21 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, DevLoop* loop
     static const bool no_fast_reduce = std::getenv("MI_ICP_NO_FAST_REDUCE") != nullptr;  // A/B switch
     if (est == kEstPt2Pl && mode == 0 && !a.pairs && a.trec && a.count > 0 && !no_fast_reduce) {
         // four elements in flight per thread; at most 512 blocks (2 per CU): measured best on the 10M bench
-        // (256 / 512 / 1024 / 2048 blocks: 0.090 / 0.079 / 0.080 / 0.091 ms, scripts/gpu_reduce_sweep.sh)
+        // (256 / 512 / 1024 / 2048 blocks: 0.090 / 0.079 / 0.080 / 0.091 ms; 6 or 8 elements in flight on 512,
+        // 768 or 1024 blocks: 0.078 - 0.084 ms -- the kernel sits at ~5.1 TB/s of the ~6.3 a pure stream reaches)
         const int g2 = std::min(grid, 512);
         static const bool no_fused_step = std::getenv("MI_ICP_NO_FUSED_STEP") != nullptr;  // A/B switch
         EvTimer t(c, 1, loop != nullptr);
-        if (fuse_step && loop && !c->comm && !no_fused_step) {
-            reduce_pt2pl_kernel<4, true><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys);
+        const MailArgs no_mail = {nullptr, nullptr, 0, 1};
+        const bool mail = c->mail_dev != nullptr;
+        if (fuse_step && loop && mail && !no_fused_step) {  // N ranks on one node: exchange + step in the finishing block
+            reduce_pt2pl_kernel<4, 2><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, mail_args(c));
+            if (stepped) *stepped = true;
+        } else if (fuse_step && loop && !c->comm && !mail && !no_fused_step) {
+            reduce_pt2pl_kernel<4, 1><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
             if (stepped) *stepped = true;
         } else {
-            reduce_pt2pl_kernel<4, false><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys);
+            reduce_pt2pl_kernel<4, 0><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
         }
         KCHK(c);
         return MI_ICP_OK;
@@ -700,7 +721,98 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, DevLoop* loop
     return MI_ICP_OK;
 }
 
+MailArgs mail_args(const mi_icp_ctx* c) {
+    MailArgs m;
+    m.box = c->mail_dev;
+    m.seq_dev = (uint32_t*)c->mail_state.p;
+    m.rank = c->rank;
+    m.nranks = c->nranks;
+    return m;
+}
+
+void mailbox_close(mi_icp_ctx* c) {
+    if (c->mail_host) {
+        (void)hipHostUnregister(c->mail_host);
+        (void)munmap(c->mail_host, c->mail_bytes);
+    }
+    if (!c->mail_name.empty()) (void)shm_unlink(c->mail_name.c_str());  // (the first rank to get here removes the name)
+    c->mail_host = c->mail_dev = nullptr;
+    c->mail_name.clear();
+}
+
+// Rank 0 creates and zeroes the box, the others wait for it (30 s), every rank registers the mapping
+// with HIP.  All ranks of a job pass the same name; it is removed again by mailbox_close.
+int mailbox_open(mi_icp_ctx* c, const std::string& name, int nranks, int rank) {
+    mailbox_close(c);
+    if (nranks > kMailRanks) return fail(c, MI_ICP_ERR_COMM, "mailbox: %d ranks (at most %d)", nranks, kMailRanks);
+    const size_t bytes = (sizeof(MailBox) + 4095) / 4096 * 4096;
+    int fd = -1;
+    if (rank == 0) {
+        (void)shm_unlink(name.c_str());  // a stale box of a crashed job
+        fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) {
+            if (fd >= 0) close(fd);
+            return fail(c, MI_ICP_ERR_COMM, "mailbox: cannot create shared memory %s", name.c_str());
+        }
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            fd = shm_open(name.c_str(), O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) break;
+            if (fd >= 0) close(fd);
+            fd = -1;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+                return fail(c, MI_ICP_ERR_COMM, "mailbox: shared memory %s did not appear", name.c_str());
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+    }
+    void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return fail(c, MI_ICP_ERR_COMM, "mailbox: mmap failed");
+    MailBox* box = (MailBox*)p;
+    if (rank == 0) {
+        std::memset(p, 0, bytes);
+        box->nranks = (uint32_t)nranks;
+        __atomic_store_n(&box->ready, 1u, __ATOMIC_RELEASE);
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (__atomic_load_n(&box->ready, __ATOMIC_ACQUIRE) != 1u) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+                (void)munmap(p, bytes);
+                return fail(c, MI_ICP_ERR_COMM, "mailbox: rank 0 did not initialise %s", name.c_str());
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        if (box->nranks != (uint32_t)nranks) {
+            (void)munmap(p, bytes);
+            return fail(c, MI_ICP_ERR_COMM, "mailbox: %s was made for %u ranks, not %d", name.c_str(), box->nranks, nranks);
+        }
+    }
+    void* dev = nullptr;
+    if (hipHostRegister(p, bytes, hipHostRegisterMapped) != hipSuccess || hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)munmap(p, bytes);
+        return fail(c, MI_ICP_ERR_COMM, "mailbox: hipHostRegister failed");
+    }
+    uint32_t* state;
+    TRY(ensure(c, c->mail_state, 64, &state));
+    HIPCHK(c, hipMemsetAsync(state, 0, 64 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->mail_host = box;
+    c->mail_dev = (MailBox*)dev;
+    c->mail_bytes = bytes;
+    c->mail_name = name;
+    return MI_ICP_OK;
+}
+
 int allreduce_system(mi_icp_ctx* c) {
+    if (c->mail_dev) {  // one-shot exchange through the mailbox
+        int32_t* state = (int32_t*)c->mail_state.p;
+        mail_allreduce_kernel<<<1, 64, 0, c->stream>>>(mail_args(c), (double*)c->sys_dev.p, state + 1);
+        KCHK(c);
+        return MI_ICP_OK;
+    }
     if (!c->comm) return MI_ICP_OK;
     double* sys = (double*)c->sys_dev.p;
     ncclResult_t r = g_rccl.AllReduce(sys, sys, kSysSize, ncclDouble, ncclSum, c->comm, c->stream);
@@ -713,8 +825,12 @@ int fetch_system(mi_icp_ctx* c, double* out) {
     double* sys = (double*)c->sys_dev.p;
     TRY(allreduce_system(c));
     HIPCHK(c, hipMemcpyAsync(c->sys_host, sys, kSysSize * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    const bool mail = c->mail_dev != nullptr;
+    int32_t* err_host = reinterpret_cast<int32_t*>(c->sys_host + 40);  // (spare words of the pinned buffer)
+    if (mail) HIPCHK(c, hipMemcpyAsync(err_host, (const int32_t*)c->mail_state.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     collect_events(c);
+    if (mail && *err_host) return fail(c, MI_ICP_ERR_COMM, "the ranks' exchange timed out (mailbox): a peer did not post its sums");
     std::memcpy(out, c->sys_host, kSysSize * sizeof(double));
     return MI_ICP_OK;
 }
@@ -787,13 +903,14 @@ void mi_icp_destroy(mi_icp_ctx* c) {
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_links) (void)hipEventDestroy(c->ev_links);
+    mailbox_close(c);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     DevBuf* all[] = {&c->trec, &c->tlreg, &c->tlinks, &c->tlinks_tmp, &c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
                      &c->cell_gstart, &c->sx, &c->sy, &c->sz,
                      &c->sperm, &c->snrm, &c->scov, &c->nn_idx, &c->nn_d2, &c->inv_s,
                      &c->user_pairs, &c->keys0, &c->keys1, &c->vals0, &c->vals1, &c->hist,
                      &c->scan_tmp, &c->bounds_part, &c->bounds, &c->partial, &c->sys_dev,
-                     &c->dense_idx, &c->flags, &c->pairs_out, &c->seg_start, &c->loop_dev, &c->ticket, &c->alt[0],
+                     &c->dense_idx, &c->flags, &c->pairs_out, &c->seg_start, &c->loop_dev, &c->ticket, &c->mail_state, &c->alt[0],
                      &c->alt[1], &c->alt[2], &c->alt[3], &c->alt[4], &c->alt[5], &c->alt[6], &c->alt[7], &c->alt[8], &c->stage[0],
                      &c->stage[1], &c->stage[2], &c->stage[3], &c->stage[4], &c->stage[5]};
     for (DevBuf* b : all) release(*b);
@@ -1309,6 +1426,10 @@ static void fill_result(const mi_icp_ctx* c, mi_icp_result* out) {
 static int loop_pull(mi_icp_ctx* c) {  // device state -> pinned mirror, synchronises
     HIPCHK(c, hipMemcpyAsync(c->loop_host, c->loop_dev.p, sizeof(DevLoop), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->loop_host->error) {
+        c->loop_active = false;
+        return fail(c, MI_ICP_ERR_COMM, "the ranks' exchange timed out (mailbox): a peer did not post its sums");
+    }
     return MI_ICP_OK;
 }
 
@@ -1319,9 +1440,11 @@ static int loop_enqueue_evaluation(mi_icp_ctx* c, bool seed) {
     TRY(launch_nn(c, I, c->loop_r2, seed, nullptr, d));
     bool stepped = false;
     TRY(launch_reduce(c, c->loop_est, 0, I, d, true, &stepped));
-    if (stepped) return MI_ICP_OK;  // (single GPU, point-to-plane: the reduction's last block took the step)
-    TRY(allreduce_system(c));
-    loop_step_kernel<<<1, 64, 0, c->stream>>>(d, (const double*)c->sys_dev.p, 0);
+    if (stepped) return MI_ICP_OK;  // (point-to-plane: the reduction's last block exchanged the sums, if need be, and took the step)
+    const bool mail = c->mail_dev != nullptr;
+    if (!mail) TRY(allreduce_system(c));  // (with a mailbox the step kernel starts with the exchange)
+    const MailArgs no_mail = {nullptr, nullptr, 0, 1};
+    loop_step_kernel<<<1, 64, 0, c->stream>>>(d, (double*)c->sys_dev.p, 0, mail ? mail_args(c) : no_mail);
     KCHK(c);
     return MI_ICP_OK;
 }
@@ -1408,7 +1531,7 @@ int mi_icp_icp_iterate(mi_icp_ctx* c, int n_iterations, mi_icp_result* out) {
         // re-open the loop for n more updates: the update for the next iteration is formed
         // from the system of the last evaluation (resume = step without stats/test)
         DevLoop* d = (DevLoop*)c->loop_dev.p;
-        loop_step_kernel<<<1, 64, 0, c->stream>>>(d, (const double*)c->sys_dev.p, n_iterations);
+        loop_step_kernel<<<1, 64, 0, c->stream>>>(d, (double*)c->sys_dev.p, n_iterations, MailArgs{nullptr, nullptr, 0, 1});
         KCHK(c);
         TRY(loop_run(c, n_iterations));
     }
@@ -2198,17 +2321,57 @@ int mi_icp_comm_init(mi_icp_ctx* c, const char* id128, int nranks, int rank) {
         return fail(c, MI_ICP_ERR_COMM, "ncclCommInitRank failed (%d)", (int)r);
     }
     c->nranks = nranks;
+    c->rank = rank;
+    // One node: the per-iteration exchange goes through the mailbox (mailbox.h) instead of an
+    // ncclAllReduce launch; the communicator stays for whatever the mailbox cannot do.  The box is named
+    // after the job's unique id.  MI_ICP_NO_MAILBOX=1, more than 16 ranks or a failed set-up: RCCL only.
+    const bool no_mailbox = std::getenv("MI_ICP_NO_MAILBOX") != nullptr;  // (read at every call: a caller may fall back)
+    if (!no_mailbox && nranks > 1 && nranks <= kMailRanks) {
+        unsigned long long h = 1469598103934665603ull;  // FNV-1a of the id
+        for (int i = 0; i < 128; ++i) h = (h ^ (unsigned char)id128[i]) * 1099511628211ull;
+        char name[64];
+        std::snprintf(name, sizeof(name), "/mi_icp_%016llx", h);
+        if (mailbox_open(c, name, nranks, rank) != MI_ICP_OK) mailbox_close(c);  // (c->err says why; not fatal)
+    }
     return MI_ICP_OK;
+}
+
+int mi_icp_comm_init_local(mi_icp_ctx* c, const char* job_name, int nranks, int rank) {
+    TRY(check_ctx(c));
+    if (!job_name || !job_name[0] || nranks < 1 || rank < 0 || rank >= nranks)
+        return fail(c, MI_ICP_ERR_INVALID, "comm_init_local: bad arguments");
+    std::string name = "/mi_icp_";
+    for (const char* p = job_name; *p && name.size() < 60; ++p)
+        name += (std::isalnum((unsigned char)*p) || *p == '_' || *p == '-') ? *p : '_';
+    c->nranks = nranks;
+    c->rank = rank;
+    // (MI_ICP_MAILBOX_SOLO: a one-rank box, to time the exchange's fixed cost on a single GPU)
+    if (nranks > 1 || std::getenv("MI_ICP_MAILBOX_SOLO")) {
+        const int rc = mailbox_open(c, name, nranks, rank);
+        if (rc != MI_ICP_OK) {
+            c->nranks = 1;
+            c->rank = 0;
+            return rc;
+        }
+    }
+    return MI_ICP_OK;
+}
+
+int mi_icp_comm_kind(const mi_icp_ctx* c) {
+    if (!c) return 0;
+    return c->mail_dev ? 2 : (c->comm ? 1 : 0);
 }
 
 int mi_icp_comm_destroy(mi_icp_ctx* c) {
     TRY(check_ctx(c));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    mailbox_close(c);
     if (c->comm) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
         g_rccl.CommDestroy(c->comm);
         c->comm = nullptr;
     }
     c->nranks = 1;
+    c->rank = 0;
     return MI_ICP_OK;
 }
 

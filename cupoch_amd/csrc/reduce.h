@@ -382,17 +382,19 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_kernel(ReduceArgs a, Xf
 // re-read slot 0; both are masked out of the sums).  Same per-element arithmetic and the same
 // per-thread summation order as reduce_kernel<point-to-plane, 0> with the same grid.
 //
-// STEP (single-GPU loops): the finishing block also takes the loop's step -- statistics, convergence
+// STEP == 1 (single-GPU loops): the finishing block also takes the loop's step -- statistics, convergence
 // test, 6x6 solve, T <- dT * T (loop.h: loop_step_body) -- instead of a launch of its own: one kernel
-// boundary and ~8 us less per iteration.  With the all-reduce between reduction and step (N > 1) the
-// step stays a kernel.  (On reduce_kernel this was tried and dropped in round 1: the solver's
+// boundary and ~8 us less per iteration.  With an ncclAllReduce between reduction and step (N > 1 without
+// a mailbox) the step stays a kernel.  (On reduce_kernel this was tried and dropped in round 1: the solver's
 // registers cost it an occupancy step; this kernel runs two blocks per CU and has them to spare.)
-template <int kU, bool STEP>
+// STEP == 2 (N > 1 on one node): the finishing block first exchanges the sums with the other ranks
+// through the mailbox (mailbox.h), then steps -- still no third launch and no collective.
+template <int kU, int STEP>
 __global__ __launch_bounds__(kReduceThreads) void reduce_pt2pl_kernel(ReduceArgs a, Xform Tv,
                                                                       DevLoop* __restrict__ loop,
                                                                       double* __restrict__ partial,
                                                                       uint32_t* __restrict__ ticket,
-                                                                      double* __restrict__ out32) {
+                                                                      double* __restrict__ out32, MailArgs mail) {
     const int64_t stride = (int64_t)gridDim.x * kReduceThreads;
     const int64_t k0 = (int64_t)blockIdx.x * kReduceThreads + threadIdx.x;
     // the first batch is requested before the loop state is even looked at
@@ -452,6 +454,7 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_pt2pl_kernel(ReduceArgs
     if (STEP && last) {
         __syncthreads();  // out32 has been written by this block's first 32 threads
         __shared__ DevLoop st_s;
+        if (STEP == 2) loop_exchange(loop, mail, out32);
         loop_step_block(loop, out32, 0, st_s);
     }
 }

@@ -534,6 +534,14 @@ class Engine:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._chk(self._L.mi_icp_comm_init(self._ctx, buf, int(nranks), int(rank)))
 
+    def comm_init_local(self, job_name, nranks, rank):
+        """node-local communicator: the shared-memory mailbox alone (csrc/mailbox.h), no RCCL"""
+        self._chk(self._L.mi_icp_comm_init_local(self._ctx, str(job_name).encode(), int(nranks), int(rank)))
+
+    def comm_kind(self):
+        """0: none, 1: RCCL all-reduce, 2: shared-memory mailbox"""
+        return int(self._L.mi_icp_comm_kind(self._ctx))
+
     def comm_destroy(self):
         self._chk(self._L.mi_icp_comm_destroy(self._ctx))
 

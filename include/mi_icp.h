@@ -371,11 +371,24 @@ MI_ICP_API int mi_icp_registration_colored_icp(mi_icp_ctx* ctx, float max_distan
 
 /* ---- multi-GPU (new: the reference is single-GPU) -------------------------
  * One context per rank/GPU, each holding the full target and its own shard of
- * the source.  After mi_icp_comm_init every accumulated system is summed
- * across ranks with one ncclAllReduce(double, 32) on the context's stream
- * before the host solve, so all ranks take identical steps. */
+ * the source.  After mi_icp_comm_init every accumulated system (32 doubles) is
+ * summed across ranks before the solve, in a fixed order, so all ranks take
+ * bit-identical steps.  How:
+ *  - ranks of ONE node (<= 16) exchange through a MAILBOX in POSIX shared memory
+ *    that every rank's GPU maps (csrc/mailbox.h): the reduction's finishing block
+ *    posts its sums, waits for the peers' and goes on to the step -- an iteration
+ *    stays two launches, no collective is launched;
+ *  - otherwise (MI_ICP_NO_MAILBOX=1, more ranks, mailbox set-up failed) one
+ *    ncclAllReduce(double, 32) on the context's stream, then the step kernel.
+ * mi_icp_comm_init: RCCL communicator from a shared ncclUniqueId + the mailbox (named after
+ * the id).  mi_icp_comm_init_local: the mailbox alone, no RCCL -- all ranks pass the same
+ * job_name (letters, digits, '_', '-'), one node only.  mi_icp_comm_kind: 0 none, 1 RCCL
+ * all-reduce, 2 mailbox.  A peer that does not post within ~10 s fails the call with
+ * MI_ICP_ERR_COMM. */
 MI_ICP_API int mi_icp_comm_unique_id(char* id128);
 MI_ICP_API int mi_icp_comm_init(mi_icp_ctx* ctx, const char* id128, int nranks, int rank);
+MI_ICP_API int mi_icp_comm_init_local(mi_icp_ctx* ctx, const char* job_name, int nranks, int rank);
+MI_ICP_API int mi_icp_comm_kind(const mi_icp_ctx* ctx);
 MI_ICP_API int mi_icp_comm_destroy(mi_icp_ctx* ctx);
 /* total source size over all ranks (fitness denominator, registration.cu:76) */
 MI_ICP_API int mi_icp_set_global_source_count(mi_icp_ctx* ctx, int64_t n_total);

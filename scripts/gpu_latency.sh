@@ -15,21 +15,17 @@ rows=list(csv.DictReader(open('gpurun_out/prof_lat/l_kernel_trace.csv')))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 names=[r['Kernel_Name'] for r in rows]
 last_build=max(i for i,n in enumerate(names) if 'kd_build_groups' in n)
-b0=max(i for i,n in enumerate(names[:last_build]) if 'bounds_partial' in n)
-while b0>0 and 'bounds' in names[b0-1]: b0-=1
+b0=last_build
+while b0>0 and 'reduce' not in names[b0-1] and 'nn_packet' not in names[b0-1]: b0-=1
 seq=rows[b0:]
 def span(s): return (int(s[-1]['End_Timestamp'])-int(s[0]['Start_Timestamp']))/1e3
 def ksum(s): return sum(int(r['End_Timestamp'])-int(r['Start_Timestamp']) for r in s)/1e3
 print('last call: %d kernels, span %.1f us, kernel time %.1f us' % (len(seq), span(seq), ksum(seq)))
-loop=[i for i,r in enumerate(seq) if 'loop_step_kernel' in r['Kernel_Name']]
-first_nn=min(i for i,r in enumerate(seq) if 'nn_packet_kernel<true' in r['Kernel_Name'])
-it=seq[first_nn:loop[-1]+1]
-n_it=sum(1 for r in it if 'loop_step_kernel' in r['Kernel_Name'])
-print('seeded iterations: %d, span %.1f us (%.1f per iteration), kernel time %.1f us (%.1f per iteration)' % (n_it, span(it), span(it)/n_it, ksum(it), ksum(it)/n_it))
-agg={}
-for r in seq:
-    k=r['Kernel_Name'].split('(')[0][:44]
-    a=agg.setdefault(k,[0,0.0]); a[0]+=1; a[1]+=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
-for k,(c,d) in sorted(agg.items(), key=lambda kv:-kv[1][1])[:14]:
-    print(k.ljust(46), str(c).rjust(4), ('%.1f us' % d).rjust(12))
+nn=[i for i,r in enumerate(seq) if 'nn_packet_kernel<true' in r['Kernel_Name']]
+it=seq[nn[1]:]           # from the second seeded pass on: the steady iterations
+n_it=sum(1 for r in it if 'nn_packet_kernel<true' in r['Kernel_Name'])
+print('steady iterations: %d, span %.1f us (%.1f per iteration), kernel time %.1f us (%.1f per iteration)' % (n_it, span(it), span(it)/n_it, ksum(it), ksum(it)/n_it))
+t0=int(seq[0]['Start_Timestamp'])
+for r in seq[:40]:
+    print('%9.1f %8.1f  %s' % ((int(r['Start_Timestamp'])-t0)/1e3,(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3, r['Kernel_Name'].split('(')[0][:50]))
 PY

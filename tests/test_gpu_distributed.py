@@ -105,3 +105,65 @@ def test_in_library_rccl_allreduce_on_a_one_rank_communicator():
     assert got.fitness == ref.fitness and got.inlier_rmse == ref.inlier_rmse
     eng.comm_destroy()
     eng.close()
+
+
+def _worker_mailbox(rank, world, job, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cupoch_amd import distributed as D
+    from cupoch_amd.engine import Engine
+    torch.cuda.set_device(0)
+    d = make_pair(N, seed=13, noise=0.03)
+    eng = Engine(0)
+    src_dev = torch.from_numpy(d["src"]).cuda()
+    mine = D.device_shard_source(eng, src_dev, rank, world)
+    eng.set_target(torch.from_numpy(d["tgt"]).cuda(), torch.from_numpy(d["tgt_nrm"]).cuda())
+    eng.set_source(src_dev[torch.from_numpy(mine).cuda()])
+    eng.comm_init_local(job, world, rank)                  # the shared-memory mailbox, no RCCL
+    assert eng.comm_kind() == 2
+    eng.set_global_source_count(N)
+    out = {}
+    # the device-resident loop: point-to-plane (exchange + step inside the reduction's finishing block) ...
+    res = eng.registration_icp(PT2PL, d["max_dist"], None, 0.0, 0.0, ITER, -1.0)
+    out["T_pl"] = np.array(res.transformation, np.float32)
+    out["stat_pl"] = np.array([res.fitness, res.inlier_rmse, res.iterations])
+    # ... point-to-point (generic reduction: the exchange opens the step kernel) ...
+    res = eng.registration_icp(1, d["max_dist"], None, 0.0, 0.0, ITER, -1.0)
+    out["T_pp"] = np.array(res.transformation, np.float32)
+    out["stat_pp"] = np.array([res.fitness, res.inlier_rmse, res.iterations])
+    # ... and a one-shot evaluation (the exchange as a kernel of its own)
+    ev = eng.evaluate_registration(d["max_dist"], None)
+    out["eval"] = np.array([ev.fitness, ev.inlier_rmse])
+    np.savez(os.path.join(out_dir, "mail_%d.npz" % rank), **out)
+    eng.comm_destroy()
+    eng.close()
+
+
+def test_mailbox_exchange_two_processes_on_one_gpu(tmp_path):
+    """The node-local communicator (csrc/mailbox.h): two processes share GPU 0, each runs the
+    DEVICE-resident loop on its shard; every evaluation's 32 sums are exchanged through the mailbox in
+    shared host memory by the kernels themselves.  Both ranks must end with bit-identical results,
+    equal (to rounding of the sums' order) to the single-process loop."""
+    from cupoch_amd.engine import Engine
+    world = 2
+    job = "test_%d_%d" % (os.getpid(), _free_port())
+    mp.spawn(_worker_mailbox, args=(world, job, str(tmp_path)), nprocs=world, join=True)
+    d = make_pair(N, seed=13, noise=0.03)
+    eng = Engine(0)
+    eng.set_target(d["tgt"], d["tgt_nrm"])
+    eng.set_source(d["src"])
+    r_pl = eng.registration_icp(PT2PL, d["max_dist"], None, 0.0, 0.0, ITER, -1.0)
+    r_pp = eng.registration_icp(1, d["max_dist"], None, 0.0, 0.0, ITER, -1.0)
+    ev = eng.evaluate_registration(d["max_dist"], None)
+    eng.close()
+    m0, m1 = np.load(tmp_path / "mail_0.npz"), np.load(tmp_path / "mail_1.npz")
+    for k in m0.files:
+        np.testing.assert_array_equal(m0[k], m1[k], err_msg=k)          # identical steps on every rank
+    for key, ref in (("pl", r_pl), ("pp", r_pp)):
+        T = m0["T_" + key]
+        assert np.linalg.norm(T - np.array(ref.transformation, np.float32)) <= 1e-6, key
+        st = m0["stat_" + key]
+        assert st[0] == pytest.approx(ref.fitness, abs=1e-6) and st[1] == pytest.approx(ref.inlier_rmse, rel=1e-5)
+        assert int(st[2]) == ref.iterations
+    assert m0["eval"][0] == pytest.approx(ev.fitness, abs=1e-6) and m0["eval"][1] == pytest.approx(ev.inlier_rmse, rel=1e-5)
