@@ -62,7 +62,8 @@ __device__ __forceinline__ bool mail_allreduce(const MailArgs& m, double* sys, u
     if (threadIdx.x == 0) __hip_atomic_store(&m.box->seq[slot][m.rank][0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((int)threadIdx.x < m.nranks) {  // thread r waits for rank r
         uint32_t spins = 0u;
-        while (__hip_atomic_load(&m.box->seq[slot][threadIdx.x][0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+        // (relaxed polls -- host memory is not cached on the GPU side -- and one acquire fence behind the barrier)
+        while (__hip_atomic_load(&m.box->seq[slot][threadIdx.x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
             if (++spins > kMailSpinLimit) {
                 s_tmp[1] = 0u;
                 break;

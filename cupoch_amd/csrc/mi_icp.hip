@@ -1344,7 +1344,8 @@ int mi_icp_evaluate_registration(mi_icp_ctx* c, float max_distance, const float*
     const Mat4 M = load_T(T);
     std::memset(out, 0, sizeof(*out));
     std::memcpy(out->transformation, M.data(), sizeof(float) * 16);
-    if (max_distance <= 0.0f || c->ns <= 0) {  // registration.cu:40-42
+    // (a rank of a sharded job goes through the motions even with an empty shard: its peers wait for its sums)
+    if (max_distance <= 0.0f || (c->ns <= 0 && c->nranks <= 1)) {  // registration.cu:40-42
         c->nn_valid = false;
         return MI_ICP_OK;
     }
@@ -1484,7 +1485,8 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
     c->loop_active = false;
     c->loop_est = est;
     c->loop_r2 = max_distance * max_distance;
-    if (max_distance <= 0.0f || c->ns <= 0) {
+    // (a rank of a sharded job goes through the motions even with an empty shard: its peers wait for its sums)
+    if (max_distance <= 0.0f || (c->ns <= 0 && c->nranks <= 1)) {
         // the reference logs an error and keeps going; every pass then yields an
         // empty result and identity updates, so the answer is `init` unchanged
         c->nn_valid = false;
