@@ -184,11 +184,19 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    # MI_ICP_BENCH_ONE_DEVICE=1: a rehearsal of the N > 1 path on a one-GPU box -- every rank on cuda:0, gloo for
+    # the host-side collectives (RCCL cannot put two ranks on one device); the numbers mean nothing, the control flow does
+    one_device = os.environ.get("MI_ICP_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
 
     n = args.points
     src, tgt, nrm, T_gt, max_dist = synth(n)
@@ -214,18 +222,21 @@ def main():
         # The exchange, best first: the node's shared-memory mailbox (the kernels exchange the 32 sums
         # themselves, csrc/mailbox.h), the in-library ncclAllReduce, a host-driven loop over
         # torch.distributed.  A way counts only if the warm-up iterations ran on EVERY rank.
-        for attempt in ("mailbox", "rccl"):
+        for attempt in ("rccl+mailbox", "mailbox", "rccl"):
             ok, why = 1, ""
             try:
-                if attempt == "rccl":
-                    os.environ["MI_ICP_NO_MAILBOX"] = "1"
-                D.init_engine_comm(eng, n)
+                if attempt == "mailbox":
+                    D.init_engine_comm_local(eng, n)       # no RCCL in the library at all
+                else:
+                    if attempt == "rccl":
+                        os.environ["MI_ICP_NO_MAILBOX"] = "1"
+                    D.init_engine_comm(eng, n)
                 eng.set_profiling(False)
                 eng.icp_begin(_lib.EST_POINT_TO_PLANE, max_dist, None, -1.0)
                 eng.icp_iterate(args.warmup)
             except Exception as e:   # noqa: BLE001 -- keep the scaling run alive, say what happened
                 ok, why = 0, str(e)
-            t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            t = torch.tensor([ok], dtype=torch.int32, device=("cpu" if one_device else "cuda"))
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             if int(t.item()) == 1:
                 begun = True
@@ -293,7 +304,7 @@ def main():
             dist.barrier()
         w = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([w], dtype=torch.float64, device="cuda")
+            t = torch.tensor([w], dtype=torch.float64, device=("cpu" if one_device else "cuda"))
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             w = float(t.item())
         windows.append(w)

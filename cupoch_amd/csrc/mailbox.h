@@ -25,7 +25,7 @@
 namespace mi {
 
 constexpr int kMailRanks = 16;
-constexpr uint32_t kMailSpinLimit = 8u << 20;  // polls of a flag in host memory (~1 us each)
+constexpr uint32_t kMailSpinLimit = 8u << 20;  // polls of a flag in host memory (~1-2 us each); MI_ICP_MAIL_SPIN_LIMIT overrides
 
 struct MailBox {
     uint32_t ready;                      // set by rank 0 once the box is zeroed
@@ -39,6 +39,7 @@ struct MailArgs {
     MailBox* box;       // device address of the registered host mapping; null: no mailbox
     uint32_t* seq_dev;  // this rank's exchange counter (device memory, zeroed with the box)
     int rank, nranks;
+    uint32_t spin_limit;
 };
 
 // One workgroup of >= 32 threads.  sys: this rank's 32 sums (global or LDS, written before a barrier);
@@ -64,7 +65,7 @@ __device__ __forceinline__ bool mail_allreduce(const MailArgs& m, double* sys, u
         uint32_t spins = 0u;
         // (relaxed polls -- host memory is not cached on the GPU side -- and one acquire fence behind the barrier)
         while (__hip_atomic_load(&m.box->seq[slot][threadIdx.x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-            if (++spins > kMailSpinLimit) {
+            if (++spins > m.spin_limit) {
                 s_tmp[1] = 0u;
                 break;
             }

@@ -77,6 +77,25 @@ def init_engine_comm(engine, n_source_total):
     return rank, world
 
 
+def init_engine_comm_local(engine, n_source_total):
+    """The node-local communicator alone (shared-memory mailbox, no RCCL): rank 0 picks the job's
+    name, everyone receives it through the already-initialised torch.distributed group."""
+    import os
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    tag = torch.zeros(2, dtype=torch.int64)
+    if rank == 0:
+        tag = torch.tensor([os.getpid(), int.from_bytes(os.urandom(6), "little")], dtype=torch.int64)
+    if dist.get_backend() == "nccl":
+        tag = tag.to(torch.device("cuda", torch.cuda.current_device()))
+    dist.broadcast(tag, src=0)
+    tag = tag.cpu()
+    engine.comm_init_local("job_%d_%x" % (int(tag[0]), int(tag[1])), world, rank)
+    engine.set_global_source_count(n_source_total)
+    return rank, world
+
+
 def gather_correspondences(local_pairs, shard_indices):
     """The job's correspondence set from the ranks' shard-local ones: source indices are
     mapped back through the shard (shard_source's result), everything is all-gathered and

@@ -167,3 +167,41 @@ def test_mailbox_exchange_two_processes_on_one_gpu(tmp_path):
         assert st[0] == pytest.approx(ref.fitness, abs=1e-6) and st[1] == pytest.approx(ref.inlier_rmse, rel=1e-5)
         assert int(st[2]) == ref.iterations
     assert m0["eval"][0] == pytest.approx(ev.fitness, abs=1e-6) and m0["eval"][1] == pytest.approx(ev.inlier_rmse, rel=1e-5)
+
+
+def _worker_lonely(_index, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MI_ICP_MAIL_SPIN_LIMIT"] = "20000"          # ~50 ms instead of ~15 s
+    from cupoch_amd.engine import Engine, MiIcpError
+    torch.cuda.set_device(0)
+    d = make_pair(20000, seed=3, noise=0.02)
+    eng = Engine(0)
+    eng.set_target(d["tgt"], d["tgt_nrm"])
+    eng.set_source(d["src"])
+    eng.comm_init_local("lonely_%d" % os.getpid(), 2, 0)    # rank 1 never shows up
+    msgs = []
+    for call in (lambda: eng.registration_icp(PT2PL, d["max_dist"], None, 0.0, 0.0, 5, -1.0),
+                 lambda: eng.evaluate_registration(d["max_dist"], None)):
+        try:
+            call()
+            msgs.append("no error")
+        except MiIcpError as e:
+            msgs.append(str(e))
+    eng.comm_destroy()
+    # ... and the context is usable again on its own
+    res = eng.registration_icp(PT2PL, d["max_dist"], None, 0.0, 0.0, 5, -1.0)
+    msgs.append("alone: fitness %.3f" % res.fitness)
+    eng.close()
+    with open(os.path.join(out_dir, "lonely.txt"), "w") as f:
+        f.write("\n".join(msgs))
+
+
+def test_mailbox_exchange_times_out_instead_of_hanging(tmp_path):
+    """A peer that never posts: the kernels give up after the spin limit, the call fails with
+    MI_ICP_ERR_COMM (no hang, no garbage result), and the context works again once the communicator is gone."""
+    mp.spawn(_worker_lonely, args=(str(tmp_path),), nprocs=1, join=True)
+    lines = open(tmp_path / "lonely.txt").read().splitlines()
+    assert "timed out" in lines[0] and "timed out" in lines[1], lines
+    assert lines[2].startswith("alone: fitness") and float(lines[2].split()[-1]) > 0.9, lines
