@@ -202,6 +202,17 @@ __global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_eu(8, 8
                 ext = fmaxf(ext, mx - mn);
             }
             delta0 = (ext > 0.0f && ext < INFINITY) ? ext * a.link_delta : 0.0f;
+            // The region is kept within one node extent (4 * delta0 at the default) of the leaf's own box.
+            // On sheet-like data (depth frames) a leaf's kd cell is a prism that runs along the surface
+            // normal through the whole scene: nothing a query near the leaf's points gains from, but the
+            // list build had to walk every record such a prism cuts -- 0.52 ms for a 307k-point frame
+            // against 0.11 ms for as many uniform points.  A smaller region is always valid.
+            const float margin = delta0 * (1.0f / a.link_delta);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                reg[d] = fmaxf(reg[d], s.bb[d * kKdChunks + tid] - margin);
+                reg[3 + d] = fminf(reg[3 + d], s.bb[(3 + d) * kKdChunks + tid] + margin);
+            }
         }
         float4* out = reinterpret_cast<float4*>(a.lreg + ((size_t)g * kKdChunks + (size_t)tid) * kLeafRegFloats);
         out[0] = make_float4(reg[0], reg[1], reg[2], 0.0f);

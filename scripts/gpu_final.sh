@@ -18,6 +18,10 @@ timeout 600 python scripts/measure_latency.py 2>&1 | grep '^{' > $O/call_latency
 timeout 600 python scripts/measure_shard.py 2>&1 | grep '^{' > $O/shard_emulation.jsonl
 MI_ICP_SHARD_MAILBOX=1 timeout 600 python scripts/measure_shard.py 2>&1 | grep '^{' >> $O/shard_emulation.jsonl
 MI_ICP_FORCE_COMM=2 timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 20 2>&1 | grep '^{"metric' | tee $O/bench_10m_mailbox_1rank.json | python scripts/benchline.py
+timeout 600 python scripts/measure_colored.py 2>&1 | grep '^{' > $O/colored.jsonl
+timeout 600 python scripts/measure_kinfu.py 2>&1 | grep '^{' > $O/kinfu.jsonl
+timeout 600 python scripts/measure_odometry.py 2>&1 | grep '^{' > $O/odometry.jsonl
+timeout 600 python scripts/measure_links_payoff.py 2>&1 | grep '^{' > $O/links_payoff.jsonl; MI_ICP_NO_LINKS=1 timeout 600 python scripts/measure_links_payoff.py 2>&1 | grep '^{' >> $O/links_payoff.jsonl
 timeout 600 python scripts/measure_knn.py 1,0.0 8,0.0 30,0.0 30,0.01 64,0.0 100,0.0 100,0.02 2>&1 | grep '^{' > $O/knn_search.jsonl
 timeout 600 scripts/gpu_reduce_sweep.sh > $O/reduce_variants.txt 2>&1
 cd /tmp
