@@ -512,6 +512,7 @@ int drain_links(mi_icp_ctx* c) {
 }
 
 // ---- nearest-neighbour pass --------------------------------------------------
+constexpr int64_t kWaitForLinksMin = 2000000;  // sources below this do not wait for a list build in flight (loop_begin)
 // sources of at least this many points make their own seeds for a first pass (tuning knob MI_ICP_COARSE_MIN)
 static int64_t coarse_first_min() {
     static const int64_t v = [] { const char* s = std::getenv("MI_ICP_COARSE_MIN"); return s ? std::atoll(s) : (int64_t)1 << 16; }();
@@ -1503,8 +1504,16 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
     // it makes its own seeds (launch_nn: locate_leaves); otherwise it walks the tree from the root while
     // the lists are built next to it on the private stream.
     c->ran_loop = true;
-    if (c->links_ready || c->links_inflight) TRY(ensure_links(c));
-    else TRY(start_links_async(c));
+    if (c->links_inflight && hipEventQuery(c->ev_links) != hipSuccess && c->ns < kWaitForLinksMin) {
+        // Still being built, and the source is small: its walk from the root (tens of microseconds) costs less
+        // than waiting for the lists (a list build is ~0.1-0.2 ms of dependent fetches whatever the size);
+        // the first seeded pass waits for whatever is left of it then.
+        (void)hipGetLastError();
+    } else if (c->links_ready || c->links_inflight) {
+        TRY(ensure_links(c));
+    } else {
+        TRY(start_links_async(c));
+    }
     TRY(loop_enqueue_evaluation(c, false));
     // from here on the packets follow the target's order (pays for itself in ~4 iterations)
     static const bool no_resort = std::getenv("MI_ICP_NO_RESORT") != nullptr;  // A/B switch for tuning

@@ -164,6 +164,8 @@ def test_first_pass_from_its_own_seeds_equals_the_walk_from_the_root(kind):
             e.icp_begin(P2P, radius, None, -1.0)
         e.set_target(cuda(tgt))
         e.set_source(cuda(src))
+        torch.cuda.synchronize()      # (the lists, started by set_target on the warm context, are complete: a small
+        #                               source would not wait for a build still in flight and walk from the root)
         res = e.icp_begin(P2P, radius, init, -1.0)
         assert e.last_search_kind() == (2 if name == "warm" else 0)
         corr = e.get_correspondences()
