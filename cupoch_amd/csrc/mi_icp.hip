@@ -99,7 +99,7 @@ struct mi_icp_ctx {
     uint32_t* cell_total_host = nullptr;  // pinned
     bool inv_t_valid = false;
     bool links_ready = false, links_allowed = false;  // leaf_links.h
-    // the neighbour lists are built on a private stream, next to the loop's first (unseeded) pass
+    // the neighbour lists are built on a private stream, next to the staging of the source or the loop's first pass
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_links = nullptr;
     bool links_inflight = false;
@@ -450,8 +450,9 @@ void collect_pooled(mi_icp_ctx* c, int executed) {
 }
 
 // Every leaf's neighbour list (leaf_links.h): what lets a seeded query whose cube pokes out of its
-// leaf's region finish without a tree walk.  Built once per target, by the first search that can
-// use it (one-shot searches, k-NN and normal estimation never pay for it).
+// leaf's region finish without a tree walk.  Built once per target: right behind the tree on a context
+// that has registered before (mi_icp_set_target), otherwise by the first registration loop / seeded
+// search (one-shot searches, k-NN and normal estimation on a fresh context never pay for it).
 int build_links(mi_icp_ctx* c, hipStream_t st) {
     static const bool no_links = std::getenv("MI_ICP_NO_LINKS") != nullptr;  // A/B switch
     uint2* links;
@@ -487,8 +488,9 @@ int ensure_links(mi_icp_ctx* c) {
 }
 
 // Start the build on the private stream (behind everything enqueued on the context's stream so
-// far): the registration loop calls this before its first, unseeded pass, which does not read
-// the lists -- the two run side by side.
+// far).  Callers: mi_icp_set_target on a context that has registered before (the build then runs next
+// to the staging of the source) and the registration loop before a first pass from the root, which
+// does not read the lists -- the two run side by side.
 int start_links_async(mi_icp_ctx* c) {
     static const bool sync_links = std::getenv("MI_ICP_LINKS_SYNC") != nullptr;  // A/B switch
     if (c->nt <= 0 || c->links_ready || c->links_inflight || sync_links) return MI_ICP_OK;
@@ -1076,7 +1078,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
         KCHK(c);
         used = (used + 7u) / 8u;
     }
-    c->links_ready = false;  // the leaves' neighbour lists are built by the registration loop / the first seeded search
+    c->links_ready = false;  // (the leaves' neighbour lists: started below, or by the registration loop / the first seeded search)
     c->links_allowed = !no_cells && (uint32_t)nleaf <= kLinkIdMask;
     c->nt = n;
     c->nts = nts;
