@@ -1506,7 +1506,8 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
     // it makes its own seeds (launch_nn: locate_leaves); otherwise it walks the tree from the root while
     // the lists are built next to it on the private stream.
     c->ran_loop = true;
-    if (c->links_inflight && hipEventQuery(c->ev_links) != hipSuccess && c->ns < kWaitForLinksMin) {
+    static const bool always_wait = std::getenv("MI_ICP_WAIT_LINKS") != nullptr;  // A/B switch (soak tests of the own-seeds pass)
+    if (c->links_inflight && !always_wait && hipEventQuery(c->ev_links) != hipSuccess && c->ns < kWaitForLinksMin) {
         // Still being built, and the source is small: its walk from the root (tens of microseconds) costs less
         // than waiting for the lists (a list build is ~0.1-0.2 ms of dependent fetches whatever the size);
         // the first seeded pass waits for whatever is left of it then.

@@ -103,3 +103,20 @@ def test_registration_matches_oracle_on_random_configurations(eng, case):
     assert abs(res.inlier_rmse - o.inlier_rmse) <= 1e-3 * max(o.inlier_rmse, spacing)
     if est == 1:
         assert np.linalg.norm(Tg - o.transformation) <= 1e-4 * max(1.0, ext)
+
+
+@pytest.mark.skipif(os.environ.get("MI_ICP_WAIT_LINKS") is not None, reason="this IS the forced run")
+def test_the_same_cases_with_every_first_pass_from_its_own_seeds():
+    """The loops' first pass normally starts from the queries' own seeds only when the target's
+    neighbour lists are complete and the source is large (launch_nn / loop_begin); the library reads
+    its A/B switches once per process, so the forced variant -- always wait for the lists, own seeds at
+    every size down to one point -- runs this file and the loop-level parity tests in a child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MI_ICP_WAIT_LINKS="1", MI_ICP_COARSE_MIN="0")
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(here, "test_gpu_fuzz.py"),
+                          os.path.join(here, "test_gpu_seeded.py")], env=env, capture_output=True, text=True,
+                         timeout=900, cwd=os.path.dirname(here))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+    assert " passed" in out.stdout
