@@ -240,3 +240,37 @@ def test_estimate_normals_leaves_a_registration_in_flight_alone(eng):
     eng.set_target(np.zeros((0, 3), np.float32))
     eng.search_radius_1nn(1.0)
     assert len(eng.get_correspondences()) == 0
+
+
+def test_list_build_in_flight_survives_retargeting_knn_and_destroy():
+    """A context that has registered before starts the leaf neighbour lists on its private stream in
+    every mi_icp_set_target.  Whatever comes next while that build is in flight -- another target, a
+    k-NN search, normals, a registration on a tiny source that does not wait for it, destroying the
+    context -- must neither hang nor change results."""
+    import numpy as np
+    from cupoch_amd.engine import Engine
+    from conftest import make_pair
+    d = make_pair(300_000, seed=17, noise=0.02)
+    small = make_pair(5_000, seed=18, noise=0.02)
+    ref_eng = Engine(0)
+    ref_eng.set_target(d["tgt"], d["tgt_nrm"])
+    ref_eng.set_source(d["src"])
+    ref = ref_eng.registration_icp(2, d["max_dist"], None, 0.0, 0.0, 6, -1.0)       # fresh context: no head start
+    k_ref = ref_eng.search_knn(d["src"][:1000], 8)
+    ref_eng.close()
+    eng = Engine(0)
+    eng.set_target(small["tgt"], small["tgt_nrm"])
+    eng.set_source(small["src"])
+    eng.registration_icp(2, small["max_dist"], None, 0.0, 0.0, 3, -1.0)              # now the context "has registered"
+    for _ in range(3):
+        eng.set_target(d["tgt"], d["tgt_nrm"])                                       # lists start ...
+        eng.set_target(small["tgt"], small["tgt_nrm"])                               # ... and are dropped
+        eng.set_target(d["tgt"], d["tgt_nrm"])
+        k = eng.search_knn(d["src"][:1000], 8)                                       # k-NN next to the build
+        assert k[0] == k_ref[0] and np.array_equal(k[1], k_ref[1]) and np.array_equal(k[2], k_ref[2])
+        eng.set_source(d["src"])
+        got = eng.registration_icp(2, d["max_dist"], None, 0.0, 0.0, 6, -1.0)
+        assert np.array_equal(np.array(got.transformation), np.array(ref.transformation))
+        assert got.fitness == ref.fitness and got.inlier_rmse == ref.inlier_rmse
+    eng.set_target(d["tgt"], d["tgt_nrm"])
+    eng.close()                                                                      # destroyed with the build in flight
