@@ -15,6 +15,7 @@ for n in 100000 1000000 5000000 20000000; do timeout 600 python bench.py --point
 timeout 900 python scripts/measure_configs.py 2>&1 | grep '^{' > $O/configs.jsonl; tail -2 $O/configs.jsonl | cut -c1-200
 timeout 600 python scripts/measure_noisy.py 2>&1 | grep '^{' > $O/noisy.jsonl
 timeout 600 python scripts/measure_latency.py 2>&1 | grep '^{' > $O/call_latency.jsonl
+MI_ICP_LATENCY_HOST=1 timeout 600 python scripts/measure_latency.py 100000 1000000 10000000 2>&1 | grep '^{' > $O/call_latency_host_inputs.jsonl
 timeout 600 python scripts/measure_shard.py 2>&1 | grep '^{' > $O/shard_emulation.jsonl
 MI_ICP_SHARD_MAILBOX=1 timeout 600 python scripts/measure_shard.py 2>&1 | grep '^{' >> $O/shard_emulation.jsonl
 MI_ICP_FORCE_COMM=2 timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 20 2>&1 | grep '^{"metric' | tee $O/bench_10m_mailbox_1rank.json | python scripts/benchline.py

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end latency of one RegistrationICP call (tree build +
-source staging + 30 point-to-plane iterations + result), inputs resident on the device.
+source staging + 30 point-to-plane iterations + result), inputs resident on the device
+(or, with MI_ICP_LATENCY_HOST=1, handed over as HOST arrays: the PCIe-inclusive figure).
 The frame-to-frame case of section 8(f)-4 (KinFu / odometry callers: small clouds,
 launch latency dominates).  One JSON object per size."""
 import json
@@ -21,7 +22,10 @@ eng = Engine(0)
 sizes = [int(s) for s in sys.argv[1:]] or [20_000, 100_000, 307_200, 1_000_000, 10_000_000]
 for n in sizes:
     src, tgt, nrm, T_gt, max_dist = synth(n)
-    d_src, d_tgt, d_nrm = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda(), torch.from_numpy(nrm).cuda()
+    if os.environ.get("MI_ICP_LATENCY_HOST") == "1":
+        d_src, d_tgt, d_nrm = src, tgt, nrm          # numpy arrays: the library stages them (mem_kind = host)
+    else:
+        d_src, d_tgt, d_nrm = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda(), torch.from_numpy(nrm).cuda()
 
     def call():
         eng.set_target(d_tgt, d_nrm)
@@ -41,7 +45,8 @@ for n in sizes:
         rows.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
     rows = np.median(np.array(rows), axis=0) * 1e3
     T = np.array(res.transformation, np.float32).reshape(4, 4).T
-    print(json.dumps({"row": "RegistrationICP call, point-to-plane, 30 iterations", "n": n,
+    print(json.dumps({"row": "RegistrationICP call, point-to-plane, 30 iterations" +
+                             (", HOST inputs (PCIe-inclusive)" if os.environ.get("MI_ICP_LATENCY_HOST") == "1" else ""), "n": n,
                       "total_ms": round(rows[0], 3), "set_target_ms": round(rows[1], 3),
                       "set_source_ms": round(rows[2], 3), "icp_30_iterations_ms": round(rows[3], 3),
                       "iterations": res.iterations, "T_err": float(np.linalg.norm(T - T_gt))}), flush=True)
