@@ -18,6 +18,8 @@ from bench import synth                      # noqa: E402
 from cupoch_amd import _lib                  # noqa: E402
 from cupoch_amd.engine import Engine         # noqa: E402
 
+if os.environ.get("MI_ICP_GRAPH") or os.environ.get("MI_ICP_OWN_STREAM"):   # (graph capture needs a non-default stream)
+    torch.cuda.set_stream(torch.cuda.Stream())
 eng = Engine(0)
 sizes = [int(s) for s in sys.argv[1:]] or [20_000, 100_000, 307_200, 1_000_000, 10_000_000]
 for n in sizes:
