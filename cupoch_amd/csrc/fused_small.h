@@ -1,0 +1,111 @@
+// fused_small.h -- ONE launch per ICP iteration for small clouds (point-to-plane, single GPU).
+//
+// On a 10M-point cloud an iteration is two bandwidth-sized kernels; on a depth frame's 20k-300k points
+// (KinFu's PoseEstimation) it is two kernels of a few dependent memory round trips
+// each, and what the iteration costs is their fixed parts: two launches, two prologues (kernel arguments,
+// loop state, transform), the reduction re-reading what the search had in registers (source point, match),
+// the reduction's own finishing block.  Here the wave that searched a packet also forms its 64 rows of the
+// 6x6 system: it gathers the matches' 24-byte {point, normal} records, 30 of its lanes total the 64 rows
+// out of LDS (fp64), and the wave's sums go through the reduction's own finish (this block's row -> the
+// last block totals the rows in a fixed order and takes the loop's step, reduce.h / loop.h).  Four packets
+// per workgroup; no occupancy bound to respect (the search body's 63 registers plus 30 fp64 sums), which
+// is why this is a kernel of its own and not a mode of nn_packet_kernel.
+// Same per-element arithmetic as reduce_pt2pl_kernel (the transformed point is the search's own, bit for
+// bit); the summation order differs, so the sums agree to ~1e-15 relative, not bitwise.
+#pragma once
+#include "nn_search.h"
+#include "reduce.h"
+
+namespace mi {
+
+constexpr int kFusedPackets = kReduceThreads / 64;  // packets per workgroup
+
+__global__ __launch_bounds__(kReduceThreads) void icp_small_iteration_kernel(
+        const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int ns,
+        const float* __restrict__ records_g, const float* __restrict__ tblk_g, const float* __restrict__ lreg_g,
+        const uint2* __restrict__ links_g, uint32_t leaf_first, float r2, uint32_t npackets, uint32_t nblocks,
+        int32_t* __restrict__ nn_idx, const float* __restrict__ trec, DevLoop* __restrict__ loop,
+        double* __restrict__ partial, uint32_t* __restrict__ ticket, double* __restrict__ out32) {
+    __shared__ PacketShared s_pk[kFusedPackets];
+    if (loop->done) return;  // (every wave of every workgroup alike)
+    const int wid = (int)(threadIdx.x >> 6);
+    uint32_t logical;
+    const bool in_range = xcd_remap(nblocks, logical);
+    const uint32_t packet = logical * (uint32_t)kFusedPackets + (uint32_t)wid;
+    PacketResult r;
+    r.valid = false;
+    r.bidx = -1;
+    r.i = 0;
+    r.best = 0.0f;
+    r.qx = r.qy = r.qz = 0.0f;
+    if (in_range && packet < npackets) {
+        const Xform none = {};
+        (void)nn_packet_body<true, false>(s_pk[wid], packet, sx, sy, sz, ns, records_g, tblk_g, lreg_g, links_g, leaf_first,
+                                          none, loop, r2, nn_idx, nullptr, nullptr, r);
+    }
+    // ---- this lane's row of the system (reduce_pt2pl_kernel's arithmetic): J[6], residual, d2 into LDS
+    // ([component][lane], component stride 65 floats: the sums below read one column per lane group without
+    // bank conflicts)
+    __shared__ float s_rows[kFusedPackets][8 * 65];
+    __shared__ ReduceRows red;
+    const int lane = lane_id();
+    const bool have = r.valid && r.bidx >= 0;
+    const F3* rec = reinterpret_cast<const F3*>(trec + (int64_t)(have ? r.bidx : 0) * 6);
+    const F3 tp = rec[0], tn = rec[1];
+    float row[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (have) {
+        const float vs[3] = {r.qx, r.qy, r.qz};
+        const float nt[3] = {tn.x, tn.y, tn.z};
+        const float d[3] = {vs[0] - tp.x, vs[1] - tp.y, vs[2] - tp.z};
+        cross3(vs, nt, row);
+        row[3] = nt[0];
+        row[4] = nt[1];
+        row[5] = nt[2];
+        row[6] = dot3(d, nt);
+        row[7] = sq3(d[0], d[1], d[2]);
+    }
+    float* mine = s_rows[wid];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mine[e * 65 + lane] = row[e];
+    const uint64_t hm = __ballot(have);
+    __builtin_amdgcn_wave_barrier();
+    // Lane k < 30 totals sum k of the wave's 64 rows, in row order (fp64; the products are exact): the 21
+    // upper-triangle entries of JtJ, the 6 of Jtr, r^2, d^2, the count -- accum_row's numbering.  One pass of
+    // 64 rows for 30 lanes instead of 30 wave-wide reductions (which made a 300k-point iteration 40 % slower
+    // than the two-kernel form).
+    if (lane < kSysSize) {
+        int ca = 6, cb = 6;  // k = 27: r * r
+        if (lane < 21) {
+            int k = lane;
+            ca = 0;
+            while (k >= 6 - ca) {
+                k -= 6 - ca;
+                ++ca;
+            }
+            cb = ca + k;
+        } else if (lane < 27) {
+            ca = lane - 21;
+            cb = 6;
+        }
+        double sum = 0.0;
+        if (lane < 28) {
+            const float* A = mine + ca * 65;
+            const float* B = mine + cb * 65;
+            for (int t = 0; t < 64; ++t) sum = __builtin_fma((double)A[t], (double)B[t], sum);
+        } else if (lane == 28) {
+            const float* A = mine + 7 * 65;
+            for (int t = 0; t < 64; ++t) sum += (double)A[t];
+        } else if (lane == 29) {
+            sum = (double)__popcll(hm);
+        }
+        red[wid][lane] = sum;  // (lanes 30, 31: zero)
+    }
+    const bool last = block_finish_rows(red, partial, ticket, out32);
+    if (last) {
+        __syncthreads();  // out32 has been written by this block's first 32 threads
+        __shared__ DevLoop st_s;
+        loop_step_block(loop, out32, 0, st_s);
+    }
+}
+
+}  // namespace mi

@@ -30,6 +30,7 @@
 #include "../../include/mi_icp_debug.h"
 #include "device_utils.h"
 #include "depth_kernels.h"
+#include "fused_small.h"
 #include "geometry_kernels.h"
 #include "host_solver.h"
 #include "kd_build.h"
@@ -1439,9 +1440,47 @@ static int loop_pull(mi_icp_ctx* c) {  // device state -> pinned mirror, synchro
     return MI_ICP_OK;
 }
 
+// Small clouds, point-to-plane, one GPU: the whole evaluation -- seeded search, the system's rows, their
+// reduction, the step -- is ONE launch (fused_small.h).  Measured, 30-iteration calls: 20k points 0.79 ms
+// against 0.90 with two launches per iteration, 50k 0.92 / 1.02, 100k 1.02 / 1.09, 150k 1.17 / 1.11,
+// 307k 1.59 / 1.24 -- past ~120k points the per-packet totals (one set of 30 sums per 64 points instead of
+// one per 4096) cost more than the second launch; MI_ICP_FUSED_MAX moves the limit.
+constexpr int64_t kFusedMax = 112000;
+static bool fused_iteration_applies(const mi_icp_ctx* c, bool seed) {
+    static const bool off = std::getenv("MI_ICP_NO_FUSED_ITERATION") != nullptr;  // A/B switch
+    static const int64_t limit = [] { const char* e = std::getenv("MI_ICP_FUSED_MAX"); return e ? std::atoll(e) : kFusedMax; }();
+    return !off && seed && c->nn_valid && c->loop_est == kEstPt2Pl && estimator_ready(c, kEstPt2Pl) && c->t_has_rec &&
+           c->trec.p != nullptr && !c->comm && !c->mail_dev && c->n_user_pairs < 0 && c->ns > 0 && c->ns <= limit &&
+           c->nt > 0;
+}
+
+static int launch_fused_iteration(mi_icp_ctx* c, DevLoop* d) {
+    TRY(ensure_links(c));
+    const uint32_t npackets = (uint32_t)((c->ns + 63) / 64);
+    const uint32_t nblocks = (npackets + kFusedPackets - 1) / kFusedPackets;
+    const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
+    double *partial, *sys;
+    TRY(ensure(c, c->partial, (size_t)std::max<uint32_t>(kReduceBlocks, grid) * kSysSize, &partial));
+    TRY(ensure(c, c->sys_dev, kSysSize, &sys));
+    if (!c->ticket.p) {
+        uint32_t* ticket;
+        TRY(ensure(c, c->ticket, 64, &ticket));
+        HIPCHK(c, hipMemsetAsync(ticket, 0, 256, c->stream));
+    }
+    EvTimer t(c, 0, true);
+    icp_small_iteration_kernel<<<grid, kReduceThreads, 0, c->stream>>>(
+            (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns, (const float*)c->nodes.p,
+            (const float*)c->tblk.p, (const float*)c->tlreg.p, (const uint2*)c->tlinks.p, c->leaf_first, c->loop_r2, npackets,
+            nblocks, (int32_t*)c->nn_idx.p, (const float*)c->trec.p, d, partial, (uint32_t*)c->ticket.p, sys);
+    KCHK(c);
+    c->last_search_kind = 1;
+    return MI_ICP_OK;
+}
+
 // one evaluation: search under the loop's transform, reduction, all-reduce, step kernel
 static int loop_enqueue_evaluation(mi_icp_ctx* c, bool seed) {
     DevLoop* d = (DevLoop*)c->loop_dev.p;
+    if (fused_iteration_applies(c, seed)) return launch_fused_iteration(c, d);
     const Mat4 I = host::identity4();
     TRY(launch_nn(c, I, c->loop_r2, seed, nullptr, d));
     bool stepped = false;

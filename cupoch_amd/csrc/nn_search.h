@@ -93,20 +93,28 @@ __device__ __forceinline__ void drain_items(PacketShared& sh, const float* tblk_
     eval_item(sh, tblk_g, have, ql, L, ox, oy, oz, r2);
 }
 
-// `loop` != nullptr: the transform comes from the device-resident loop state and the
-// kernel is a no-op once that loop is done; otherwise Tv (by value) is used.
+// What a packet's search leaves in every lane (for callers that go on with it: fused_small.h)
+struct PacketResult {
+    bool valid;     // the lane holds a source point
+    int i;          // its position in the staged source
+    int32_t bidx;   // its match (sorted target slot) or -1
+    float best;     // squared distance to it
+    float qx, qy, qz;  // the transformed source point
+};
+
+// One packet = 64 consecutive source points, searched by one wave (`sh`: the wave's LDS, `packet`: its
+// index; wave-uniform).  `loop` != nullptr: the transform comes from the device-resident loop state and
+// nothing is done once that loop is finished (returns false, wave-uniformly); otherwise Tv (by value) is
+// used.  Stores the matches (and distances / statistics when asked) itself.
 template <bool SEED, bool STATS>
-__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_packet_kernel(
+__device__ __forceinline__ bool nn_packet_body(
+        PacketShared& sh, uint32_t packet,
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
         int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
-        const float* __restrict__ lreg_g, const uint2* __restrict__ links_g, uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, uint32_t nblocks, int32_t* __restrict__ nn_idx,
-        float* __restrict__ nn_d2, unsigned long long* __restrict__ stats) {
-    __shared__ PacketShared s_pk[kNNPacketsPerBlock];
-    uint32_t logical;
-    if (!xcd_remap(nblocks, logical)) return;
-    PacketShared& sh = s_pk[threadIdx.x >> 6];
+        const float* __restrict__ lreg_g, const uint2* __restrict__ links_g, uint32_t leaf_first, const Xform& Tv, const DevLoop* __restrict__ loop, float r2, int32_t* __restrict__ nn_idx,
+        float* __restrict__ nn_d2, unsigned long long* __restrict__ stats, PacketResult& out) {
     const int lane = lane_id();
-    const int i = (int)((logical * (uint32_t)kNNPacketsPerBlock + (threadIdx.x >> 6)) * 64u) + lane;  // (ns < 2^31)
+    const int i = (int)(packet * 64u) + lane;  // (ns < 2^31)
     const bool valid = i < ns;
     // Everything this lane needs from global memory that does not depend on anything else is
     // requested FIRST, branch-free (lanes past the end re-read element 0), so that these loads,
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     const float rx = sx[ic], ry = sy[ic], rz = sz[ic];
     Xform T = Tv;
     if (loop) {
-        if (loop->done) return;
+        if (loop->done) return false;
         T = loop->X;
     }
     if (!valid) seed_j = -1;
@@ -345,6 +353,30 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
         atomicAdd(stats + 2, 1ull);
         atomicMax(stats + 3, (unsigned long long)steps + (unsigned long long)batches);  // slowest packet
     }
+    out.valid = valid;
+    out.i = i;
+    out.bidx = bidx;
+    out.best = best;
+    out.qx = qx;
+    out.qy = qy;
+    out.qz = qz;
+    return true;
+}
+
+// The search as a kernel of its own: one packet per workgroup (the dispatcher refills wave slots one at a
+// time: 3 % faster than 4 packets per workgroup), 8 waves per SIMD.
+template <bool SEED, bool STATS>
+__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_packet_kernel(
+        const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+        int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
+        const float* __restrict__ lreg_g, const uint2* __restrict__ links_g, uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, uint32_t nblocks, int32_t* __restrict__ nn_idx,
+        float* __restrict__ nn_d2, unsigned long long* __restrict__ stats) {
+    __shared__ PacketShared s_pk[kNNPacketsPerBlock];
+    uint32_t logical;
+    if (!xcd_remap(nblocks, logical)) return;
+    PacketResult unused;
+    (void)nn_packet_body<SEED, STATS>(s_pk[0], logical, sx, sy, sz, ns, records_g, tblk_g, lreg_g, links_g, leaf_first, Tv, loop,
+                                      r2, nn_idx, nn_d2, stats, unused);
 }
 
 // ---------------------------------------------------------------------------

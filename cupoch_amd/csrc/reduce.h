@@ -87,20 +87,13 @@ struct ReduceArgs {
 // release -> ticket -> acquire) totals the rows in a fixed order into out32, so the result is
 // bitwise reproducible; the ticket is the only atomic.
 // Returns true (to every thread of the block) in the block that wrote out32.
-__device__ __forceinline__ bool block_finish(const double* acc, double* __restrict__ partial,
-                                             uint32_t* __restrict__ ticket, double* __restrict__ out32) {
-    __shared__ double red[kReduceThreads / 32][kSysSize];
+typedef double ReduceRows[kReduceThreads / 32][kSysSize];
+
+// ... from the point where red[w][k] (w < 4 waves, k < 32) holds every wave's sums (written, not yet
+// behind a barrier)
+__device__ __forceinline__ bool block_finish_rows(ReduceRows& red, double* __restrict__ partial,
+                                                  uint32_t* __restrict__ ticket, double* __restrict__ out32) {
     __shared__ uint32_t s_last;
-    const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
-#pragma unroll
-    for (int k = 0; k < 30; ++k) {
-        const double v = wave_sum(acc[k]);
-        if (lane == kWaveSumLane) red[wid][k] = v;
-    }
-    if (lane == kWaveSumLane) {
-        red[wid][30] = 0.0;
-        red[wid][31] = 0.0;
-    }
     __syncthreads();
     if (threadIdx.x < kSysSize) {
         const int k = (int)threadIdx.x;
@@ -155,6 +148,22 @@ __device__ __forceinline__ bool block_finish(const double* acc, double* __restri
         if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return true;
+}
+
+__device__ __forceinline__ bool block_finish(const double* acc, double* __restrict__ partial,
+                                             uint32_t* __restrict__ ticket, double* __restrict__ out32) {
+    __shared__ ReduceRows red;
+    const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
+#pragma unroll
+    for (int k = 0; k < 30; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == kWaveSumLane) red[wid][k] = v;
+    }
+    if (lane == kWaveSumLane) {
+        red[wid][30] = 0.0;
+        red[wid][31] = 0.0;
+    }
+    return block_finish_rows(red, partial, ticket, out32);
 }
 
 // MODE 0: accumulate the linear system; MODE 1: accumulate only the
