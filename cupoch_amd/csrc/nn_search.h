@@ -111,7 +111,7 @@ __device__ __forceinline__ bool nn_packet_body(
         PacketShared& sh, uint32_t packet,
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
         int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
-        const float* __restrict__ lreg_g, const uint2* __restrict__ links_g, uint32_t leaf_first, const Xform& Tv, const DevLoop* __restrict__ loop, float r2, int32_t* __restrict__ nn_idx,
+        const float* __restrict__ lreg_g, const uint2* __restrict__ links_g, uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, int32_t* __restrict__ nn_idx,
         float* __restrict__ nn_d2, unsigned long long* __restrict__ stats, PacketResult& out) {
     const int lane = lane_id();
     const int i = (int)(packet * 64u) + lane;  // (ns < 2^31)
