@@ -3,6 +3,8 @@ return exactly what an unseeded search and the oracle return, after the transfor
 lot or by an ulp, on uniform / clustered / surface data, before and after the loop's
 match-order re-sort of the source.  Bit-exact d2; an index may differ only on an exact tie.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -183,3 +185,43 @@ def test_first_pass_from_its_own_seeds_equals_the_walk_from_the_root(kind):
             assert np.array_equal(alt, od[ne, 0]), name
     assert np.array_equal(got["fresh"][0], got["warm"][0])
     assert got["fresh"][1] == got["warm"][1] and got["fresh"][2] == pytest.approx(got["warm"][2], rel=1e-6)
+
+
+def _run_small_loop(path):
+    """(child process) a 40k-point point-to-plane registration, results to `path`"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from cupoch_amd.engine import Engine
+    from conftest import make_pair
+    d = make_pair(40_000, seed=77, noise=0.05)
+    e = Engine(0)
+    e.set_target(d["tgt"], d["tgt_nrm"])
+    e.set_source(d["src"])
+    res = e.registration_icp(PT2PL, d["max_dist"], None, 1e-6, 1e-6, 25, -1.0)
+    corr = e.get_correspondences()
+    np.savez(path, T=np.array(res.transformation, np.float32), stat=np.array([res.fitness, res.inlier_rmse, res.iterations]),
+             corr=corr)
+    e.close()
+
+
+def test_one_launch_iteration_equals_the_two_kernel_form(tmp_path):
+    """Sources of up to ~110k points run search + system rows + reduction + step as ONE kernel per
+    iteration (fused_small.h).  Same loop with MI_ICP_NO_FUSED_ITERATION=1 in a child process (the switch
+    is read once per process): same iteration count, same correspondence set, transformation and statistics
+    equal to the rounding of the sums' order."""
+    import subprocess
+    import sys
+    here = os.path.abspath(__file__)
+    outs = {}
+    for name, extra in (("fused", {}), ("split", {"MI_ICP_NO_FUSED_ITERATION": "1"})):
+        path = str(tmp_path / (name + ".npz"))
+        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_seeded as t; t._run_small_loop(%r)"
+                % (os.path.dirname(here), os.path.dirname(os.path.dirname(here)), path))
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(path)
+    a, b = outs["fused"], outs["split"]
+    assert int(a["stat"][2]) == int(b["stat"][2])
+    assert np.linalg.norm(a["T"] - b["T"]) <= 1e-6
+    assert a["stat"][0] == pytest.approx(b["stat"][0], abs=1e-7) and a["stat"][1] == pytest.approx(b["stat"][1], rel=1e-5)
+    assert np.array_equal(a["corr"], b["corr"])
