@@ -100,11 +100,11 @@ __global__ __launch_bounds__(kReduceThreads) void icp_small_iteration_kernel(
         }
         red[wid][lane] = sum;  // (lanes 30, 31: zero)
     }
-    const bool last = block_finish_rows(red, partial, ticket, out32);
+    StepPre pre{true, loop_state_word(loop), 0.0};
+    const bool last = block_finish_rows(red, partial, ticket, out32, &pre.sum);
     if (last) {
-        __syncthreads();  // out32 has been written by this block's first 32 threads
         __shared__ DevLoop st_s;
-        loop_step_block(loop, out32, 0, st_s);
+        loop_step_block(loop, out32, 0, st_s, pre);
     }
 }
 

@@ -4,15 +4,17 @@
 // device pass (correspondences + reduction) with a tiny host step (6x6 solve, compose
 // T, convergence test).  At 10M points the host round trip is 5 % of an iteration; with
 // the source sharded over 8 GPUs it would be a third.  Here the tiny step runs on the
-// device too (`loop_step_kernel`, one thread, the same __host__ __device__ solver code
-// as the one-shot C ABI entry points), the current transform lives in device memory,
+// device too (`loop_step_kernel`: one workgroup; the same __host__ __device__ solver code
+// as the one-shot C ABI entry points, or wave_solver.h's bit-identical wave-wide form of it), the current transform lives in device memory,
 // and the search / reduction kernels read it from there.  The host only ENQUEUES
 // iterations; once the loop has converged the remaining enqueued kernels see
 // `done != 0` and return immediately.
 #pragma once
+#include <cstddef>
 #include "device_utils.h"
 #include "host_solver.h"
 #include "mailbox.h"
+#include "wave_solver.h"
 
 namespace mi {
 
@@ -74,28 +76,77 @@ __host__ __device__ inline void stats_from_system(const double* sys, int64_t n_s
     *rmse = sqrtf((float)sys[28] / (float)count);
 }
 
+// element i of a register-held array (compile-time indexing only)
+__device__ __forceinline__ float select16(const float* m, int i) {
+    float v = m[0];
+#pragma unroll
+    for (int t = 1; t < 16; ++t) v = (i == t) ? m[t] : v;
+    return v;
+}
+
+constexpr int kStepThreads = 192;  // the least a block that steps may have: three waves with a role each
+
+// What a block that is about to step may already hold in registers: word threadIdx.x of the loop state
+// (read at any point of the same kernel -- nothing else writes the state while it runs) and, for its first
+// 32 threads, this evaluation's sums.  Saves the step two dependent trips to L2.
+struct StepPre {
+    bool have;
+    uint32_t word;
+    double sum;
+};
+
+__device__ __forceinline__ uint32_t loop_state_word(const DevLoop* st_g) {
+    constexpr int kWords = (int)(sizeof(DevLoop) / 4);
+    return (threadIdx.x < (unsigned)kWords) ? reinterpret_cast<const uint32_t*>(st_g)[threadIdx.x] : 0u;
+}
+
+
 // Runs after every evaluation (search + reduction [+ all-reduce]) of the loop:
 // statistics, the convergence test of registration.cu:165-170 against the previous
 // evaluation, and -- unless finished -- the next update (registration.cu:157-160).
 // resume > 0 instead re-opens a finished loop for `resume` more updates (stepping API):
 // no statistics / test, just the update from the system of the last evaluation.
-// One workgroup (any size >= 32): the state is staged through LDS -- one coalesced read, one thread
-// of scalar work at LDS latency, one coalesced write (a thread poking at global memory field by
-// field took 13 us; this takes ~3).  sys_in may have been written by this very block just before
-// (behind a __syncthreads()), or by an earlier kernel.
-__device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys_in, int resume, DevLoop& st_s) {
+// One workgroup of >= kStepThreads threads.  The state is staged through LDS (one coalesced read, one
+// coalesced write; a thread poking at global memory field by field took 13 us), and what used to be one
+// thread's ~2000 dependent instructions (3.6-4.2 us: two 6x6 eliminations, two 4x4 products) is spread
+// over three waves and their lanes:
+//   wave 0  the update: LDL^T solve with a matrix row per lane (wave_solver.h; the estimators that end in
+//           SolveJacobianSystemAndObtainExtrinsicMatrix -- the serial routines remain for the others),
+//           then, behind the barrier, update * T and update * A with an output element per lane;
+//   wave 1  the determinant check of the same system (partial-pivot LU, a row per lane);
+//   wave 2  statistics and the convergence test.
+// sys_in may have been written by this very block just before (behind a __syncthreads()), or by an
+// earlier kernel.
+__device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys_in, int resume, DevLoop& st_s,
+                                                const StepPre pre = StepPre{false, 0u, 0.0}) {
     constexpr int kWords = (int)(sizeof(DevLoop) / 4);
-    static_assert(sizeof(DevLoop) % 4 == 0, "DevLoop is copied word by word");
-    const int nth = (int)blockDim.x;
+    constexpr int kSysWord0 = (int)(offsetof(DevLoop, sys) / 4);
+    static_assert(sizeof(DevLoop) % 4 == 0 && kWords <= kStepThreads, "DevLoop is copied a word per thread");
+    static_assert(kSysWord0 + 64 == kWords, "sys closes the state");
+    const int tid = (int)threadIdx.x, wid = tid >> 6, lane = tid & 63;
     uint32_t* dst = reinterpret_cast<uint32_t*>(&st_s);
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(st_g);
-    for (int i = (int)threadIdx.x; i < kWords; i += nth) dst[i] = src[i];
+    // the state's words and -- over its sys field, unless resuming -- this evaluation's sums: one round of loads
+    if (tid < ((resume <= 0) ? kSysWord0 : kWords)) dst[tid] = pre.have ? pre.word : reinterpret_cast<const uint32_t*>(st_g)[tid];
+    if (tid < 32 && resume <= 0) st_s.sys[tid] = pre.have ? pre.sum : sys_in[tid];
     __syncthreads();
     if (resume <= 0 && st_s.done) return;  // uniform: every thread reads the same flag
-    if (threadIdx.x < 32 && resume <= 0) st_s.sys[threadIdx.x] = sys_in[threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        DevLoop* st = &st_s;
+    __shared__ host::Mat4 s_update;
+    __shared__ int s_det_ok, s_update_now;
+    DevLoop* st = &st_s;
+    const int est = st->est;
+    const bool wave_case = (est == 2 || est == 4 || est == 5) && st->ready != 0 && st->sys[29] > 0.0;
+    if (wid == 0) {
+        if (wave_case) {
+            const host::Mat4 U = wave_solve_update(st->sys);
+            if (lane < 16) s_update.m[lane] = select16(U.m, lane);
+        } else if (lane == 0) {
+            s_update = solve_update(est, st->ready != 0, st->sys, st->det_thresh, st->n_source_global);
+        }
+    } else if (wid == 1) {
+        // est 5: no det check (generalized_icp.cu:180)
+        const bool ok = !(wave_case && est != 5 && st->det_thresh > 0.0f) || wave_det_passes(st->sys, st->det_thresh);
+        if (lane == 0) s_det_ok = ok ? 1 : 0;
+    } else if (wid == 2 && lane == 0) {
         bool update_now = true;
         if (resume > 0) {
             st->max_iterations = st->iterations + resume;
@@ -116,21 +167,32 @@ __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys
                 update_now = false;
             }
         }
-        if (update_now) {
+        s_update_now = update_now ? 1 : 0;
+    }
+    __syncthreads();
+    if (wid == 0 && s_update_now) {
+        // host::mul4(update, T) and (update, A): lane = 16 * matrix + 4 * column + row; a failed determinant
+        // check leaves the identity as the update (solve_system)
+        const int r = lane & 3, c = (lane >> 2) & 3;
+        const host::Mat4& B = (lane & 16) ? st->A : st->T;
+        const bool ok = s_det_ok != 0;
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sum += (ok ? host::at(s_update, r, k) : ((r == k) ? 1.0f : 0.0f)) * host::at(B, k, c);
+        __builtin_amdgcn_wave_barrier();  // all of T, A read before any of it is written
+        if (lane < 16) st->T.m[lane] = sum;
+        else if (lane < 32) st->A.m[lane - 16] = sum;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 12) reinterpret_cast<float*>(&st->X)[lane] = host::at(st->A, lane >> 2, lane & 3);
+        if (lane == 0) {
             st->prev_fitness = st->fitness;
             st->prev_rmse = st->rmse;
             st->have_prev = 1;
-            const host::Mat4 update =
-                    solve_update(st->est, st->ready != 0, st->sys, st->det_thresh, st->n_source_global);
-            st->T = host::mul4(update, st->T);
-            st->A = host::mul4(update, st->A);
-            st->X = xform_from(st->A);
             st->iterations += 1;
         }
     }
     __syncthreads();
-    uint32_t* out = reinterpret_cast<uint32_t*>(st_g);
-    for (int i = (int)threadIdx.x; i < kWords; i += nth) out[i] = dst[i];
+    if (tid < kWords) reinterpret_cast<uint32_t*>(st_g)[tid] = dst[tid];
 }
 
 // The ranks' exchange (mailbox.h) in front of the step, for a block that already holds this rank's
@@ -143,7 +205,7 @@ __device__ __forceinline__ void loop_exchange(DevLoop* st_g, const MailArgs& mai
     __syncthreads();
 }
 
-__global__ __launch_bounds__(64) void loop_step_kernel(DevLoop* st_g, double* sys_in, int resume, MailArgs mail) {
+__global__ __launch_bounds__(kStepThreads) void loop_step_kernel(DevLoop* st_g, double* sys_in, int resume, MailArgs mail) {
     __shared__ DevLoop st_s;
     if (resume <= 0) loop_exchange(st_g, mail, sys_in);
     loop_step_block(st_g, sys_in, resume, st_s);

@@ -863,6 +863,26 @@ int check_ctx(mi_icp_ctx* c) {
 // ============================================================================
 // C ABI
 // ============================================================================
+// mi_icp_debug_solve_both: the step's serial and wave-wide solves on the same systems
+namespace mi {
+__global__ __launch_bounds__(64) void solve_both_kernel(const double* systems, float det_thresh, float* out_serial,
+                                                        float* out_wave, int32_t* ok_serial, int32_t* ok_wave) {
+    __shared__ double s_sys[32];
+    const int n = (int)blockIdx.x;
+    if (threadIdx.x < 32) s_sys[threadIdx.x] = systems[(int64_t)n * 32 + threadIdx.x];
+    __syncthreads();
+    host::Mat4 W;
+    const bool okw = wave_solve_system(s_sys, det_thresh, W);
+    if (threadIdx.x < 16) out_wave[(int64_t)n * 16 + threadIdx.x] = select16(W.m, (int)threadIdx.x);
+    if (threadIdx.x == 0) {
+        ok_wave[n] = okw ? 1 : 0;
+        host::Mat4 S;
+        ok_serial[n] = host::solve_system(s_sys, det_thresh, S) ? 1 : 0;
+        for (int e = 0; e < 16; ++e) out_serial[(int64_t)n * 16 + e] = S.m[e];
+    }
+}
+}  // namespace mi
+
 extern "C" {
 
 const char* mi_icp_version(void) { return "mi_icp 0.1 (gfx950)"; }
@@ -1489,7 +1509,7 @@ static int loop_enqueue_evaluation(mi_icp_ctx* c, bool seed) {
     const bool mail = c->mail_dev != nullptr;
     if (!mail) TRY(allreduce_system(c));  // (with a mailbox the step kernel starts with the exchange)
     const MailArgs no_mail = {nullptr, nullptr, 0, 1, 0u};
-    loop_step_kernel<<<1, 64, 0, c->stream>>>(d, (double*)c->sys_dev.p, 0, mail ? mail_args(c) : no_mail);
+    loop_step_kernel<<<1, kStepThreads, 0, c->stream>>>(d, (double*)c->sys_dev.p, 0, mail ? mail_args(c) : no_mail);
     KCHK(c);
     return MI_ICP_OK;
 }
@@ -1586,7 +1606,7 @@ int mi_icp_icp_iterate(mi_icp_ctx* c, int n_iterations, mi_icp_result* out) {
         // re-open the loop for n more updates: the update for the next iteration is formed
         // from the system of the last evaluation (resume = step without stats/test)
         DevLoop* d = (DevLoop*)c->loop_dev.p;
-        loop_step_kernel<<<1, 64, 0, c->stream>>>(d, (double*)c->sys_dev.p, n_iterations, MailArgs{nullptr, nullptr, 0, 1, 0u});
+        loop_step_kernel<<<1, kStepThreads, 0, c->stream>>>(d, (double*)c->sys_dev.p, n_iterations, MailArgs{nullptr, nullptr, 0, 1, 0u});
         KCHK(c);
         TRY(loop_run(c, n_iterations));
     }
@@ -2528,6 +2548,32 @@ int mi_icp_debug_get_leaf_links(mi_icp_ctx* c, uint32_t* links_out) {
 }
 
 int mi_icp_debug_last_search_kind(const mi_icp_ctx* c) { return c ? c->last_search_kind : -1; }
+
+int mi_icp_debug_solve_both(int device, const double* systems, int n, float det_thresh, float* out_serial,
+                            float* out_wave, int32_t* ok_serial, int32_t* ok_wave) {
+    if (!systems || n <= 0 || !out_serial || !out_wave || !ok_serial || !ok_wave) return MI_ICP_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return MI_ICP_ERR_NO_DEVICE;
+    double* d_sys = nullptr;
+    float* d_out = nullptr;
+    int32_t* d_ok = nullptr;
+    int rc = MI_ICP_ERR_HIP;
+    if (hipMalloc(&d_sys, (size_t)n * 32 * sizeof(double)) == hipSuccess &&
+        hipMalloc(&d_out, (size_t)n * 32 * sizeof(float)) == hipSuccess &&
+        hipMalloc(&d_ok, (size_t)n * 2 * sizeof(int32_t)) == hipSuccess &&
+        hipMemcpy(d_sys, systems, (size_t)n * 32 * sizeof(double), hipMemcpyHostToDevice) == hipSuccess) {
+        mi::solve_both_kernel<<<n, 64>>>(d_sys, det_thresh, d_out, d_out + (size_t)n * 16, d_ok, d_ok + n);
+        if (hipDeviceSynchronize() == hipSuccess &&
+            hipMemcpy(out_serial, d_out, (size_t)n * 16 * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(out_wave, d_out + (size_t)n * 16, (size_t)n * 16 * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(ok_serial, d_ok, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(ok_wave, d_ok + n, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess)
+            rc = MI_ICP_OK;
+    }
+    (void)hipFree(d_sys);
+    (void)hipFree(d_out);
+    (void)hipFree(d_ok);
+    return rc;
+}
 
 int mi_icp_debug_drop_seeds(mi_icp_ctx* c) {
     TRY(check_ctx(c));

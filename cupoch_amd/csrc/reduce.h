@@ -92,7 +92,8 @@ typedef double ReduceRows[kReduceThreads / 32][kSysSize];
 // ... from the point where red[w][k] (w < 4 waves, k < 32) holds every wave's sums (written, not yet
 // behind a barrier)
 __device__ __forceinline__ bool block_finish_rows(ReduceRows& red, double* __restrict__ partial,
-                                                  uint32_t* __restrict__ ticket, double* __restrict__ out32) {
+                                                  uint32_t* __restrict__ ticket, double* __restrict__ out32,
+                                                  double* own = nullptr) {
     __shared__ uint32_t s_last;
     __syncthreads();
     if (threadIdx.x < kSysSize) {
@@ -144,6 +145,7 @@ __device__ __forceinline__ bool block_finish_rows(ReduceRows& red, double* __res
 #pragma unroll
             for (int p = 0; p < kParts; ++p) t += red[p][k];
             out32[k] = t;
+            if (own) *own = t;  // (the finishing block's first 32 threads keep their total: loop.h StepPre)
         }
         if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -151,7 +153,8 @@ __device__ __forceinline__ bool block_finish_rows(ReduceRows& red, double* __res
 }
 
 __device__ __forceinline__ bool block_finish(const double* acc, double* __restrict__ partial,
-                                             uint32_t* __restrict__ ticket, double* __restrict__ out32) {
+                                             uint32_t* __restrict__ ticket, double* __restrict__ out32,
+                                             double* own = nullptr) {
     __shared__ ReduceRows red;
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
 #pragma unroll
@@ -163,7 +166,7 @@ __device__ __forceinline__ bool block_finish(const double* acc, double* __restri
         red[wid][30] = 0.0;
         red[wid][31] = 0.0;
     }
-    return block_finish_rows(red, partial, ticket, out32);
+    return block_finish_rows(red, partial, ticket, out32, own);
 }
 
 // MODE 0: accumulate the linear system; MODE 1: accumulate only the
@@ -459,12 +462,16 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_pt2pl_kernel(ReduceArgs
             accum_row(acc, J, r);
         }
     }
-    const bool last = block_finish(acc, partial, ticket, out32);
+    // (every block reads its word of the loop state while it waits on the finish's barriers anyway; the
+    // exchange of STEP == 2 rewrites the sums and may flag the state: it steps from memory)
+    StepPre pre{STEP == 1, 0u, 0.0};
+    if (STEP == 1) pre.word = loop_state_word(loop);
+    const bool last = block_finish(acc, partial, ticket, out32, &pre.sum);
     if (STEP && last) {
         __syncthreads();  // out32 has been written by this block's first 32 threads
         __shared__ DevLoop st_s;
         if (STEP == 2) loop_exchange(loop, mail, out32);
-        loop_step_block(loop, out32, 0, st_s);
+        loop_step_block(loop, out32, 0, st_s, pre);
     }
 }
 

@@ -35,6 +35,13 @@ MI_ICP_API int mi_icp_debug_drop_seeds(mi_icp_ctx* ctx);
  * loop's first pass does when the target's neighbour lists were built ahead, mi_icp_set_target on a
  * context that has registered before), -1 = no pass yet. */
 MI_ICP_API int mi_icp_debug_last_search_kind(const mi_icp_ctx* ctx);
+/* The loop step's two forms of utility::SolveJacobianSystemAndObtainExtrinsicMatrix side by side, on the
+ * device: n systems of 32 doubles each (host memory; the reduction's layout: 21 upper-triangle sums of
+ * JtJ, 6 of Jtr, ...) are solved by one thread with the serial routines and by a wave with a matrix row
+ * per lane.  out_serial / out_wave: n * 16 floats (column-major 4x4); ok_serial / ok_wave: n flags
+ * (0 = the determinant check failed, result identity).  The two must agree bit for bit. */
+MI_ICP_API int mi_icp_debug_solve_both(int device, const double* systems, int n, float det_thresh,
+                                       float* out_serial, float* out_wave, int32_t* ok_serial, int32_t* ok_wave);
 /* The target's tree as built by mi_icp_set_target, for invariant tests.  info5 = {slots
  * (padded sorted positions), leaves, leaf_first (id of the first leaf-level node), records,
  * points}.  records_out (records * 64 floats: 8 child boxes as 4 sibling pairs of 12,
