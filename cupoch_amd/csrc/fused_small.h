@@ -100,8 +100,8 @@ __global__ __launch_bounds__(kReduceThreads) void icp_small_iteration_kernel(
         }
         red[wid][lane] = sum;  // (lanes 30, 31: zero)
     }
-    StepPre pre{true, loop_state_word(loop), 0.0};
-    const bool last = block_finish_rows(red, partial, ticket, out32, &pre.sum);
+    StepPre pre{true, 0u, 0.0};
+    const bool last = block_finish_rows(red, partial, ticket, out32, &pre, loop);
     if (last) {
         __shared__ DevLoop st_s;
         loop_step_block(loop, out32, 0, st_s, pre);

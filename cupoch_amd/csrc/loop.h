@@ -87,8 +87,9 @@ __device__ __forceinline__ float select16(const float* m, int i) {
 constexpr int kStepThreads = 192;  // the least a block that steps may have: three waves with a role each
 
 // What a block that is about to step may already hold in registers: word threadIdx.x of the loop state
-// (read at any point of the same kernel -- nothing else writes the state while it runs) and, for its first
-// 32 threads, this evaluation's sums.  Saves the step two dependent trips to L2.
+// (nothing else writes the state while the kernel runs; reduce.h's finishing block asks for it together
+// with the rows it totals) and, for its first 32 threads, this evaluation's sums.  Saves the step two
+// dependent trips to L2.
 struct StepPre {
     bool have;
     uint32_t word;

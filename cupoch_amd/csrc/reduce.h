@@ -93,29 +93,34 @@ typedef double ReduceRows[kReduceThreads / 32][kSysSize];
 // behind a barrier)
 __device__ __forceinline__ bool block_finish_rows(ReduceRows& red, double* __restrict__ partial,
                                                   uint32_t* __restrict__ ticket, double* __restrict__ out32,
-                                                  double* own = nullptr) {
+                                                  StepPre* pre = nullptr, const DevLoop* pre_state = nullptr) {
     __shared__ uint32_t s_last;
     __syncthreads();
-    if (threadIdx.x < kSysSize) {
-        const int k = (int)threadIdx.x;
-        // ---- hand-off to the finishing block (cdna_hip_programming.md section 6, Guideline 16; MI355X_MICROARCH.md,
-        // "publish" rows): the row is stored WRITE-THROUGH (agent-scope relaxed atomic store = global_store ... sc1),
-        // drained with vmcnt(0), and only then is the ticket taken.  The first version used plain stores +
-        // fence(release, "agent"): that fence is a buffer_wbl2 -- a write-back of the whole XCD's L2 per block,
-        // and those serialise: ~50 ns per block of the grid, 50 us of a 115-us launch with 1024 blocks.
-        __hip_atomic_store(&partial[(int64_t)blockIdx.x * kSysSize + k],
-                           ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == gridDim.x - 1u) ? 1u : 0u;
+    if (threadIdx.x < 64) {  // the rows' 32 threads and the ticket's are one wave: no barrier between store and ticket
+        if (threadIdx.x < kSysSize) {
+            const int k = (int)threadIdx.x;
+            // ---- hand-off to the finishing block (cdna_hip_programming.md section 6, Guideline 16; MI355X_MICROARCH.md,
+            // "publish" rows): the row is stored WRITE-THROUGH (agent-scope relaxed atomic store = global_store ... sc1),
+            // drained with vmcnt(0), and only then is the ticket taken.  The first version used plain stores +
+            // fence(release, "agent"): that fence is a buffer_wbl2 -- a write-back of the whole XCD's L2 per block,
+            // and those serialise: ~50 ns per block of the grid, 50 us of a 115-us launch with 1024 blocks.
+            __hip_atomic_store(&partial[(int64_t)blockIdx.x * kSysSize + k],
+                               ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = t == gridDim.x - 1u;
+            if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // before any wave of this block reads a row
+            s_last = last ? 1u : 0u;
+        }
     }
     __syncthreads();
     if (!s_last) return false;
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
+    // The finishing block goes on to step the loop: its word of the loop state travels with the rows.  (Read by
+    // EVERY block ahead of the ticket it was 512 blocks asking one L2 channel for the same eight lines just as the
+    // grid drains: +1.2 us on the 10M reduction.)
+    if (pre && pre_state) pre->word = loop_state_word(pre_state);
     {   // fixed-order total of the per-block partials (independent of which block finishes)
         const int k = (int)(threadIdx.x & 31u), part = (int)(threadIdx.x >> 5);
         constexpr int kParts = kReduceThreads / 32;
@@ -133,7 +138,18 @@ __device__ __forceinline__ bool block_finish_rows(ReduceRows& red, double* __res
 #pragma unroll
             for (int u = 0; u < kU; ++u) acc16[u] += pk[(int64_t)(b + u * kParts) * kSysSize];
         }
-        for (; b < nb; b += kParts) acc16[0] += pk[(int64_t)b * kSysSize];
+        // A grid that is not a multiple of 16 x 8 rows ends in a partly filled round: rows past the end
+        // re-read row 0 and add nothing -- one more round trip, not one per leftover row (a 306-block grid,
+        // an eighth of the 10M bench, used to spend 6 dependent misses here, a 489-block one 13: 2.3 us of a
+        // 2M-point iteration).  Kept out of the full rounds: there the index arithmetic costs 0.5-1 us.
+        if (b < nb) {
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int bb = b + u * kParts;
+                const double v = pk[(int64_t)(bb < nb ? bb : 0) * kSysSize];
+                acc16[u] += (bb < nb) ? v : 0.0;
+            }
+        }
 #pragma unroll
         for (int w = kU / 2; w > 0; w >>= 1)
 #pragma unroll
@@ -145,7 +161,7 @@ __device__ __forceinline__ bool block_finish_rows(ReduceRows& red, double* __res
 #pragma unroll
             for (int p = 0; p < kParts; ++p) t += red[p][k];
             out32[k] = t;
-            if (own) *own = t;  // (the finishing block's first 32 threads keep their total: loop.h StepPre)
+            if (pre) pre->sum = t;  // (the finishing block's first 32 threads keep their total: loop.h StepPre)
         }
         if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -154,7 +170,7 @@ __device__ __forceinline__ bool block_finish_rows(ReduceRows& red, double* __res
 
 __device__ __forceinline__ bool block_finish(const double* acc, double* __restrict__ partial,
                                              uint32_t* __restrict__ ticket, double* __restrict__ out32,
-                                             double* own = nullptr) {
+                                             StepPre* pre = nullptr, const DevLoop* pre_state = nullptr) {
     __shared__ ReduceRows red;
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
 #pragma unroll
@@ -166,7 +182,7 @@ __device__ __forceinline__ bool block_finish(const double* acc, double* __restri
         red[wid][30] = 0.0;
         red[wid][31] = 0.0;
     }
-    return block_finish_rows(red, partial, ticket, out32, own);
+    return block_finish_rows(red, partial, ticket, out32, pre, pre_state);
 }
 
 // MODE 0: accumulate the linear system; MODE 1: accumulate only the
@@ -462,13 +478,11 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_pt2pl_kernel(ReduceArgs
             accum_row(acc, J, r);
         }
     }
-    // (every block reads its word of the loop state while it waits on the finish's barriers anyway; the
-    // exchange of STEP == 2 rewrites the sums and may flag the state: it steps from memory)
+    // (the exchange of STEP == 2 rewrites the sums and may flag the state: it steps from memory)
     StepPre pre{STEP == 1, 0u, 0.0};
-    if (STEP == 1) pre.word = loop_state_word(loop);
-    const bool last = block_finish(acc, partial, ticket, out32, &pre.sum);
+    const bool last = block_finish(acc, partial, ticket, out32, &pre, (STEP == 1) ? loop : nullptr);
     if (STEP && last) {
-        __syncthreads();  // out32 has been written by this block's first 32 threads
+        if (STEP == 2) __syncthreads();  // out32 has been written by this block's first 32 threads
         __shared__ DevLoop st_s;
         if (STEP == 2) loop_exchange(loop, mail, out32);
         loop_step_block(loop, out32, 0, st_s, pre);
