@@ -1461,11 +1461,11 @@ static int loop_pull(mi_icp_ctx* c) {  // device state -> pinned mirror, synchro
 }
 
 // Small clouds, point-to-plane, one GPU: the whole evaluation -- seeded search, the system's rows, their
-// reduction, the step -- is ONE launch (fused_small.h).  Measured, 30-iteration calls: 20k points 0.79 ms
-// against 0.90 with two launches per iteration, 50k 0.92 / 1.02, 100k 1.02 / 1.09, 150k 1.17 / 1.11,
-// 307k 1.59 / 1.24 -- past ~120k points the per-packet totals (one set of 30 sums per 64 points instead of
+// reduction, the step -- is ONE launch (fused_small.h).  Measured, the loop of a 30-iteration call, one launch /
+// two launches per iteration: 20k points 0.47 / 0.55 ms, 80k 0.61, 112k 0.70, 150k 0.78 / 0.81, 200k 0.89 / 0.84,
+// 307k 1.18 / 0.91 -- past ~170k points the per-packet totals (one set of 30 sums per 64 points instead of
 // one per 4096) cost more than the second launch; MI_ICP_FUSED_MAX moves the limit.
-constexpr int64_t kFusedMax = 112000;
+constexpr int64_t kFusedMax = 170000;
 static bool fused_iteration_applies(const mi_icp_ctx* c, bool seed) {
     static const bool off = std::getenv("MI_ICP_NO_FUSED_ITERATION") != nullptr;  // A/B switch
     static const int64_t limit = [] { const char* e = std::getenv("MI_ICP_FUSED_MAX"); return e ? std::atoll(e) : kFusedMax; }();
