@@ -11,12 +11,16 @@
 //
 // The box lives in POSIX shared memory (one node), registered with HIP by every rank
 // (hipHostRegister): host memory is coherent for all GPUs at system scope, needs no peer mapping and no
-// IPC handles.  A post is {32 sums, then -- behind a system-scope release -- the sequence number};
-// slots alternate with the sequence number's parity, so a rank that is already one exchange ahead
-// cannot overwrite what a slower rank still has to read (to get two ahead it needs everybody's post
-// of the exchange in between).  Sequence numbers count a rank's exchanges since the box was made and
-// never repeat; every rank performs the same exchanges (the loop's control flow depends only on the
-// all-reduced sums, which are identical everywhere).
+// IPC handles.  A post is 64 eight-byte words, each one SELF-VALIDATING: {exchange number << 32 | half of
+// a sum's bits}.  An aligned 8-byte store lands whole, so a reader that finds this exchange's number in
+// every word of a rank's post has that rank's sums -- no flag behind a release, no fence, and ONE read
+// round trip over the link per poll for all ranks at once (the first version -- sums, system-scope
+// release, flag; readers: poll the flags, acquire, then read the sums rank after rank -- took three
+// dependent trips plus one per rank).  Slots alternate with the exchange number's parity, so a rank that
+// is already one exchange ahead cannot overwrite what a slower rank still has to read (to get two ahead
+// it needs everybody's post of the exchange in between).  Exchange numbers count a rank's exchanges since
+// the box was made and never repeat (a word's zeroed state is no exchange's); every rank performs the same
+// exchanges (the loop's control flow depends only on the all-reduced sums, which are identical everywhere).
 // A rank that does not hear from a peer within ~10 s gives up: the loop is marked failed and the host
 // call returns MI_ICP_ERR_COMM (bench.py then falls back to the RCCL path).
 #pragma once
@@ -31,8 +35,7 @@ struct MailBox {
     uint32_t ready;                      // set by rank 0 once the box is zeroed
     uint32_t nranks;
     uint32_t pad_[14];
-    uint32_t seq[2][kMailRanks][16];     // one 64-byte line per flag
-    unsigned long long sums[2][kMailRanks][32];  // doubles, as bits
+    unsigned long long words[2][kMailRanks][64];  // [slot][rank]: exchange << 32 | low / high half of sum k's bits at 2k / 2k + 1
 };
 
 struct MailArgs {
@@ -42,11 +45,13 @@ struct MailArgs {
     uint32_t spin_limit;
 };
 
-// One workgroup of >= 32 threads.  sys: this rank's 32 sums (global or LDS, written before a barrier);
-// on return (all threads past a barrier) it holds the ranks' totals.  s_tmp: two LDS words.
-// False: a peer did not post in time.
+// One workgroup of whole waves (>= 64 threads).  sys: this rank's 32 sums (global or LDS, written before a
+// barrier); on return (all threads past a barrier) it holds the ranks' totals, added in rank order.
+// s_tmp: two LDS words.  False: a peer did not post in time.
 __device__ __forceinline__ bool mail_allreduce(const MailArgs& m, double* sys, uint32_t* s_tmp) {
-    if (threadIdx.x == 0) {
+    __shared__ unsigned long long s_words[kMailRanks][64];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = (int)(blockDim.x >> 6);
+    if (tid == 0) {
         const uint32_t s = *m.seq_dev + 1u;
         *m.seq_dev = s;
         s_tmp[0] = s;
@@ -55,31 +60,49 @@ __device__ __forceinline__ bool mail_allreduce(const MailArgs& m, double* sys, u
     __syncthreads();
     const uint32_t seq = s_tmp[0];
     const int slot = (int)(seq & 1u);
-    if (threadIdx.x < 32)
-        __hip_atomic_store(&m.box->sums[slot][m.rank][threadIdx.x], (unsigned long long)__double_as_longlong(sys[threadIdx.x]),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&m.box->seq[slot][m.rank][0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if ((int)threadIdx.x < m.nranks) {  // thread r waits for rank r
+    const unsigned long long tag = (unsigned long long)seq << 32;
+    if (tid < 64) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(sys[tid >> 1]);
+        const unsigned long long half = (tid & 1) ? (bits >> 32) : (bits & 0xffffffffull);
+        __hip_atomic_store(&m.box->words[slot][m.rank][tid], tag | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // wave w waits for the ranks w, w + nw, ... -- up to four at a time, their loads in flight together
+    constexpr int kAtOnce = 4;
+    for (int r0 = wid; r0 < m.nranks; r0 += nw * kAtOnce) {
+        unsigned long long w[kAtOnce];
         uint32_t spins = 0u;
-        // (relaxed polls -- host memory is not cached on the GPU side -- and one acquire fence behind the barrier)
-        while (__hip_atomic_load(&m.box->seq[slot][threadIdx.x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+        while (true) {
+#pragma unroll
+            for (int j = 0; j < kAtOnce; ++j) {
+                const int r = r0 + j * nw;
+                w[j] = tag;  // (no such rank: valid as it stands)
+                if (r < m.nranks)
+                    w[j] = __hip_atomic_load(&m.box->words[slot][r][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            bool stale = false;
+#pragma unroll
+            for (int j = 0; j < kAtOnce; ++j) stale = stale || (uint32_t)(w[j] >> 32) != seq;
+            if (__ballot(stale) == 0ull) break;
             if (++spins > m.spin_limit) {
-                s_tmp[1] = 0u;
+                if (lane == 0) s_tmp[1] = 0u;
                 break;
             }
             __builtin_amdgcn_s_sleep(16);
         }
+#pragma unroll
+        for (int j = 0; j < kAtOnce; ++j) {
+            const int r = r0 + j * nw;
+            if (r < m.nranks) s_words[r][lane] = w[j];
+        }
     }
     __syncthreads();
-    __threadfence_system();
-    if (threadIdx.x < 32) {
+    if (tid < 32) {
         double s = 0.0;
-        for (int r = 0; r < m.nranks; ++r)
-            s += __longlong_as_double((long long)__hip_atomic_load(&m.box->sums[slot][r][threadIdx.x], __ATOMIC_RELAXED,
-                                                                   __HIP_MEMORY_SCOPE_SYSTEM));
-        sys[threadIdx.x] = s;
+        for (int r = 0; r < m.nranks; ++r) {
+            const unsigned long long lo = s_words[r][2 * tid] & 0xffffffffull, hi = s_words[r][2 * tid + 1] & 0xffffffffull;
+            s += __longlong_as_double((long long)((hi << 32) | lo));
+        }
+        sys[tid] = s;
     }
     __syncthreads();
     return s_tmp[1] != 0u;
