@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kReduceThreads) void icp_small_iteration_kernel(
         }
         red[wid][lane] = sum;  // (lanes 30, 31: zero)
     }
-    StepPre pre{true, 0u, 0.0};
+    StepPre pre{true, 0u, 0.0, 0u};
     const bool last = block_finish_rows(red, partial, ticket, out32, &pre, loop);
     if (last) {
         __shared__ DevLoop st_s;

@@ -94,6 +94,7 @@ struct StepPre {
     bool have;
     uint32_t word;
     double sum;
+    uint32_t mail_seq;  // (with a mailbox) this rank's exchange counter
 };
 
 __device__ __forceinline__ uint32_t loop_state_word(const DevLoop* st_g) {
@@ -118,8 +119,13 @@ __device__ __forceinline__ uint32_t loop_state_word(const DevLoop* st_g) {
 //   wave 2  statistics and the convergence test.
 // sys_in may have been written by this very block just before (behind a __syncthreads()), or by an
 // earlier kernel.
+// mail.box != nullptr (N ranks, one node): the ranks' exchange (mailbox.h) sits between the staging and the
+// step and works on the staged sums in LDS -- this rank's sums in, every rank's total out; a finished loop
+// exchanges nothing (on every rank alike: the flag derives from the all-reduced sums), a failed exchange
+// finishes the loop with its error flag set.
 __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys_in, int resume, DevLoop& st_s,
-                                                const StepPre pre = StepPre{false, 0u, 0.0}) {
+                                                const StepPre pre = StepPre{false, 0u, 0.0, 0u},
+                                                const MailArgs mail = MailArgs{nullptr, nullptr, 0, 1, 0u}) {
     constexpr int kWords = (int)(sizeof(DevLoop) / 4);
     constexpr int kSysWord0 = (int)(offsetof(DevLoop, sys) / 4);
     static_assert(sizeof(DevLoop) % 4 == 0 && kWords <= kStepThreads, "DevLoop is copied a word per thread");
@@ -131,6 +137,12 @@ __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys
     if (tid < 32 && resume <= 0) st_s.sys[tid] = pre.have ? pre.sum : sys_in[tid];
     __syncthreads();
     if (resume <= 0 && st_s.done) return;  // uniform: every thread reads the same flag
+    if (mail.box != nullptr && resume <= 0) {
+        __shared__ uint32_t s_mail[2];
+        const bool ok = mail_allreduce(mail, st_s.sys, s_mail, pre.have ? &pre.mail_seq : nullptr);
+        if (!ok && tid == 0) st_s.error = 1;
+        __syncthreads();
+    }
     __shared__ host::Mat4 s_update;
     __shared__ int s_det_ok, s_update_now;
     DevLoop* st = &st_s;
@@ -196,20 +208,9 @@ __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys
     if (tid < kWords) reinterpret_cast<uint32_t*>(st_g)[tid] = dst[tid];
 }
 
-// The ranks' exchange (mailbox.h) in front of the step, for a block that already holds this rank's
-// sums in sys (global memory, written before a barrier or by an earlier kernel).  A finished loop
-// exchanges nothing -- on every rank alike, the flag derives from the all-reduced sums.
-__device__ __forceinline__ void loop_exchange(DevLoop* st_g, const MailArgs& mail, double* sys) {
-    __shared__ uint32_t s_mail[2];
-    if (mail.box == nullptr || st_g->done) return;  // (uniform)
-    if (!mail_allreduce(mail, sys, s_mail) && threadIdx.x == 0) st_g->error = 1;
-    __syncthreads();
-}
-
 __global__ __launch_bounds__(kStepThreads) void loop_step_kernel(DevLoop* st_g, double* sys_in, int resume, MailArgs mail) {
     __shared__ DevLoop st_s;
-    if (resume <= 0) loop_exchange(st_g, mail, sys_in);
-    loop_step_block(st_g, sys_in, resume, st_s);
+    loop_step_block(st_g, sys_in, resume, st_s, StepPre{false, 0u, 0.0, 0u}, mail);
 }
 
 }  // namespace mi

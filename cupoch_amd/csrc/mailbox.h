@@ -48,11 +48,13 @@ struct MailArgs {
 // One workgroup of whole waves (>= 64 threads).  sys: this rank's 32 sums (global or LDS, written before a
 // barrier); on return (all threads past a barrier) it holds the ranks' totals, added in rank order.
 // s_tmp: two LDS words.  False: a peer did not post in time.
-__device__ __forceinline__ bool mail_allreduce(const MailArgs& m, double* sys, uint32_t* s_tmp) {
+// pre_seq: the value of *m.seq_dev, if the caller has read it already (saves the exchange a trip to L2).
+__device__ __forceinline__ bool mail_allreduce(const MailArgs& m, double* sys, uint32_t* s_tmp,
+                                               const uint32_t* pre_seq = nullptr) {
     __shared__ unsigned long long s_words[kMailRanks][64];
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = (int)(blockDim.x >> 6);
     if (tid == 0) {
-        const uint32_t s = *m.seq_dev + 1u;
+        const uint32_t s = (pre_seq ? *pre_seq : *m.seq_dev) + 1u;
         *m.seq_dev = s;
         s_tmp[0] = s;
         s_tmp[1] = 1u;

@@ -93,7 +93,8 @@ typedef double ReduceRows[kReduceThreads / 32][kSysSize];
 // behind a barrier)
 __device__ __forceinline__ bool block_finish_rows(ReduceRows& red, double* __restrict__ partial,
                                                   uint32_t* __restrict__ ticket, double* __restrict__ out32,
-                                                  StepPre* pre = nullptr, const DevLoop* pre_state = nullptr) {
+                                                  StepPre* pre = nullptr, const DevLoop* pre_state = nullptr,
+                                                  const uint32_t* pre_mail_seq = nullptr) {
     __shared__ uint32_t s_last;
     __syncthreads();
     if (threadIdx.x < 64) {  // the rows' 32 threads and the ticket's are one wave: no barrier between store and ticket
@@ -121,6 +122,7 @@ __device__ __forceinline__ bool block_finish_rows(ReduceRows& red, double* __res
     // EVERY block ahead of the ticket it was 512 blocks asking one L2 channel for the same eight lines just as the
     // grid drains: +1.2 us on the 10M reduction.)
     if (pre && pre_state) pre->word = loop_state_word(pre_state);
+    if (pre && pre_mail_seq) pre->mail_seq = *pre_mail_seq;
     {   // fixed-order total of the per-block partials (independent of which block finishes)
         const int k = (int)(threadIdx.x & 31u), part = (int)(threadIdx.x >> 5);
         constexpr int kParts = kReduceThreads / 32;
@@ -170,7 +172,8 @@ __device__ __forceinline__ bool block_finish_rows(ReduceRows& red, double* __res
 
 __device__ __forceinline__ bool block_finish(const double* acc, double* __restrict__ partial,
                                              uint32_t* __restrict__ ticket, double* __restrict__ out32,
-                                             StepPre* pre = nullptr, const DevLoop* pre_state = nullptr) {
+                                             StepPre* pre = nullptr, const DevLoop* pre_state = nullptr,
+                                             const uint32_t* pre_mail_seq = nullptr) {
     __shared__ ReduceRows red;
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
 #pragma unroll
@@ -182,7 +185,7 @@ __device__ __forceinline__ bool block_finish(const double* acc, double* __restri
         red[wid][30] = 0.0;
         red[wid][31] = 0.0;
     }
-    return block_finish_rows(red, partial, ticket, out32, pre, pre_state);
+    return block_finish_rows(red, partial, ticket, out32, pre, pre_state, pre_mail_seq);
 }
 
 // MODE 0: accumulate the linear system; MODE 1: accumulate only the
@@ -478,14 +481,14 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_pt2pl_kernel(ReduceArgs
             accum_row(acc, J, r);
         }
     }
-    // (the exchange of STEP == 2 rewrites the sums and may flag the state: it steps from memory)
-    StepPre pre{STEP == 1, 0u, 0.0};
-    const bool last = block_finish(acc, partial, ticket, out32, &pre, (STEP == 1) ? loop : nullptr);
+    // (the finishing block keeps its word of the loop state, its totals and -- STEP == 2 -- the exchange counter in
+    // registers: loop.h StepPre)
+    StepPre pre{STEP != 0, 0u, 0.0, 0u};
+    const bool last = block_finish(acc, partial, ticket, out32, &pre, STEP ? loop : nullptr,
+                                   (STEP == 2) ? mail.seq_dev : nullptr);
     if (STEP && last) {
-        if (STEP == 2) __syncthreads();  // out32 has been written by this block's first 32 threads
         __shared__ DevLoop st_s;
-        if (STEP == 2) loop_exchange(loop, mail, out32);
-        loop_step_block(loop, out32, 0, st_s, pre);
+        loop_step_block(loop, out32, 0, st_s, pre, (STEP == 2) ? mail : MailArgs{nullptr, nullptr, 0, 1, 0u});
     }
 }
 

@@ -23,3 +23,7 @@ timeout 600 python scripts/measure_odometry.py 2>&1 | grep '^{' > $O/odometry.js
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_stats -o r02 -- python $R/bench.py --no-cpu-baseline --no-secondary > $R/$O/rocprof_stats.log 2>&1; echo "stats rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_cold -o r02cold -- python $R/scripts/measure_latency.py 10000000 > $R/$O/rocprof_cold.log 2>&1; echo "cold stats rc=$?"
+cd $R
+# rehearsal of the N > 1 bench path on this one GPU (every rank on cuda:0; gloo for torch's own collectives)
+for n in 2 4; do MI_ICP_BENCH_ONE_DEVICE=1 timeout 280 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2951$n bench.py --gpus $n --steps 20 --warmup 5 2>&1 | grep '^{"metric'; done > $O/bench_rehearsal_one_device.jsonl
+python scripts/benchline.py < $O/bench_rehearsal_one_device.jsonl
