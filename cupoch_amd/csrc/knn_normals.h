@@ -377,7 +377,6 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
             off = off * 8 + 1;
         }
         const uint32_t own = (id - leaf_first) * 8u;          // first leaf under the node reached
-        const uint32_t par = ((id & ~7u) - leaf_first) * 8u;  // first leaf under its parent
         const uint32_t nleaf_u = (uint32_t)nleaf;
         // leaf lb + s of every lane that takes part, s = 0..7
         auto offer_leaves = [&](uint32_t lb, bool take) {
