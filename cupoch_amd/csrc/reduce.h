@@ -25,7 +25,7 @@ namespace mi {
 constexpr int kEstP2P = 1, kEstPt2Pl = 2, kEstSym = 3, kEstColored = 4, kEstGICP = 5;
 constexpr int kSysSize = 32;
 constexpr int kReduceThreads = 256;
-constexpr int kReduceBlocks = 1024;  // 4 per CU (measured: 512 blocks is 25% slower); finished by one 1024-thread block
+constexpr int kReduceBlocks = 1024;  // the generic reduction's grid limit (4 per CU); the last block to arrive totals the rows (block_finish_rows)
 
 // R * C * R^T for a column-major 3x3 read from memory (geometry_utils.cu:257-265)
 __device__ __forceinline__ void rotate_cov(const Xform& T, const float* C, M3& out) {
