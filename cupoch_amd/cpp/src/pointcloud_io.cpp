@@ -58,6 +58,7 @@ std::vector<std::string> Split(const std::string& line) {
 // one scalar of a binary record as float: (type, size) in PCD's letters
 float Scalar(const unsigned char* p, char type, int size, bool swap = false) {
     unsigned char b[8];
+    if (size < 1 || size > 8) return 0.0f;   // (headers are checked against this as well: ValidScalar)
     std::memcpy(b, p, (size_t)size);
     if (swap) std::reverse(b, b + size);
     switch (type) {
@@ -78,6 +79,26 @@ float Scalar(const unsigned char* p, char type, int size, bool swap = false) {
     }
     return 0.0f;
 }
+
+// the (type, size) pairs a record may hold: everything else is rejected with the header
+bool ValidScalar(char type, int size) {
+    if (type == 'I' || type == 'U') return size == 1 || size == 2 || size == 4;
+    if (type == 'F') return size == 4 || size == 8;
+    return false;
+}
+
+// bytes left in a stream from the current position (-1: not seekable)
+long long BytesLeft(std::istream& in) {
+    const std::streampos here = in.tellg();
+    if (here == std::streampos(-1)) return -1;
+    in.seekg(0, std::ios::end);
+    const std::streampos end = in.tellg();
+    in.seekg(here);
+    if (end == std::streampos(-1) || !in) return -1;
+    return (long long)(end - here);
+}
+
+constexpr long long kMaxPoints = 0x7fffff00ll;   // what the engine takes (mi_icp_set_source / set_target)
 
 // ---------------------------------------------------------------------------- PCD
 struct PcdField {
@@ -131,17 +152,21 @@ bool ReadPcdHeader(std::istream& in, PcdHeader& h) {
         }
     }
     if (!got_data || h.fields.empty()) return false;
+    if (h.width < 0 || h.height < 0 || h.width > kMaxPoints || h.height > kMaxPoints) return false;
     if (h.points < 0) h.points = h.width * h.height;
-    int off = 0, el = 0;
+    if (h.points > kMaxPoints) return false;
+    long long off = 0, el = 0;
     for (auto& f : h.fields) {
-        if (f.size <= 0 || f.count <= 0) return false;
-        f.offset = off;
-        f.element = el;
-        off += f.size * f.count;
+        // untrusted input: a size the record decoder has no case for would overrun its 8-byte buffer
+        if (!ValidScalar(f.type, f.size) || f.count <= 0 || f.count > 4096) return false;
+        f.offset = (int)off;
+        f.element = (int)el;
+        off += (long long)f.size * f.count;
         el += f.count;
+        if (off > (1 << 20)) return false;
     }
-    h.record = off;
-    h.elements = el;
+    h.record = (int)off;
+    h.elements = (int)el;
     return h.points > 0 && h.record > 0 && h.find("x") && h.find("y") && h.find("z");
 }
 
@@ -156,6 +181,13 @@ bool ReadPcdData(std::istream& in, const PcdHeader& h, HostCloud& out) {
     const PcdField* fc = h.find("rgb") ? h.find("rgb") : h.find("rgba");
     const bool has_n = nx && ny && nz;
     const size_t n = (size_t)h.points;
+    // the point count of the header against what the file can hold (before anything is allocated for it)
+    const long long left = BytesLeft(in);
+    if (left >= 0) {
+        if (h.mode == 1 && (unsigned long long)left < (unsigned long long)n * (unsigned long long)h.record) return false;
+        if (h.mode == 0 && (unsigned long long)left < (unsigned long long)n * 2ull * (unsigned long long)h.elements - 1ull) return false;   // "v " per value
+        if (h.mode == 2 && left < 8) return false;
+    }
     out.points.resize(n);
     if (has_n) out.normals.resize(n);
     if (fc) out.colors.resize(n);
@@ -206,6 +238,7 @@ bool ReadPcdData(std::istream& in, const PcdHeader& h, HostCloud& out) {
     in.read((char*)&csize, 4);
     in.read((char*)&usize, 4);
     if (!in || usize != (uint64_t)n * (uint64_t)h.record) return false;
+    if (left >= 0 && (long long)csize > left - 8) return false;
     std::vector<unsigned char> comp(csize);
     in.read((char*)comp.data(), csize);
     if ((uint32_t)in.gcount() != csize) return false;
@@ -273,6 +306,7 @@ bool ReadPly(const std::string& filename, HostCloud& out) {
             PlyElement e;
             e.name = st[1];
             e.count = std::atol(st[2].c_str());
+            if (e.count < 0 || (e.name == "vertex" && e.count > kMaxPoints)) return false;
             elements.push_back(e);
         } else if (st[0] == "property" && !elements.empty()) {
             PlyProp p;
@@ -305,6 +339,8 @@ bool ReadPly(const std::string& filename, HostCloud& out) {
         const bool has_n = vertex && ix[3] >= 0 && ix[4] >= 0 && ix[5] >= 0;
         const bool has_c = vertex && ix[6] >= 0 && ix[7] >= 0 && ix[8] >= 0;
         if (vertex) {
+            const long long left = BytesLeft(in);   // at least a byte per property and vertex must follow
+            if (left >= 0 && (unsigned long long)left < (unsigned long long)e.count * (unsigned long long)std::max<size_t>(e.props.size(), 1)) return false;
             out.points.resize((size_t)e.count);
             if (has_n) out.normals.resize((size_t)e.count);
             if (has_c) out.colors.resize((size_t)e.count);
@@ -333,7 +369,7 @@ bool ReadPly(const std::string& filename, HostCloud& out) {
                         if (!cs || !in.read((char*)b, cs)) return false;
                         const long items = (long)Scalar(b, letter, cs, swap);
                         const int is = PlyTypeSize(e.props[p].list_item, nullptr);
-                        if (!is) return false;
+                        if (!is || items < 0) return false;
                         in.seekg((std::streamoff)items * is, std::ios::cur);
                         continue;
                     }
@@ -373,7 +409,20 @@ void RemoveNonFinite(HostCloud& h, bool remove_nan, bool remove_inf) {   // poin
     if (hc) h.colors.resize(k);
 }
 
+bool ReadHostUnguarded(const std::string& filename, const std::string& ext, HostCloud& h);
+
+// (a header may promise more than memory holds: the readers return false, they do not throw)
 bool ReadHost(const std::string& filename, const std::string& ext, HostCloud& h) {
+    try {
+        return ReadHostUnguarded(filename, ext, h);
+    } catch (const std::exception& e) {
+        LogWarning((std::string("Read geometry::PointCloud failed: ") + e.what()).c_str());
+        h = HostCloud();
+        return false;
+    }
+}
+
+bool ReadHostUnguarded(const std::string& filename, const std::string& ext, HostCloud& h) {
     if (ext == "pcd") {
         std::ifstream in(filename, std::ios::binary);
         if (!in) {
@@ -505,17 +554,22 @@ bool WritePointCloudToPCD(const std::string& filename, const geometry::PointClou
             }
             if (hc) at(i, e) = PackColor(h.colors[i]);
         }
-        const uint32_t bytes = (uint32_t)(buf.size() * sizeof(float));
+        const size_t bytes = buf.size() * sizeof(float);
         if (!compressed) {
             ok = std::fwrite(buf.data(), 1, bytes, f) == bytes;
+        } else if (bytes > 0xffffffffull) {
+            // the format's two size words are 32 bits wide
+            LogWarning("[WritePCDData] binary_compressed cannot hold more than 4 GiB of data.");
+            ok = false;
         } else {
-            std::vector<unsigned char> comp((size_t)bytes * 2 + 16);
-            const uint32_t csize = (uint32_t)mi_icp_lzf_compress(buf.data(), bytes, comp.data(), (int64_t)comp.size());
-            if (csize == 0) {
+            std::vector<unsigned char> comp(bytes * 2 + 16);
+            const int64_t clen = mi_icp_lzf_compress(buf.data(), (int64_t)bytes, comp.data(), (int64_t)comp.size());
+            const uint32_t csize = (uint32_t)clen, usize = (uint32_t)bytes;
+            if (clen <= 0 || clen > 0xffffffffll) {
                 LogWarning("[WritePCDData] Failed to compress data.");
                 ok = false;
             } else {
-                ok = std::fwrite(&csize, 4, 1, f) == 1 && std::fwrite(&bytes, 4, 1, f) == 1 &&
+                ok = std::fwrite(&csize, 4, 1, f) == 1 && std::fwrite(&usize, 4, 1, f) == 1 &&
                      std::fwrite(comp.data(), 1, csize, f) == csize;
             }
         }

@@ -30,7 +30,8 @@ struct GroupBuildArgs {
     float* tcov;              // [ngroups * 4096 * 9] or null
     float* records;
     float* lreg;              // [ngroups * 512][8] leaf regions (below)
-    float link_delta;         // start bound of the neighbour lists as a fraction of the leaf-level node's extent
+    float link_delta;         // bound of the halos (leaf_halo.h) as a fraction of the leaf-level node's extent
+    float region_margin;      // a leaf's region is kept within this many bounds of its own box
 };
 
 // LEAF REGIONS.  Every leaf (8 slots) also gets its kd cell -- the box that is free of points
@@ -186,12 +187,12 @@ __global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_eu(8, 8
                     }
             }
         }
-        // float 7: the bound the neighbour-list build starts from (leaf_links.h) -- a.link_delta (a
-        // quarter) of the leaf-level node's largest extent, i.e. about one point spacing on volumetric data
+        // float 7: the bound of the leaf's halo (leaf_halo.h) -- a.link_delta (a quarter) of the leaf-level node's
+        // size, i.e. about one point spacing on volumetric data
         float delta0 = 0.0f;
         if (own_flag) {
             const int n0 = tid & ~7;
-            float ext = 0.0f;
+            float ext = 0.0f, vol = 1.0f;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 float mn = INFINITY, mx = -INFINITY;
@@ -200,14 +201,20 @@ __global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_eu(8, 8
                     mx = fmaxf(mx, s.bb[(3 + d) * kKdChunks + n0 + c]);
                 }
                 ext = fmaxf(ext, mx - mn);
+                vol *= mx - mn;
             }
-            delta0 = (ext > 0.0f && ext < INFINITY) ? ext * a.link_delta : 0.0f;
-            // The region is kept within one node extent (4 * delta0 at the default) of the leaf's own box.
-            // On sheet-like data (depth frames) a leaf's kd cell is a prism that runs along the surface
-            // normal through the whole scene: nothing a query near the leaf's points gains from, but the
-            // list build had to walk every record such a prism cuts -- 0.52 ms for a 307k-point frame
-            // against 0.11 ms for as many uniform points.  A smaller region is always valid.
-            const float margin = delta0 * (1.0f / a.link_delta);
+            // (the node's largest extent varies with its aspect ratio -- 3 to 5.4 spacings on uniform data --, the
+            // cube root of its volume does not; half the largest extent takes over on sheets and lines)
+            const float scale = fmaxf(1.1f * cbrtf(fmaxf(vol, 0.0f)), 0.5f * ext);
+            delta0 = (scale > 0.0f && scale < INFINITY) ? scale * a.link_delta : 0.0f;
+            // The region is kept within half the bound (an eighth of the node's extent at the default, about
+            // half a point spacing) of the leaf's own box.  On sheet-like data (depth frames) a leaf's kd cell
+            // is a prism that runs along the surface normal through the whole scene, at the rim of a cloud it
+            // runs out to infinity: nothing a query near the leaf's points gains from, but the halo build had
+            // to walk every record such a prism cuts (0.52 ms for a 307k-point frame against 0.11 ms for as
+            // many uniform points), and a face line's members fill a slab of the region's cross-section --
+            // the larger that is, the shorter the line's reach (leaf_halo.h).  A smaller region is always valid.
+            const float margin = delta0 * a.region_margin;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 reg[d] = fmaxf(reg[d], s.bb[d * kKdChunks + tid] - margin);

@@ -39,7 +39,7 @@
 #include "knn_normals.h"
 #include "lbvh.h"
 #include "lzf.h"
-#include "leaf_links.h"
+#include "leaf_halo.h"
 #include "loop.h"
 #include "nn_search.h"
 #include "odometry.h"
@@ -95,11 +95,11 @@ struct mi_icp_ctx {
     int64_t nts = 0;  // sorted positions of the target incl. padding slots (kd_cells.h)
     uint32_t leaf_first = 1, nrecords = 0;  // 8-ary tree: first last-level node id, record count
     bool t_has_nrm = false, t_has_cov = false, t_has_int = false, t_has_grad = false, t_has_rec = false;
-    DevBuf tblk, tnrm, trec, tcov, tgrad, nodes, inv_t, tlreg, tlinks, tlinks_tmp;
+    DevBuf tblk, tnrm, trec, tcov, tgrad, nodes, inv_t, tlreg, thalo, tlinks_tmp;
     DevBuf cell_planes, cell_samples, cell_cstart, cell_gstart;
     uint32_t* cell_total_host = nullptr;  // pinned
     bool inv_t_valid = false;
-    bool links_ready = false, links_allowed = false;  // leaf_links.h
+    bool links_ready = false, links_allowed = false;  // leaf_halo.h
     // the neighbour lists are built on a private stream, next to the staging of the source or the loop's first pass
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_links = nullptr;
@@ -450,27 +450,24 @@ void collect_pooled(mi_icp_ctx* c, int executed) {
     }
 }
 
-// Every leaf's neighbour list (leaf_links.h): what lets a seeded query whose cube pokes out of its
-// leaf's region finish without a tree walk.  Built once per target: right behind the tree on a context
-// that has registered before (mi_icp_set_target), otherwise by the first registration loop / seeded
-// search (one-shot searches, k-NN and normal estimation on a fresh context never pay for it).
+// Every leaf's halo (leaf_halo.h): what lets a seeded query whose cube pokes out of its leaf's region
+// finish without a tree walk.  Built once per target: right behind the tree on a context that has
+// registered before (mi_icp_set_target), otherwise by the first registration loop / seeded search
+// (one-shot searches, k-NN and normal estimation on a fresh context never pay for it).
 int build_links(mi_icp_ctx* c, hipStream_t st) {
     static const bool no_links = std::getenv("MI_ICP_NO_LINKS") != nullptr;  // A/B switch
-    uint2* links;
+    if (!c->links_allowed || no_links) return MI_ICP_OK;  // (every leaf's largest reach is 0 as built: no query asks for a line)
+    float* halo;
     const size_t ntiles = ((size_t)c->nleaf + 63) / 64;
-    TRY(ensure(c, c->tlinks, ntiles * 64 * kLinkSlots, &links));
-    if (c->links_allowed && !no_links) {
-        uint2* cand;  // scratch: up to 64 candidates per leaf
-        TRY(ensure(c, c->tlinks_tmp, ntiles * 64 * kLinkCand, &cand));
-        const uint32_t lblocks = (uint32_t)ntiles;
-        leaf_links_collect<<<((lblocks + 7u) / 8u) * 8u, 64, 0, st>>>(
-                (const float*)c->nodes.p, c->leaf_first, c->nleaf, lblocks, (float*)c->tlreg.p, cand);
-        KCHK(c);
-        leaf_links_select<<<(unsigned)ntiles, 64, 0, st>>>((float*)c->tlreg.p, c->nleaf, cand, links);
-        KCHK(c);
-    } else {
-        HIPCHK(c, hipMemsetAsync(links, 0xff, ntiles * 64 * kLinkSlots * sizeof(uint2), st));
-    }
+    TRY(ensure(c, c->thalo, ntiles * 64 * kHaloLines * kHaloLineFloats, &halo));
+    uint2* cand;  // scratch: up to 64 candidate leaves per leaf
+    TRY(ensure(c, c->tlinks_tmp, ntiles * 64 * kLinkCand, &cand));
+    const uint32_t lblocks = (uint32_t)ntiles;
+    leaf_halo_collect<<<((lblocks + 7u) / 8u) * 8u, 64, 0, st>>>(
+            (const float*)c->nodes.p, c->leaf_first, c->nleaf, lblocks, (float*)c->tlreg.p, cand);
+    KCHK(c);
+    leaf_halo_build<<<(unsigned)ntiles, 64 * kHaloWaves, 0, st>>>((float*)c->tlreg.p, c->nleaf, cand, (const float*)c->tblk.p, halo);
+    KCHK(c);
     return MI_ICP_OK;
 }
 
@@ -540,7 +537,7 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
     const bool use_seed = seed && c->nn_valid;
     if (use_seed) TRY(ensure_links(c));
     EvTimer t(c, 0, loop != nullptr);
-    const uint2* links = (const uint2*)c->tlinks.p;
+    const float* links = (const float*)c->thalo.p;
     bool self_seeded = false;
     static const bool no_coarse = std::getenv("MI_ICP_NO_COARSE_FIRST") != nullptr;  // A/B switch
     auto launch = [&](bool seeded, const float* sx, const float* sy, const float* sz, int64_t ns, int32_t* out_idx,
@@ -931,7 +928,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
     if (c->ev_links) (void)hipEventDestroy(c->ev_links);
     mailbox_close(c);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    DevBuf* all[] = {&c->trec, &c->tlreg, &c->tlinks, &c->tlinks_tmp, &c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
+    DevBuf* all[] = {&c->trec, &c->tlreg, &c->thalo, &c->tlinks_tmp, &c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
                      &c->cell_gstart, &c->sx, &c->sy, &c->sz,
                      &c->sperm, &c->snrm, &c->scov, &c->nn_idx, &c->nn_d2, &c->inv_s,
                      &c->user_pairs, &c->keys0, &c->keys1, &c->vals0, &c->vals1, &c->hist,
@@ -1086,6 +1083,8 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
         ga.lreg = lreg;
         static const float link_delta = [] { const char* e = std::getenv("MI_ICP_LINK_DELTA"); const float v = e ? (float)std::atof(e) : 0.0f; return v > 0.0f ? v : 0.25f; }();
         ga.link_delta = link_delta;
+        static const float region_margin = [] { const char* e = std::getenv("MI_ICP_REGION_MARGIN"); const float v = e ? (float)std::atof(e) : 0.0f; return v > 0.0f ? v : 0.5f; }();
+        ga.region_margin = region_margin;
         kd_build_groups<<<(unsigned)lay.ngroups, kKdThreads, 0, c->stream>>>(ga);
         KCHK(c);
         first = leaf_first >> 9;  // the groups' own boxes sit in the records of this level
@@ -1490,7 +1489,7 @@ static int launch_fused_iteration(mi_icp_ctx* c, DevLoop* d) {
     EvTimer t(c, 0, true);
     icp_small_iteration_kernel<<<grid, kReduceThreads, 0, c->stream>>>(
             (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns, (const float*)c->nodes.p,
-            (const float*)c->tblk.p, (const float*)c->tlreg.p, (const uint2*)c->tlinks.p, c->leaf_first, c->loop_r2, npackets,
+            (const float*)c->tblk.p, (const float*)c->tlreg.p, (const float*)c->thalo.p, c->leaf_first, c->loop_r2, npackets,
             nblocks, (int32_t*)c->nn_idx.p, (const float*)c->trec.p, d, partial, (uint32_t*)c->ticket.p, sys);
     KCHK(c);
     c->last_search_kind = 1;
@@ -2507,17 +2506,30 @@ int mi_icp_debug_morton_order(mi_icp_ctx* c, const float* xyz, int64_t n, uint32
     return mi_icp_spatial_order(c, xyz, n, order_out, MI_ICP_HOST);
 }
 
-int mi_icp_debug_nn_stats(mi_icp_ctx* c, const float* T, float radius, int use_seed, uint64_t* out4) {
+int mi_icp_debug_nn_stats8(mi_icp_ctx* c, const float* T, float radius, int use_seed, uint64_t* out8) {
     TRY(check_ctx(c));
-    if (!out4 || c->ns <= 0 || c->nt <= 0) return fail(c, MI_ICP_ERR_INVALID, "debug_nn_stats: bad state/arguments");
+    if (!out8 || c->ns <= 0 || c->nt <= 0) return fail(c, MI_ICP_ERR_INVALID, "debug_nn_stats: bad state/arguments");
     unsigned long long* d;
-    TRY(ensure(c, c->flags, 8, (unsigned long long**)&d));
-    HIPCHK(c, hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), c->stream));
+    TRY(ensure(c, c->flags, 16, (unsigned long long**)&d));
+    HIPCHK(c, hipMemsetAsync(d, 0, 16 * sizeof(unsigned long long), c->stream));
     TRY(launch_nn(c, load_T(T), radius * radius, use_seed != 0, d));
-    HIPCHK(c, hipMemcpyAsync(c->sys_host, d, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sys_host, d, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     collect_events(c);
-    std::memcpy(out4, c->sys_host, 4 * sizeof(uint64_t));
+    if (std::getenv("MI_ICP_CENSUS_WHY")) {
+        const unsigned long long* w = (const unsigned long long*)c->sys_host;
+        std::fprintf(stderr, "walkers: no seed %llu, no region %llu, no halo %llu, beyond far reach %llu, far lines short %llu\n",
+                     w[8], w[9], w[10], w[11], w[12]);
+    }
+    std::memcpy(out8, c->sys_host, 8 * sizeof(uint64_t));
+    return MI_ICP_OK;
+}
+
+int mi_icp_debug_nn_stats(mi_icp_ctx* c, const float* T, float radius, int use_seed, uint64_t* out4) {
+    uint64_t all[8];
+    if (!out4) return MI_ICP_ERR_INVALID;
+    TRY(mi_icp_debug_nn_stats8(c, T, radius, use_seed, all));
+    std::memcpy(out4, all, 4 * sizeof(uint64_t));
     return MI_ICP_OK;
 }
 
@@ -2530,20 +2542,17 @@ int mi_icp_debug_get_leaf_regions(mi_icp_ctx* c, float* regions_out) {
     return MI_ICP_OK;
 }
 
-int mi_icp_debug_get_leaf_links(mi_icp_ctx* c, uint32_t* links_out) {
+int mi_icp_debug_get_leaf_halos(mi_icp_ctx* c, float* halos_out) {
     TRY(check_ctx(c));
-    if (!links_out || c->nt <= 0) return fail(c, MI_ICP_ERR_INVALID, "debug_get_leaf_links: no target / bad arguments");
+    if (!halos_out || c->nt <= 0) return fail(c, MI_ICP_ERR_INVALID, "debug_get_leaf_halos: no target / bad arguments");
     TRY(ensure_links(c));
-    // device layout: tiles of 64 leaves, 32-byte chunks (4 entries) chunk-major -> rows per leaf
-    const size_t ntiles = ((size_t)c->nleaf + 63) / 64;
-    std::vector<uint32_t> raw(ntiles * 64 * kLinkSlots * 2);
-    HIPCHK(c, hipMemcpyAsync(raw.data(), c->tlinks.p, raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    const size_t count = (size_t)c->nleaf * kHaloLines * kHaloLineFloats;
+    if (!c->thalo.p) {  // no halos on this tree (MI_ICP_NO_CELLS / MI_ICP_NO_LINKS)
+        std::memset(halos_out, 0, count * sizeof(float));
+        return MI_ICP_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(halos_out, c->thalo.p, count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int64_t L = 0; L < c->nleaf; ++L)
-        for (int k = 0; k < kLinkSlots / 4; ++k)
-            std::memcpy(links_out + ((size_t)L * kLinkSlots + (size_t)k * 4) * 2,
-                        raw.data() + (((size_t)(L >> 6) * (kLinkSlots / 4) + (size_t)k) * 64 + (size_t)(L & 63)) * 8,
-                        8 * sizeof(uint32_t));
     return MI_ICP_OK;
 }
 

@@ -37,12 +37,24 @@ constexpr int kNNPacketsPerBlock = kNNThreads / 64;
 // item's query comes over ds_bpermute, the leaf's 8 points over per-lane vector loads, the
 // result goes back with an LDS atomic min on (d2 bits << 32 | slot) -- d2 >= 0, so the
 // integer order is the float order and equal distances resolve to the lowest slot.
-constexpr int kItemQueue = 64 + 8 * 64;  // a drain leaves < 64 behind, one record adds <= 512
-constexpr int kLinkSlotsNN = 32;         // entries per leaf neighbour list (leaf_links.h: kLinkSlots)
+constexpr int kHaloFaces = 6;            // faces of a leaf's region (leaf_halo.h)
+constexpr int kHaloPrimary = 18;         // a leaf's primary halo lines: 6 for the faces, 12 for the edges between faces of different axes
+constexpr int kHaloExt = 8;              // ... and its extension lines, given to primary lines that have more than 7 members within the bound
+constexpr int kHaloNear = 3;             // ... and its near lines: the 21 nearest points whatever faces they lie beyond, 7 per line
+constexpr int kHaloNearFirst = kHaloPrimary + kHaloExt;
+constexpr int kHaloLines = kHaloNearFirst + kHaloNear;
+constexpr int kHaloLineFloats = 32;      // x[8] y[8] z[8] slot[8] like a leaf line; x[7] = the line's reach
+constexpr int kItemQueue = 64 + 8 * 64;  // tree walk: a drain leaves < 64 behind, one record adds <= 512; halo phase: 16-bit items, <= 18 per lane
+static_assert(kItemQueue * 2 >= 64 * 18, "a lane through all six faces queues 6 face and 12 edge lines");
+
+// Halo line of the edge between faces f < g of different axes (f = 2a + side, g = 2b + side, a < b)
+__host__ __device__ constexpr int halo_edge_line(int f, int g) {
+    return kHaloFaces + ((f >> 1) + (g >> 1) - 1) * 4 + (f & 1) * 2 + (g & 1);
+}
 
 struct PacketShared {
     unsigned long long best[64];  // per lane: d2 bits << 32 | slot
-    uint32_t queue[kItemQueue];   // lane << 26 | leaf
+    uint32_t queue[kItemQueue];   // lane << 26 | leaf (tree walk); as 16-bit entries lane << 5 | line (halo lines)
 };
 
 // One item: the 8 points of leaf L against query (ox, oy, oz) of lane ql; the result goes to
@@ -93,6 +105,88 @@ __device__ __forceinline__ void drain_items(PacketShared& sh, const float* tblk_
     eval_item(sh, tblk_g, have, ql, L, ox, oy, oz, r2);
 }
 
+// The 8 entries of a leaf / halo line against one query: the smallest squared distance (lowest entry among
+// equals) -- the arithmetic of the oracle: d2 = fma(dz, dz, fma(dy, dy, dx * dx)).
+struct LineMin {
+    float m;
+    int k;
+};
+__device__ __forceinline__ LineMin line_min(const float4& x0, const float4& x1, const float4& y0, const float4& y1,
+                                            const float4& z0, const float4& z1, float ox, float oy, float oz) {
+    const float px[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    const float py[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+    const float pz[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+    float d[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float dx = ox - px[k], dy = oy - py[k], dz = oz - pz[k];
+        d[k] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    }
+    LineMin r;
+    r.m = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+    int k = 7;
+    k = (d[6] == r.m) ? 6 : k;
+    k = (d[5] == r.m) ? 5 : k;
+    k = (d[4] == r.m) ? 4 : k;
+    k = (d[3] == r.m) ? 3 : k;
+    k = (d[2] == r.m) ? 2 : k;
+    k = (d[1] == r.m) ? 1 : k;
+    k = (d[0] == r.m) ? 0 : k;
+    r.k = k;
+    return r;
+}
+
+// One batch of HALO items (leaf_halo.h): lane t evaluates halo line `line` of the seed leaf of lane ql --
+// the same 8-point evaluation as a leaf line (the eighth "point" is x = the line's reach, y = z = +inf:
+// infinitely far); a line that beats what its owner holds fetches the winner's slot from the line's fourth
+// row (ascending inside a line, so the first of equal distances is the lowest slot).  A primary line that
+// has an extension (slot[7] >= 0) and does not reach as far as the owner's overhang queues the extension
+// behind the items already there; returns the new end of the queue.  Halo items are 16 bits (lane << 5 |
+// line): 18 per lane at most fit the queue's bytes, so nothing is drained while they are being pushed.
+__device__ __forceinline__ uint32_t drain_halo(PacketShared& sh, const float* halo_g, uint32_t first, uint32_t count,
+                                               uint32_t qend, uint32_t seed_leaf, float over, float qx, float qy, float qz,
+                                               float r2) {
+    const int lane = lane_id();
+    uint16_t* q16 = reinterpret_cast<uint16_t*>(sh.queue);
+    const bool have = (uint32_t)lane < count;
+    const uint32_t item = have ? (uint32_t)q16[first + (uint32_t)lane] : 0u;
+    const int ql = (int)(item >> 5);
+    const uint32_t f = item & 31u;
+    const uint32_t L = (uint32_t)__builtin_amdgcn_ds_bpermute(ql << 2, (int)seed_leaf);
+    const float ox = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(qx)));
+    const float oy = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(qy)));
+    const float oz = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(qz)));
+    const float oover = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(over)));
+    bool follow = false;
+    uint32_t ext = 0u;
+    if (have) {
+        const float* lf = halo_g + ((size_t)L * kHaloLines + f) * kHaloLineFloats;
+        const float4* line = reinterpret_cast<const float4*>(lf);
+        const float4 x0 = line[0], x1 = line[1], y0 = line[2], y1 = line[3], z0 = line[4], z1 = line[5];
+        const int e = __float_as_int(lf[31]);
+        const uint32_t held_bits = (uint32_t)(sh.best[ql] >> 32);  // what the owner holds (or a batch-mate has found)
+        const LineMin w = line_min(x0, x1, y0, y1, z0, z1, ox, oy, oz);
+        // (equal distances: the lower slot must win, so an equal candidate goes to the atomic as well)
+        if (w.m < r2 && __float_as_uint(w.m) <= held_bits) {
+            const uint32_t slot = __float_as_uint(lf[24 + w.k]);
+            const unsigned long long cand = ((unsigned long long)__float_as_uint(w.m) << 32) | (unsigned long long)slot;
+            __hip_atomic_fetch_min(&sh.best[ql], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        follow = e >= 0 && !(oover < x1.w);
+        ext = (uint32_t)e;
+    }
+    const uint64_t fmask = __ballot(follow);
+    if (fmask != 0ull) {
+        if (follow) {
+            const uint32_t pos = qend + __builtin_amdgcn_mbcnt_hi((uint32_t)(fmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fmask, 0u));
+            q16[pos] = (uint16_t)(((uint32_t)ql << 5) | ext);
+        }
+        qend += (uint32_t)__popcll(fmask);
+        __builtin_amdgcn_wave_barrier();
+    }
+    return qend;
+}
+
 // What a packet's search leaves in every lane (for callers that go on with it: fused_small.h)
 struct PacketResult {
     bool valid;     // the lane holds a source point
@@ -111,7 +205,7 @@ __device__ __forceinline__ bool nn_packet_body(
         PacketShared& sh, uint32_t packet,
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
         int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
-        const float* __restrict__ lreg_g, const uint2* __restrict__ links_g, uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, int32_t* __restrict__ nn_idx,
+        const float* __restrict__ lreg_g, const float* __restrict__ halo_g, uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, int32_t* __restrict__ nn_idx,
         float* __restrict__ nn_d2, unsigned long long* __restrict__ stats, PacketResult& out) {
     const int lane = lane_id();
     const int i = (int)(packet * 64u) + lane;  // (ns < 2^31)
@@ -136,13 +230,14 @@ __device__ __forceinline__ bool nn_packet_body(
     float best = valid ? r2 : -1.0f;
     int32_t bidx = -1;
 
-    uint32_t my_node = 0u;  // leaf-level node of the lane's previous match (traverse_seeded), 0: none
-    uint32_t seed_leaf = 0xffffffffu;
+    // (the lane's seed leaf, seed_j >> 3, and its leaf-level node are derived from seed_j where they are used: the
+    // kernel has 64 registers and the halo phase needs them)
     bool retired = !valid;  // this lane's search is complete
-    bool linked = false;    // ... will be once the neighbour list of its seed leaf has been scanned
-    float over = 0.0f;      // overhang of the cube beyond the seed leaf's region
+    bool linked = false;    // its cube pokes out of the seed leaf's region by less than that leaf's halo reaches
+    float over = 0.0f;      // ... by this much
+    uint32_t nnear = 0u;    // ... so little that this many of the leaf's near lines hold all it can find (0: face / edge lines); kept in `faces` bits 6, 7
+    uint32_t why = 0u;      // (census) 1: seed leaf without a region, 2: without a halo, 3: overhang beyond its reach
     uint32_t faces = 0u;    // faces it pokes through
-    Cube cube;
     if (SEED) {
         // The previous iteration's match: its whole LEAF is evaluated right here (one 128-B line,
         // the same the old single-point gather touched), which gives the search radius -- and if
@@ -159,8 +254,6 @@ __device__ __forceinline__ bool nn_packet_body(
         const float4 g0 = rg[0], g1 = rg[1];
         if (j >= 0) {
             const uint32_t L = Lc;
-            seed_leaf = L;
-            my_node = leaf_first + (L >> 3);
             const float px[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
             const float py[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
             const float pz[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
@@ -191,35 +284,134 @@ __device__ __forceinline__ bool nn_packet_body(
                                        fminf(g1.y - qy, g1.z - qz));
             if (inside >= rb) {  // (NaN anywhere: not finished)
                 retired = true;
-                cube.lox = cube.loy = cube.loz = INFINITY;
-                cube.hix = cube.hiy = cube.hiz = -INFINITY;
             } else {
+                Cube cube;  // (formed again behind the halo phase for the lanes that walk: six registers less across it)
                 set_cube(cube, qx, qy, qz, best);
                 // The cube pokes out of the region: by how much (L-infinity overhang), and through which
-                // faces.  Below the REACH of the leaf's neighbour list (leaf_links.h) the list names
-                // every leaf the cube can touch outside its own.
+                // faces.  The leaf's halo (leaf_halo.h) serves an overhang below g1.w: one, two or three
+                // NEAR lines -- the leaf's 7 / 14 / 21 nearest points of other leaves, shared by all its
+                // lanes -- up to the three reaches packed into g0.w (10-bit fractions of g1.w), the lines of
+                // the poked faces and the edges between them beyond that.
                 const float ux = cube.hix - g1.x, uy = cube.hiy - g1.y, uz = cube.hiz - g1.z;
                 const float lx = g0.x - cube.lox, ly = g0.y - cube.loy, lz = g0.z - cube.loz;
                 over = fmaxf(fmaxf(fmaxf(ux, lx), fmaxf(uy, ly)), fmaxf(uz, lz)) * 1.000001f;
                 faces = (ux > 0.0f ? 1u : 0u) | (lx > 0.0f ? 2u : 0u) | (uy > 0.0f ? 4u : 0u) | (ly > 0.0f ? 8u : 0u) |
                         (uz > 0.0f ? 16u : 0u) | (lz > 0.0f ? 32u : 0u);
-                linked = links_g != nullptr && over < g0.w;  // (NaN from inf - inf: false; no lists (yet): walk)
+                linked = halo_g != nullptr && over < g1.w;  // (NaN from inf - inf: false; no halos (yet): walk)
+                const uint32_t pk = __float_as_uint(g0.w);
+                const float unit = g1.w * 0.0009765625f;
+                const float r0 = unit * (float)(pk & 1023u), r1 = unit * (float)((pk >> 10) & 1023u), r2 = unit * (float)((pk >> 20) & 1023u);
+                if (halo_g != nullptr && over < r2) {
+                    linked = true;
+                    nnear = (over < r0) ? 1u : ((over < r1) ? 2u : 3u);
+                }
+                faces |= nnear << 6;
+                if (STATS) why = !(g0.x <= g1.x) ? 1u : (g1.w == 0.0f ? 2u : (!linked ? 3u : 0u));
             }
-        } else {
-            set_cube(cube, qx, qy, qz, best);
         }
-    } else {
-        set_cube(cube, qx, qy, qz, best);  // invalid lanes: best = -1 -> empty cube
-    }
-    if (retired) {  // an empty cube takes no part in box tests
-        cube.lox = cube.loy = cube.loz = INFINITY;
-        cube.hix = cube.hiy = cube.hiz = -INFINITY;
     }
     // the lane's running result lives in LDS, where any lane may improve it
     sh.best[lane] = ((unsigned long long)__float_as_uint(fmaxf(best, 0.0f)) << 32) | (unsigned long long)(uint32_t)bidx;
     __builtin_amdgcn_wave_barrier();
 
-    uint32_t queued = 0u, batches = 0u;  // wave-uniform
+    uint32_t queued = 0u, batches = 0u, halo_items = 0u;  // wave-uniform
+    if (SEED && __ballot(linked) != 0ull) {
+        // ---- halo lines (leaf_halo.h).  A lane with a small overhang reads the first one, two or three of
+        // its seed leaf's NEAR lines (the leaf's nearest points of other leaves, whatever they lie beyond;
+        // the same lines for all lanes of the leaf).  Beyond their reach: a point of another leaf that lies
+        // in the cube lies on or beyond one, two or three faces of the seed leaf's region, all of them faces
+        // the cube pokes through; the leaf keeps, per face, the nearest points beyond that face ONLY, and per
+        // edge (two faces of different axes) the nearest beyond both.  So the lines to read follow from
+        // `faces` alone -- one for a lane that pokes through one face, three for two, six for three -- no
+        // scan, no filter.  A line with more members than it holds names its extension line, read when the
+        // overhang calls for it.  With the overhang below the leaf's reaches (tested in the prologue) that
+        // is everything the cube can hold.
+        const uint32_t seed_leaf = linked ? ((uint32_t)seed_j >> 3) : 0u;
+        const uint32_t nn = linked ? (faces >> 6) : 0u;             // near lines this lane reads
+        const uint32_t fm = (linked && nn == 0u) ? (faces & 63u) : 0u;  // faces whose lines (and edge lines) it reads
+        if (__ballot(fm != 0u || nn > 1u) == 0ull) {
+            // every lane that needs anything needs its leaf's first near line only: each evaluates its own
+            // (no queue, no exchange; the common case of small noise)
+            if (STATS) ++batches, halo_items += (uint32_t)__popcll(__ballot(linked));
+            const float* lf = halo_g + ((size_t)seed_leaf * kHaloLines + kHaloNearFirst) * kHaloLineFloats;
+            const float4* line = reinterpret_cast<const float4*>(lf);
+            const float4 x0 = line[0], x1 = line[1], y0 = line[2], y1 = line[3], z0 = line[4], z1 = line[5];
+            if (linked) {
+                const LineMin w = line_min(x0, x1, y0, y1, z0, z1, qx, qy, qz);
+                if (w.m < r2 && w.m <= best) {
+                    const int32_t slot = __float_as_int(lf[24 + w.k]);
+                    // (the seed leaf's own points have other slots; equal distances: the lower slot)
+                    if (w.m < best || slot < bidx || bidx < 0) {
+                        best = w.m;
+                        bidx = slot;
+                    }
+                }
+                retired = true;
+            }
+            if (__ballot(!retired) != 0ull)  // (lanes that go on to the walk read their slot of sh.best again)
+                sh.best[lane] = ((unsigned long long)__float_as_uint(fmaxf(best, 0.0f)) << 32) | (unsigned long long)(uint32_t)bidx;
+        } else {
+            uint16_t* q16 = reinterpret_cast<uint16_t*>(sh.queue);
+            auto push = [&](bool mine, uint32_t line) {
+                const uint64_t m = __ballot(mine);
+                if (m != 0ull) {
+                    if (mine) {
+                        const uint32_t pos = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        q16[pos] = (uint16_t)(((uint32_t)lane << 5) | line);
+                    }
+                    queued += (uint32_t)__popcll(m);
+                }
+            };
+#pragma unroll
+            for (int k = 0; k < kHaloNear; ++k) push(nn > (uint32_t)k, (uint32_t)(kHaloNearFirst + k));
+            if (__ballot(fm != 0u) != 0ull) {
+#pragma unroll
+                for (int f = 0; f < kHaloFaces; ++f) push((fm >> f) & 1u, (uint32_t)f);
+            }
+            if (__ballot((fm & (fm - 1u)) != 0u) != 0ull) {  // some lane pokes through two faces or more
+#pragma unroll
+                for (int f = 0; f < kHaloFaces; ++f)
+#pragma unroll
+                    for (int g = (f | 1) + 1; g < kHaloFaces; ++g) {
+                        const uint32_t both = (1u << f) | (1u << g);
+                        push((fm & both) == both, (uint32_t)halo_edge_line(f, g));
+                    }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // the newest (up to) 64 items at a time; the extensions they ask for (at most as many) take their place
+            while (queued != 0u) {
+                const uint32_t n = min(64u, queued);
+                if (STATS) ++batches, halo_items += n;
+                const uint32_t end = drain_halo(sh, halo_g, queued - n, n, queued, seed_leaf, over, qx, qy, qz, r2);
+                const uint32_t nf = end - queued;  // wave-uniform
+                if (nf != 0u) {
+                    uint16_t v = 0;
+                    if ((uint32_t)lane < nf) v = q16[queued + (uint32_t)lane];
+                    __builtin_amdgcn_wave_barrier();
+                    if ((uint32_t)lane < nf) q16[queued - n + (uint32_t)lane] = v;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                queued = queued - n + nf;
+            }
+            if (linked) retired = true;
+            {  // what the evaluated lines left in this lane's slot
+                const unsigned long long bb = sh.best[lane];
+                if (valid && (int32_t)(uint32_t)bb != bidx) {
+                    best = __uint_as_float((uint32_t)(bb >> 32));
+                    bidx = (int32_t)(uint32_t)bb;
+                }
+            }
+        }
+    }
+    // the search cube of the lanes that go on (an empty one takes no part in box tests; invalid lanes: best = -1 -> empty)
+    Cube cube;
+    if (retired) {
+        cube.lox = cube.loy = cube.loz = INFINITY;
+        cube.hix = cube.hiy = cube.hiz = -INFINITY;
+    } else {
+        set_cube(cube, qx, qy, qz, best);
+    }
     constexpr uint32_t kNoItem = 0xffffffffu;
     uint32_t held = kNoItem;             // this lane's one pending leaf while no lane has had a second
     bool spilled = false;                // wave-uniform: the held items have moved into the LDS queue
@@ -240,7 +432,10 @@ __device__ __forceinline__ bool nn_packet_body(
     };
     auto on_leaf_record = [&](uint32_t lbase, uint32_t vm, uint32_t hit) {
         // the lane's seed leaf has been evaluated in the prologue
-        if (SEED && (seed_leaf & ~7u) == lbase) vm &= ~(1u << (seed_leaf & 7u));
+        if (SEED) {
+            const uint32_t seed_leaf = (uint32_t)seed_j >> 3;  // (no previous match: 0x1fffffff, no leaf's index)
+            if ((seed_leaf & ~7u) == lbase) vm &= ~(1u << (seed_leaf & 7u));
+        }
         // The steady state of a converged loop: every lane overlaps ONE leaf in the whole walk
         // (its match's).  A lane's first item therefore stays in a register; only when some
         // lane gets a second one do the held items move into the LDS queue (below), where items
@@ -283,53 +478,19 @@ __device__ __forceinline__ bool nn_packet_body(
             drain(queued, 64u);
         }
     };
-    if (SEED && __ballot(linked) != 0ull) {
-        // ---- neighbour lists: lane-private scans of the seed leaves' lists (the 8 or so lanes that
-        // share a seed leaf read the same 32-byte pieces).  Entries come sorted by distance, so a
-        // lane stops at the first one beyond its overhang; an entry whose box lies beyond a face
-        // the cube does not poke through cannot overlap it.  What passes is queued as a
-        // (lane, leaf) item like any leaf the tree walk would have found.
-        // chunk k4 of leaf L: 32 bytes at ((L / 64 * 8 + k4) * 64 + L % 64) * 32 (leaf_links.h)
-        const uint32_t sl = linked ? seed_leaf : 0u;
-        const uint4* lk = reinterpret_cast<const uint4*>(links_g) + ((size_t)(sl >> 6) * (kLinkSlotsNN / 4) * 64u + (sl & 63u)) * 2u;
-        bool scanning = linked;
-        spilled = true;
-        for (int k4 = 0; k4 < kLinkSlotsNN / 4; ++k4) {
-            if (__ballot(scanning) == 0ull) break;
-            uint4 e0 = make_uint4(0u, 0x7f800000u, 0u, 0x7f800000u), e1 = e0;
-            if (scanning) {
-                e0 = lk[(size_t)k4 * 128u];
-                e1 = lk[(size_t)k4 * 128u + 1u];
-            }
-            const uint32_t ids[4] = {e0.x, e0.z, e1.x, e1.z};
-            const uint32_t dw[4] = {e0.y, e0.w, e1.y, e1.w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                scanning = scanning && (__uint_as_float(dw[u] & ~63u) <= over);
-                const bool push = scanning && ((dw[u] & 63u & ~faces) == 0u);
-                const uint64_t m = __ballot(push);
-                if (push) {
-                    const uint32_t pos = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    sh.queue[pos] = ((uint32_t)lane << 26) | ids[u];
-                }
-                queued += (uint32_t)__popcll(m);
-            }
-            __builtin_amdgcn_wave_barrier();
-            while (queued >= 64u) {
-                queued -= 64u;
-                drain(queued, 64u);
-            }
-        }
-        if (linked) {  // everything this lane can still find is in the queue
-            retired = true;
-            cube.lox = cube.loy = cube.loz = INFINITY;
-            cube.hix = cube.hiy = cube.hiz = -INFINITY;
+    uint32_t steps = 0u;
+    const uint32_t walkers = STATS ? (uint32_t)__popcll(__ballot(!retired)) : 0u;
+    if (STATS && SEED) {  // why the walkers walk
+        for (uint32_t w = 0u; w < 5u; ++w) {
+            const uint32_t nw = (uint32_t)__popcll(__ballot(!retired && (seed_j < 0 ? 0u : why) == w && (w != 0u || seed_j < 0)));
+            if (lane == 0 && nw) atomicAdd(stats + 8 + w, (unsigned long long)nw);
         }
     }
-    uint32_t steps = 0u;
     if (!SEED) steps = traverse_from(records_g, leaf_first, 1u, cube, on_leaf_record);
-    else if (__ballot(!retired) != 0ull) steps = traverse_seeded(records_g, leaf_first, my_node, cube, retired, on_leaf_record);
+    else if (__ballot(!retired) != 0ull) {
+        const uint32_t my_node = (seed_j >= 0) ? leaf_first + ((uint32_t)seed_j >> 6) : 0u;  // leaf-level node of the previous match
+        steps = traverse_seeded(records_g, leaf_first, my_node, cube, retired, on_leaf_record);
+    }
     if (!spilled) {  // one item per lane at most: each lane evaluates its own
         if (__ballot(held != kNoItem) != 0ull) {
             if (STATS) ++batches;
@@ -352,6 +513,10 @@ __device__ __forceinline__ bool nn_packet_body(
         atomicAdd(stats + 1, (unsigned long long)batches);  // 64-item leaf batches
         atomicAdd(stats + 2, 1ull);
         atomicMax(stats + 3, (unsigned long long)steps + (unsigned long long)batches);  // slowest packet
+        atomicAdd(stats + 4, (unsigned long long)halo_items);       // halo lines evaluated
+        atomicAdd(stats + 5, halo_items ? 1ull : 0ull);              // packets with a halo phase
+        atomicAdd(stats + 6, steps ? 1ull : 0ull);                   // packets that walk the tree
+        atomicAdd(stats + 7, (unsigned long long)walkers);          // lanes unfinished when the walk starts
     }
     out.valid = valid;
     out.i = i;
@@ -369,13 +534,13 @@ template <bool SEED, bool STATS>
 __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_packet_kernel(
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
         int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
-        const float* __restrict__ lreg_g, const uint2* __restrict__ links_g, uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, uint32_t nblocks, int32_t* __restrict__ nn_idx,
+        const float* __restrict__ lreg_g, const float* __restrict__ halo_g, uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, uint32_t nblocks, int32_t* __restrict__ nn_idx,
         float* __restrict__ nn_d2, unsigned long long* __restrict__ stats) {
     __shared__ PacketShared s_pk[kNNPacketsPerBlock];
     uint32_t logical;
     if (!xcd_remap(nblocks, logical)) return;
     PacketResult unused;
-    (void)nn_packet_body<SEED, STATS>(s_pk[0], logical, sx, sy, sz, ns, records_g, tblk_g, lreg_g, links_g, leaf_first, Tv, loop,
+    (void)nn_packet_body<SEED, STATS>(s_pk[0], logical, sx, sy, sz, ns, records_g, tblk_g, lreg_g, halo_g, leaf_first, Tv, loop,
                                       r2, nn_idx, nn_d2, stats, unused);
 }
 

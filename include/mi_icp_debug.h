@@ -26,6 +26,11 @@ MI_ICP_API int mi_icp_debug_morton_order(mi_icp_ctx* ctx, const float* xyz, int6
  * use_seed != 0 seeds from the previous pass. */
 MI_ICP_API int mi_icp_debug_nn_stats(mi_icp_ctx* ctx, const float* T, float radius, int use_seed,
                                      uint64_t* out4);
+/* the same pass with four more counters: out8[4] = halo lines evaluated (leaf_halo.h), [5] = packets
+ * that evaluated any, [6] = packets that walked the tree, [7] = lanes unfinished when their packet's walk
+ * started. */
+MI_ICP_API int mi_icp_debug_nn_stats8(mi_icp_ctx* ctx, const float* T, float radius, int use_seed,
+                                      uint64_t* out8);
 /* Forget the previous search result: the next nearest-neighbour pass starts top-down instead of
  * from its predecessor's matches (tests compare the two; the results must be identical).  The
  * context has no correspondence set until that pass has run. */
@@ -50,16 +55,24 @@ MI_ICP_API int mi_icp_debug_solve_both(int device, const double* systems, int n,
  * sizes only. */
 MI_ICP_API int mi_icp_debug_get_tree(mi_icp_ctx* ctx, int64_t* info5, float* records_out,
                                      float* leaf_lines_out);
-/* Per leaf (mi_icp_debug_get_tree's info5[1] leaves) 8 floats: region lo.xyz, reach of the
- * leaf's neighbour list, region hi.xyz, unused.  The region is free of points of any other
- * leaf (an invalid one is +inf / -inf: nothing is inside). */
+/* Per leaf (mi_icp_debug_get_tree's info5[1] leaves) 8 floats: region lo.xyz, the reaches of the leaf's
+ * three near halo lines as 10-bit fractions (bits 0-9, 10-19, 20-29, in 1/1024) of float 7, region hi.xyz,
+ * the smallest reach of the leaf's face / edge halo lines (0: no halo).  The region is free of points of any
+ * other leaf (an invalid one is +inf / -inf: nothing is inside). */
 MI_ICP_API int mi_icp_debug_get_leaf_regions(mi_icp_ctx* ctx, float* regions_out);
-/* Per leaf 32 entries of 2 words (builds the lists if no seeded search has yet): leaf id, fp32
- * bits of the L-infinity distance between that leaf's bounding box and this leaf's region with the
- * 6 low mantissa bits replaced by the direction mask (bit 2a: beyond the upper face of axis a,
- * 2a+1: beyond the lower one); ascending in distance; unused entries 0xffffffff / +inf.  Call
- * mi_icp_debug_get_leaf_regions afterwards for the lists' reach (float 3). */
-MI_ICP_API int mi_icp_debug_get_leaf_links(mi_icp_ctx* ctx, uint32_t* links_out);
+/* Per leaf 29 halo lines of 32 floats (builds them if no seeded search has yet): x[8] y[8] z[8] slot[8].
+ * Line f < 6, face f of the leaf's region (+x, -x, +y, -y, +z, -z): the up to 7 points of OTHER leaves
+ * nearest to the region (L-infinity distance to the box) among those on or beyond face f and no other
+ * face.  Line 6 + ((a + b - 1) * 4 + 2 * side_a + side_b), the edge between the faces 2a + side_a and
+ * 2b + side_b of the axes a < b: the up to 7 nearest among those on or beyond both faces.  Points ascend in
+ * slot (sorted target position, as an integer's bits; unused entries +inf / -1); x[7] is the line's reach:
+ * every member nearer to the region than that is in the line (y[7] = z[7] = +inf).  slot[7] of these 18
+ * primary lines: -1, or the one of the lines 18..25 that holds the line's next 7 members and the reach of the
+ * two together (lines 18..25 that no primary line names are unwritten).  Lines 26..28: the 7 / 14 / 21
+ * points of other leaves nearest to the region whatever faces they lie beyond; x[7] of line 26 + k: every
+ * point of another leaf nearer than that is in the lines 26 .. 26 + k.  Call mi_icp_debug_get_leaf_regions
+ * afterwards for the regions. */
+MI_ICP_API int mi_icp_debug_get_leaf_halos(mi_icp_ctx* ctx, float* halos_out);
 #ifdef __cplusplus
 }
 #endif

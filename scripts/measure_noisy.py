@@ -32,11 +32,13 @@ for sigma in (0.0, 0.05, 0.15, 0.3):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     p1 = eng.get_profile()
     T = np.array(res.transformation, np.float32).reshape(4, 4).T
-    out = (C.c_uint64 * 4)()
+    out = (C.c_uint64 * 8)()
     a = np.ascontiguousarray(T.T)
-    eng._chk(eng._L.mi_icp_debug_nn_stats(eng._ctx, a.ctypes.data_as(C.c_void_p), float(max_dist), 1, out))
+    eng._chk(eng._L.mi_icp_debug_nn_stats8(eng._ctx, a.ctypes.data_as(C.c_void_p), float(max_dist), 1, out))
     print(json.dumps({"row": "10M target, 60 %% of it as source + noise", "sigma_over_spacing": sigma, "n_source": len(src),
                       "ms_per_iter": dt / 20 * 1e3, "nn_ms": (p1["nn_ms"] - p0["nn_ms"]) / 20, "reduce_ms": (p1["reduce_ms"] - p0["reduce_ms"]) / 20,
                       "records_per_packet": out[0] / out[2], "leaf_batches_per_packet": out[1] / out[2],
+                      "halo_lines_per_packet": out[4] / out[2], "packets_with_halo_phase": out[5] / out[2],
+                      "packets_that_walk": out[6] / out[2], "lanes_walking_per_walking_packet": out[7] / max(out[6], 1),
                       "fitness": res.fitness, "rmse_over_spacing": res.inlier_rmse / s,
                       "T_err": float(np.linalg.norm(T - T_gt))}), flush=True)
