@@ -1,53 +1,45 @@
-// leaf_halo.h -- every leaf's HALO: the nearest points of other leaves around its region, grouped
-// by the faces of the region they lie beyond.
+// leaf_halo.h -- every leaf's HALO: the nearest points of other leaves around its region, in rings.
 //
 // Why.  A seeded query (nn_search.h) whose search cube lies inside its previous match's leaf
 // region is finished without touching the tree.  With measurement noise the cube -- half-width =
 // the distance to the current match -- pokes out of that region for every query that sits closer
 // to a face than to its match (a third to a half of them at sigma = 0.15 spacings).  What such a
-// query can still find are the few points just beyond the faces it pokes through.  Round 2 kept,
-// per leaf, a distance-ordered list of the 32 nearest neighbour LEAVES with direction masks: a
-// lane scanned it in lock-step with the rest of its wave (~12 wave-instructions per entry, 12-28
-// entries for the slowest lane, most of them excluded by their mask) and then evaluated the 3-5
-// leaves that passed: 0.12 / 0.18 / 0.25 ms per 6M-query pass at sigma = 0.05 / 0.15 / 0.3 against
-// 0.055 on exact data.  Here the POINTS are kept instead, in the leaf lines' own format (128 bytes:
-// x[8] y[8] z[8] slot[8]), 18 primary lines per leaf with region R:
-//   * face line f (0: +x, 1: -x, 2: +y, 3: -y, 4: +z, 5: -z -- the search's `faces` mask): the 7
-//     points of other leaves nearest to R (L-infinity distance to the box) among those that lie on
-//     or beyond face f and NO other face, i.e. inside R's extent along the other two axes;
-//   * edge line (f, g), faces of different axes (halo_edge_line): the 7 nearest among those on or
-//     beyond both f and g -- including the points beyond a third face (they are in three edge lines).
-// Points ascend in slot inside a line; the eighth x holds the line's REACH: every member point
-// nearer to R than that is in the line (y[7] = z[7] = +inf: as a point it is infinitely far away, so
-// a halo line is evaluated by the same code as a leaf line).  A primary line with more than 7 members
-// within the bound gets one of the leaf's 8 EXTENSION lines (the next 7 members and the reach of the
-// two together; the primary's slot[7] names it, -1: none): on uniform data 2.6 of a leaf's 18 lines
-// have an eighth member within the bound, a fifteenth practically never.
-// A point of another leaf lies on or beyond at least one face of R (the region's defining
-// property), and if it lies inside a query's cube the cube pokes through every face the point is
-// beyond.  So a query whose cube pokes through the faces F reads the face lines of F and the edge
-// lines of the pairs in F -- 1 line for one face, 3 for two, 6 for three; no scan, no filter -- and
-// has then seen every point its cube can hold that is nearer to R than those lines' reaches; its
-// distance to R is at most the cube's overhang.  Splitting by the exact set of faces is what makes
-// the reach long: a face line's members fill a slab of R's own cross-section (~4 points per spacing
-// of depth on uniform data), an edge line's a quarter-pipe, so a line of 7 normally ends beyond the
-// bound the candidates were collected to, about one spacing -- every lane up to that overhang is
-// served.  (First attempt: per face the 7 + 7 nearest beyond that face whatever else they are
-// beyond -- the slab then includes the rim around R's cross-section, the 8th / 15th point came at
-// 0.64 / 0.89 spacings in the median and 0.26 / 0.52 for 1 % of the lines, and ONE lane of a packet
-// beyond its lines' reach sends the whole wave up the tree: 1.2 / 12.8 records per packet at
-// sigma = 0.15 / 0.3.)
+// query can still find are the few points just outside the region.  Round 2 kept, per leaf, a
+// distance-ordered list of the 32 nearest neighbour LEAVES with direction masks: a lane scanned it
+// in lock-step with the rest of its wave (~12 wave-instructions per entry, 12-28 entries for the
+// slowest lane, most of them excluded by their mask) and then evaluated the 3-5 leaves that
+// passed: 0.12 / 0.18 / 0.25 ms per 6M-query pass at sigma = 0.05 / 0.15 / 0.3 against 0.055 on
+// exact data.  Here the POINTS are kept instead, in the leaf lines' own format (128 bytes:
+// x[8] y[8] z[8] slot[8]): halo line k of leaf L with region R holds the points of other leaves
+// that are 8k+1-th .. 8k+8-th nearest to R (L-infinity distance to the box), ascending in slot
+// inside the line, 8 lines = 64 points per leaf; REACH k: every point of another leaf nearer to R
+// than that is in the lines 0 .. k (the distance of the first point behind them, or the bound the
+// candidates were collected to, about one spacing).  The eight reaches travel with the region, in
+// the two spare words of its record (halo_pack_reaches below): a query whose cube pokes out of R
+// by `over` -- every point of another leaf inside the cube is then within `over` of R -- knows
+// from the record it has anyway how many lines to read, reads them (no scan, no filter; the lanes
+// of a leaf read the same lines) and is finished.  Mean reaches on uniform data: 0.2 / 0.37 / 0.51
+// ... spacings for 1 / 2 / 3 lines, the bound for all eight.
+// Tried on the way (all exact, all measured on the 6M-query noisy pass): lines per FACE of the
+// region (the 7 + 7 nearest beyond each face: one or two lines per poked face, but the 8th / 15th
+// point came at 0.64 / 0.89 spacings in the median and 0.26 / 0.52 for 1 % of the lines, and ONE
+// lane of a packet beyond its lines' reach sends the whole wave up the tree: 1.2 / 12.8 records
+// per packet at sigma = 0.15 / 0.3); lines per face and per EDGE of the region with extension
+// lines (18 + 8 lines: reach = the bound almost everywhere, 0.101 / 0.144 / 0.234 ms with three
+// ring lines in front) -- but 3.7 KB per leaf, 3.8 GB for a 10M-point target, whose build took
+// 5.6 ms, and nearly every line a lane read was its own 128 bytes from HBM.
 //
 // Built in two launches.  leaf_halo_collect: one wave per 64 consecutive leaves with the packet
 // walk of traverse.h -- lane = leaf, search cube = R grown by the lane's bound (lreg[7] = a quarter
-// of the leaf-level node's extent, about one point spacing on volumetric data), the walk starts
-// at the node that holds the 64 leaves and climbs until every lane's cube is inside a completed
+// of the leaf-level node's size, about one point spacing on volumetric data), the walk starts at
+// the node that holds the 64 leaves and climbs until every lane's cube is inside a completed
 // subtree's region; every leaf box a lane's cube overlaps is appended to the lane's row of a
 // scratch tile (no LDS, so the walk -- a chain of dependent record fetches -- runs at full
 // occupancy).  A row of 64 candidates that fills up stops accepting and its bound drops to the
 // nearest box it turned away (rare).  leaf_halo_build: a wave per leaf gathers the candidates'
 // points (8 leaves per round, one point per lane), keeps those nearer than the bound, sorts them by
-// distance (register bitonic network, 128 keys) and deals the first 7 members of every line to it.
+// distance (register bitonic network, 128 keys): lane l then holds the l-th nearest point, i.e.
+// entry l % 8 of line l / 8.
 #pragma once
 #include "device_utils.h"
 #include "nn_search.h"
@@ -57,7 +49,7 @@ namespace mi {
 
 constexpr uint32_t kLinkIdMask = 0x3ffffffu;  // leaf ids fit 26 bits
 constexpr int kLinkCand = 64;                 // candidate leaves per leaf (scratch)
-static_assert(kHaloFaces == 6 && kHaloPrimary == 18 && kHaloExt == 8 && kHaloNear == 3 && kHaloLineFloats == kLeafFloats, "nn_search.h evaluates halo lines as leaf lines");
+static_assert(kHaloLines == 8 && kHaloLineFloats == kLeafFloats, "nn_search.h evaluates halo lines as leaf lines");
 
 // Scratch: tiles of 64 consecutive leaves, candidate t of leaf L at link_temp_index (slot-major inside the
 // tile: the build's loads are coalesced).
@@ -132,45 +124,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     lreg[(size_t)L * kLeafRegFloats + 7] = __int_as_float(count);
 }
 
-// Wave-wide bitonic sort of 128 keys, ascending: element e = r * 64 + lane.
-__device__ __forceinline__ void halo_sort128(uint32_t (&key)[2], int lane) {
-#pragma unroll
-    for (int k = 2; k <= 128; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j == 64) {  // k = 128: the partner is the other register, ascending throughout
-                const uint32_t mn = min(key[0], key[1]), mx = max(key[0], key[1]);
-                key[0] = mn;
-                key[1] = mx;
-            } else {
-                const bool lower = (lane & j) == 0;
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    // direction of the merge this element takes part in: bit k of e (k = 64: r, k = 128: 0)
-                    const bool asc = (k == 128) ? true : ((k == 64) ? (r == 0) : ((lane & k) == 0));
-                    const uint32_t o = (uint32_t)__shfl_xor((int)key[r], j, 64);
-                    key[r] = (lower == asc) ? min(key[r], o) : max(key[r], o);
-                }
-            }
-        }
-    }
+// lane ^ J's value of v for a compile-time J < 64: DPP inside a quad, ds_swizzle (no address register, no memory)
+// inside 32 lanes, ds_bpermute across the halves
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+    if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);       // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+    else if constexpr (J < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (J << 10) | 0x1f);   // bit mode: and 0x1f, xor J
+    else return (uint32_t)__shfl_xor((int)v, J, 64);
 }
 
-constexpr int kHaloWaves = 4;                  // waves per workgroup = per tile of 64 leaves
-constexpr uint32_t kHaloDistMask = 0xffff8000u;  // key: 17 bits of the distance | 6 of the face mask | 9 of the point's index
-constexpr float kHaloShrink = 0.999999f;       // the reach is reported a little short, the overhang a little long
+template <int K, int J>
+__device__ __forceinline__ void halo_sort_stage(uint32_t (&key)[2], int lane) {
+    if constexpr (J == 64) {  // K = 128: the partner is the other register, ascending throughout
+        const uint32_t mn = min(key[0], key[1]), mx = max(key[0], key[1]);
+        key[0] = mn;
+        key[1] = mx;
+    } else {
+        const bool lower = (lane & J) == 0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            // direction of the merge this element takes part in: bit K of e = r * 64 + lane (K = 64: r, K = 128: 0)
+            const bool asc = (K == 128) ? true : ((K == 64) ? (r == 0) : ((lane & K) == 0));
+            const uint32_t o = lane_xor<J>(key[r]);
+            key[r] = (lower == asc) ? min(key[r], o) : max(key[r], o);
+        }
+    }
+    if constexpr (J > 1) halo_sort_stage<K, J / 2>(key, lane);
+}
+template <int K>
+__device__ __forceinline__ void halo_sort_merges(uint32_t (&key)[2], int lane) {
+    if constexpr (K > 2) halo_sort_merges<K / 2>(key, lane);
+    halo_sort_stage<K, K / 2>(key, lane);
+}
+// Wave-wide bitonic sort of 128 keys, ascending: element e = r * 64 + lane.
+__device__ __forceinline__ void halo_sort128(uint32_t (&key)[2], int lane) { halo_sort_merges<128>(key, lane); }
 
-// One workgroup per tile of 64 leaves, a wave per leaf (16 leaves each).  halo: [nleaf][18 + 8 + 3] lines of 32 floats;
-// lreg[L][7] <- the smallest reach of the leaf's face / edge lines (0: no halo), lreg[L][3] <- the near lines' reaches
-// as fractions of it (what the search tests the overhang against).
+constexpr int kHaloWaves = 4;                    // waves per workgroup = per tile of 64 leaves
+constexpr uint32_t kHaloDistMask = 0xfffffe00u;  // key: 23 bits of the distance | 9 of the point's index
+constexpr float kHaloShrink = 0.999999f;         // reaches are reported a little short, the overhang a little long
+
+// One workgroup per tile of 64 leaves, a wave per leaf (16 leaves each).  halo: [nleaf][8] lines of 32 floats;
+// lreg[L][3], [7] <- the rings' reaches, packed (halo_pack_reaches; both 0: no halo).
 __global__ __launch_bounds__(64 * kHaloWaves) void leaf_halo_build(float* __restrict__ lreg, int nleaf,
                                                                    const uint2* __restrict__ cand,
                                                                    const float* __restrict__ tblk,
                                                                    float* __restrict__ halo) {
     __shared__ uint32_t s_ids[64 * 65];           // [leaf of the tile][candidate], row stride 65: conflict-free both ways
     __shared__ uint32_t s_keys[kHaloWaves][128];  // a wave's in-bound keys, compacted
-    __shared__ uint32_t s_sel[kHaloWaves][kHaloPrimary * 16 + 32];  // [primary line][rank]: its first 15 members in distance order | the 22 nearest of all
-    __shared__ int s_ext[kHaloWaves][kHaloPrimary + kHaloExt];   // extension line of a primary line (-1: none) | primary line of an extension
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t tile = blockIdx.x;
     // the tile's candidate ids: coalesced rows of the scratch tile -> LDS, transposed
@@ -186,9 +187,6 @@ __global__ __launch_bounds__(64 * kHaloWaves) void leaf_halo_build(float* __rest
     }
     __syncthreads();
     uint32_t* keys = s_keys[wid];
-    uint32_t* sel = s_sel[wid];
-    int* ext_of = s_ext[wid];
-    int* ext_src = s_ext[wid] + kHaloPrimary;
     for (int li = wid; li < 64; li += kHaloWaves) {
         const uint32_t L = tile * 64u + (uint32_t)li;  // wave-uniform
         if (L >= (uint32_t)nleaf) break;
@@ -205,7 +203,8 @@ __global__ __launch_bounds__(64 * kHaloWaves) void leaf_halo_build(float* __rest
             }
             continue;
         }
-        // ---- gather: round r covers candidates 8r .. 8r+7, lane = (candidate, slot)
+        // ---- gather: round r covers candidates 8r .. 8r+7, lane = (candidate, slot); key = distance to the
+        // region (L-infinity distance to the box; 23 bits, rounded down) | index of the point in the gather
         const int rounds = (count + 7) >> 3;
         uint32_t key[8];
         {
@@ -228,15 +227,11 @@ __global__ __launch_bounds__(64 * kHaloWaves) void leaf_halo_build(float* __rest
             for (int r = 0; r < 8; ++r) {
                 key[r] = 0xffffffffu;
                 if (r < rounds) {
-                    // gaps to R's faces: >= 0 means on or beyond that face
                     const float ux = px[r] - g1.x, lx = g0.x - px[r], uy = py[r] - g1.y, ly = g0.y - py[r];
                     const float uz = pz[r] - g1.z, lz = g0.z - pz[r];
                     const float dist = fmaxf(fmaxf(fmaxf(ux, lx), fmaxf(uy, ly)), fmaxf(fmaxf(uz, lz), 0.0f));
-                    const uint32_t mask = (ux >= 0.0f ? 1u : 0u) | (lx >= 0.0f ? 2u : 0u) | (uy >= 0.0f ? 4u : 0u) |
-                                          (ly >= 0.0f ? 8u : 0u) | (uz >= 0.0f ? 16u : 0u) | (lz >= 0.0f ? 32u : 0u);
-                    // (padding slots are +inf: dist = +inf; NaN coordinates: dist compares false below)
-                    if (dist < INFINITY && mask != 0u)
-                        key[r] = (__float_as_uint(dist) & kHaloDistMask) | (mask << 9) | (uint32_t)(r * 64 + lane);
+                    // (padding slots are +inf: dist = +inf; NaN coordinates compare false)
+                    if (dist < INFINITY) key[r] = (__float_as_uint(dist) & kHaloDistMask) | (uint32_t)(r * 64 + lane);
                 }
             }
         }
@@ -268,69 +263,25 @@ __global__ __launch_bounds__(64 * kHaloWaves) void leaf_halo_build(float* __rest
         sk[0] = ((uint32_t)lane < n_in) ? keys[lane] : 0xffffffffu;
         sk[1] = ((uint32_t)lane + 64u < n_in) ? keys[64 + lane] : 0xffffffffu;
         halo_sort128(sk, lane);
-        // ---- per primary line, in distance order: the first 7 members go to it, the next 7 to its extension
-        // line if it gets one, the first member left out gives the reach (none left out: the bound).  Members
-        // of face line f: the points beyond that face only; of edge line (f, g): beyond both (a point beyond
-        // three faces is a member of three edge lines).
-        for (int t = lane; t < kHaloPrimary * 16; t += 64) sel[t] = 0xffffffffu;
-        if (lane < 32) sel[kHaloPrimary * 16 + lane] = sk[0];  // the nearest of all, in distance order (sorted element e = r * 64 + lane)
-        __builtin_amdgcn_wave_barrier();
-        auto deal = [&](int line, uint32_t want, uint32_t care) {
-            uint32_t base = 0u;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const bool has = sk[r] != 0xffffffffu && (((sk[r] >> 9) & care) == want);
-                const uint64_t m = __ballot(has);
-                if (m != 0ull && base < 15u) {
-                    const uint32_t rank = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (has && rank < 15u) sel[line * 16 + (int)rank] = sk[r];
-                }
-                base += (uint32_t)__popcll(m);
-            }
-        };
-#pragma unroll
-        for (int f = 0; f < kHaloFaces; ++f) deal(f, 1u << f, 63u);
-#pragma unroll
-        for (int f = 0; f < kHaloFaces; ++f)
-#pragma unroll
-            for (int g = (f | 1) + 1; g < kHaloFaces; ++g) deal(halo_edge_line(f, g), (1u << f) | (1u << g), (1u << f) | (1u << g));
-        __builtin_amdgcn_wave_barrier();
-        // extension lines go to the primary lines with an eighth member, in line order, while there are any
-        {
-            const bool need = lane < kHaloPrimary && sel[lane * 16 + 7] != 0xffffffffu;
-            const uint64_t m = __ballot(need);
-            const uint32_t nth = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            const bool gets = need && nth < (uint32_t)kHaloExt;
-            if (lane < kHaloPrimary) ext_of[lane] = gets ? (int)(kHaloPrimary + nth) : -1;
-            if (lane < kHaloExt) ext_src[lane] = -1;
-            __builtin_amdgcn_wave_barrier();
-            if (gets) ext_src[nth] = lane;
+        // ---- the rings: sorted elements 8k .. 8k+7 are line k, i.e. lane = (line, entry) holds its point already
+        uint32_t slot = 0xffffffffu;
+        if (lane < 8 * kHaloLines && sk[0] != 0xffffffffu) {
+            const uint32_t idx = sk[0] & 511u;  // r * 64 + lane of the gather: candidate 8r + lane/8, slot lane%8
+            const uint32_t c = (idx >> 6) * 8u + ((idx >> 3) & 7u);
+            slot = (s_ids[li * 65 + (int)c] & kLinkIdMask) * (uint32_t)kLeaf + (idx & 7u);
         }
-        __builtin_amdgcn_wave_barrier();
-        float reach_min = INFINITY, reach_mine = INFINITY;
-        // one pass writes 6 lines: lanes 0..47 = (line, rank): the chosen points by ascending slot, rank 7 = the
-        // reach and, in the fourth row, the line's extension (-1: none)
-        auto write_lines = [&](int line, int sel_at, bool primary, int src, bool active) {
-            const int j = lane & 7;
-            const bool is_reach = j == 7;
-            uint32_t e = 0xffffffffu;
-            if (active) e = sel[sel_at + j];  // (the eighth: the first member this line leaves out)
-            uint32_t slot = 0xffffffffu;
-            if (active && !is_reach && e != 0xffffffffu) {
-                const uint32_t idx = e & 511u;  // r * 64 + lane of the gather: candidate 8r + lane/8, slot lane%8
-                const uint32_t c = (idx >> 6) * 8u + ((idx >> 3) & 7u);
-                slot = (s_ids[li * 65 + (int)c] & kLinkIdMask) * (uint32_t)kLeaf + (idx & 7u);
-            }
-            // sort the 8 lanes of a line by slot (equal distances must resolve to the lowest slot: nn_search.h takes
-            // the first of equals inside a line); rank 7 holds 0xffffffff and stays last
-#pragma unroll
-            for (int k = 2; k <= 8; k <<= 1)
-#pragma unroll
-                for (int jj = k >> 1; jj > 0; jj >>= 1) {
-                    const uint32_t o = (uint32_t)__shfl_xor((int)slot, jj, 64);
-                    const bool asc = (k == 8) ? true : ((lane & k) == 0);
-                    slot = (((lane & jj) == 0) == asc) ? min(slot, o) : max(slot, o);
-                }
+        // a line's entries ascend in slot (equal distances must resolve to the lowest slot: nn_search.h takes the
+        // first of equals inside a line)
+        {
+            uint32_t o;
+            o = lane_xor<1>(slot); slot = (((lane & 1) == 0) == ((lane & 2) == 0)) ? min(slot, o) : max(slot, o);
+            o = lane_xor<2>(slot); slot = (((lane & 2) == 0) == ((lane & 4) == 0)) ? min(slot, o) : max(slot, o);
+            o = lane_xor<1>(slot); slot = (((lane & 1) == 0) == ((lane & 4) == 0)) ? min(slot, o) : max(slot, o);
+            o = lane_xor<4>(slot); slot = ((lane & 4) == 0) ? min(slot, o) : max(slot, o);
+            o = lane_xor<2>(slot); slot = ((lane & 2) == 0) ? min(slot, o) : max(slot, o);
+            o = lane_xor<1>(slot); slot = ((lane & 1) == 0) ? min(slot, o) : max(slot, o);
+        }
+        if (lane < 8 * kHaloLines) {
             float x = INFINITY, y = INFINITY, z = INFINITY;
             if (slot != 0xffffffffu) {
                 const float* ln = tblk + (size_t)(slot >> 3) * kLeafFloats + (slot & 7u);
@@ -338,55 +289,41 @@ __global__ __launch_bounds__(64 * kHaloWaves) void leaf_halo_build(float* __rest
                 y = ln[8];
                 z = ln[16];
             }
-            int fourth = (int)slot;
-            if (is_reach) {
-                x = ((e != 0xffffffffu) ? __uint_as_float(e & kHaloDistMask) : bound) * kHaloShrink;
-                const int ext = (active && primary) ? ext_of[src] : -1;
-                fourth = ext;
-                // the line's reach together with its extension is the extension's (written by its own pass)
-                if (active && ext < 0) reach_mine = x;
-            }
-            if (active) {
-                float* ln = lines + line * kHaloLineFloats + j;
-                ln[0] = x;
-                ln[8] = y;
-                ln[16] = z;
-                ln[24] = __int_as_float(fourth);
-            }
-        };
-#pragma unroll
-        for (int p = 0; p < kHaloPrimary / 6; ++p) {
-            reach_mine = INFINITY;
-            write_lines(p * 6 + (lane >> 3), (p * 6 + (lane >> 3)) * 16, true, p * 6 + (lane >> 3), lane < 48);
-            reach_min = fminf(reach_min, reach_mine);
+            float* ln = lines + (lane >> 3) * kHaloLineFloats + (lane & 7);
+            ln[0] = x;
+            ln[8] = y;
+            ln[16] = z;
+            ln[24] = __int_as_float((int)slot);
         }
-        {
-            // extension lines (8 of them: all 64 lanes); unused ones are never named by a primary line
-            const int src = ext_src[lane >> 3];
-            reach_mine = INFINITY;
-            write_lines(kHaloPrimary + (lane >> 3), (src < 0 ? 0 : src) * 16 + 7, false, 0, src >= 0);
-            reach_min = fminf(reach_min, reach_mine);
-        }
-        // near lines: the 7 / 14 / 21 nearest of all; each one's reach covers the lines before it as well
-        reach_mine = INFINITY;
-        write_lines(kHaloNearFirst + (lane >> 3), kHaloPrimary * 16 + 7 * (lane >> 3), false, 0, lane < 8 * kHaloNear);
-        // What the search compares a cube's overhang with before it reads any line: float 7 = the smallest reach
-        // of the face / edge lines, float 3 = the three near reaches as 10-bit fractions of it, rounded down (with
-        // the search's own arithmetic).
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) reach_min = fminf(reach_min, __shfl_xor(reach_min, o, 64));
+        // ---- reaches: ring k ends where the first point behind it begins (none: the bound)
+        uint32_t nx = (uint32_t)__shfl((int)sk[0], (lane < 7) ? 8 * (lane + 1) : 0, 64);  // lanes 0..6: sorted element 8 (k + 1)
+        const uint32_t nx7 = (uint32_t)__shfl((int)sk[1], 0, 64);                         // sorted element 64
+        if (lane == 7) nx = nx7;
         uint32_t q = 0u;
-        if (lane < 8 * kHaloNear && (lane & 7) == 7 && reach_min > 0.0f && reach_min < INFINITY) {
-            const float unit = reach_min * 0.0009765625f;
-            q = (uint32_t)fminf(reach_mine / unit, 1023.0f);
-            while (q > 0u && !(unit * (float)q <= reach_mine)) --q;
+        const uint32_t bbits = __float_as_uint(bound * kHaloShrink) & 0xffff0000u;  // the bound, 16 bits, rounded down
+        const float unit = __uint_as_float(bbits) * kHaloUnit;
+        if (lane < kHaloLines && unit > 0.0f) {
+            const float reach = fminf((nx != 0xffffffffu) ? __uint_as_float(nx & kHaloDistMask) * kHaloShrink : INFINITY,
+                                      __uint_as_float(bbits));
+            q = (uint32_t)fminf(reach / unit, 63.0f);
+            while (q > 0u && !(unit * (float)q <= reach)) --q;  // (the search's own arithmetic)
         }
-        const uint32_t q0 = (uint32_t)__shfl((int)q, 7, 64), q1 = (uint32_t)__shfl((int)q, 15, 64), q2 = (uint32_t)__shfl((int)q, 23, 64);
+        uint32_t wa = 0u, wb = bbits;
+#pragma unroll
+        for (int k = 0; k < kHaloLines; ++k) {
+            const uint32_t qk = (uint32_t)__shfl((int)q, k, 64);
+            if (k < 5) wa |= qk << (6 * k);
+            else if (k < 7) wb |= qk << (6 * (k - 5));
+            else {
+                wa |= (qk & 3u) << 30;
+                wb |= (qk >> 2) << 12;
+            }
+        }
         if (lane == 0) {
-            lreg[(size_t)L * kLeafRegFloats + 3] = __uint_as_float(q0 | (q1 << 10) | (q2 << 20));
-            lreg[(size_t)L * kLeafRegFloats + 7] = (reach_min < INFINITY) ? reach_min : 0.0f;
+            lreg[(size_t)L * kLeafRegFloats + 3] = __uint_as_float(wa);
+            lreg[(size_t)L * kLeafRegFloats + 7] = (unit > 0.0f) ? __uint_as_float(wb) : 0.0f;
         }
-        __builtin_amdgcn_wave_barrier();  // (sel / keys are rewritten by the next leaf)
+        __builtin_amdgcn_wave_barrier();  // (keys are rewritten by the next leaf)
     }
 }
 

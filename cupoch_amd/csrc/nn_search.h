@@ -37,24 +37,32 @@ constexpr int kNNPacketsPerBlock = kNNThreads / 64;
 // item's query comes over ds_bpermute, the leaf's 8 points over per-lane vector loads, the
 // result goes back with an LDS atomic min on (d2 bits << 32 | slot) -- d2 >= 0, so the
 // integer order is the float order and equal distances resolve to the lowest slot.
-constexpr int kHaloFaces = 6;            // faces of a leaf's region (leaf_halo.h)
-constexpr int kHaloPrimary = 18;         // a leaf's primary halo lines: 6 for the faces, 12 for the edges between faces of different axes
-constexpr int kHaloExt = 8;              // ... and its extension lines, given to primary lines that have more than 7 members within the bound
-constexpr int kHaloNear = 3;             // ... and its near lines: the 21 nearest points whatever faces they lie beyond, 7 per line
-constexpr int kHaloNearFirst = kHaloPrimary + kHaloExt;
-constexpr int kHaloLines = kHaloNearFirst + kHaloNear;
-constexpr int kHaloLineFloats = 32;      // x[8] y[8] z[8] slot[8] like a leaf line; x[7] = the line's reach
-constexpr int kItemQueue = 64 + 8 * 64;  // tree walk: a drain leaves < 64 behind, one record adds <= 512; halo phase: 16-bit items, <= 18 per lane
-static_assert(kItemQueue * 2 >= 64 * 18, "a lane through all six faces queues 6 face and 12 edge lines");
+constexpr int kHaloLines = 8;            // halo lines per leaf (leaf_halo.h): the 64 nearest points of other leaves, 8 per line, in rings
+constexpr int kHaloLineFloats = 32;      // x[8] y[8] z[8] slot[8]: a leaf line with the points' slots in its fourth row
+constexpr float kHaloUnit = 1.0f / 64.0f;
+constexpr int kItemQueue = 64 + 8 * 64;  // tree walk: a drain leaves < 64 behind, one record adds <= 512; halo phase: 16-bit items, <= 8 per lane
 
-// Halo line of the edge between faces f < g of different axes (f = 2a + side, g = 2b + side, a < b)
-__host__ __device__ constexpr int halo_edge_line(int f, int g) {
-    return kHaloFaces + ((f >> 1) + (g >> 1) - 1) * 4 + (f & 1) * 2 + (g & 1);
+// The reaches of a leaf's eight halo lines travel in the two spare words of its region record, as 6-bit
+// fractions q_k of the bound (the reach a line has when no point lies behind it): word A = q0 .. q4 from bit 0,
+// the low two bits of q7 on top; word B = q5, q6 from bit 0, the high four bits of q7 from bit 12, the bound
+// -- the upper 16 bits of an fp32, rounded down -- on top; reach k = bound / 64 * q_k, rounded down when packed.
+__host__ __device__ __forceinline__ uint32_t halo_reach_fraction(uint32_t wa, uint32_t wb, int k) {
+    return (k < 5) ? ((wa >> (6 * k)) & 63u) : ((k < 7) ? ((wb >> (6 * (k - 5))) & 63u) : ((wa >> 30) | (((wb >> 12) & 15u) << 2)));
+}
+// How many lines a cube that pokes out of the region by `over` has to read: 1 .. 8, or 9: beyond them all.
+__device__ __forceinline__ uint32_t halo_lines_needed(float wa_f, float wb_f, float over) {
+    const uint32_t wa = __float_as_uint(wa_f), wb = __float_as_uint(wb_f);
+    const float unit = __uint_as_float(wb & 0xffff0000u) * kHaloUnit;
+    uint32_t n = 1u;
+#pragma unroll
+    for (int k = 0; k < kHaloLines; ++k)
+        n += (over < unit * (float)halo_reach_fraction(wa, wb, k)) ? 0u : 1u;  // (NaN: every line and then the walk)
+    return n;
 }
 
 struct PacketShared {
     unsigned long long best[64];  // per lane: d2 bits << 32 | slot
-    uint32_t queue[kItemQueue];   // lane << 26 | leaf (tree walk); as 16-bit entries lane << 5 | line (halo lines)
+    uint32_t queue[kItemQueue];   // lane << 26 | leaf (tree walk); as 16-bit entries lane << 3 | line (halo lines)
 };
 
 // One item: the 8 points of leaf L against query (ox, oy, oz) of lane ql; the result goes to
@@ -136,34 +144,26 @@ __device__ __forceinline__ LineMin line_min(const float4& x0, const float4& x1, 
     return r;
 }
 
-// One batch of HALO items (leaf_halo.h): lane t evaluates halo line `line` of the seed leaf of lane ql --
-// the same 8-point evaluation as a leaf line (the eighth "point" is x = the line's reach, y = z = +inf:
-// infinitely far); a line that beats what its owner holds fetches the winner's slot from the line's fourth
-// row (ascending inside a line, so the first of equal distances is the lowest slot).  A primary line that
-// has an extension (slot[7] >= 0) and does not reach as far as the owner's overhang queues the extension
-// behind the items already there; returns the new end of the queue.  Halo items are 16 bits (lane << 5 |
-// line): 18 per lane at most fit the queue's bytes, so nothing is drained while they are being pushed.
-__device__ __forceinline__ uint32_t drain_halo(PacketShared& sh, const float* halo_g, uint32_t first, uint32_t count,
-                                               uint32_t qend, uint32_t seed_leaf, float over, float qx, float qy, float qz,
-                                               float r2) {
+// One batch of HALO items (leaf_halo.h): lane t evaluates halo line `line` of the seed leaf of lane ql like
+// a leaf line; a line that beats what its owner holds fetches the winner's slot from the line's fourth row
+// (ascending inside a line, so the first of equal distances is the lowest slot).  Halo items are 16 bits
+// (lane << 3 | line).
+__device__ __forceinline__ void drain_halo(PacketShared& sh, const float* halo_g, uint32_t first, uint32_t count,
+                                           uint32_t seed_leaf, float qx, float qy, float qz, float r2) {
     const int lane = lane_id();
-    uint16_t* q16 = reinterpret_cast<uint16_t*>(sh.queue);
+    const uint16_t* q16 = reinterpret_cast<const uint16_t*>(sh.queue);
     const bool have = (uint32_t)lane < count;
     const uint32_t item = have ? (uint32_t)q16[first + (uint32_t)lane] : 0u;
-    const int ql = (int)(item >> 5);
-    const uint32_t f = item & 31u;
+    const int ql = (int)(item >> 3);
+    const uint32_t f = item & 7u;
     const uint32_t L = (uint32_t)__builtin_amdgcn_ds_bpermute(ql << 2, (int)seed_leaf);
     const float ox = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(qx)));
     const float oy = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(qy)));
     const float oz = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(qz)));
-    const float oover = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(over)));
-    bool follow = false;
-    uint32_t ext = 0u;
     if (have) {
         const float* lf = halo_g + ((size_t)L * kHaloLines + f) * kHaloLineFloats;
         const float4* line = reinterpret_cast<const float4*>(lf);
         const float4 x0 = line[0], x1 = line[1], y0 = line[2], y1 = line[3], z0 = line[4], z1 = line[5];
-        const int e = __float_as_int(lf[31]);
         const uint32_t held_bits = (uint32_t)(sh.best[ql] >> 32);  // what the owner holds (or a batch-mate has found)
         const LineMin w = line_min(x0, x1, y0, y1, z0, z1, ox, oy, oz);
         // (equal distances: the lower slot must win, so an equal candidate goes to the atomic as well)
@@ -172,19 +172,7 @@ __device__ __forceinline__ uint32_t drain_halo(PacketShared& sh, const float* ha
             const unsigned long long cand = ((unsigned long long)__float_as_uint(w.m) << 32) | (unsigned long long)slot;
             __hip_atomic_fetch_min(&sh.best[ql], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        follow = e >= 0 && !(oover < x1.w);
-        ext = (uint32_t)e;
     }
-    const uint64_t fmask = __ballot(follow);
-    if (fmask != 0ull) {
-        if (follow) {
-            const uint32_t pos = qend + __builtin_amdgcn_mbcnt_hi((uint32_t)(fmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fmask, 0u));
-            q16[pos] = (uint16_t)(((uint32_t)ql << 5) | ext);
-        }
-        qend += (uint32_t)__popcll(fmask);
-        __builtin_amdgcn_wave_barrier();
-    }
-    return qend;
 }
 
 // What a packet's search leaves in every lane (for callers that go on with it: fused_small.h)
@@ -234,10 +222,8 @@ __device__ __forceinline__ bool nn_packet_body(
     // kernel has 64 registers and the halo phase needs them)
     bool retired = !valid;  // this lane's search is complete
     bool linked = false;    // its cube pokes out of the seed leaf's region by less than that leaf's halo reaches
-    float over = 0.0f;      // ... by this much
-    uint32_t nnear = 0u;    // ... so little that this many of the leaf's near lines hold all it can find (0: face / edge lines); kept in `faces` bits 6, 7
+    uint32_t nlines = 0u;   // ... so that this many of the leaf's halo lines hold all it can find
     uint32_t why = 0u;      // (census) 1: seed leaf without a region, 2: without a halo, 3: overhang beyond its reach
-    uint32_t faces = 0u;    // faces it pokes through
     if (SEED) {
         // The previous iteration's match: its whole LEAF is evaluated right here (one 128-B line,
         // the same the old single-point gather touched), which gives the search radius -- and if
@@ -287,26 +273,16 @@ __device__ __forceinline__ bool nn_packet_body(
             } else {
                 Cube cube;  // (formed again behind the halo phase for the lanes that walk: six registers less across it)
                 set_cube(cube, qx, qy, qz, best);
-                // The cube pokes out of the region: by how much (L-infinity overhang), and through which
-                // faces.  The leaf's halo (leaf_halo.h) serves an overhang below g1.w: one, two or three
-                // NEAR lines -- the leaf's 7 / 14 / 21 nearest points of other leaves, shared by all its
-                // lanes -- up to the three reaches packed into g0.w (10-bit fractions of g1.w), the lines of
-                // the poked faces and the edges between them beyond that.
+                // The cube pokes out of the region: by how much (L-infinity overhang) says how many of the
+                // leaf's halo lines (leaf_halo.h: its nearest points of other leaves, in rings) hold every
+                // point the cube can touch outside its own leaf -- the rings' reaches are packed into the
+                // region record's spare words.
                 const float ux = cube.hix - g1.x, uy = cube.hiy - g1.y, uz = cube.hiz - g1.z;
                 const float lx = g0.x - cube.lox, ly = g0.y - cube.loy, lz = g0.z - cube.loz;
-                over = fmaxf(fmaxf(fmaxf(ux, lx), fmaxf(uy, ly)), fmaxf(uz, lz)) * 1.000001f;
-                faces = (ux > 0.0f ? 1u : 0u) | (lx > 0.0f ? 2u : 0u) | (uy > 0.0f ? 4u : 0u) | (ly > 0.0f ? 8u : 0u) |
-                        (uz > 0.0f ? 16u : 0u) | (lz > 0.0f ? 32u : 0u);
-                linked = halo_g != nullptr && over < g1.w;  // (NaN from inf - inf: false; no halos (yet): walk)
-                const uint32_t pk = __float_as_uint(g0.w);
-                const float unit = g1.w * 0.0009765625f;
-                const float r0 = unit * (float)(pk & 1023u), r1 = unit * (float)((pk >> 10) & 1023u), r2 = unit * (float)((pk >> 20) & 1023u);
-                if (halo_g != nullptr && over < r2) {
-                    linked = true;
-                    nnear = (over < r0) ? 1u : ((over < r1) ? 2u : 3u);
-                }
-                faces |= nnear << 6;
-                if (STATS) why = !(g0.x <= g1.x) ? 1u : (g1.w == 0.0f ? 2u : (!linked ? 3u : 0u));
+                const float over = fmaxf(fmaxf(fmaxf(ux, lx), fmaxf(uy, ly)), fmaxf(uz, lz)) * 1.000001f;
+                nlines = halo_lines_needed(g0.w, g1.w, over);
+                linked = halo_g != nullptr && nlines <= (uint32_t)kHaloLines;  // (no halos (yet), or beyond their reach: walk)
+                if (STATS) why = !(g0.x <= g1.x) ? 1u : (__float_as_uint(g1.w) == 0u ? 2u : (!linked ? 3u : 0u));
             }
         }
     }
@@ -316,24 +292,15 @@ __device__ __forceinline__ bool nn_packet_body(
 
     uint32_t queued = 0u, batches = 0u, halo_items = 0u;  // wave-uniform
     if (SEED && __ballot(linked) != 0ull) {
-        // ---- halo lines (leaf_halo.h).  A lane with a small overhang reads the first one, two or three of
-        // its seed leaf's NEAR lines (the leaf's nearest points of other leaves, whatever they lie beyond;
-        // the same lines for all lanes of the leaf).  Beyond their reach: a point of another leaf that lies
-        // in the cube lies on or beyond one, two or three faces of the seed leaf's region, all of them faces
-        // the cube pokes through; the leaf keeps, per face, the nearest points beyond that face ONLY, and per
-        // edge (two faces of different axes) the nearest beyond both.  So the lines to read follow from
-        // `faces` alone -- one for a lane that pokes through one face, three for two, six for three -- no
-        // scan, no filter.  A line with more members than it holds names its extension line, read when the
-        // overhang calls for it.  With the overhang below the leaf's reaches (tested in the prologue) that
-        // is everything the cube can hold.
+        // ---- halo lines (leaf_halo.h): the first `nlines` of the seed leaf's lines hold every point of another
+        // leaf the cube can touch -- no scan, no filter, and the lanes of a leaf read the same lines.
         const uint32_t seed_leaf = linked ? ((uint32_t)seed_j >> 3) : 0u;
-        const uint32_t nn = linked ? (faces >> 6) : 0u;             // near lines this lane reads
-        const uint32_t fm = (linked && nn == 0u) ? (faces & 63u) : 0u;  // faces whose lines (and edge lines) it reads
-        if (__ballot(fm != 0u || nn > 1u) == 0ull) {
-            // every lane that needs anything needs its leaf's first near line only: each evaluates its own
-            // (no queue, no exchange; the common case of small noise)
+        const uint32_t nn = linked ? nlines : 0u;
+        if (__ballot(nn > 1u) == 0ull) {
+            // every lane that needs anything needs its leaf's first line only: each evaluates its own (no queue,
+            // no exchange; the common case of small noise)
             if (STATS) ++batches, halo_items += (uint32_t)__popcll(__ballot(linked));
-            const float* lf = halo_g + ((size_t)seed_leaf * kHaloLines + kHaloNearFirst) * kHaloLineFloats;
+            const float* lf = halo_g + (size_t)seed_leaf * (kHaloLines * kHaloLineFloats);
             const float4* line = reinterpret_cast<const float4*>(lf);
             const float4 x0 = line[0], x1 = line[1], y0 = line[2], y1 = line[3], z0 = line[4], z1 = line[5];
             if (linked) {
@@ -352,48 +319,26 @@ __device__ __forceinline__ bool nn_packet_body(
                 sh.best[lane] = ((unsigned long long)__float_as_uint(fmaxf(best, 0.0f)) << 32) | (unsigned long long)(uint32_t)bidx;
         } else {
             uint16_t* q16 = reinterpret_cast<uint16_t*>(sh.queue);
-            auto push = [&](bool mine, uint32_t line) {
+#pragma unroll
+            for (int k = 0; k < kHaloLines; ++k) {
+                const bool mine = nn > (uint32_t)k;
                 const uint64_t m = __ballot(mine);
-                if (m != 0ull) {
-                    if (mine) {
-                        const uint32_t pos = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        q16[pos] = (uint16_t)(((uint32_t)lane << 5) | line);
-                    }
-                    queued += (uint32_t)__popcll(m);
+                if (m == 0ull) break;
+                if (mine) {
+                    const uint32_t pos = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    q16[pos] = (uint16_t)(((uint32_t)lane << 3) | (uint32_t)k);
                 }
-            };
-#pragma unroll
-            for (int k = 0; k < kHaloNear; ++k) push(nn > (uint32_t)k, (uint32_t)(kHaloNearFirst + k));
-            if (__ballot(fm != 0u) != 0ull) {
-#pragma unroll
-                for (int f = 0; f < kHaloFaces; ++f) push((fm >> f) & 1u, (uint32_t)f);
-            }
-            if (__ballot((fm & (fm - 1u)) != 0u) != 0ull) {  // some lane pokes through two faces or more
-#pragma unroll
-                for (int f = 0; f < kHaloFaces; ++f)
-#pragma unroll
-                    for (int g = (f | 1) + 1; g < kHaloFaces; ++g) {
-                        const uint32_t both = (1u << f) | (1u << g);
-                        push((fm & both) == both, (uint32_t)halo_edge_line(f, g));
-                    }
+                queued += (uint32_t)__popcll(m);
             }
             __builtin_amdgcn_wave_barrier();
-            // the newest (up to) 64 items at a time; the extensions they ask for (at most as many) take their place
-            while (queued != 0u) {
-                const uint32_t n = min(64u, queued);
-                if (STATS) ++batches, halo_items += n;
-                const uint32_t end = drain_halo(sh, halo_g, queued - n, n, queued, seed_leaf, over, qx, qy, qz, r2);
-                const uint32_t nf = end - queued;  // wave-uniform
-                if (nf != 0u) {
-                    uint16_t v = 0;
-                    if ((uint32_t)lane < nf) v = q16[queued + (uint32_t)lane];
-                    __builtin_amdgcn_wave_barrier();
-                    if ((uint32_t)lane < nf) q16[queued - n + (uint32_t)lane] = v;
-                    __builtin_amdgcn_wave_barrier();
-                }
-                queued = queued - n + nf;
+            if (STATS) halo_items += queued;
+            for (uint32_t first = 0u; first < queued; first += 64u) {
+                if (STATS) ++batches;
+                drain_halo(sh, halo_g, first, min(64u, queued - first), seed_leaf, qx, qy, qz, r2);
             }
+            queued = 0u;
+            __builtin_amdgcn_wave_barrier();
             if (linked) retired = true;
             {  // what the evaluated lines left in this lane's slot
                 const unsigned long long bb = sh.best[lane];

@@ -55,23 +55,18 @@ MI_ICP_API int mi_icp_debug_solve_both(int device, const double* systems, int n,
  * sizes only. */
 MI_ICP_API int mi_icp_debug_get_tree(mi_icp_ctx* ctx, int64_t* info5, float* records_out,
                                      float* leaf_lines_out);
-/* Per leaf (mi_icp_debug_get_tree's info5[1] leaves) 8 floats: region lo.xyz, the reaches of the leaf's
- * three near halo lines as 10-bit fractions (bits 0-9, 10-19, 20-29, in 1/1024) of float 7, region hi.xyz,
- * the smallest reach of the leaf's face / edge halo lines (0: no halo).  The region is free of points of any
- * other leaf (an invalid one is +inf / -inf: nothing is inside). */
+/* Per leaf (mi_icp_debug_get_tree's info5[1] leaves) 8 floats: region lo.xyz, word A, region hi.xyz,
+ * word B.  The region is free of points of any other leaf (an invalid one is +inf / -inf: nothing is
+ * inside).  Words A and B pack the reaches of the leaf's eight halo lines as 6-bit fractions of the bound:
+ * A = q0 .. q4 (6 bits each from bit 0), bits 30-31 the low two bits of q7; B = q5 (bits 0-5), q6 (6-11),
+ * the high four bits of q7 (12-15), the bound (the upper 16 bits of an fp32) on top; reach k = bound / 64 *
+ * q_k.  B = 0: no halo. */
 MI_ICP_API int mi_icp_debug_get_leaf_regions(mi_icp_ctx* ctx, float* regions_out);
-/* Per leaf 29 halo lines of 32 floats (builds them if no seeded search has yet): x[8] y[8] z[8] slot[8].
- * Line f < 6, face f of the leaf's region (+x, -x, +y, -y, +z, -z): the up to 7 points of OTHER leaves
- * nearest to the region (L-infinity distance to the box) among those on or beyond face f and no other
- * face.  Line 6 + ((a + b - 1) * 4 + 2 * side_a + side_b), the edge between the faces 2a + side_a and
- * 2b + side_b of the axes a < b: the up to 7 nearest among those on or beyond both faces.  Points ascend in
- * slot (sorted target position, as an integer's bits; unused entries +inf / -1); x[7] is the line's reach:
- * every member nearer to the region than that is in the line (y[7] = z[7] = +inf).  slot[7] of these 18
- * primary lines: -1, or the one of the lines 18..25 that holds the line's next 7 members and the reach of the
- * two together (lines 18..25 that no primary line names are unwritten).  Lines 26..28: the 7 / 14 / 21
- * points of other leaves nearest to the region whatever faces they lie beyond; x[7] of line 26 + k: every
- * point of another leaf nearer than that is in the lines 26 .. 26 + k.  Call mi_icp_debug_get_leaf_regions
- * afterwards for the regions. */
+/* Per leaf 8 halo lines of 32 floats (builds them if no seeded search has yet): x[8] y[8] z[8] slot[8] --
+ * line k holds the points of OTHER leaves that are 8k+1-th .. 8k+8-th nearest to the leaf's region
+ * (L-infinity distance to the box), ascending in slot (sorted target position, as an integer's bits; unused
+ * entries +inf / -1).  Every point of another leaf nearer to the region than reach k is in the lines 0 .. k.
+ * Call mi_icp_debug_get_leaf_regions afterwards for the regions and reaches. */
 MI_ICP_API int mi_icp_debug_get_leaf_halos(mi_icp_ctx* ctx, float* halos_out);
 #ifdef __cplusplus
 }

@@ -99,92 +99,59 @@ def check_tree(eng, pts, expect_all_flagged):
     return flagged, total
 
 
-def halo_lines():
-    """(line, faces that a member lies beyond, exact?) for the 18 halo lines of a leaf (leaf_halo.h)."""
-    out = [(f, (f,), True) for f in range(6)]
-    for f in range(6):
-        for g in range((f | 1) + 1, 6):
-            out.append((6 + ((f >> 1) + (g >> 1) - 1) * 4 + (f & 1) * 2 + (g & 1), (f, g), False))
-    return out
+def halo_reaches(wa, wb):
+    """The eight reaches packed into a region record's floats 3 and 7 (nn_search.h: halo_reach_fraction)."""
+    wa, wb = int(wa), int(wb)
+    unit = np.array([wb & 0xffff0000], np.uint32).view(np.float32)[0] * np.float32(1.0 / 64.0)
+    q = [(wa >> (6 * k)) & 63 for k in range(5)] + [(wb >> (6 * k)) & 63 for k in range(2)] + [(wa >> 30) | (((wb >> 12) & 15) << 2)]
+    return [np.float32(unit * np.float32(v)) for v in q]
 
 
 def check_leaf_halos(eng, nleaf, xyz, finite):
     """The halo lines (leaf_halo.h) of a leaf with region R hold points of OTHER leaves with their true
-    coordinates and slots, ascending in slot: face line f the points on or beyond face f of R and no other
-    face, edge line (f, g) those on or beyond both; EVERY such point that is nearer to R (L-infinity distance
-    to the box) than the line's reach (x[7]) is in the line -- or, where the line names an extension line
-    (slot[7] >= 18), nearer than the extension's reach in one of the two; the region record's float 3 is the
-    smallest of these reaches.  Lines 26..28 are the NEAR lines: the 7 / 14 / 21 nearest points of other
-    leaves whatever they lie beyond, each line's reach covering the lines before it; the region record's float
-    3 packs their reaches as three 10-bit fractions of float 7, rounded down."""
-    NL = 29
+    coordinates and slots, ascending in slot inside a line; EVERY point of another leaf that is nearer to R
+    (L-infinity distance to the box) than reach k -- packed into the region record -- is in the lines 0 .. k;
+    the reaches ascend."""
+    NL = 8
     halos = np.empty((nleaf, NL, 32), np.float32)
     eng._chk(eng._L.mi_icp_debug_get_leaf_halos(eng._ctx, halos.ctypes.data_as(C.c_void_p)))
     reg = np.empty((nleaf, 8), np.float32)
     eng._chk(eng._L.mi_icp_debug_get_leaf_regions(eng._ctx, reg.ctypes.data_as(C.c_void_p)))
-    lo, hi, reach_min, packed = reg[:, 0:3], reg[:, 4:7], reg[:, 7], reg[:, 3].copy().view(np.uint32)
-    have = np.flatnonzero(reach_min > 0)
+    lo, hi = reg[:, 0:3], reg[:, 4:7]
+    wa, wb = reg[:, 3].copy().view(np.uint32), reg[:, 7].copy().view(np.uint32)
+    have = np.flatnonzero(wb != 0)
     if os.environ.get("MI_ICP_NO_CELLS") is not None or os.environ.get("MI_ICP_NO_LINKS") is not None:
         assert len(have) == 0
         return 0
     leaf_of = np.arange(len(xyz)) // 8
     pts = xyz.astype(np.float64)
-    lines = halo_lines()
-    assert sorted(l for l, _, _ in lines) == list(range(18))
-    with_points = extended = 0
-
-    def read_line(L, line_no, member):
-        line = halos[L, line_no]
-        slots = line[24:31].copy().view(np.int32)
-        used = slots >= 0
-        assert (np.diff(slots[used]) > 0).all(), (int(L), line_no, slots)
-        assert used.all() or not used[np.argmin(used):].any()                         # unused entries at the end
-        got = np.stack([line[0:7], line[8:15], line[16:23]], -1)
-        assert np.array_equal(got[used], xyz[slots[used]]), (int(L), line_no)
-        assert np.isinf(got[~used]).all()
-        assert np.isinf(line[15]) and np.isinf(line[23])                              # the reach is no point
-        assert member[slots[used]].all(), (int(L), line_no, "not a member: the leaf's own, or beyond other faces")
-        return set(slots[used].tolist()), float(line[7]), int(line[31:32].copy().view(np.int32)[0])
-
+    with_points = long_reach = 0
     for L in np.random.default_rng(6).permutation(have)[:300]:
         foreign = finite & (leaf_of != L)
         up = pts - hi[L].astype(np.float64)                   # >= 0: on or beyond the upper face
         dn = lo[L].astype(np.float64) - pts                   # >= 0: on or beyond the lower face
         with np.errstate(invalid="ignore"):
             dist = np.maximum(np.maximum(up, dn).max(1), 0.0)
-            beyond = np.stack([up[:, 0] >= 0, dn[:, 0] >= 0, up[:, 1] >= 0, dn[:, 1] >= 0, up[:, 2] >= 0, dn[:, 2] >= 0], 1)
-        final_reaches, named = [], set()
-        for line_no, faces, exact in lines:
-            member = foreign & beyond[:, list(faces)].all(1)
-            if exact:
-                member &= beyond.sum(1) == 1
-            seen, reach, ext = read_line(L, line_no, member)
-            must = np.flatnonzero(member & (dist < reach))
-            assert set(must.tolist()) <= seen, (int(L), line_no, reach, must[:5], sorted(seen))
-            if ext >= 0:
-                assert 18 <= ext < NL and ext not in named and len(seen) == 7, (int(L), line_no, ext)
-                named.add(ext)
-                more, reach2, none = read_line(L, ext, member)
-                assert none == -1 and reach2 >= reach and not (seen & more)
-                must = np.flatnonzero(member & (dist < reach2))
-                assert set(must.tolist()) <= (seen | more), (int(L), line_no, ext, reach2, must[:5])
-                reach = reach2
-                extended += 1
-            final_reaches.append(reach)
-            with_points += int(bool(seen))
-        assert np.isclose(float(reach_min[L]), min(final_reaches), rtol=1e-6), (int(L), reach_min[L], final_reaches)
+        reaches = halo_reaches(wa[L], wb[L])
+        assert all(reaches[k] <= reaches[k + 1] for k in range(NL - 1)), (int(L), reaches)
         seen = set()
-        for k in range(3):
-            more, reach, none = read_line(L, 26 + k, foreign)
-            assert none == -1 and not (seen & more)
-            seen |= more
-            must = np.flatnonzero(foreign & (dist < reach))
-            assert set(must.tolist()) <= seen, (int(L), "near", k, reach, must[:5])
-            q = (int(packed[L]) >> (10 * k)) & 1023
-            promised = np.float32(reach_min[L]) * np.float32(0.0009765625) * np.float32(q)
-            assert promised <= np.float32(reach), (int(L), "near", k, promised, reach)
-            assert promised >= 0.99 * min(float(reach), float(reach_min[L])) - 2e-3 * float(reach_min[L])
-    assert len(have) == 0 or with_points > 0
+        for k in range(NL):
+            must = np.flatnonzero(foreign & (dist < float(reaches[k])))
+            line = halos[L, k]
+            slots = line[24:32].copy().view(np.int32)
+            used = slots >= 0
+            assert (np.diff(slots[used]) > 0).all(), (int(L), k, slots)
+            assert used.all() or not used[np.argmin(used):].any()                         # unused entries at the end
+            got = np.stack([line[0:8], line[8:16], line[16:24]], -1)
+            assert np.array_equal(got[used], xyz[slots[used]]), (int(L), k)
+            assert np.isinf(got[~used]).all()
+            assert foreign[slots[used]].all(), (int(L), k, "the leaf's own point, or padding")
+            assert not (seen & set(slots[used].tolist()))
+            seen |= set(slots[used].tolist())
+            assert set(must.tolist()) <= seen, (int(L), k, float(reaches[k]), must[:5])
+            with_points += int(used.any())
+        long_reach += int(float(reaches[NL - 1]) > 0)
+    assert len(have) == 0 or (with_points > 0 and long_reach > 0)
     return len(have)
 
 
