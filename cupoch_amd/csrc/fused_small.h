@@ -24,7 +24,7 @@ __global__ __launch_bounds__(kReduceThreads) void icp_small_iteration_kernel(
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int ns,
         const float* __restrict__ records_g, const float* __restrict__ tblk_g, const float* __restrict__ lreg_g,
         const float* __restrict__ halo_g, uint32_t leaf_first, float r2, uint32_t npackets, uint32_t nblocks,
-        int32_t* __restrict__ nn_idx, const float* __restrict__ trec, DevLoop* __restrict__ loop,
+        int32_t* __restrict__ nn_idx, uint32_t* __restrict__ want, const float* __restrict__ trec, DevLoop* __restrict__ loop,
         double* __restrict__ partial, uint32_t* __restrict__ ticket, double* __restrict__ out32) {
     __shared__ PacketShared s_pk[kFusedPackets];
     if (loop->done) return;  // (every wave of every workgroup alike)
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kReduceThreads) void icp_small_iteration_kernel(
     if (in_range && packet < npackets) {
         const Xform none = {};
         (void)nn_packet_body<true, false>(s_pk[wid], packet, sx, sy, sz, ns, records_g, tblk_g, lreg_g, halo_g, leaf_first,
-                                          none, loop, r2, nn_idx, nullptr, nullptr, r);
+                                          none, loop, r2, nn_idx, nullptr, nullptr, want, r);
     }
     // ---- this lane's row of the system (reduce_pt2pl_kernel's arithmetic): J[6], residual, d2 into LDS
     // ([component][lane], component stride 65 floats: the sums below read one column per lane group without

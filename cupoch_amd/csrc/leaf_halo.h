@@ -124,6 +124,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     lreg[(size_t)L * kLeafRegFloats + 7] = __int_as_float(count);
 }
 
+// inclusive prefix sum over the wave on the DPP network (row_shr 1, 2, 4, 8 scan each row of 16 lanes,
+// row_bcast:15 / row_bcast:31 carry the row totals across)
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 // lane ^ J's value of v for a compile-time J < 64: DPP inside a quad, ds_swizzle (no address register, no memory)
 // inside 32 lanes, ds_bpermute across the halves
 template <int J>
@@ -159,6 +171,21 @@ __device__ __forceinline__ void halo_sort_merges(uint32_t (&key)[2], int lane) {
 }
 // Wave-wide bitonic sort of 128 keys, ascending: element e = r * 64 + lane.
 __device__ __forceinline__ void halo_sort128(uint32_t (&key)[2], int lane) { halo_sort_merges<128>(key, lane); }
+
+// ... of 64 keys, one per lane
+template <int K, int J>
+__device__ __forceinline__ void halo_sort64_stage(uint32_t& key, int lane) {
+    const bool asc = (K == 64) ? true : ((lane & K) == 0);
+    const uint32_t o = lane_xor<J>(key);
+    key = (((lane & J) == 0) == asc) ? min(key, o) : max(key, o);
+    if constexpr (J > 1) halo_sort64_stage<K, J / 2>(key, lane);
+}
+template <int K>
+__device__ __forceinline__ void halo_sort64_merges(uint32_t& key, int lane) {
+    if constexpr (K > 2) halo_sort64_merges<K / 2>(key, lane);
+    halo_sort64_stage<K, K / 2>(key, lane);
+}
+__device__ __forceinline__ void halo_sort64(uint32_t& key, int lane) { halo_sort64_merges<64>(key, lane); }
 
 constexpr int kHaloWaves = 4;                    // waves per workgroup = per tile of 64 leaves
 constexpr uint32_t kHaloDistMask = 0xfffffe00u;  // key: 23 bits of the distance | 9 of the point's index
@@ -203,72 +230,88 @@ __global__ __launch_bounds__(64 * kHaloWaves) void leaf_halo_build(float* __rest
             }
             continue;
         }
-        // ---- gather: round r covers candidates 8r .. 8r+7, lane = (candidate, slot); key = distance to the
-        // region (L-infinity distance to the box; 23 bits, rounded down) | index of the point in the gather
-        const int rounds = (count + 7) >> 3;
+        // ---- gather: round r covers candidates 32r .. 32r+31, lane = (candidate, half of its line): three 16-byte
+        // loads bring four points (12 one-float loads per leaf cost the texture path more than everything else here);
+        // key = distance to the region (L-infinity distance to the box; 23 bits, rounded down) | index of the point
+        // = candidate * 8 + slot
+        const int rounds = (count + 31) >> 5;
         uint32_t key[8];
         {
-            float px[8], py[8], pz[8];
+            float4 px[2], py[2], pz[2];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                px[r] = py[r] = pz[r] = INFINITY;
+            for (int r = 0; r < 2; ++r) {
+                px[r] = py[r] = pz[r] = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
                 if (r < rounds) {
-                    const int c = r * 8 + (lane >> 3);
+                    const int c = r * 32 + (lane >> 1);
                     if (c < count) {
                         const uint32_t id = s_ids[li * 65 + c] & kLinkIdMask;
-                        const float* ln = tblk + (size_t)id * kLeafFloats + (lane & 7);
+                        const float4* ln = reinterpret_cast<const float4*>(tblk + (size_t)id * kLeafFloats) + (lane & 1);
                         px[r] = ln[0];
-                        py[r] = ln[8];
-                        pz[r] = ln[16];
+                        py[r] = ln[2];
+                        pz[r] = ln[4];
                     }
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                key[r] = 0xffffffffu;
-                if (r < rounds) {
-                    const float ux = px[r] - g1.x, lx = g0.x - px[r], uy = py[r] - g1.y, ly = g0.y - py[r];
-                    const float uz = pz[r] - g1.z, lz = g0.z - pz[r];
-                    const float dist = fmaxf(fmaxf(fmaxf(ux, lx), fmaxf(uy, ly)), fmaxf(fmaxf(uz, lz), 0.0f));
-                    // (padding slots are +inf: dist = +inf; NaN coordinates compare false)
-                    if (dist < INFINITY) key[r] = (__float_as_uint(dist) & kHaloDistMask) | (uint32_t)(r * 64 + lane);
+            for (int r = 0; r < 2; ++r) {
+                const float xs[4] = {px[r].x, px[r].y, px[r].z, px[r].w}, ys[4] = {py[r].x, py[r].y, py[r].z, py[r].w};
+                const float zs[4] = {pz[r].x, pz[r].y, pz[r].z, pz[r].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    key[r * 4 + j] = 0xffffffffu;
+                    if (r < rounds) {
+                        const float ux = xs[j] - g1.x, lx = g0.x - xs[j], uy = ys[j] - g1.y, ly = g0.y - ys[j];
+                        const float uz = zs[j] - g1.z, lz = g0.z - zs[j];
+                        const float dist = fmaxf(fmaxf(fmaxf(ux, lx), fmaxf(uy, ly)), fmaxf(fmaxf(uz, lz), 0.0f));
+                        // (padding slots are +inf: dist = +inf; NaN coordinates compare false)
+                        if (dist < INFINITY)
+                            key[r * 4 + j] = (__float_as_uint(dist) & kHaloDistMask) | (uint32_t)((r * 32 + (lane >> 1)) * 8 + (lane & 1) * 4 + j);
+                    }
                 }
             }
         }
         // ---- the points nearer than the bound, at most 128 of them (halve the bound until they are)
-        uint32_t n_in;
+        const int nk = rounds * 4;  // keys in use
+        // (a lane's keys go to consecutive places: its count of them, a wave-wide scan of the counts, then one LDS
+        // store per key -- a ballot and two bit counts per key register were a tenth of this kernel's instructions)
+        uint32_t n_in, mine, incl;
         for (;;) {
             const uint32_t bb = __float_as_uint(bound);
-            n_in = 0u;
+            mine = 0u;
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-                if (r < rounds) n_in += (uint32_t)__popcll(__ballot(key[r] != 0xffffffffu && (key[r] & kHaloDistMask) < bb));
+            for (int t = 0; t < 8; ++t)
+                if (t < nk) {
+                    if ((key[t] & kHaloDistMask) >= bb) key[t] = 0xffffffffu;  // (also the invalid ones: all bits set)
+                    mine += (key[t] != 0xffffffffu) ? 1u : 0u;
+                }
+            incl = wave_inclusive_sum(mine);
+            n_in = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             if (n_in <= 128u) break;
             bound *= 0.5f;  // (reaches 0 eventually: nothing is nearer than that)
         }
         {
-            const uint32_t bb = __float_as_uint(bound);
-            uint32_t base = 0u;
+            uint32_t pos = incl - mine;
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-                if (r < rounds) {
-                    const bool in = key[r] != 0xffffffffu && (key[r] & kHaloDistMask) < bb;
-                    const uint64_t m = __ballot(in);
-                    if (in) keys[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = key[r];
-                    base += (uint32_t)__popcll(m);
+            for (int t = 0; t < 8; ++t)
+                if (t < nk) {
+                    if (key[t] != 0xffffffffu) keys[pos++] = key[t];
                 }
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t sk[2];
         sk[0] = ((uint32_t)lane < n_in) ? keys[lane] : 0xffffffffu;
-        sk[1] = ((uint32_t)lane + 64u < n_in) ? keys[64 + lane] : 0xffffffffu;
-        halo_sort128(sk, lane);
+        sk[1] = 0xffffffffu;
+        if (n_in <= 64u) {  // (about half of the leaves on uniform data: a third of the larger network's exchanges)
+            halo_sort64(sk[0], lane);
+        } else {
+            sk[1] = ((uint32_t)lane + 64u < n_in) ? keys[64 + lane] : 0xffffffffu;
+            halo_sort128(sk, lane);
+        }
         // ---- the rings: sorted elements 8k .. 8k+7 are line k, i.e. lane = (line, entry) holds its point already
         uint32_t slot = 0xffffffffu;
         if (lane < 8 * kHaloLines && sk[0] != 0xffffffffu) {
-            const uint32_t idx = sk[0] & 511u;  // r * 64 + lane of the gather: candidate 8r + lane/8, slot lane%8
-            const uint32_t c = (idx >> 6) * 8u + ((idx >> 3) & 7u);
-            slot = (s_ids[li * 65 + (int)c] & kLinkIdMask) * (uint32_t)kLeaf + (idx & 7u);
+            const uint32_t idx = sk[0] & 511u;  // candidate * 8 + slot
+            slot = (s_ids[li * 65 + (int)(idx >> 3)] & kLinkIdMask) * (uint32_t)kLeaf + (idx & 7u);
         }
         // a line's entries ascend in slot (equal distances must resolve to the lowest slot: nn_search.h takes the
         // first of equals inside a line)
@@ -299,26 +342,30 @@ __global__ __launch_bounds__(64 * kHaloWaves) void leaf_halo_build(float* __rest
         uint32_t nx = (uint32_t)__shfl((int)sk[0], (lane < 7) ? 8 * (lane + 1) : 0, 64);  // lanes 0..6: sorted element 8 (k + 1)
         const uint32_t nx7 = (uint32_t)__shfl((int)sk[1], 0, 64);                         // sorted element 64
         if (lane == 7) nx = nx7;
-        uint32_t q = 0u;
         const uint32_t bbits = __float_as_uint(bound * kHaloShrink) & 0xffff0000u;  // the bound, 16 bits, rounded down
         const float unit = __uint_as_float(bbits) * kHaloUnit;
+        uint32_t pa = 0u, pb = 0u;  // this lane's bits of the two words (halo_reach_fraction)
         if (lane < kHaloLines && unit > 0.0f) {
             const float reach = fminf((nx != 0xffffffffu) ? __uint_as_float(nx & kHaloDistMask) * kHaloShrink : INFINITY,
                                       __uint_as_float(bbits));
-            q = (uint32_t)fminf(reach / unit, 63.0f);
+            uint32_t q = (uint32_t)fminf(reach * __builtin_amdgcn_rcpf(unit) + 1.0f, 63.0f);
             while (q > 0u && !(unit * (float)q <= reach)) --q;  // (the search's own arithmetic)
-        }
-        uint32_t wa = 0u, wb = bbits;
-#pragma unroll
-        for (int k = 0; k < kHaloLines; ++k) {
-            const uint32_t qk = (uint32_t)__shfl((int)q, k, 64);
-            if (k < 5) wa |= qk << (6 * k);
-            else if (k < 7) wb |= qk << (6 * (k - 5));
+            if (lane < 5) pa = q << (6 * lane);
+            else if (lane < 7) pb = q << (6 * (lane - 5));
             else {
-                wa |= (qk & 3u) << 30;
-                wb |= (qk >> 2) << 12;
+                pa = (q & 3u) << 30;
+                pb = (q >> 2) << 12;
             }
         }
+        // OR over the lanes 0..7 (one row of the DPP network)
+        pa |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pa, 0x111, 0xf, 0xf, false);  // row_shr:1
+        pb |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pb, 0x111, 0xf, 0xf, false);
+        pa |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pa, 0x112, 0xf, 0xf, false);  // row_shr:2
+        pb |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pb, 0x112, 0xf, 0xf, false);
+        pa |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pa, 0x114, 0xf, 0xf, false);  // row_shr:4
+        pb |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pb, 0x114, 0xf, 0xf, false);
+        const uint32_t wa = (uint32_t)__builtin_amdgcn_readlane((int)pa, 7);
+        const uint32_t wb = bbits | (uint32_t)__builtin_amdgcn_readlane((int)pb, 7);
         if (lane == 0) {
             lreg[(size_t)L * kLeafRegFloats + 3] = __uint_as_float(wa);
             lreg[(size_t)L * kLeafRegFloats + 7] = (unit > 0.0f) ? __uint_as_float(wb) : 0.0f;

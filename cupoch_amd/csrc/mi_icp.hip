@@ -105,7 +105,13 @@ struct mi_icp_ctx {
     hipEvent_t ev_fork = nullptr, ev_links = nullptr;
     bool links_inflight = false;
     int last_search_kind = -1;  // mi_icp_debug.h
-    bool ran_loop = false;  // a context that has registered before builds the lists right behind the tree
+    // Halos are built when a registration loop's searches ask for them (nn_search.h counts the lanes one would
+    // serve): clean data never does.  A context whose loops have asked before starts the build with the loop.
+    bool halo_sticky = false;
+    bool ran_loop = false;  // (a context that has registered before and gets a SMALL target starts the build behind the tree)
+    bool halo_declined = false;  // this loop's searches have been looked at and did not ask
+    bool halo_use = false;       // the loop's launches take the halos (looked up once per chunk: an event query costs microseconds)
+    DevBuf halo_want;            // the counter (one word)
 
     // ---- source (Morton order) ----
     int64_t ns = 0, ns_global = 0;
@@ -471,7 +477,8 @@ int build_links(mi_icp_ctx* c, hipStream_t st) {
     return MI_ICP_OK;
 }
 
-// The lists must be complete before the next kernel on the context's stream reads them.
+// The halos must be complete before the next kernel on the context's stream reads them (one-shot searches,
+// tests, the debug export: builds them on the spot if nobody has yet).
 int ensure_links(mi_icp_ctx* c) {
     if (c->nt <= 0) return MI_ICP_OK;
     if (c->links_inflight) {
@@ -485,13 +492,23 @@ int ensure_links(mi_icp_ctx* c) {
     return MI_ICP_OK;
 }
 
-// Start the build on the private stream (behind everything enqueued on the context's stream so
-// far).  Callers: mi_icp_set_target on a context that has registered before (the build then runs next
-// to the staging of the source) and the registration loop before a first pass from the root, which
-// does not read the lists -- the two run side by side.
+// Are they there?  Never waits: a build in flight counts once its event has completed.
+bool halo_poll(mi_icp_ctx* c) {
+    if (c->links_inflight && hipEventQuery(c->ev_links) == hipSuccess) {
+        c->links_inflight = false;
+        c->links_ready = true;
+    }
+    (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+    static const bool no_links = std::getenv("MI_ICP_NO_LINKS") != nullptr;
+    return c->links_ready && c->links_allowed && !no_links && c->thalo.p != nullptr;
+}
+
+// Start the build on the private stream (behind everything enqueued on the context's stream so far); the
+// registration loop goes on meanwhile and uses the halos from the first chunk of iterations that finds them done.
 int start_links_async(mi_icp_ctx* c) {
     static const bool sync_links = std::getenv("MI_ICP_LINKS_SYNC") != nullptr;  // A/B switch
-    if (c->nt <= 0 || c->links_ready || c->links_inflight || sync_links) return MI_ICP_OK;
+    if (c->nt <= 0 || c->links_ready || c->links_inflight || !c->links_allowed) return MI_ICP_OK;
+    if (sync_links) return ensure_links(c);
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
     TRY(build_links(c, c->side));
@@ -512,7 +529,7 @@ int drain_links(mi_icp_ctx* c) {
 }
 
 // ---- nearest-neighbour pass --------------------------------------------------
-constexpr int64_t kWaitForLinksMin = 2000000;  // sources below this do not wait for a list build in flight (loop_begin)
+constexpr int64_t kHaloAheadMax = 2000000;  // targets below this get their halos right behind the tree on a context that has registered before
 // sources of at least this many points make their own seeds for a first pass (tuning knob MI_ICP_COARSE_MIN)
 static int64_t coarse_first_min() {
     static const int64_t v = [] { const char* s = std::getenv("MI_ICP_COARSE_MIN"); return s ? std::atoll(s) : (int64_t)1 << 16; }();
@@ -535,9 +552,19 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
     }
     const Xform X = make_xform(T);
     const bool use_seed = seed && c->nn_valid;
-    if (use_seed) TRY(ensure_links(c));
+    // Inside a registration loop the halos are used if they are there and asked for if they are not (loop_run
+    // decides about building them); a one-shot seeded search builds them on the spot.
+    static const bool always_wait = std::getenv("MI_ICP_WAIT_LINKS") != nullptr;  // A/B switch (soak tests)
+    if (!loop && use_seed) TRY(ensure_links(c));
+    if (loop && always_wait) {
+        TRY(start_links_async(c));
+        TRY(ensure_links(c));
+        c->halo_use = halo_poll(c);
+    }
+    const bool have_halo = loop ? c->halo_use : halo_poll(c);
     EvTimer t(c, 0, loop != nullptr);
-    const float* links = (const float*)c->thalo.p;
+    const float* links = have_halo ? (const float*)c->thalo.p : nullptr;
+    uint32_t* want = (loop && !have_halo && !c->links_inflight && !c->halo_declined && c->links_allowed) ? (uint32_t*)c->halo_want.p : nullptr;
     bool self_seeded = false;
     static const bool no_coarse = std::getenv("MI_ICP_NO_COARSE_FIRST") != nullptr;  // A/B switch
     auto launch = [&](bool seeded, const float* sx, const float* sy, const float* sz, int64_t ns, int32_t* out_idx,
@@ -546,7 +573,7 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
         const uint32_t nblocks = (npackets + kNNPacketsPerBlock - 1) / kNNPacketsPerBlock;
         const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
 #define MI_NN_ARGS sx, sy, sz, (int)ns, (const float*)c->nodes.p, (const float*)c->tblk.p, (const float*)c->tlreg.p, \
-                   links, c->leaf_first, X, loop, r2, nblocks, out_idx, out_d2, stats
+                   links, c->leaf_first, X, loop, r2, nblocks, out_idx, out_d2, stats, want
         if (stats) {
             if (seeded) nn_packet_kernel<true, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
             else nn_packet_kernel<false, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
@@ -556,9 +583,11 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
         }
 #undef MI_NN_ARGS
     };
-    if (!use_seed && !stats && !no_coarse && c->links_ready && !c->links_inflight && c->ns >= coarse_first_min()) {
-        // No previous matches, but the leaves' neighbour lists are there: every query takes the leaf a
-        // greedy descent lands in as its seed (nn_search.h: locate_leaves) and the seeded search does the rest.
+    // No previous matches, but the target's halos are there: every query takes the leaf a greedy descent lands in
+    // as its seed (nn_search.h: locate_leaves) and the seeded search does the rest.  (Without halos every lane
+    // whose seed leaf's region does not finish it walks up from there -- under the displacement a registration
+    // starts with that is most packets, and costs more than the walk from the root: 10M points 3.9 against 1.2 ms.)
+    if (!use_seed && !stats && !no_coarse && c->leaf_first > 1u && c->ns >= coarse_first_min() && have_halo) {
         locate_leaves<<<blocks_for(c->ns), 256, 0, c->stream>>>((const float*)c->sx.p, (const float*)c->sy.p,
                                                                 (const float*)c->sz.p, (int)c->ns,
                                                                 (const float*)c->nodes.p, c->leaf_first,
@@ -928,7 +957,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
     if (c->ev_links) (void)hipEventDestroy(c->ev_links);
     mailbox_close(c);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    DevBuf* all[] = {&c->trec, &c->tlreg, &c->thalo, &c->tlinks_tmp, &c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
+    DevBuf* all[] = {&c->trec, &c->tlreg, &c->thalo, &c->tlinks_tmp, &c->halo_want, &c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
                      &c->cell_gstart, &c->sx, &c->sy, &c->sz,
                      &c->sperm, &c->snrm, &c->scov, &c->nn_idx, &c->nn_d2, &c->inv_s,
                      &c->user_pairs, &c->keys0, &c->keys1, &c->vals0, &c->vals1, &c->hist,
@@ -1105,9 +1134,11 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     c->nleaf = nleaf;
     c->leaf_first = leaf_first;
     c->nrecords = nrecords;
-    // A context that has run a registration loop will run another: the lists are started now, on the
-    // private stream, next to the staging of the source (its first pass then has them, see loop_begin).
-    if (c->ran_loop && c->links_allowed) TRY(start_links_async(c));
+    // A context that has run a registration loop will run another.  For a small target (frame-to-frame callers:
+    // KinFu, odometry) the halos are started right away, on the private stream, next to the staging of the source:
+    // they cost that little, and the loop's first seeded iterations find them ready.  For a large one the build
+    // would fight the staging for the memory system; there the loop's own searches say whether it is wanted.
+    if (c->ran_loop && c->links_allowed && n < kHaloAheadMax) TRY(start_links_async(c));
     if (c->profiling) {
         (void)hipEventRecord(e1, c->stream);
         (void)hipStreamSynchronize(c->stream);
@@ -1474,7 +1505,14 @@ static bool fused_iteration_applies(const mi_icp_ctx* c, bool seed) {
 }
 
 static int launch_fused_iteration(mi_icp_ctx* c, DevLoop* d) {
-    TRY(ensure_links(c));
+    static const bool always_wait = std::getenv("MI_ICP_WAIT_LINKS") != nullptr;  // A/B switch (soak tests)
+    if (always_wait) {
+        TRY(start_links_async(c));
+        TRY(ensure_links(c));
+        c->halo_use = halo_poll(c);
+    }
+    const bool have_halo = c->halo_use;
+    uint32_t* want = (!have_halo && !c->links_inflight && !c->halo_declined && c->links_allowed) ? (uint32_t*)c->halo_want.p : nullptr;
     const uint32_t npackets = (uint32_t)((c->ns + 63) / 64);
     const uint32_t nblocks = (npackets + kFusedPackets - 1) / kFusedPackets;
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
@@ -1489,8 +1527,8 @@ static int launch_fused_iteration(mi_icp_ctx* c, DevLoop* d) {
     EvTimer t(c, 0, true);
     icp_small_iteration_kernel<<<grid, kReduceThreads, 0, c->stream>>>(
             (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns, (const float*)c->nodes.p,
-            (const float*)c->tblk.p, (const float*)c->tlreg.p, (const float*)c->thalo.p, c->leaf_first, c->loop_r2, npackets,
-            nblocks, (int32_t*)c->nn_idx.p, (const float*)c->trec.p, d, partial, (uint32_t*)c->ticket.p, sys);
+            (const float*)c->tblk.p, (const float*)c->tlreg.p, have_halo ? (const float*)c->thalo.p : nullptr, c->leaf_first,
+            c->loop_r2, npackets, nblocks, (int32_t*)c->nn_idx.p, want, (const float*)c->trec.p, d, partial, (uint32_t*)c->ticket.p, sys);
     KCHK(c);
     c->last_search_kind = 1;
     return MI_ICP_OK;
@@ -1513,18 +1551,49 @@ static int loop_enqueue_evaluation(mi_icp_ctx* c, bool seed) {
     return MI_ICP_OK;
 }
 
-// Enqueue up to `budget` iterations in chunks, looking at `done` between chunks.
+// Enqueue up to `budget` iterations in chunks, looking at `done` between chunks -- and, while the target has
+// no halos, at how many lanes of the seeded searches asked for one.  The first seeded iteration of a
+// registration is still displaced and asks whatever the data; the second one tells noise from convergence.  So a
+// large source's first two seeded iterations are chunks of their own, and if the second still has more than ~3 %
+// of the lanes asking, the build is started on the private stream; the chunks stay short until it is done (every
+// launch takes the halos if they are there, launch_nn).  Small sources (a walk costs them little, a host
+// synchronisation much) decide at their first regular chunk's end.
 static int loop_run(mi_icp_ctx* c, int budget) {
     constexpr int kChunk = 8;
+    constexpr int64_t kLarge = 500000;
+    int64_t asked_before = 0;
+    int looked = 0;
     while (budget > 0) {
+        const bool undecided = !c->links_ready && !c->links_inflight && !c->halo_declined && c->links_allowed && c->nt > 0;
         // (a short remainder rides along: one host synchronisation less than it would cost)
-        const int n = (budget <= kChunk + kChunk / 2) ? budget : kChunk;
+        int n = (budget <= kChunk + kChunk / 2) ? budget : kChunk;
+        if (c->ns >= kLarge) {
+            if (undecided) n = 1;
+            else if (c->links_inflight) n = std::min(n, 4);
+        }
         const int passes_before = c->loop_host->passes;
+        // (a small source lets its stream wait for a build in flight -- tens of microseconds -- rather than walk)
+        if (c->links_inflight && c->ns < kLarge) TRY(ensure_links(c));
+        c->halo_use = halo_poll(c);
         for (int i = 0; i < n; ++i) TRY(loop_enqueue_evaluation(c, true));
+        if (undecided) HIPCHK(c, hipMemcpyAsync(c->u_host + 8, c->halo_want.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         TRY(loop_pull(c));
-        collect_pooled(c, c->loop_host->passes - passes_before);
+        const int executed = c->loop_host->passes - passes_before;
+        collect_pooled(c, executed);
         budget -= n;
         if (c->loop_host->done) break;
+        if (undecided) {
+            const int64_t asked = (int64_t)c->u_host[8] - asked_before;  // by this chunk's iterations
+            asked_before = (int64_t)c->u_host[8];
+            ++looked;
+            const bool many = asked * 32 > c->ns * (int64_t)std::max(executed, 1);
+            if (!many) {
+                c->halo_declined = true;
+            } else if (looked >= 2 || c->ns < kLarge) {
+                c->halo_sticky = true;
+                TRY(start_links_async(c));
+            }
+        }
     }
     return MI_ICP_OK;
 }
@@ -1560,21 +1629,18 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
     TRY(ensure(c, c->loop_dev, 1, &d));
     HIPCHK(c, hipMemcpyAsync(d, &L, sizeof(DevLoop), hipMemcpyHostToDevice, c->stream));
     c->loop_active = true;
-    // The first pass has no previous matches.  With the neighbour lists at hand (started by set_target)
-    // it makes its own seeds (launch_nn: locate_leaves); otherwise it walks the tree from the root while
-    // the lists are built next to it on the private stream.
+    // The first pass has no previous matches; launch_nn picks how it starts.  Halos: a context whose loops
+    // have asked for them before starts the build now, next to the first pass; otherwise the first seeded
+    // iteration says whether this loop needs them (loop_run).
+    c->halo_declined = false;
     c->ran_loop = true;
-    static const bool always_wait = std::getenv("MI_ICP_WAIT_LINKS") != nullptr;  // A/B switch (soak tests of the own-seeds pass)
-    if (c->links_inflight && !always_wait && hipEventQuery(c->ev_links) != hipSuccess && c->ns < kWaitForLinksMin) {
-        // Still being built, and the source is small: its walk from the root (tens of microseconds) costs less
-        // than waiting for the lists (a list build is ~0.1-0.2 ms of dependent fetches whatever the size);
-        // the first seeded pass waits for whatever is left of it then.
-        (void)hipGetLastError();
-    } else if (c->links_ready || c->links_inflight) {
-        TRY(ensure_links(c));
-    } else {
-        TRY(start_links_async(c));
+    {
+        uint32_t* want;
+        TRY(ensure(c, c->halo_want, 64, &want));
+        HIPCHK(c, hipMemsetAsync(want, 0, sizeof(uint32_t), c->stream));
     }
+    c->halo_use = halo_poll(c);
+    if (c->halo_sticky && !c->halo_use) TRY(start_links_async(c));
     TRY(loop_enqueue_evaluation(c, false));
     // from here on the packets follow the target's order (pays for itself in ~4 iterations)
     static const bool no_resort = std::getenv("MI_ICP_NO_RESORT") != nullptr;  // A/B switch for tuning

@@ -194,7 +194,7 @@ __device__ __forceinline__ bool nn_packet_body(
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
         int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
         const float* __restrict__ lreg_g, const float* __restrict__ halo_g, uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, int32_t* __restrict__ nn_idx,
-        float* __restrict__ nn_d2, unsigned long long* __restrict__ stats, PacketResult& out) {
+        float* __restrict__ nn_d2, unsigned long long* __restrict__ stats, uint32_t* __restrict__ want, PacketResult& out) {
     const int lane = lane_id();
     const int i = (int)(packet * 64u) + lane;  // (ns < 2^31)
     const bool valid = i < ns;
@@ -285,6 +285,12 @@ __device__ __forceinline__ bool nn_packet_body(
                 if (STATS) why = !(g0.x <= g1.x) ? 1u : (__float_as_uint(g1.w) == 0u ? 2u : (!linked ? 3u : 0u));
             }
         }
+    }
+    // No halos (yet): the lanes one would serve are counted, so that the host can tell whether to build them
+    // (clean data never needs them: every lane ends in its seed leaf's region).
+    if (SEED && want != nullptr) {
+        const uint64_t m = __ballot(valid && !retired && seed_j >= 0);
+        if (m != 0ull && lane == 0) atomicAdd(want, (uint32_t)__popcll(m));
     }
     // the lane's running result lives in LDS, where any lane may improve it
     sh.best[lane] = ((unsigned long long)__float_as_uint(fmaxf(best, 0.0f)) << 32) | (unsigned long long)(uint32_t)bidx;
@@ -480,13 +486,13 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
         int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
         const float* __restrict__ lreg_g, const float* __restrict__ halo_g, uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, uint32_t nblocks, int32_t* __restrict__ nn_idx,
-        float* __restrict__ nn_d2, unsigned long long* __restrict__ stats) {
+        float* __restrict__ nn_d2, unsigned long long* __restrict__ stats, uint32_t* __restrict__ want) {
     __shared__ PacketShared s_pk[kNNPacketsPerBlock];
     uint32_t logical;
     if (!xcd_remap(nblocks, logical)) return;
     PacketResult unused;
     (void)nn_packet_body<SEED, STATS>(s_pk[0], logical, sx, sy, sz, ns, records_g, tblk_g, lreg_g, halo_g, leaf_first, Tv, loop,
-                                      r2, nn_idx, nn_d2, stats, unused);
+                                      r2, nn_idx, nn_d2, stats, want, unused);
 }
 
 // ---------------------------------------------------------------------------

@@ -137,13 +137,21 @@ def test_seeded_search_tiny_radius_and_all_misses(eng):
     tree.close()
 
 
+def build_halos(e):
+    """Have the target's halos built now (the debug export waits for them)."""
+    import ctypes as C
+    info = (C.c_int64 * 5)()
+    e._chk(e._L.mi_icp_debug_get_tree(e._ctx, info, None, None))
+    out = np.empty((int(info[1]), 8, 32), np.float32)
+    e._chk(e._L.mi_icp_debug_get_leaf_halos(e._ctx, out.ctypes.data_as(C.c_void_p)))
+
+
 @pytest.mark.parametrize("kind", ["uniform", "clustered", "surface"])
 def test_first_pass_from_its_own_seeds_equals_the_walk_from_the_root(kind):
-    """A context that has registered before builds the leaves' neighbour lists right behind the tree
-    and its loops' FIRST pass starts every query from the leaf a greedy descent lands in (launch_nn:
-    locate_leaves) instead of walking the tree from the root.  Same correspondences, bit for bit,
-    as a fresh context's first pass (from the root) and as the oracle -- under a poor initial guess,
-    with partial overlap and noise."""
+    """Where the target's halos exist already, a registration loop's FIRST pass starts every query from the
+    leaf a greedy descent lands in (launch_nn: locate_leaves) instead of walking the tree from the root.
+    Same correspondences, bit for bit, as the first pass of a loop without halos and a one-shot search (both
+    walk from the root) and as the oracle -- under a poor initial guess, with partial overlap and noise."""
     from cupoch_amd.engine import Engine
     n = 160_000
     rng = np.random.default_rng({"uniform": 41, "clustered": 42, "surface": 43}[kind])
@@ -157,23 +165,27 @@ def test_first_pass_from_its_own_seeds_equals_the_walk_from_the_root(kind):
     _, oi, od = tree.search_radius(orc.transform_points(init, src), radius, 1)
     tree.close()
     oi = oi[:, 0]
+    never = os.environ.get("MI_ICP_NO_COARSE_FIRST") is not None    # (A/B switches of the library, read once per process)
+    always = os.environ.get("MI_ICP_WAIT_LINKS") is not None
     got = {}
-    for name in ("fresh", "warm"):
+    for name in ("root", "loop", "seeds+halos"):
         e = Engine(0)
-        if name == "warm":                                   # one registration on other clouds first
-            e.set_target(tgt[:70_000])
-            e.set_source(src[:70_000])
-            e.icp_begin(P2P, radius, None, -1.0)
         e.set_target(cuda(tgt))
         e.set_source(cuda(src))
-        torch.cuda.synchronize()      # (the lists, started by set_target on the warm context, are complete: a small
-        #                               source would not wait for a build still in flight and walk from the root)
-        res = e.icp_begin(P2P, radius, init, -1.0)
-        assert e.last_search_kind() == (2 if name == "warm" else 0)
-        corr = e.get_correspondences()
-        dense = np.full(len(src), -1, np.int32)
-        dense[corr[:, 0]] = corr[:, 1]
-        got[name] = (dense, res.fitness, res.inlier_rmse)
+        if name == "root":                                   # a one-shot search has no seeds of any kind
+            dense, d2, st = e.search_radius_1nn(radius, init)
+            assert e.last_search_kind() == 0
+            fit, rmse = st[0] / len(src), float(np.sqrt(st[1] / max(st[0], 1)))
+        else:
+            if name == "seeds+halos":
+                build_halos(e)
+            res = e.icp_begin(P2P, radius, init, -1.0)
+            assert e.last_search_kind() == (2 if (name == "seeds+halos" or always) and not never else 0)
+            corr = e.get_correspondences()
+            dense = np.full(len(src), -1, np.int32)
+            dense[corr[:, 0]] = corr[:, 1]
+            fit, rmse = res.fitness, res.inlier_rmse
+        got[name] = (np.asarray(dense), fit, rmse)
         e.close()
     for name, (dense, fit, rmse) in got.items():
         assert np.array_equal(dense < 0, oi < 0), name
@@ -183,8 +195,9 @@ def test_first_pass_from_its_own_seeds_equals_the_walk_from_the_root(kind):
             dd = q - tgt[dense[ne]]
             alt = (dd[:, 2] * dd[:, 2] + (dd[:, 1] * dd[:, 1] + dd[:, 0] * dd[:, 0])).astype(np.float32)
             assert np.array_equal(alt, od[ne, 0]), name
-    assert np.array_equal(got["fresh"][0], got["warm"][0])
-    assert got["fresh"][1] == got["warm"][1] and got["fresh"][2] == pytest.approx(got["warm"][2], rel=1e-6)
+    for name in ("loop", "seeds+halos"):
+        assert np.array_equal(got["root"][0], got[name][0]), name
+        assert got["root"][1] == pytest.approx(got[name][1], abs=1e-7) and got["root"][2] == pytest.approx(got[name][2], rel=1e-5)
 
 
 def _run_small_loop(path):
