@@ -110,6 +110,10 @@ struct mi_icp_ctx {
     bool halo_sticky = false;
     bool ran_loop = false;  // (a context that has registered before and gets a SMALL target starts the build behind the tree)
     bool halo_declined = false;  // this loop's searches have been looked at and did not ask
+    int64_t halo_iters = 0;      // seeded iterations against this target since it was set ...
+    int64_t halo_asked = 0;      // ... and the lanes that asked for a halo in them
+    int64_t halo_want_seen = 0;  // the counter's value at the last look (it is zeroed when a loop begins)
+    int halo_looks = 0;          // looks of this loop while undecided
     bool halo_use = false;       // the loop's launches take the halos (looked up once per chunk: an event query costs microseconds)
     DevBuf halo_want;            // the counter (one word)
 
@@ -564,7 +568,7 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
     const bool have_halo = loop ? c->halo_use : halo_poll(c);
     EvTimer t(c, 0, loop != nullptr);
     const float* links = have_halo ? (const float*)c->thalo.p : nullptr;
-    uint32_t* want = (loop && !have_halo && !c->links_inflight && !c->halo_declined && c->links_allowed) ? (uint32_t*)c->halo_want.p : nullptr;
+    uint32_t* want = (loop && !have_halo && !c->links_inflight && c->links_allowed) ? (uint32_t*)c->halo_want.p : nullptr;
     bool self_seeded = false;
     static const bool no_coarse = std::getenv("MI_ICP_NO_COARSE_FIRST") != nullptr;  // A/B switch
     auto launch = [&](bool seeded, const float* sx, const float* sy, const float* sz, int64_t ns, int32_t* out_idx,
@@ -1127,7 +1131,8 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
         KCHK(c);
         used = (used + 7u) / 8u;
     }
-    c->links_ready = false;  // (the leaves' neighbour lists: started below, or by the registration loop / the first seeded search)
+    c->links_ready = false;  // (the leaves' halos: started below, or by the registration loop / the first seeded search)
+    c->halo_iters = c->halo_asked = 0;
     c->links_allowed = !no_cells && (uint32_t)nleaf <= kLinkIdMask;
     c->nt = n;
     c->nts = nts;
@@ -1512,7 +1517,7 @@ static int launch_fused_iteration(mi_icp_ctx* c, DevLoop* d) {
         c->halo_use = halo_poll(c);
     }
     const bool have_halo = c->halo_use;
-    uint32_t* want = (!have_halo && !c->links_inflight && !c->halo_declined && c->links_allowed) ? (uint32_t*)c->halo_want.p : nullptr;
+    uint32_t* want = (!have_halo && !c->links_inflight && c->links_allowed) ? (uint32_t*)c->halo_want.p : nullptr;
     const uint32_t npackets = (uint32_t)((c->ns + 63) / 64);
     const uint32_t nblocks = (npackets + kFusedPackets - 1) / kFusedPackets;
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
@@ -1554,46 +1559,54 @@ static int loop_enqueue_evaluation(mi_icp_ctx* c, bool seed) {
 // Enqueue up to `budget` iterations in chunks, looking at `done` between chunks -- and, while the target has
 // no halos, at how many lanes of the seeded searches asked for one.  The first seeded iteration of a
 // registration is still displaced and asks whatever the data; the second one tells noise from convergence.  So a
-// large source's first two seeded iterations are chunks of their own, and if the second still has more than ~3 %
-// of the lanes asking, the build is started on the private stream; the chunks stay short until it is done (every
-// launch takes the halos if they are there, launch_nn).  Small sources (a walk costs them little, a host
-// synchronisation much) decide at their first regular chunk's end.
+// large source's first two seeded iterations are chunks of their own: if more than 40 % of the lanes ask in the
+// first, or more than ~3 % still do in the second, the halos are built -- on the private stream, and the loop's
+// stream waits for them: an iteration that walks instead costs a 10M-point loop half of what the build does.
+// Small sources (a walk costs them little, a host synchronisation much) decide at their first regular chunk's end.
+// Clean data leaves a few lanes in a few thousand asking (a converged query within rounding of a face of its
+// match's region): their packets' one-record walks are ~4 % of a search -- not worth a build to one registration,
+// worth it to a target that keeps being registered against: after kHaloLongRun iterations on the same target the
+// build is started in the background and taken up whenever it is done.
 static int loop_run(mi_icp_ctx* c, int budget) {
     constexpr int kChunk = 8;
-    constexpr int64_t kLarge = 500000;
-    int64_t asked_before = 0;
-    int looked = 0;
+    constexpr int64_t kLarge = 500000, kHaloLongRun = 40;
     while (budget > 0) {
-        const bool undecided = !c->links_ready && !c->links_inflight && !c->halo_declined && c->links_allowed && c->nt > 0;
+        const bool no_halo = !c->links_ready && !c->links_inflight && c->links_allowed && c->nt > 0;
+        const bool undecided = no_halo && !c->halo_declined;
+        // (a build the loop's decision started -- or one started with the loop on a context that has asked
+        // before, or behind a small target's tree: the stream waits for what is left of it rather than walk)
+        if (c->links_inflight && !c->halo_declined) TRY(ensure_links(c));
         // (a short remainder rides along: one host synchronisation less than it would cost)
         int n = (budget <= kChunk + kChunk / 2) ? budget : kChunk;
-        if (c->ns >= kLarge) {
-            if (undecided) n = 1;
-            else if (c->links_inflight) n = std::min(n, 4);
-        }
+        if (undecided && c->ns >= kLarge) n = 1;
         const int passes_before = c->loop_host->passes;
-        // (a small source lets its stream wait for a build in flight -- tens of microseconds -- rather than walk)
-        if (c->links_inflight && c->ns < kLarge) TRY(ensure_links(c));
         c->halo_use = halo_poll(c);
         for (int i = 0; i < n; ++i) TRY(loop_enqueue_evaluation(c, true));
-        if (undecided) HIPCHK(c, hipMemcpyAsync(c->u_host + 8, c->halo_want.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        if (no_halo) HIPCHK(c, hipMemcpyAsync(c->u_host + 8, c->halo_want.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         TRY(loop_pull(c));
         const int executed = c->loop_host->passes - passes_before;
         collect_pooled(c, executed);
         budget -= n;
-        if (c->loop_host->done) break;
-        if (undecided) {
-            const int64_t asked = (int64_t)c->u_host[8] - asked_before;  // by this chunk's iterations
-            asked_before = (int64_t)c->u_host[8];
-            ++looked;
-            const bool many = asked * 32 > c->ns * (int64_t)std::max(executed, 1);
-            if (!many) {
-                c->halo_declined = true;
-            } else if (looked >= 2 || c->ns < kLarge) {
-                c->halo_sticky = true;
-                TRY(start_links_async(c));
+        c->halo_iters += executed;
+        if (no_halo) {
+            const int64_t asked = (int64_t)c->u_host[8] - c->halo_want_seen;  // by this chunk's iterations
+            c->halo_want_seen = (int64_t)c->u_host[8];
+            c->halo_asked += asked;
+            if (undecided) {
+                ++c->halo_looks;
+                const int64_t per = std::max(executed, 1);
+                const bool many = asked * 32 > c->ns * per, most = asked * 5 > 2 * c->ns * per;
+                if (!many) {
+                    c->halo_declined = true;
+                } else if (most || c->halo_looks >= 2 || c->ns < kLarge) {
+                    c->halo_sticky = true;
+                    TRY(start_links_async(c));
+                }
+            } else if (c->halo_iters >= kHaloLongRun && c->halo_asked > 0) {
+                TRY(start_links_async(c));  // (in the background: halo_declined stays, nothing waits)
             }
         }
+        if (c->loop_host->done) break;
     }
     return MI_ICP_OK;
 }
@@ -1633,6 +1646,8 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
     // have asked for them before starts the build now, next to the first pass; otherwise the first seeded
     // iteration says whether this loop needs them (loop_run).
     c->halo_declined = false;
+    c->halo_want_seen = 0;
+    c->halo_looks = 0;
     c->ran_loop = true;
     {
         uint32_t* want;

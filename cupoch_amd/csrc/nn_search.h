@@ -288,7 +288,7 @@ __device__ __forceinline__ bool nn_packet_body(
     }
     // No halos (yet): the lanes one would serve are counted, so that the host can tell whether to build them
     // (clean data never needs them: every lane ends in its seed leaf's region).
-    if (SEED && want != nullptr) {
+    if (SEED && __builtin_expect(want != nullptr, 0)) {
         const uint64_t m = __ballot(valid && !retired && seed_j >= 0);
         if (m != 0ull && lane == 0) atomicAdd(want, (uint32_t)__popcll(m));
     }
@@ -297,7 +297,7 @@ __device__ __forceinline__ bool nn_packet_body(
     __builtin_amdgcn_wave_barrier();
 
     uint32_t queued = 0u, batches = 0u, halo_items = 0u;  // wave-uniform
-    if (SEED && __ballot(linked) != 0ull) {
+    if (SEED && __builtin_expect(__ballot(linked) != 0ull, 0)) {  // (unlikely: keeps the streaming case's instructions together)
         // ---- halo lines (leaf_halo.h): the first `nlines` of the seed leaf's lines hold every point of another
         // leaf the cube can touch -- no scan, no filter, and the lanes of a leaf read the same lines.
         const uint32_t seed_leaf = linked ? ((uint32_t)seed_j >> 3) : 0u;
@@ -438,7 +438,7 @@ __device__ __forceinline__ bool nn_packet_body(
         }
     }
     if (!SEED) steps = traverse_from(records_g, leaf_first, 1u, cube, on_leaf_record);
-    else if (__ballot(!retired) != 0ull) {
+    else if (__builtin_expect(__ballot(!retired) != 0ull, 0)) {
         const uint32_t my_node = (seed_j >= 0) ? leaf_first + ((uint32_t)seed_j >> 6) : 0u;  // leaf-level node of the previous match
         steps = traverse_seeded(records_g, leaf_first, my_node, cube, retired, on_leaf_record);
     }
