@@ -19,7 +19,8 @@
 // dependent trips plus one per rank).  Slots alternate with the exchange number's parity, so a rank that
 // is already one exchange ahead cannot overwrite what a slower rank still has to read (to get two ahead
 // it needs everybody's post of the exchange in between).  Exchange numbers count a rank's exchanges since
-// the box was made and never repeat (a word's zeroed state is no exchange's); every rank performs the same
+// the box was made (32 bits, wrapping past 0 -- a word's zeroed state -- with the parity kept: only the two
+// most recent numbers can ever be in a slot); every rank performs the same
 // exchanges (the loop's control flow depends only on the all-reduced sums, which are identical everywhere).
 // A rank that does not hear from a peer within ~10 s gives up: the loop is marked failed and the host
 // call returns MI_ICP_ERR_COMM (bench.py then falls back to the RCCL path).
@@ -34,7 +35,9 @@ constexpr uint32_t kMailSpinLimit = 8u << 20;  // polls of a flag in host memory
 struct MailBox {
     uint32_t ready;                      // set by rank 0 once the box is zeroed
     uint32_t nranks;
-    uint32_t pad_[14];
+    uint32_t attached;                   // ranks > 0 that have mapped and registered the box
+    uint32_t go;                         // set by rank 0 when all have: the box is in use (a box found with go != 0 is another job's)
+    uint32_t pad_[12];
     unsigned long long words[2][kMailRanks][64];  // [slot][rank]: exchange << 32 | low / high half of sum k's bits at 2k / 2k + 1
 };
 
@@ -54,7 +57,8 @@ __device__ __forceinline__ bool mail_allreduce(const MailArgs& m, double* sys, u
     __shared__ unsigned long long s_words[kMailRanks][64];
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = (int)(blockDim.x >> 6);
     if (tid == 0) {
-        const uint32_t s = (pre_seq ? *pre_seq : *m.seq_dev) + 1u;
+        uint32_t s = (pre_seq ? *pre_seq : *m.seq_dev) + 1u;
+        if (s == 0u) s = 2u;  // (after 2^32 exchanges: 0 is a word's zeroed state, and the slots' parity keeps alternating)
         *m.seq_dev = s;
         s_tmp[0] = s;
         s_tmp[1] = 1u;

@@ -154,6 +154,8 @@ struct mi_icp_ctx {
     MailBox* mail_dev = nullptr;
     size_t mail_bytes = 0;
     std::string mail_name;
+    bool mail_linked = false;   // the name still exists and is this context's to remove
+    bool comm_broken = false;   // an exchange has failed: the ranks' counters are apart
     DevBuf mail_state;  // [0]: this rank's exchange counter, [1]: error flag of the one-shot exchange
 
     // ---- private scratch context: PointCloud::EstimateNormals builds its own tree there, so
@@ -771,65 +773,130 @@ void mailbox_close(mi_icp_ctx* c) {
         (void)hipHostUnregister(c->mail_host);
         (void)munmap(c->mail_host, c->mail_bytes);
     }
-    if (!c->mail_name.empty()) (void)shm_unlink(c->mail_name.c_str());  // (the first rank to get here removes the name)
+    // (the name is rank 0's to remove, and only while it still refers to this box: once every rank has
+    // attached rank 0 unlinks it at once, so that no later job -- or crash -- finds it)
+    if (c->mail_linked && !c->mail_name.empty()) (void)shm_unlink(c->mail_name.c_str());
+    c->mail_linked = false;
     c->mail_host = c->mail_dev = nullptr;
     c->mail_name.clear();
 }
 
-// Rank 0 creates and zeroes the box, the others wait for it (30 s), every rank registers the mapping
-// with HIP.  All ranks of a job pass the same name; it is removed again by mailbox_close.
+static long mail_attach_timeout_ms() {
+    static const long v = [] { const char* e = std::getenv("MI_ICP_MAIL_ATTACH_MS"); const long t = e ? std::atol(e) : 0; return t > 0 ? t : 30000L; }();
+    return v;
+}
+
+// Rank 0 creates and zeroes the box and waits until every other rank has mapped AND registered it with
+// HIP (`attached`), then declares it in use (`go`) and removes the name.  The others open the name, wait for
+// `ready`, refuse a box that is in use already (a leftover of another job under the same name: its `go` is
+// set -- they retry until rank 0 has replaced it), register, attach and wait for `go`.  All ranks of a job
+// pass the same name.  MI_ICP_MAIL_ATTACH_MS: how long anybody waits (default 30 s).
 int mailbox_open(mi_icp_ctx* c, const std::string& name, int nranks, int rank) {
     mailbox_close(c);
     if (nranks > kMailRanks) return fail(c, MI_ICP_ERR_COMM, "mailbox: %d ranks (at most %d)", nranks, kMailRanks);
     const size_t bytes = (sizeof(MailBox) + 4095) / 4096 * 4096;
-    int fd = -1;
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto late = [&] { return std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(mail_attach_timeout_ms()); };
+    MailBox* box = nullptr;
+    void* dev = nullptr;
+    auto drop = [&](void* p) {
+        if (dev) (void)hipHostUnregister(p);
+        dev = nullptr;
+        (void)munmap(p, bytes);
+    };
+    auto map_fd = [&](int fd) -> void* {
+        void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        return p == MAP_FAILED ? nullptr : p;
+    };
+    auto reg = [&](void* p) {
+        if (hipHostRegister(p, bytes, hipHostRegisterMapped) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipHostUnregister(p);
+            dev = nullptr;
+            return false;
+        }
+        return true;
+    };
     if (rank == 0) {
         (void)shm_unlink(name.c_str());  // a stale box of a crashed job
-        fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        int fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
         if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) {
             if (fd >= 0) close(fd);
+            (void)shm_unlink(name.c_str());
             return fail(c, MI_ICP_ERR_COMM, "mailbox: cannot create shared memory %s", name.c_str());
         }
-    } else {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {
-            fd = shm_open(name.c_str(), O_RDWR, 0600);
-            struct stat st;
-            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) break;
-            if (fd >= 0) close(fd);
-            fd = -1;
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
-                return fail(c, MI_ICP_ERR_COMM, "mailbox: shared memory %s did not appear", name.c_str());
-            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        void* p = map_fd(fd);
+        if (!p || !reg(p)) {
+            if (p) (void)munmap(p, bytes);
+            (void)shm_unlink(name.c_str());
+            return fail(c, MI_ICP_ERR_COMM, "mailbox: cannot map / register shared memory %s", name.c_str());
         }
-    }
-    void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (p == MAP_FAILED) return fail(c, MI_ICP_ERR_COMM, "mailbox: mmap failed");
-    MailBox* box = (MailBox*)p;
-    if (rank == 0) {
+        box = (MailBox*)p;
         std::memset(p, 0, bytes);
         box->nranks = (uint32_t)nranks;
         __atomic_store_n(&box->ready, 1u, __ATOMIC_RELEASE);
-    } else {
-        const auto t0 = std::chrono::steady_clock::now();
-        while (__atomic_load_n(&box->ready, __ATOMIC_ACQUIRE) != 1u) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
-                (void)munmap(p, bytes);
-                return fail(c, MI_ICP_ERR_COMM, "mailbox: rank 0 did not initialise %s", name.c_str());
+        while (__atomic_load_n(&box->attached, __ATOMIC_ACQUIRE) != (uint32_t)(nranks - 1)) {
+            if (late()) {
+                drop(p);
+                (void)shm_unlink(name.c_str());
+                return fail(c, MI_ICP_ERR_COMM, "mailbox: not all of the %d other ranks attached to %s in time", nranks - 1, name.c_str());
             }
-            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
         }
-        if (box->nranks != (uint32_t)nranks) {
-            (void)munmap(p, bytes);
-            return fail(c, MI_ICP_ERR_COMM, "mailbox: %s was made for %u ranks, not %d", name.c_str(), box->nranks, nranks);
+        __atomic_store_n(&box->go, 1u, __ATOMIC_RELEASE);
+        (void)shm_unlink(name.c_str());  // every rank holds its mapping: the name has done its job
+    } else {
+        for (;;) {
+            if (late()) return fail(c, MI_ICP_ERR_COMM, "mailbox: no usable shared memory %s appeared in time", name.c_str());
+            int fd = shm_open(name.c_str(), O_RDWR, 0600);
+            struct stat st;
+            if (fd < 0 || fstat(fd, &st) != 0 || (size_t)st.st_size < bytes) {
+                if (fd >= 0) close(fd);
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                continue;
+            }
+            void* p = map_fd(fd);
+            if (!p) return fail(c, MI_ICP_ERR_COMM, "mailbox: mmap failed");
+            box = (MailBox*)p;
+            bool usable = false;
+            while (!late()) {
+                if (__atomic_load_n(&box->go, __ATOMIC_ACQUIRE) != 0u) break;            // in use: not ours
+                if (__atomic_load_n(&box->ready, __ATOMIC_ACQUIRE) == 1u) {
+                    usable = true;
+                    break;
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+            if (!usable || __atomic_load_n(&box->go, __ATOMIC_ACQUIRE) != 0u) {
+                (void)munmap(p, bytes);
+                box = nullptr;
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                continue;
+            }
+            if (box->nranks != (uint32_t)nranks) {
+                const uint32_t made_for = box->nranks;
+                (void)munmap(p, bytes);
+                return fail(c, MI_ICP_ERR_COMM, "mailbox: %s was made for %u ranks, not %d", name.c_str(), made_for, nranks);
+            }
+            if (!reg(p)) {
+                (void)munmap(p, bytes);
+                return fail(c, MI_ICP_ERR_COMM, "mailbox: hipHostRegister failed");
+            }
+            (void)__atomic_fetch_add(&box->attached, 1u, __ATOMIC_ACQ_REL);
+            while (__atomic_load_n(&box->go, __ATOMIC_ACQUIRE) != 1u) {
+                if (late()) {  // (e.g. the box was a crashed job's, caught between its `ready` and its `go`)
+                    drop(p);
+                    return fail(c, MI_ICP_ERR_COMM, "mailbox: rank 0 did not start %s in time", name.c_str());
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+            break;
         }
-    }
-    void* dev = nullptr;
-    if (hipHostRegister(p, bytes, hipHostRegisterMapped) != hipSuccess || hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        (void)munmap(p, bytes);
-        return fail(c, MI_ICP_ERR_COMM, "mailbox: hipHostRegister failed");
     }
     uint32_t* state;
     TRY(ensure(c, c->mail_state, 64, &state));
@@ -839,10 +906,29 @@ int mailbox_open(mi_icp_ctx* c, const std::string& name, int nranks, int rank) {
     c->mail_dev = (MailBox*)dev;
     c->mail_bytes = bytes;
     c->mail_name = name;
+    c->mail_linked = false;  // (rank 0 has removed the name already)
+    c->comm_broken = false;
+    return MI_ICP_OK;
+}
+
+// A failed exchange leaves the ranks' exchange counters apart: whatever they post from now on could be taken
+// for another exchange's.  The mailbox is given up and every call that would exchange fails until the
+// communicator has been destroyed / initialised again.
+int comm_failed(mi_icp_ctx* c, const char* what) {
+    mailbox_close(c);
+    c->comm_broken = true;
+    c->loop_active = false;
+    return fail(c, MI_ICP_ERR_COMM, "%s; the communicator is void: destroy it and initialise a new one", what);
+}
+
+int comm_usable(mi_icp_ctx* c) {
+    if (c->comm_broken)
+        return fail(c, MI_ICP_ERR_COMM, "the communicator is void after a failed exchange (timed out): destroy it and initialise a new one");
     return MI_ICP_OK;
 }
 
 int allreduce_system(mi_icp_ctx* c) {
+    TRY(comm_usable(c));
     if (c->mail_dev) {  // one-shot exchange through the mailbox
         int32_t* state = (int32_t*)c->mail_state.p;
         mail_allreduce_kernel<<<1, 64, 0, c->stream>>>(mail_args(c), (double*)c->sys_dev.p, state + 1);
@@ -866,7 +952,7 @@ int fetch_system(mi_icp_ctx* c, double* out) {
     if (mail) HIPCHK(c, hipMemcpyAsync(err_host, (const int32_t*)c->mail_state.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     collect_events(c);
-    if (mail && *err_host) return fail(c, MI_ICP_ERR_COMM, "the ranks' exchange timed out (mailbox): a peer did not post its sums");
+    if (mail && *err_host) return comm_failed(c, "the ranks' exchange timed out (mailbox): a peer did not post its sums");
     std::memcpy(out, c->sys_host, kSysSize * sizeof(double));
     return MI_ICP_OK;
 }
@@ -1488,10 +1574,7 @@ static void fill_result(const mi_icp_ctx* c, mi_icp_result* out) {
 static int loop_pull(mi_icp_ctx* c) {  // device state -> pinned mirror, synchronises
     HIPCHK(c, hipMemcpyAsync(c->loop_host, c->loop_dev.p, sizeof(DevLoop), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->loop_host->error) {
-        c->loop_active = false;
-        return fail(c, MI_ICP_ERR_COMM, "the ranks' exchange timed out (mailbox): a peer did not post its sums");
-    }
+    if (c->loop_host->error) return comm_failed(c, "the ranks' exchange timed out (mailbox): a peer did not post its sums");
     return MI_ICP_OK;
 }
 
@@ -1615,6 +1698,7 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
                       int max_iterations, float rel_fitness, float rel_rmse) {
     if (!known_estimator(est))
         return fail(c, MI_ICP_ERR_INVALID, "unknown estimation type %d", est);
+    TRY(comm_usable(c));
     DevLoop& L = *c->loop_host;
     std::memset(&L, 0, sizeof(L));
     L.est = est;
@@ -2481,12 +2565,27 @@ int mi_icp_comm_init(mi_icp_ctx* c, const char* id128, int nranks, int rank) {
     // ncclAllReduce launch; the communicator stays for whatever the mailbox cannot do.  The box is named
     // after the job's unique id.  MI_ICP_NO_MAILBOX=1, more than 16 ranks or a failed set-up: RCCL only.
     const bool no_mailbox = std::getenv("MI_ICP_NO_MAILBOX") != nullptr;  // (read at every call: a caller may fall back)
+    c->comm_broken = false;
     if (!no_mailbox && nranks > 1 && nranks <= kMailRanks) {
         unsigned long long h = 1469598103934665603ull;  // FNV-1a of the id
         for (int i = 0; i < 128; ++i) h = (h ^ (unsigned char)id128[i]) * 1099511628211ull;
         char name[64];
         std::snprintf(name, sizeof(name), "/mi_icp_%016llx", h);
-        if (mailbox_open(c, name, nranks, rank) != MI_ICP_OK) mailbox_close(c);  // (c->err says why; not fatal)
+        const int opened = mailbox_open(c, name, nranks, rank) == MI_ICP_OK ? 1 : 0;  // (c->err says why not; not fatal)
+        // The ranks must AGREE on how they exchange: one that could not open the box while its peers did would
+        // wait in an ncclAllReduce nobody joins, and they for a post that never comes.  So: a min over the
+        // communicator that exists by now, and the mailbox only if every rank has it.
+        int32_t* flag;
+        TRY(ensure(c, c->mail_state, 64, (uint32_t**)&flag));
+        int32_t* agree = flag + 32;  // (behind the exchange counter and its error word)
+        HIPCHK(c, hipMemcpyAsync(agree, &opened, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        ncclResult_t ar = g_rccl.AllReduce(agree, agree, 1, ncclInt32, ncclMin, c->comm, c->stream);
+        int32_t all = 0;
+        if (ar == ncclSuccess) {
+            HIPCHK(c, hipMemcpyAsync(&all, agree, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        if (ar != ncclSuccess || all != 1) mailbox_close(c);
     }
     return MI_ICP_OK;
 }
@@ -2500,6 +2599,7 @@ int mi_icp_comm_init_local(mi_icp_ctx* c, const char* job_name, int nranks, int 
         name += (std::isalnum((unsigned char)*p) || *p == '_' || *p == '-') ? *p : '_';
     c->nranks = nranks;
     c->rank = rank;
+    c->comm_broken = false;
     // (MI_ICP_MAILBOX_SOLO: a one-rank box, to time the exchange's fixed cost on a single GPU)
     if (nranks > 1 || std::getenv("MI_ICP_MAILBOX_SOLO")) {
         const int rc = mailbox_open(c, name, nranks, rank);
@@ -2527,6 +2627,7 @@ int mi_icp_comm_destroy(mi_icp_ctx* c) {
     }
     c->nranks = 1;
     c->rank = 0;
+    c->comm_broken = false;
     return MI_ICP_OK;
 }
 

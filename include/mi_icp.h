@@ -387,8 +387,12 @@ MI_ICP_API int mi_icp_registration_colored_icp(mi_icp_ctx* ctx, float max_distan
  * mi_icp_comm_init: RCCL communicator from a shared ncclUniqueId + the mailbox (named after
  * the id).  mi_icp_comm_init_local: the mailbox alone, no RCCL -- all ranks pass the same
  * job_name (letters, digits, '_', '-'), one node only.  mi_icp_comm_kind: 0 none, 1 RCCL
- * all-reduce, 2 mailbox.  A peer that does not post within ~10 s fails the call with
- * MI_ICP_ERR_COMM. */
+ * all-reduce, 2 mailbox.  Set-up: rank 0 makes the box and waits (MI_ICP_MAIL_ATTACH_MS, default 30 s)
+ * until every other rank has mapped and registered it; mi_icp_comm_init then lets the ranks agree over the
+ * RCCL communicator whether ALL of them have it (else none uses it).  A peer that does not post within ~10 s
+ * fails the call with MI_ICP_ERR_COMM; the communicator is void from then on (the ranks' exchange counters
+ * are apart): every further call that would exchange fails the same way until mi_icp_comm_destroy /
+ * mi_icp_comm_init[_local] have made a new one. */
 MI_ICP_API int mi_icp_comm_unique_id(char* id128);
 MI_ICP_API int mi_icp_comm_init(mi_icp_ctx* ctx, const char* id128, int nranks, int rank);
 MI_ICP_API int mi_icp_comm_init_local(mi_icp_ctx* ctx, const char* job_name, int nranks, int rank);

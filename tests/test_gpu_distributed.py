@@ -169,8 +169,9 @@ def test_mailbox_exchange_two_processes_on_one_gpu(tmp_path):
     assert m0["eval"][0] == pytest.approx(ev.fitness, abs=1e-6) and m0["eval"][1] == pytest.approx(ev.inlier_rmse, rel=1e-5)
 
 
-def _worker_lonely(_index, out_dir):
+def _worker_lonely(rank, job, out_dir):
     import sys
+    import time
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MI_ICP_MAIL_SPIN_LIMIT"] = "20000"          # ~50 ms instead of ~15 s
@@ -180,7 +181,11 @@ def _worker_lonely(_index, out_dir):
     eng = Engine(0)
     eng.set_target(d["tgt"], d["tgt_nrm"])
     eng.set_source(d["src"])
-    eng.comm_init_local("lonely_%d" % os.getpid(), 2, 0)    # rank 1 never shows up
+    eng.comm_init_local(job, 2, rank)                       # both ranks attach ...
+    if rank == 1:                                           # ... and rank 1 never posts anything
+        time.sleep(3.0)
+        eng.close()
+        return
     msgs = []
     for call in (lambda: eng.registration_icp(PT2PL, d["max_dist"], None, 0.0, 0.0, 5, -1.0),
                  lambda: eng.evaluate_registration(d["max_dist"], None)):
@@ -189,6 +194,7 @@ def _worker_lonely(_index, out_dir):
             msgs.append("no error")
         except MiIcpError as e:
             msgs.append(str(e))
+    msgs.append("kind %d" % eng.comm_kind())
     eng.comm_destroy()
     # ... and the context is usable again on its own
     res = eng.registration_icp(PT2PL, d["max_dist"], None, 0.0, 0.0, 5, -1.0)
@@ -199,9 +205,105 @@ def _worker_lonely(_index, out_dir):
 
 
 def test_mailbox_exchange_times_out_instead_of_hanging(tmp_path):
-    """A peer that never posts: the kernels give up after the spin limit, the call fails with
-    MI_ICP_ERR_COMM (no hang, no garbage result), and the context works again once the communicator is gone."""
-    mp.spawn(_worker_lonely, args=(str(tmp_path),), nprocs=1, join=True)
+    """A peer that attaches and then never posts: the kernels give up after the spin limit, the call fails
+    with MI_ICP_ERR_COMM (no hang, no garbage result), the communicator is void from then on (the mailbox is
+    given up: a later post could be taken for another exchange's) and every further exchange fails at once;
+    the context works again once the communicator is gone."""
+    job = "lonely_%d_%d" % (os.getpid(), _free_port())
+    mp.spawn(_worker_lonely, args=(job, str(tmp_path)), nprocs=2, join=True)
     lines = open(tmp_path / "lonely.txt").read().splitlines()
-    assert "timed out" in lines[0] and "timed out" in lines[1], lines
-    assert lines[2].startswith("alone: fitness") and float(lines[2].split()[-1]) > 0.9, lines
+    assert "timed out" in lines[0] and "void" in lines[0], lines
+    assert "void" in lines[1], lines
+    assert lines[2] == "kind 0", lines
+    assert lines[3].startswith("alone: fitness") and float(lines[3].split()[-1]) > 0.9, lines
+
+
+def _worker_attach_alone(_index, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MI_ICP_MAIL_ATTACH_MS"] = "300"
+    from cupoch_amd.engine import Engine, MiIcpError
+    torch.cuda.set_device(0)
+    eng = Engine(0)
+    try:
+        eng.comm_init_local("alone_%d" % os.getpid(), 2, 0)     # rank 1 never shows up
+        msg = "no error"
+    except MiIcpError as e:
+        msg = str(e)
+    kind = eng.comm_kind()
+    eng.close()
+    with open(os.path.join(out_dir, "alone.txt"), "w") as f:
+        f.write("%s\nkind %d" % (msg, kind))
+
+
+def test_mailbox_setup_fails_cleanly_without_its_peers(tmp_path):
+    """Rank 0 waits for every rank to attach before the box is declared in use; without them the set-up
+    fails after MI_ICP_MAIL_ATTACH_MS and leaves no communicator (and no shared-memory name) behind."""
+    mp.spawn(_worker_attach_alone, args=(str(tmp_path),), nprocs=1, join=True)
+    lines = open(tmp_path / "alone.txt").read().splitlines()
+    assert "attached" in lines[0] and lines[1] == "kind 0", lines
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("mi_icp_alone_")]
+
+
+N8, ITER8 = 64000, 6
+
+
+def _worker_eight(rank, world, job, out_dir):
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cupoch_amd import distributed as D
+    from cupoch_amd.engine import Engine
+    torch.cuda.set_device(0)
+    d = make_pair(N8, seed=21, noise=0.03)
+    eng = Engine(0)
+    src_dev = torch.from_numpy(d["src"]).cuda()
+    mine = D.device_shard_source(eng, src_dev, rank, world)
+    eng.set_target(torch.from_numpy(d["tgt"]).cuda(), torch.from_numpy(d["tgt_nrm"]).cuda())
+    eng.set_source(src_dev[torch.from_numpy(mine).cuda()])
+    eng.comm_init_local(job, world, rank)
+    assert eng.comm_kind() == 2
+    eng.set_global_source_count(N8)
+    if rank == 5:
+        time.sleep(0.7)                                     # a deliberately slow rank: its peers' kernels wait for its posts
+    out = {}
+    res = eng.registration_icp(PT2PL, d["max_dist"], None, 0.0, 0.0, ITER8, -1.0)
+    out["T"] = np.array(res.transformation, np.float32)
+    out["stat"] = np.array([res.fitness, res.inlier_rmse, res.iterations])
+    if rank == 2:
+        time.sleep(0.3)                                     # ... and another one, one loop later (the slots' parity at work)
+    res = eng.registration_icp(1, d["max_dist"], None, 0.0, 0.0, ITER8 + 1, -1.0)
+    out["T_pp"] = np.array(res.transformation, np.float32)
+    ev = eng.evaluate_registration(d["max_dist"], None)
+    out["eval"] = np.array([ev.fitness, ev.inlier_rmse])
+    np.savez(os.path.join(out_dir, "eight_%d.npz" % rank), **out)
+    eng.comm_destroy()
+    eng.close()
+
+
+def test_mailbox_exchange_eight_processes_on_one_gpu(tmp_path):
+    """The exchange at the width of a node: eight processes share GPU 0, each with an eighth of the source;
+    8 posts per exchange, odd and even numbers of exchanges (both slots), ranks that arrive late.  All ranks
+    end bit-identical, equal to the single-process loop."""
+    from cupoch_amd.engine import Engine
+    world = 8
+    job = "eight_%d_%d" % (os.getpid(), _free_port())
+    mp.spawn(_worker_eight, args=(world, job, str(tmp_path)), nprocs=world, join=True)
+    d = make_pair(N8, seed=21, noise=0.03)
+    eng = Engine(0)
+    eng.set_target(d["tgt"], d["tgt_nrm"])
+    eng.set_source(d["src"])
+    ref = eng.registration_icp(PT2PL, d["max_dist"], None, 0.0, 0.0, ITER8, -1.0)
+    ref_pp = eng.registration_icp(1, d["max_dist"], None, 0.0, 0.0, ITER8 + 1, -1.0)
+    ev = eng.evaluate_registration(d["max_dist"], None)
+    eng.close()
+    m = [np.load(tmp_path / ("eight_%d.npz" % r)) for r in range(world)]
+    for r in range(1, world):
+        for k in m[0].files:
+            np.testing.assert_array_equal(m[0][k], m[r][k], err_msg="%s rank %d" % (k, r))
+    assert np.linalg.norm(m[0]["T"] - np.array(ref.transformation, np.float32)) <= 1e-6
+    assert np.linalg.norm(m[0]["T_pp"] - np.array(ref_pp.transformation, np.float32)) <= 1e-6
+    assert m[0]["stat"][0] == pytest.approx(ref.fitness, abs=1e-6) and int(m[0]["stat"][2]) == ref.iterations
+    assert m[0]["eval"][0] == pytest.approx(ev.fitness, abs=1e-6) and m[0]["eval"][1] == pytest.approx(ev.inlier_rmse, rel=1e-5)
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("mi_icp_eight_")]     # the name went once all had attached
