@@ -57,6 +57,9 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+ITERATION_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_float, C.c_float)   # mi_icp_iteration_fn
+
+
 class Params(C.Structure):
     _fields_ = [("relative_fitness", C.c_float), ("relative_rmse", C.c_float),
                 ("max_iteration", C.c_int32), ("det_thresh", C.c_float)]
@@ -124,6 +127,7 @@ SIGNATURES = {
     "mi_icp_comm_destroy": (_I, [_P]),
     "mi_icp_set_global_source_count": (_I, [_P, _L]),
     "mi_icp_spatial_order": (_I, [_P, _P, _L, _P, _I]),
+    "mi_icp_set_iteration_callback": (_I, [_P, _P, _P]),
     "mi_icp_set_profiling": (_I, [_P, _I]),
     "mi_icp_get_profile": (_I, [_P, _P]),
     # include/mi_icp_debug.h (test-only)

@@ -14,6 +14,7 @@
 #include <stdexcept>
 
 #include "cupoch/cupoch.h"
+#include "cupoch/utility/console.h"
 #include "mi_icp.h"
 
 namespace cupoch {
@@ -67,6 +68,12 @@ std::pair<bool, Eigen::Matrix4f> SolveJacobianSystemAndObtainExtrinsicMatrix(
     const int ok = mi_icp_solve_system(sys, det_thresh, T.data());
     return {ok > 0, T};
 }
+
+namespace {
+VerbosityLevel g_verbosity = VerbosityLevel::Info;   // the reference's default (spdlog: info)
+}
+void SetVerbosityLevel(VerbosityLevel level) { g_verbosity = level; }
+VerbosityLevel GetVerbosityLevel() { return g_verbosity; }
 
 }  // namespace utility
 
@@ -438,7 +445,15 @@ RegistrationResult RegistrationICP(const geometry::PointCloud& source, const geo
         LoadClouds(source, target);
         mi_icp_params prm = {criteria.relative_fitness_, criteria.relative_rmse_, criteria.max_iteration_, det};
         mi_icp_result r;
-        Check(mi_icp_registration_icp(Engine(), EstType(type), max_correspondence_distance, init.data(), &prm, &r));
+        // utility::LogDebug("ICP Iteration #{:d}: Fitness {:.4f}, RMSE {:.4f}", ...) (registration.cu:155-156)
+        const bool debug = utility::GetVerbosityLevel() <= utility::VerbosityLevel::Debug;
+        if (debug)
+            mi_icp_set_iteration_callback(Engine(), [](void*, int i, float fitness, float rmse) {
+                std::fprintf(stderr, "[cupoch_amd] Debug: ICP Iteration #%d: Fitness %.4f, RMSE %.4f\n", i, fitness, rmse);
+            }, nullptr);
+        const int rc = mi_icp_registration_icp(Engine(), EstType(type), max_correspondence_distance, init.data(), &prm, &r);
+        if (debug) mi_icp_set_iteration_callback(Engine(), nullptr, nullptr);
+        Check(rc);
         return MakeResult(r);
     }
 

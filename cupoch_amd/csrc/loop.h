@@ -30,6 +30,7 @@ struct DevLoop {
     float rel_fitness, rel_rmse;  // < 0: never converges (stepping API; |d| < negative is false)
     float fitness, rmse, prev_fitness, prev_rmse;
     int64_t n_source_global;
+    uint64_t history;    // device address of float2[kLoopHistory] or 0: (fitness, rmse) an update started from, by iteration
     int32_t ready;       // estimator inputs present (normals / covariances)
     int32_t error;       // != 0: the ranks' exchange failed (mailbox.h); the loop is finished, its result void
     host::Mat4 T;        // reported transformation (column-major)
@@ -84,6 +85,7 @@ __device__ __forceinline__ float select16(const float* m, int i) {
     return v;
 }
 
+constexpr int kLoopHistory = 4096;  // entries of the per-iteration record (a ring: iteration i at i % kLoopHistory)
 constexpr int kStepThreads = 192;  // the least a block that steps may have: three waves with a role each
 
 // What a block that is about to step may already hold in registers: word threadIdx.x of the loop state
@@ -180,6 +182,9 @@ __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys
                 update_now = false;
             }
         }
+        // what registration.cu:155-156 logs: the evaluation an update starts from, by iteration number
+        if (update_now && st->history != 0ull)
+            reinterpret_cast<float2*>(st->history)[st->iterations & (kLoopHistory - 1)] = make_float2(st->fitness, st->rmse);
         s_update_now = update_now ? 1 : 0;
     }
     __syncthreads();

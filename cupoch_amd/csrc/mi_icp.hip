@@ -143,6 +143,11 @@ struct mi_icp_ctx {
     DevBuf loop_dev, ticket;
     DevLoop* loop_host = nullptr;  // pinned mirror of the device state
     bool loop_active = false;
+    mi_icp_iteration_fn iter_fn = nullptr;  // per-iteration report (mi_icp_set_iteration_callback)
+    void* iter_user = nullptr;
+    DevBuf loop_hist;
+    float* hist_host = nullptr;  // pinned, kLoopHistory * 2 floats
+    int iter_reported = 0;       // iterations of this loop the callback has seen
     float loop_r2 = 0.0f;
     int loop_est = 0;
 
@@ -1047,7 +1052,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
     if (c->ev_links) (void)hipEventDestroy(c->ev_links);
     mailbox_close(c);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    DevBuf* all[] = {&c->trec, &c->tlreg, &c->thalo, &c->tlinks_tmp, &c->halo_want, &c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
+    DevBuf* all[] = {&c->trec, &c->tlreg, &c->thalo, &c->tlinks_tmp, &c->halo_want, &c->loop_hist, &c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
                      &c->cell_gstart, &c->sx, &c->sy, &c->sz,
                      &c->sperm, &c->snrm, &c->scov, &c->nn_idx, &c->nn_d2, &c->inv_s,
                      &c->user_pairs, &c->keys0, &c->keys1, &c->vals0, &c->vals1, &c->hist,
@@ -1062,6 +1067,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
     if (c->u_host) (void)hipHostFree(c->u_host);
     if (c->od_host) (void)hipHostFree(c->od_host);
     if (c->loop_host) (void)hipHostFree(c->loop_host);
+    if (c->hist_host) (void)hipHostFree(c->hist_host);
     for (int k = 0; k < 2; ++k)
         for (int i = 0; i < mi_icp_ctx::kEvPairs; ++i)
             for (int e = 0; e < 2; ++e)
@@ -1072,6 +1078,13 @@ void mi_icp_destroy(mi_icp_ctx* c) {
 }
 
 const char* mi_icp_last_error(const mi_icp_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int mi_icp_set_iteration_callback(mi_icp_ctx* c, mi_icp_iteration_fn fn, void* user) {
+    if (!c) return MI_ICP_ERR_INVALID;
+    c->iter_fn = fn;
+    c->iter_user = user;
+    return MI_ICP_OK;
+}
 
 int mi_icp_set_stream(mi_icp_ctx* c, void* hip_stream) {
     if (c && c->aux) c->aux->stream = (hipStream_t)hip_stream;
@@ -1575,6 +1588,18 @@ static int loop_pull(mi_icp_ctx* c) {  // device state -> pinned mirror, synchro
     HIPCHK(c, hipMemcpyAsync(c->loop_host, c->loop_dev.p, sizeof(DevLoop), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->loop_host->error) return comm_failed(c, "the ranks' exchange timed out (mailbox): a peer did not post its sums");
+    if (c->iter_fn && c->loop_host->history != 0ull && c->loop_host->iterations > c->iter_reported) {
+        // the iterations started since the last look, in order (a ring: at most kLoopHistory of them per look)
+        const int upto = c->loop_host->iterations;
+        const int from = std::max(c->iter_reported, upto - kLoopHistory);
+        HIPCHK(c, hipMemcpyAsync(c->hist_host, c->loop_hist.p, sizeof(float) * 2 * kLoopHistory, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->iter_reported = upto;
+        for (int i = from; i < upto; ++i) {
+            const float* e = c->hist_host + 2 * (size_t)(i & (kLoopHistory - 1));
+            c->iter_fn(c->iter_user, i, e[0], e[1]);
+        }
+    }
     return MI_ICP_OK;
 }
 
@@ -1711,6 +1736,14 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
     L.rel_rmse = rel_rmse;
     L.n_source_global = c->ns_global > 0 ? c->ns_global : c->ns;
     L.ready = estimator_ready(c, est) ? 1 : 0;
+    L.history = 0ull;
+    c->iter_reported = 0;
+    if (c->iter_fn) {
+        float* hist;
+        TRY(ensure(c, c->loop_hist, (size_t)2 * kLoopHistory, &hist));
+        if (!c->hist_host) HIPCHK(c, hipHostMalloc((void**)&c->hist_host, sizeof(float) * 2 * kLoopHistory, hipHostMallocDefault));
+        L.history = (uint64_t)(uintptr_t)hist;
+    }
     c->loop_active = false;
     c->loop_est = est;
     c->loop_r2 = max_distance * max_distance;

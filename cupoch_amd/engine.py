@@ -545,6 +545,13 @@ class Engine:
     def comm_destroy(self):
         self._chk(self._L.mi_icp_comm_destroy(self._ctx))
 
+    def set_iteration_callback(self, fn):
+        """fn(iteration, fitness, inlier_rmse) once per iteration of the following loops, in order (what the
+        reference logs at debug verbosity, registration.cu:155-156); None removes it."""
+        from ._lib import ITERATION_FN
+        self._iter_cb = None if fn is None else ITERATION_FN(lambda _user, i, f, r: fn(int(i), float(f), float(r)))
+        self._chk(self._L.mi_icp_set_iteration_callback(self._ctx, C.cast(self._iter_cb, C.c_void_p) if self._iter_cb else None, None))
+
     def set_profiling(self, enable=True):
         self._chk(self._L.mi_icp_set_profiling(self._ctx, 1 if enable else 0))
 

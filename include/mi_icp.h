@@ -407,6 +407,16 @@ MI_ICP_API int mi_icp_set_global_source_count(mi_icp_ctx* ctx, int64_t n_total);
 MI_ICP_API int mi_icp_spatial_order(mi_icp_ctx* ctx, const float* xyz, int64_t n, uint32_t* order_out,
                                     int mem_kind);
 
+/* ---- per-iteration report (registration.cu:155-156: utility::LogDebug("ICP Iteration #{:d}: Fitness {:.4f},
+ * RMSE {:.4f}", i, ...) at the top of every iteration) ----------------------------------------------
+ * The loop runs on the device, several iterations per host look; with a callback set every update records
+ * the evaluation it starts from, and the callback is called -- on the calling thread, in iteration order,
+ * from inside mi_icp_registration_icp / mi_icp_icp_begin / mi_icp_icp_iterate / mi_icp_registration_colored_icp
+ * -- once per iteration with the iteration's number (from 0), fitness and inlier RMSE: the values the reference
+ * logs.  NULL removes it.  Costs one small device-to-host copy per look; nothing when unset. */
+typedef void (*mi_icp_iteration_fn)(void* user, int iteration, float fitness, float inlier_rmse);
+MI_ICP_API int mi_icp_set_iteration_callback(mi_icp_ctx* ctx, mi_icp_iteration_fn fn, void* user);
+
 /* ---- instrumentation ----------------------------------------------------
  * enable != 0: every nearest-neighbour and reduction launch is bracketed by
  * hipEvents on the context's stream.  out[8] = {nn_ms_total, nn_launches,

@@ -216,3 +216,32 @@ def test_error_conventions_of_the_reference():
     # empty clouds
     res = cph.registration.evaluate_registration(cph.geometry.PointCloud(), target, 0.1)
     assert res.fitness == 0.0 and len(res.correspondence_set) == 0
+
+
+def test_iteration_callback_reports_what_the_reference_logs():
+    """mi_icp_set_iteration_callback: once per iteration, in order, the fitness / inlier RMSE of the evaluation
+    the iteration's update starts from (registration.cu:155-156) -- the values the stepping interface returns
+    evaluation by evaluation; nothing is reported once the callback is removed."""
+    from conftest import make_pair
+    from cupoch_amd.engine import Engine
+    d = make_pair(30000, seed=9, noise=0.05)
+    eng = Engine(0)
+    eng.set_target(d["tgt"], d["tgt_nrm"])
+    eng.set_source(d["src"])
+    seen = []
+    eng.set_iteration_callback(lambda i, f, r: seen.append((i, f, r)))
+    res = eng.registration_icp(2, d["max_dist"], None, 0.0, 0.0, 21, -1.0)
+    assert res.iterations == 21 and [s[0] for s in seen] == list(range(21))
+    eng.set_iteration_callback(None)
+    step = [eng.icp_begin(2, d["max_dist"], None, -1.0)]
+    for _ in range(20):
+        step.append(eng.icp_iterate(1))
+    assert len(seen) == 21                                   # (no callback any more)
+    for (i, f, r), s in zip(seen, step):
+        assert f == s.fitness and r == s.inlier_rmse, i
+    # a loop that converges early reports the iterations it ran
+    seen.clear()
+    eng.set_iteration_callback(lambda i, f, r: seen.append(i))
+    res = eng.registration_icp(2, d["max_dist"], None, 1e-6, 1e-6, 30, -1.0)
+    assert seen == list(range(res.iterations)) and res.iterations < 30
+    eng.close()
