@@ -22,6 +22,11 @@
 // the box was made (32 bits, wrapping past 0 -- a word's zeroed state -- with the parity kept: only the two
 // most recent numbers can ever be in a slot); every rank performs the same
 // exchanges (the loop's control flow depends only on the all-reduced sums, which are identical everywhere).
+// DEVICE INBOXES (MI_ICP_MAILBOX=device; set up through the box above, mi_icp.hip: mailbox_open).  Host memory costs
+// every poll a trip over PCIe.  With an inbox per rank in fine-grained DEVICE memory, opened by every other rank
+// through HIP IPC, a rank stores its 64 words into all inboxes -- over xGMI between GPUs, posted writes -- and polls
+// its OWN inbox, i.e. local memory.  Same words, same slots, same numbers.  Exercised here by several processes on
+// one GPU; not the default until it has been measured across GPUs.
 // A rank that does not hear from a peer within ~10 s gives up: the loop is marked failed and the host
 // call returns MI_ICP_ERR_COMM (bench.py then falls back to the RCCL path).
 #pragma once
@@ -37,15 +42,26 @@ struct MailBox {
     uint32_t nranks;
     uint32_t attached;                   // ranks > 0 that have mapped and registered the box
     uint32_t go;                         // set by rank 0 when all have: the box is in use (a box found with go != 0 is another job's)
-    uint32_t pad_[12];
+    uint32_t device_mode;                // rank 0's wish: the posts travel GPU to GPU (device inboxes, below) instead of through `words`
+    uint32_t device_failed;              // set by any rank that could not set its part of that up: everybody stays with `words`
+    uint32_t pad_[10];
+    // device mode: every rank's inbox (fine-grained device memory, [slot][rank][64] words like `words`) as an IPC handle,
+    // and the ranks' progress through the set-up (1: handle published, 2: every peer's inbox opened) and the tear-down
+    hipIpcMemHandle_t inbox[kMailRanks];
+    uint32_t inbox_state[kMailRanks];
+    uint32_t inbox_closed[kMailRanks];
     unsigned long long words[2][kMailRanks][64];  // [slot][rank]: exchange << 32 | low / high half of sum k's bits at 2k / 2k + 1
 };
+constexpr size_t kMailInboxWords = (size_t)2 * kMailRanks * 64;
 
 struct MailArgs {
     MailBox* box;       // device address of the registered host mapping; null: no mailbox
     uint32_t* seq_dev;  // this rank's exchange counter (device memory, zeroed with the box)
     int rank, nranks;
     uint32_t spin_limit;
+    // device mode (else null): this rank's inbox and the device addresses of all ranks' inboxes (its own included)
+    unsigned long long* inbox;
+    unsigned long long* const* peers;
 };
 
 // One workgroup of whole waves (>= 64 threads).  sys: this rank's 32 sums (global or LDS, written before a
@@ -67,10 +83,17 @@ __device__ __forceinline__ bool mail_allreduce(const MailArgs& m, double* sys, u
     const uint32_t seq = s_tmp[0];
     const int slot = (int)(seq & 1u);
     const unsigned long long tag = (unsigned long long)seq << 32;
+    const bool direct = m.peers != nullptr;  // device inboxes: a post is WRITTEN to every rank's inbox, a poll reads local memory
     if (tid < 64) {
         const unsigned long long bits = (unsigned long long)__double_as_longlong(sys[tid >> 1]);
         const unsigned long long half = (tid & 1) ? (bits >> 32) : (bits & 0xffffffffull);
-        __hip_atomic_store(&m.box->words[slot][m.rank][tid], tag | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (direct) {
+            const size_t at = ((size_t)slot * kMailRanks + (size_t)m.rank) * 64 + (size_t)tid;
+            for (int r = 0; r < m.nranks; ++r)
+                __hip_atomic_store(m.peers[r] + at, tag | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            __hip_atomic_store(&m.box->words[slot][m.rank][tid], tag | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     // wave w waits for the ranks w, w + nw, ... -- up to four at a time, their loads in flight together
     constexpr int kAtOnce = 4;
@@ -82,8 +105,11 @@ __device__ __forceinline__ bool mail_allreduce(const MailArgs& m, double* sys, u
             for (int j = 0; j < kAtOnce; ++j) {
                 const int r = r0 + j * nw;
                 w[j] = tag;  // (no such rank: valid as it stands)
-                if (r < m.nranks)
-                    w[j] = __hip_atomic_load(&m.box->words[slot][r][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (r < m.nranks) {
+                    const unsigned long long* src = direct ? m.inbox + ((size_t)slot * kMailRanks + (size_t)r) * 64 + (size_t)lane
+                                                           : &m.box->words[slot][r][lane];
+                    w[j] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
             bool stale = false;
 #pragma unroll

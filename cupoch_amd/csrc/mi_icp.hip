@@ -22,6 +22,7 @@
 #include <chrono>
 #include <cctype>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -160,6 +161,10 @@ struct mi_icp_ctx {
     size_t mail_bytes = 0;
     std::string mail_name;
     bool mail_linked = false;   // the name still exists and is this context's to remove
+    // device inboxes (mailbox.h): this rank's, the peers' as opened through HIP IPC, and the device-side table of all
+    unsigned long long* inbox = nullptr;
+    unsigned long long* inbox_peer[kMailRanks] = {};
+    DevBuf inbox_table;
     bool comm_broken = false;   // an exchange has failed: the ranks' counters are apart
     DevBuf mail_state;  // [0]: this rank's exchange counter, [1]: error flag of the one-shot exchange
 
@@ -766,6 +771,8 @@ MailArgs mail_args(const mi_icp_ctx* c) {
     MailArgs m;
     m.box = c->mail_dev;
     m.seq_dev = (uint32_t*)c->mail_state.p;
+    m.inbox = c->inbox;
+    m.peers = c->inbox ? (unsigned long long* const*)c->inbox_table.p : nullptr;
     m.rank = c->rank;
     m.nranks = c->nranks;
     static const uint32_t limit = [] { const char* e = std::getenv("MI_ICP_MAIL_SPIN_LIMIT"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : kMailSpinLimit; }();
@@ -773,7 +780,93 @@ MailArgs mail_args(const mi_icp_ctx* c) {
     return m;
 }
 
+// Device inboxes: nobody may free an inbox a peer's kernel could still write to.  Every rank closes what it opened
+// and says so in the box; an inbox is freed once every peer has (or after 2 s: a peer that died holds no kernel).
+void inbox_close(mi_icp_ctx* c) {
+    if (!c->inbox) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (int r = 0; r < c->nranks && r < kMailRanks; ++r)
+        if (r != c->rank && c->inbox_peer[r]) (void)hipIpcCloseMemHandle(c->inbox_peer[r]);
+    for (auto& p : c->inbox_peer) p = nullptr;
+    if (c->mail_host) {
+        MailBox* box = c->mail_host;
+        __atomic_store_n(&box->inbox_closed[c->rank], 1u, __ATOMIC_RELEASE);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            bool all = true;
+            for (int r = 0; r < c->nranks && r < kMailRanks; ++r) all = all && __atomic_load_n(&box->inbox_closed[r], __ATOMIC_ACQUIRE) != 0u;
+            if (all || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    }
+    (void)hipFree(c->inbox);
+    c->inbox = nullptr;
+    (void)hipGetLastError();
+}
+
+// ... set up after the box itself (every rank is attached): inbox, handle into the box, wait for the peers', open
+// them.  All ranks end in the same mode: a rank that fails says so in the box before the others look.
+bool inbox_open(mi_icp_ctx* c, MailBox* box, int nranks, int rank, const std::function<bool()>& late) {
+    auto wait_all = [&](uint32_t state) {
+        for (;;) {
+            bool all = true;
+            for (int r = 0; r < nranks; ++r) all = all && __atomic_load_n(&box->inbox_state[r], __ATOMIC_ACQUIRE) >= state;
+            if (all) return true;
+            if (late()) return false;
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    };
+    auto give_up = [&] { __atomic_store_n(&box->device_failed, 1u, __ATOMIC_RELEASE); };
+    const size_t bytes = kMailInboxWords * sizeof(unsigned long long);
+    void* mine = nullptr;
+    if (hipExtMallocWithFlags(&mine, bytes, hipDeviceMallocFinegrained) != hipSuccess || hipMemset(mine, 0, bytes) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess || hipIpcGetMemHandle(&box->inbox[rank], mine) != hipSuccess) {
+        (void)hipGetLastError();
+        give_up();
+    }
+    __atomic_store_n(&box->inbox_state[rank], 1u, __ATOMIC_RELEASE);
+    if (!wait_all(1u)) give_up();
+    bool ok = __atomic_load_n(&box->device_failed, __ATOMIC_ACQUIRE) == 0u;
+    if (ok) {
+        for (int r = 0; r < nranks && ok; ++r) {
+            if (r == rank) {
+                c->inbox_peer[r] = (unsigned long long*)mine;
+            } else {
+                void* p = nullptr;
+                if (hipIpcOpenMemHandle(&p, box->inbox[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+                    (void)hipGetLastError();
+                    give_up();
+                    ok = false;
+                } else {
+                    c->inbox_peer[r] = (unsigned long long*)p;
+                }
+            }
+        }
+    }
+    __atomic_store_n(&box->inbox_state[rank], 2u, __ATOMIC_RELEASE);
+    if (!wait_all(2u)) give_up();
+    ok = __atomic_load_n(&box->device_failed, __ATOMIC_ACQUIRE) == 0u;
+    unsigned long long** table = nullptr;
+    if (ok && (ensure(c, c->inbox_table, kMailRanks, &table) != MI_ICP_OK ||
+               hipMemcpy(table, c->inbox_peer, sizeof(c->inbox_peer), hipMemcpyHostToDevice) != hipSuccess)) {
+        // (too late to tell the others: they will wait for this rank's posts in vain and time out; cannot happen short of an out-of-memory)
+        ok = false;
+    }
+    if (!ok) {
+        for (int r = 0; r < nranks; ++r)
+            if (r != rank && c->inbox_peer[r]) (void)hipIpcCloseMemHandle(c->inbox_peer[r]);
+        for (auto& p : c->inbox_peer) p = nullptr;
+        __atomic_store_n(&box->inbox_closed[rank], 1u, __ATOMIC_RELEASE);
+        if (mine) (void)hipFree(mine);
+        (void)hipGetLastError();
+        return false;
+    }
+    c->inbox = (unsigned long long*)mine;
+    return true;
+}
+
 void mailbox_close(mi_icp_ctx* c) {
+    inbox_close(c);
     if (c->mail_host) {
         (void)hipHostUnregister(c->mail_host);
         (void)munmap(c->mail_host, c->mail_bytes);
@@ -844,6 +937,8 @@ int mailbox_open(mi_icp_ctx* c, const std::string& name, int nranks, int rank) {
         box = (MailBox*)p;
         std::memset(p, 0, bytes);
         box->nranks = (uint32_t)nranks;
+        const char* mode = std::getenv("MI_ICP_MAILBOX");   // "device": inboxes in device memory (mailbox.h)
+        box->device_mode = (mode && std::strcmp(mode, "device") == 0) ? 1u : 0u;
         __atomic_store_n(&box->ready, 1u, __ATOMIC_RELEASE);
         while (__atomic_load_n(&box->attached, __ATOMIC_ACQUIRE) != (uint32_t)(nranks - 1)) {
             if (late()) {
@@ -913,6 +1008,9 @@ int mailbox_open(mi_icp_ctx* c, const std::string& name, int nranks, int rank) {
     c->mail_name = name;
     c->mail_linked = false;  // (rank 0 has removed the name already)
     c->comm_broken = false;
+    c->nranks = nranks;
+    c->rank = rank;
+    if (box->device_mode) (void)inbox_open(c, box, nranks, rank, late);  // (failing that, on every rank alike: the box's own words)
     return MI_ICP_OK;
 }
 
@@ -2647,7 +2745,7 @@ int mi_icp_comm_init_local(mi_icp_ctx* c, const char* job_name, int nranks, int 
 
 int mi_icp_comm_kind(const mi_icp_ctx* c) {
     if (!c) return 0;
-    return c->mail_dev ? 2 : (c->comm ? 1 : 0);
+    return c->mail_dev ? (c->inbox ? 3 : 2) : (c->comm ? 1 : 0);
 }
 
 int mi_icp_comm_destroy(mi_icp_ctx* c) {

@@ -107,10 +107,11 @@ def test_in_library_rccl_allreduce_on_a_one_rank_communicator():
     eng.close()
 
 
-def _worker_mailbox(rank, world, job, out_dir):
+def _worker_mailbox(rank, world, job, out_dir, mode="host"):
     import sys
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MI_ICP_MAILBOX"] = mode
     from cupoch_amd import distributed as D
     from cupoch_amd.engine import Engine
     torch.cuda.set_device(0)
@@ -121,7 +122,7 @@ def _worker_mailbox(rank, world, job, out_dir):
     eng.set_target(torch.from_numpy(d["tgt"]).cuda(), torch.from_numpy(d["tgt_nrm"]).cuda())
     eng.set_source(src_dev[torch.from_numpy(mine).cuda()])
     eng.comm_init_local(job, world, rank)                  # the shared-memory mailbox, no RCCL
-    assert eng.comm_kind() == 2
+    assert eng.comm_kind() == (3 if mode == "device" else 2)
     eng.set_global_source_count(N)
     out = {}
     # the device-resident loop: point-to-plane (exchange + step inside the reduction's finishing block) ...
@@ -140,15 +141,17 @@ def _worker_mailbox(rank, world, job, out_dir):
     eng.close()
 
 
-def test_mailbox_exchange_two_processes_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("mode", ["host", "device"])
+def test_mailbox_exchange_two_processes_on_one_gpu(tmp_path, mode):
     """The node-local communicator (csrc/mailbox.h): two processes share GPU 0, each runs the
-    DEVICE-resident loop on its shard; every evaluation's 32 sums are exchanged through the mailbox in
-    shared host memory by the kernels themselves.  Both ranks must end with bit-identical results,
-    equal (to rounding of the sums' order) to the single-process loop."""
+    DEVICE-resident loop on its shard; every evaluation's 32 sums are exchanged by the kernels themselves --
+    through the mailbox in shared host memory, or (MI_ICP_MAILBOX=device) by writing them into each other's
+    inboxes in device memory, opened through HIP IPC.  Both ranks must end with bit-identical results, equal
+    (to rounding of the sums' order) to the single-process loop."""
     from cupoch_amd.engine import Engine
     world = 2
     job = "test_%d_%d" % (os.getpid(), _free_port())
-    mp.spawn(_worker_mailbox, args=(world, job, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_mailbox, args=(world, job, str(tmp_path), mode), nprocs=world, join=True)
     d = make_pair(N, seed=13, noise=0.03)
     eng = Engine(0)
     eng.set_target(d["tgt"], d["tgt_nrm"])
@@ -248,11 +251,12 @@ def test_mailbox_setup_fails_cleanly_without_its_peers(tmp_path):
 N8, ITER8 = 64000, 6
 
 
-def _worker_eight(rank, world, job, out_dir):
+def _worker_eight(rank, world, job, out_dir, mode="host"):
     import sys
     import time
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MI_ICP_MAILBOX"] = mode
     from cupoch_amd import distributed as D
     from cupoch_amd.engine import Engine
     torch.cuda.set_device(0)
@@ -263,7 +267,7 @@ def _worker_eight(rank, world, job, out_dir):
     eng.set_target(torch.from_numpy(d["tgt"]).cuda(), torch.from_numpy(d["tgt_nrm"]).cuda())
     eng.set_source(src_dev[torch.from_numpy(mine).cuda()])
     eng.comm_init_local(job, world, rank)
-    assert eng.comm_kind() == 2
+    assert eng.comm_kind() == (3 if mode == "device" else 2)
     eng.set_global_source_count(N8)
     if rank == 5:
         time.sleep(0.7)                                     # a deliberately slow rank: its peers' kernels wait for its posts
@@ -282,14 +286,16 @@ def _worker_eight(rank, world, job, out_dir):
     eng.close()
 
 
-def test_mailbox_exchange_eight_processes_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("mode", ["host", "device"])
+def test_mailbox_exchange_eight_processes_on_one_gpu(tmp_path, mode):
     """The exchange at the width of a node: eight processes share GPU 0, each with an eighth of the source;
-    8 posts per exchange, odd and even numbers of exchanges (both slots), ranks that arrive late.  All ranks
-    end bit-identical, equal to the single-process loop."""
+    8 posts per exchange, odd and even numbers of exchanges (both slots), ranks that arrive late -- through the
+    host-memory box and through device inboxes (56 IPC mappings among the eight).  All ranks end bit-identical,
+    equal to the single-process loop."""
     from cupoch_amd.engine import Engine
     world = 8
     job = "eight_%d_%d" % (os.getpid(), _free_port())
-    mp.spawn(_worker_eight, args=(world, job, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_eight, args=(world, job, str(tmp_path), mode), nprocs=world, join=True)
     d = make_pair(N8, seed=21, noise=0.03)
     eng = Engine(0)
     eng.set_target(d["tgt"], d["tgt_nrm"])
