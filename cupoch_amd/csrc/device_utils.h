@@ -14,7 +14,7 @@ namespace mi {
 constexpr int kWave = 64;
 constexpr int kLeaf = 8;          // points per LBVH leaf
 constexpr int kLeafFloats = 32;   // x[8] y[8] z[8] orig_idx[8] = one 128-B line
-constexpr int kLeafRegFloats = 8; // per leaf: region lo.xyz, reach of its neighbour list | hi.xyz, - (kd_build.h)
+constexpr int kLeafRegFloats = 8; // per leaf: region lo.xyz, A | hi.xyz, B (kd_build.h); A, B: the reaches of its halo lines (leaf_halo.h)
 
 // Row-major 3x4 rigid transform passed by value as a kernel argument (SGPRs).
 struct Xform {

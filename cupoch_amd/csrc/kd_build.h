@@ -43,7 +43,7 @@ struct GroupBuildArgs {
 // sibling half.  Cutting along ANY axis at the sibling's exact extreme keeps the defining
 // property (every sibling point lies on or beyond the new face), so the axis is simply
 // recomputed as the longest axis of the parent's box -- the rule the sort used.
-// Float 3 is the REACH of the leaf's neighbour list (leaf_links.h); 0: none.
+// Floats 3 and 7 later carry the reaches of the leaf's halo lines (leaf_halo.h); until then: 0 and the halo's bound.
 
 
 // (two 1024-thread workgroups per CU = 8 waves per SIMD: at most 64 VGPRs)

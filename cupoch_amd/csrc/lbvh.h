@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void build_level(float* __restrict__ records, 
     store_box(records, id, mn, mx);
 }
 
-// leaf regions of a tree that has none (Morton-run fallback): nothing is inside, no neighbour list
+// leaf regions of a tree that has none (Morton-run fallback): nothing is inside, no halo
 __global__ __launch_bounds__(256) void fill_invalid_leaf_regions(float* __restrict__ lreg, int nleaf) {
     const int L = (int)(blockIdx.x * 256 + threadIdx.x);
     if (L >= nleaf) return;

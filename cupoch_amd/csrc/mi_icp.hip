@@ -101,7 +101,7 @@ struct mi_icp_ctx {
     uint32_t* cell_total_host = nullptr;  // pinned
     bool inv_t_valid = false;
     bool links_ready = false, links_allowed = false;  // leaf_halo.h
-    // the neighbour lists are built on a private stream, next to the staging of the source or the loop's first pass
+    // the halos are built on a private stream (start_links_async)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_links = nullptr;
     bool links_inflight = false;
@@ -1120,7 +1120,7 @@ int mi_icp_create(int device, mi_icp_ctx** out) {
               hipHostMalloc((void**)&c->u_host, 16 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&c->loop_host, sizeof(DevLoop), hipHostMallocDefault) == hipSuccess;
     for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
-    // (lowest priority: the neighbour-list build fills what the context's own stream leaves idle)
+    // (lowest priority: the halo build fills what the context's own stream leaves idle)
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     ok = ok && hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_least) == hipSuccess &&

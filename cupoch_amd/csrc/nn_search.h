@@ -505,7 +505,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8
 // every query walks down the tree on its own, at each record into the child whose box is nearest
 // (inside: distance 0), and takes the leaf it arrives at as its seed.  No backtracking, so the leaf
 // is only near the true match -- the seeded search above turns it into the exact answer through
-// that leaf's region and neighbour list.  Consecutive queries are spatial neighbours (the source is
+// that leaf's region and halo.  Consecutive queries are spatial neighbours (the source is
 // staged in Morton order): the upper records are the same for a whole wave, the lower ones shared
 // by many lanes, so the 12 vector loads per level mostly hit the same few lines.
 // (While a wave's lanes still agree on the node -- the upper levels -- its record comes through the

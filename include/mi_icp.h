@@ -102,10 +102,12 @@ MI_ICP_API int mi_icp_synchronize(mi_icp_ctx* ctx);
  * kdtree_cuda_builder.h:401-700): partitions the target into kd cells and
  * builds the implicit 8-ary tree over them.  normals / covs may be NULL.
  * Synchronous (the tree's size is read back once); at most ~3e8 points.
- * On a context that has run a registration before, the call also starts the
- * build of the leaves' neighbour lists (what the seeded searches of a loop
- * use) on a private low-priority stream, next to whatever the caller enqueues
- * next; the first call that needs them waits for them.
+ * The leaves' HALOS (what a loop's seeded searches use once the matches are no
+ * longer exact; csrc/leaf_halo.h) are built on demand, on a private low-priority
+ * stream: when a registration loop's searches ask for them, with the loop on a
+ * context whose loops have asked before, and -- for a target below 2M points on a
+ * context that has registered before -- right behind the tree, next to whatever
+ * the caller enqueues next.
  * mi_icp_set_source replaces `geometry::PointCloud pcd = source`
  * (registration/registration.cu:147): the engine keeps a Morton-sorted SoA
  * copy and never mutates the caller's cloud.  Stream-ordered. */

@@ -37,8 +37,7 @@ MI_ICP_API int mi_icp_debug_nn_stats8(mi_icp_ctx* ctx, const float* T, float rad
 MI_ICP_API int mi_icp_debug_drop_seeds(mi_icp_ctx* ctx);
 /* How the last nearest-neighbour pass started: 0 = from the root (no previous matches), 1 = from the
  * previous pass's matches, 2 = from seeds it made itself (a greedy descent per query; what a registration
- * loop's first pass does when the target's neighbour lists were built ahead, mi_icp_set_target on a
- * context that has registered before), -1 = no pass yet. */
+ * loop's first pass does when the target's halos exist already), -1 = no pass yet. */
 MI_ICP_API int mi_icp_debug_last_search_kind(const mi_icp_ctx* ctx);
 /* The loop step's two forms of utility::SolveJacobianSystemAndObtainExtrinsicMatrix side by side, on the
  * device: n systems of 32 doubles each (host memory; the reduction's layout: 21 upper-triangle sums of

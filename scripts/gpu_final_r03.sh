@@ -1,0 +1,79 @@
+#!/bin/bash
+# Round 3: the validation + every measurement that goes into profiles/r03_* (run on the MI355X box:
+# gpurun -- scripts/gpu_final_r03.sh [sections]).  Everything lands under gpurun_out/r03/.
+# sections (default: all): tests bench rows stats pmc traffic pmcrows
+O=gpurun_out/r03
+mkdir -p $O
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+S=${*:-tests bench rows stats pmc traffic pmcrows}
+has() { [[ " $S " == *" $1 "* ]]; }
+prof() { (cd /tmp && timeout 300 rocprofv3 "$@"); }
+if has tests; then
+  python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1; echo "build rc=$?"
+  timeout 1500 python -m pytest tests -m gpu -q --timeout=900 > $O/t_gpu.log 2>&1; echo "gpu tests rc=$?"; grep -E "passed|failed" $O/t_gpu.log
+  timeout 300 python __graft_entry__.py smoke 2>&1 | grep -v amdgpu.ids | tail -2 | tee $O/smoke.log
+fi
+if has bench; then
+  timeout 900 python bench.py 2>&1 | grep '^{"metric' | tee $O/bench_10m.json | python scripts/benchline.py
+  timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | grep '^{"metric' | tee $O/bench_10m_steps20_warmup5.json | python scripts/benchline.py
+  for n in 100000 1000000 5000000 20000000; do timeout 600 python bench.py --points $n --no-cpu-baseline --no-secondary 2>&1 | grep '^{"metric'; done > $O/bench_by_size.jsonl
+  MI_ICP_FORCE_COMM=1 timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 20 2>&1 | grep '^{"metric' | tee $O/bench_10m_rccl_1rank.json | python scripts/benchline.py
+  MI_ICP_FORCE_COMM=2 timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 20 2>&1 | grep '^{"metric' | tee $O/bench_10m_mailbox_1rank.json | python scripts/benchline.py
+fi
+if has rows; then
+  timeout 900 python scripts/measure_configs.py 2>&1 | grep '^{' > $O/configs.jsonl; tail -2 $O/configs.jsonl | cut -c1-200
+  timeout 600 python scripts/measure_noisy.py 2>&1 | grep '^{' > $O/noisy.jsonl; cut -c60-180 $O/noisy.jsonl
+  timeout 600 python scripts/measure_latency.py 2>&1 | grep '^{' > $O/call_latency.jsonl
+  MI_ICP_LATENCY_HOST=1 timeout 600 python scripts/measure_latency.py 100000 1000000 10000000 2>&1 | grep '^{' > $O/call_latency_host_inputs.jsonl
+  timeout 600 python scripts/measure_shard.py 2>&1 | grep '^{' > $O/shard_emulation.jsonl
+  MI_ICP_SHARD_MAILBOX=1 timeout 600 python scripts/measure_shard.py 2>&1 | grep '^{' >> $O/shard_emulation.jsonl
+  MI_ICP_MAILBOX=device MI_ICP_SHARD_MAILBOX=1 timeout 600 python scripts/measure_shard.py 2>&1 | grep '^{' >> $O/shard_emulation.jsonl
+  timeout 600 python scripts/measure_colored.py 2>&1 | grep '^{' > $O/colored.jsonl
+  timeout 600 python scripts/measure_kinfu.py 2>&1 | grep '^{' > $O/kinfu.jsonl
+  timeout 600 python scripts/measure_odometry.py 2>&1 | grep '^{' > $O/odometry.jsonl
+  timeout 600 python scripts/measure_knn.py 1,0.0 8,0.0 30,0.0 30,0.01 64,0.0 100,0.0 2>&1 | grep '^{' > $O/knn_search.jsonl
+  timeout 600 python scripts/measure_normals_10m.py 2>&1 | grep normals > $O/normals_10m.txt
+  timeout 900 python scripts/measure_config1.py > $O/config1_cpu_p2p_100k.json 2>/dev/null; cut -c1-300 $O/config1_cpu_p2p_100k.json
+fi
+if has stats; then
+  prof --kernel-trace --stats --output-format csv -d $R/$O/st_head -o s -- python $R/bench.py --no-cpu-baseline --no-secondary > $O/st_head.log 2>&1; echo "stats head rc=$?"
+  prof --kernel-trace --stats --output-format csv -d $R/$O/st_cold -o s -- python $R/scripts/measure_latency.py 10000000 > $O/st_cold.log 2>&1; echo "stats cold rc=$?"
+  prof --kernel-trace --stats --output-format csv -d $R/$O/st_noisy -o s -- python $R/scripts/dev/noisy_one.py 0.15 > $O/st_noisy.log 2>&1; echo "stats noisy rc=$?"
+  prof --kernel-trace --stats --output-format csv -d $R/$O/st_configs -o s -- python $R/scripts/measure_configs.py > $O/st_configs.log 2>&1; echo "stats configs rc=$?"
+  prof --kernel-trace --stats --output-format csv -d $R/$O/st_knn -o s -- python $R/scripts/measure_knn.py 30,0.0 100,0.0 > $O/st_knn.log 2>&1; echo "stats knn rc=$?"
+  prof --kernel-trace --stats --output-format csv -d $R/$O/st_transient -o s -- python $R/scripts/dev/transient_one.py > $O/st_transient.log 2>&1; echo "stats transient rc=$?"
+fi
+if has pmc; then
+  i=0
+  for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    prof --kernel-trace --pmc $set --output-format csv -d $R/$O/pmc_head$i -o p -- python $R/bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-secondary > $O/pmc_head$i.log 2>&1; echo "pmc head $i rc=$?"
+    [ $i -le 3 ] && { prof --kernel-trace --pmc $set --output-format csv -d $R/$O/pmc_noisy$i -o p -- python $R/scripts/dev/noisy_one.py 0.15 > $O/pmc_noisy$i.log 2>&1; echo "pmc noisy $i rc=$?"; }
+  done
+  { echo "# rocprofv3 --pmc passes of: python bench.py --steps 6 --warmup 2 --repeats 1 (10M-vs-10M point-to-plane, exact correspondences); averages per launch"
+    python scripts/pmc_kernels.py "$O/pmc_head*/p_counter_collection.csv" "nn_packet_kernel<true" reduce_pt2pl
+    echo "# the same counters on the noisy workload (scripts/dev/noisy_one.py 0.15: 10M target, 6M noisy source, sigma = 0.15 spacings, converged iterations with halos)"
+    python scripts/pmc_kernels.py "$O/pmc_noisy*/p_counter_collection.csv" "nn_packet_kernel<true" leaf_halo; } | tee $O/pmc_summary.txt
+fi
+if has traffic; then
+  scripts/gpu_traffic.sh > $O/traffic.log 2>&1; tail -6 $O/traffic.log
+  for c in FETCH_SIZE WRITE_SIZE; do
+    prof --kernel-trace --pmc $c --output-format csv -d $R/$O/pmc_noisy_$c -o p -- python $R/scripts/dev/noisy_one.py 0.15 > $O/pmc_noisy_$c.log 2>&1; echo "pmc noisy $c rc=$?"
+  done
+  { echo "# FETCH_SIZE / WRITE_SIZE (KB per launch as reported: vector loads count at half their bytes, profiles/r02_fetch_calibration.txt) on the noisy workload"
+    python scripts/pmc_kernels.py "$O/pmc_noisy_*SIZE/p_counter_collection.csv" "nn_packet_kernel<true" leaf_halo; } | tee $O/pmc_noisy_traffic.txt
+fi
+if has pmcrows; then
+  # counter evidence for the rows the headline does not exercise: instruction mix + L2 / HBM
+  # traffic of the GICP reduction, the tree build, VoxelDownSample, EstimateNormals and the k-NN search kernels
+  i=0
+  for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i+1))
+    prof --kernel-trace --pmc $set --output-format csv -d $R/$O/pmc_rows$i -o p -- python $R/scripts/measure_configs.py > $O/pmc_rows$i.log 2>&1; echo "pmc rows $i rc=$?"
+    [ $i -le 2 ] && { prof --kernel-trace --pmc $set --output-format csv -d $R/$O/pmc_knn$i -o p -- python $R/scripts/measure_knn.py 30,0.0 100,0.0 > $O/pmc_knn$i.log 2>&1; echo "pmc knn $i rc=$?"; }
+  done
+  { echo "# rocprofv3 --pmc passes of scripts/measure_configs.py (config 2, config 5 = GICP 5M, builds and one-time costs at 10M, EstimateNormals 2M) and scripts/measure_knn.py 30,0.0 100,0.0; averages per launch"
+    python scripts/pmc_kernels.py "$O/pmc_rows*/p_counter_collection.csv" reduce_kernel kd_build_groups cells_ voxel knn_normals rs_scatter transform_cloud cov_from
+    python scripts/pmc_kernels.py "$O/pmc_knn*/p_counter_collection.csv" knn_search; } | tee $O/pmc_rows_summary.txt
+fi

@@ -103,7 +103,7 @@ n = 10_000_000
 src, tgt, nrm, T_gt, max_dist = synth(n)
 d_src, d_tgt, d_nrm = gpu(src), gpu(tgt), gpu(nrm)
 t = timed(lambda: (eng.set_target(d_tgt, d_nrm)), 3)
-emit(row="LBVH build (set_target, with normals)", n=n, ms=t * 1e3, algorithmic_GBps=36 * n / t / 1e9)
+emit(row="target tree build (set_target, with normals; kd cells + 8-ary records)", n=n, ms=t * 1e3, algorithmic_GBps=36 * n / t / 1e9)
 t = timed(lambda: (eng.set_source(d_src)), 3)
 emit(row="source Morton staging (set_source)", n=n, ms=t * 1e3)
 pts = d_src.clone()

@@ -40,6 +40,6 @@ for world in (1, 2, 4, 8):
     eng.icp_iterate(30)
     p1 = eng.get_profile()
     eng.set_profiling(False)
-    print(json.dumps({"exchange": "mailbox against itself" if SOLO else "none", "ranks": world, "source_points_on_this_rank": int(len(mine)), "ms_per_step_compute_only": round(dt * 1e3, 4),
+    print(json.dumps({"exchange": ("mailbox against itself (%s)" % ("device inbox" if eng.comm_kind() == 3 else "host memory")) if SOLO else "none", "ranks": world, "source_points_on_this_rank": int(len(mine)), "ms_per_step_compute_only": round(dt * 1e3, 4),
                       "nn_ms": round((p1["nn_ms"] - p0["nn_ms"]) / 30, 4), "reduce_ms": round((p1["reduce_ms"] - p0["reduce_ms"]) / 30, 4),
                       "speedup_vs_1_rank": round(base_ms / (dt * 1e3), 2)}), flush=True)

@@ -107,10 +107,10 @@ def test_registration_matches_oracle_on_random_configurations(eng, case):
 
 @pytest.mark.skipif(os.environ.get("MI_ICP_WAIT_LINKS") is not None, reason="this IS the forced run")
 def test_the_same_cases_with_every_first_pass_from_its_own_seeds():
-    """The loops' first pass normally starts from the queries' own seeds only when the target's
-    neighbour lists are complete and the source is large (launch_nn / loop_begin); the library reads
-    its A/B switches once per process, so the forced variant -- always wait for the lists, own seeds at
-    every size down to one point -- runs this file and the loop-level parity tests in a child process."""
+    """The loops normally get their target's halos on demand and start a first pass from the queries' own
+    seeds only when halos exist and the source is large (launch_nn / loop_run); the library reads its A/B
+    switches once per process, so the forced variant -- halos for every loop, own seeds at every size down
+    to one point -- runs this file and the loop-level parity tests in a child process."""
     import subprocess
     import sys
     env = dict(os.environ, MI_ICP_WAIT_LINKS="1", MI_ICP_COARSE_MIN="0")

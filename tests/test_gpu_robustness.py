@@ -243,8 +243,8 @@ def test_estimate_normals_leaves_a_registration_in_flight_alone(eng):
 
 
 def test_list_build_in_flight_survives_retargeting_knn_and_destroy():
-    """A context that has registered before starts the leaf neighbour lists on its private stream in
-    every mi_icp_set_target.  Whatever comes next while that build is in flight -- another target, a
+    """A context that has registered before starts the halos of a target below 2M points on its private
+    stream in mi_icp_set_target.  Whatever comes next while that build is in flight -- another target, a
     k-NN search, normals, a registration on a tiny source that does not wait for it, destroying the
     context -- must neither hang nor change results."""
     import numpy as np
@@ -263,7 +263,7 @@ def test_list_build_in_flight_survives_retargeting_knn_and_destroy():
     eng.set_source(small["src"])
     eng.registration_icp(2, small["max_dist"], None, 0.0, 0.0, 3, -1.0)              # now the context "has registered"
     for _ in range(3):
-        eng.set_target(d["tgt"], d["tgt_nrm"])                                       # lists start ...
+        eng.set_target(d["tgt"], d["tgt_nrm"])                                       # halos start ...
         eng.set_target(small["tgt"], small["tgt_nrm"])                               # ... and are dropped
         eng.set_target(d["tgt"], d["tgt_nrm"])
         k = eng.search_knn(d["src"][:1000], 8)                                       # k-NN next to the build
