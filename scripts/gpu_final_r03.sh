@@ -61,7 +61,7 @@ if has traffic; then
   for c in FETCH_SIZE WRITE_SIZE; do
     prof --kernel-trace --pmc $c --output-format csv -d $R/$O/pmc_noisy_$c -o p -- python $R/scripts/dev/noisy_one.py 0.15 > $O/pmc_noisy_$c.log 2>&1; echo "pmc noisy $c rc=$?"
   done
-  { echo "# FETCH_SIZE / WRITE_SIZE (KB per launch as reported: vector loads count at half their bytes, profiles/r02_fetch_calibration.txt) on the noisy workload"
+  { echo "# FETCH_SIZE / WRITE_SIZE (KB per launch as reported: vector loads count at half their bytes, profiles/r03_fetch_calibration.txt) on the noisy workload"
     python scripts/pmc_kernels.py "$O/pmc_noisy_*SIZE/p_counter_collection.csv" "nn_packet_kernel<true" leaf_halo; } | tee $O/pmc_noisy_traffic.txt
 fi
 if has pmcrows; then
