@@ -28,17 +28,19 @@
 
 namespace mi {
 
-// Candidate lists come in two capacities: 32 slots (two waves per workgroup, 16 KB of LDS per
-// wave: every caller on the ICP path -- normals with 30, GICP 20, colour gradients 30) and 104 slots
-// for anything up to knn::NUM_MAX_NN = 100 (knn/kdtree_search_param.h:26; one wave per workgroup,
-// 52 KB of LDS: three workgroups per CU -- slower per query, same results).
+// Candidate lists come in two capacities: 32 slots (every caller on the ICP path -- normals with 30,
+// GICP 20, colour gradients 30) and 104 slots for anything up to knn::NUM_MAX_NN = 100
+// (knn/kdtree_search_param.h:26).  One wave per workgroup: a wave's life depends on its packet, and a
+// workgroup of two held its LDS until the slower one was done (normals of 10M points 29.4 -> 24.2 ms).
+// The small lists keep only the DISTANCES in LDS (8 KB per wave: 20 waves per CU); the candidates'
+// indices -- written on every accepted candidate, read once at the end -- go to a slab in global memory,
+// [packet][slot][lane] (the packet's 8 KB stay in L2 while it runs).  The big lists keep both in LDS
+// (52 KB: three waves per CU -- slower per query, same results).
 constexpr int kMaxKnn = 32;       // capacity of the small instantiation
 constexpr int kMaxKnnBig = 104;   // ... of the big one (a multiple of 8: the maxima are tracked per group of 8)
 constexpr int kKnnLimit = 100;    // NUM_MAX_NN: the most neighbours a search may ask for
-__host__ __device__ constexpr int knn_waves(int kcap) { return kcap <= kMaxKnn ? 2 : 1; }
-constexpr int kKnnThreads = 128;
-constexpr int kKnnWaves = kKnnThreads / 64;
-constexpr int kKnnLeavesPerBlock = kKnnWaves * 8;
+__host__ __device__ constexpr int knn_waves(int) { return 1; }
+__host__ __device__ constexpr bool knn_idx_in_global(int kcap) { return kcap <= kMaxKnn; }
 constexpr int kKnnSeedBefore = 4, kKnnSeedAfter = 12;  // leaves around the packet's first leaf
 
 template <int KCAP>
@@ -132,18 +134,20 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_normals_kernel(
         const float* __restrict__ records_g, const float* __restrict__ tblk_g, uint32_t leaf_first, int64_t n,
         int nleaf,
         int k, float r2, uint32_t nblocks, float* __restrict__ normals_out,
-        const float4* __restrict__ tnrm, float4* __restrict__ tgrad) {
+        const float4* __restrict__ tnrm, float4* __restrict__ tgrad, int32_t* __restrict__ idx_slab) {
     constexpr int kWaves = knn_waves(KCAP);
     __shared__ float s_d2[kWaves][KCAP * 64];
-    __shared__ int32_t s_idx[kWaves][KCAP * 64];
+    __shared__ int32_t s_idx[kWaves][knn_idx_in_global(KCAP) ? 1 : KCAP * 64];
     uint32_t logical;
     if (!xcd_remap(nblocks, logical)) return;
     const cfloat_p tblk = (cfloat_p)(uintptr_t)tblk_g;
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
     float* kd2 = s_d2[wid];
-    int32_t* kidx = s_idx[wid];
 
     const int pkt = (int)logical * kWaves + wid;
+    int32_t* kidx;
+    if constexpr (knn_idx_in_global(KCAP)) kidx = idx_slab + (size_t)pkt * (KCAP * 64);
+    else kidx = s_idx[wid];
     const int leaf0 = pkt * 8;
     if (leaf0 >= nleaf) return;  // whole wave out of range (no block barriers below)
     const int64_t i = (int64_t)pkt * 64 + lane;
@@ -310,16 +314,19 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
         const float* __restrict__ records_g, const float* __restrict__ tblk_g, uint32_t leaf_first,
         const float* __restrict__ qx_g, const float* __restrict__ qy_g, const float* __restrict__ qz_g,
         const int32_t* __restrict__ qperm, int nq, int nleaf, int k, float r2, uint32_t nblocks,
-        int32_t* __restrict__ idx_out, float* __restrict__ d2_out, unsigned long long* __restrict__ found) {
+        int32_t* __restrict__ idx_out, float* __restrict__ d2_out, unsigned long long* __restrict__ found,
+        int32_t* __restrict__ idx_slab) {
     constexpr int kWaves = knn_waves(KCAP);
     __shared__ float s_d2[kWaves][KCAP * 64];
-    __shared__ int32_t s_idx[kWaves][KCAP * 64];
+    __shared__ int32_t s_idx[kWaves][knn_idx_in_global(KCAP) ? 1 : KCAP * 64];
     uint32_t logical;
     if (!xcd_remap(nblocks, logical)) return;
     const cfloat_p tblk = (cfloat_p)(uintptr_t)tblk_g;
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
     float* kd2 = s_d2[wid];
-    int32_t* kidx = s_idx[wid];
+    int32_t* kidx;
+    if constexpr (knn_idx_in_global(KCAP)) kidx = idx_slab + ((size_t)logical * kWaves + wid) * (KCAP * 64);
+    else kidx = s_idx[wid];
     const int64_t i = ((int64_t)logical * kWaves + wid) * 64 + lane;
     if (i - lane >= nq) return;  // whole wave out of range (no block barriers below)
     const bool valid = i < nq;

@@ -135,6 +135,7 @@ struct mi_icp_ctx {
     DevBuf keys0, keys1, vals0, vals1, hist, scan_tmp, bounds_part, bounds;
     DevBuf partial, sys_dev, dense_idx, flags, pairs_out, seg_start;
     DevBuf stage[6];
+    DevBuf knn_idx;  // candidate indices of the small k-NN lists, [packet][slot][lane] (knn_normals.h)
     double* sys_host = nullptr;  // pinned, 32 doubles + spare
     float* f_host = nullptr;     // pinned, 16 floats
     uint32_t* u_host = nullptr;  // pinned, 4 words
@@ -1157,7 +1158,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
                      &c->scan_tmp, &c->bounds_part, &c->bounds, &c->partial, &c->sys_dev,
                      &c->dense_idx, &c->flags, &c->pairs_out, &c->seg_start, &c->loop_dev, &c->ticket, &c->mail_state, &c->alt[0],
                      &c->alt[1], &c->alt[2], &c->alt[3], &c->alt[4], &c->alt[5], &c->alt[6], &c->alt[7], &c->alt[8], &c->stage[0],
-                     &c->stage[1], &c->stage[2], &c->stage[3], &c->stage[4], &c->stage[5]};
+                     &c->stage[1], &c->stage[2], &c->stage[3], &c->stage[4], &c->stage[5], &c->knn_idx};
     for (DevBuf* b : all) release(*b);
     if (c->sys_host) (void)hipHostFree(c->sys_host);
     if (c->cell_total_host) (void)hipHostFree(c->cell_total_host);
@@ -2508,18 +2509,19 @@ static int estimate_normals_impl(mi_icp_ctx* c, const float* xyz, int64_t n, int
         TRY(mi_icp_set_target(a, xyz, nullptr, nullptr, n, mem_kind));
         float* dn = normals;
         if (mem_kind == MI_ICP_HOST) TRY(ensure(a, a->stage[1], (size_t)n * 3, &dn));
-        // (lists of up to 32 neighbours: two waves per workgroup; up to NUM_MAX_NN = 100: one)
         const int waves = knn_waves(knn <= kMaxKnn ? kMaxKnn : kMaxKnnBig);
         const uint32_t nblocks = (uint32_t)((a->nleaf + waves * 8 - 1) / (waves * 8));
         const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
+        int32_t* slab = nullptr;
+        if (knn <= kMaxKnn) TRY(ensure(a, a->knn_idx, (size_t)nblocks * waves * kMaxKnn * 64, &slab));
         if (knn <= kMaxKnn)
             knn_normals_kernel<0, kMaxKnn><<<grid, waves * 64, 0, a->stream>>>(
                     (const float*)a->nodes.p, (const float*)a->tblk.p, a->leaf_first, a->nts, a->nleaf, knn, r2, nblocks,
-                    dn, nullptr, nullptr);
+                    dn, nullptr, nullptr, slab);
         else
             knn_normals_kernel<0, kMaxKnnBig><<<grid, waves * 64, 0, a->stream>>>(
                     (const float*)a->nodes.p, (const float*)a->tblk.p, a->leaf_first, a->nts, a->nleaf, knn, r2, nblocks,
-                    dn, nullptr, nullptr);
+                    dn, nullptr, nullptr, nullptr);
         KCHK(a);
         if (mem_kind == MI_ICP_HOST) TRY(from_device(a, (const float*)dn, normals, (size_t)n * 3, mem_kind));
         HIPCHK(a, hipStreamSynchronize(a->stream));
@@ -2566,9 +2568,11 @@ int mi_icp_search_knn(mi_icp_ctx* c, const float* queries, int64_t nq, int knn, 
     const int waves = knn_waves(knn <= kMaxKnn ? kMaxKnn : kMaxKnnBig);
     const uint32_t nblocks = (npackets + waves - 1) / waves;
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
+    int32_t* slab = nullptr;
+    if (knn <= kMaxKnn) TRY(ensure(c, c->knn_idx, (size_t)nblocks * waves * kMaxKnn * 64, &slab));
 #define MI_KNN_ARGS (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, (const float*)c->sx.p, \
                     (const float*)c->sy.p, (const float*)c->sz.p, (const int32_t*)c->sperm.p, (int)nq, c->nleaf, knn, \
-                    radius > 0.0f ? radius * radius : INFINITY, nblocks, d_idx, d_d2, cnt
+                    radius > 0.0f ? radius * radius : INFINITY, nblocks, d_idx, d_d2, cnt, slab
     if (knn <= kMaxKnn) knn_search_kernel<kMaxKnn><<<grid, waves * 64, 0, c->stream>>>(MI_KNN_ARGS);
     else knn_search_kernel<kMaxKnnBig><<<grid, waves * 64, 0, c->stream>>>(MI_KNN_ARGS);
 #undef MI_KNN_ARGS
@@ -2637,14 +2641,16 @@ int mi_icp_compute_color_gradients(mi_icp_ctx* c, float radius, int max_nn, floa
     const int waves = knn_waves(max_nn <= kMaxKnn ? kMaxKnn : kMaxKnnBig);
     const uint32_t nblocks = (uint32_t)((c->nleaf + waves * 8 - 1) / (waves * 8));
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
+    int32_t* slab = nullptr;
+    if (max_nn <= kMaxKnn) TRY(ensure(c, c->knn_idx, (size_t)nblocks * waves * kMaxKnn * 64, &slab));
     if (max_nn <= kMaxKnn)
         knn_normals_kernel<1, kMaxKnn><<<grid, waves * 64, 0, c->stream>>>(
                 (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, c->nts, c->nleaf, max_nn,
-                radius * radius, nblocks, dg, (const float4*)c->tnrm.p, tgrad);
+                radius * radius, nblocks, dg, (const float4*)c->tnrm.p, tgrad, slab);
     else
         knn_normals_kernel<1, kMaxKnnBig><<<grid, waves * 64, 0, c->stream>>>(
                 (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, c->nts, c->nleaf, max_nn,
-                radius * radius, nblocks, dg, (const float4*)c->tnrm.p, tgrad);
+                radius * radius, nblocks, dg, (const float4*)c->tnrm.p, tgrad, nullptr);
     KCHK(c);
     c->t_has_grad = true;
     if (gradients_out) {
