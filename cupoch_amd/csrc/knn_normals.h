@@ -32,15 +32,16 @@ namespace mi {
 // GICP 20, colour gradients 30) and 104 slots for anything up to knn::NUM_MAX_NN = 100
 // (knn/kdtree_search_param.h:26).  One wave per workgroup: a wave's life depends on its packet, and a
 // workgroup of two held its LDS until the slower one was done (normals of 10M points 29.4 -> 24.2 ms).
-// The small lists keep only the DISTANCES in LDS (8 KB per wave: 20 waves per CU); the candidates'
-// indices -- written on every accepted candidate, read once at the end -- go to a slab in global memory,
-// [packet][slot][lane] (the packet's 8 KB stay in L2 while it runs).  The big lists keep both in LDS
-// (52 KB: three waves per CU -- slower per query, same results).
+// Only the DISTANCES live in LDS (8 KB per wave with 32 slots: 20 waves per CU; 26 KB with 104: 6); the
+// candidates' indices -- written on every accepted candidate, read once at the end -- go to a slab in
+// global memory, [packet][slot][lane] (normals of 10M points 24.2 -> 16.0 ms: the kernel went from 6 waves
+// per CU and 42 % of the vector ALUs' cycles to 83 %).
 constexpr int kMaxKnn = 32;       // capacity of the small instantiation
+constexpr int kMaxKnnMid = 64;    // ... of the middle one (16 KB of LDS: 10 waves per CU)
 constexpr int kMaxKnnBig = 104;   // ... of the big one (a multiple of 8: the maxima are tracked per group of 8)
 constexpr int kKnnLimit = 100;    // NUM_MAX_NN: the most neighbours a search may ask for
 __host__ __device__ constexpr int knn_waves(int) { return 1; }
-__host__ __device__ constexpr bool knn_idx_in_global(int kcap) { return kcap <= kMaxKnn; }
+__host__ __device__ constexpr int knn_capacity(int k) { return k <= kMaxKnn ? kMaxKnn : (k <= kMaxKnnMid ? kMaxKnnMid : kMaxKnnBig); }
 constexpr int kKnnSeedBefore = 4, kKnnSeedAfter = 12;  // leaves around the packet's first leaf
 
 template <int KCAP>
@@ -137,7 +138,6 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_normals_kernel(
         const float4* __restrict__ tnrm, float4* __restrict__ tgrad, int32_t* __restrict__ idx_slab) {
     constexpr int kWaves = knn_waves(KCAP);
     __shared__ float s_d2[kWaves][KCAP * 64];
-    __shared__ int32_t s_idx[kWaves][knn_idx_in_global(KCAP) ? 1 : KCAP * 64];
     uint32_t logical;
     if (!xcd_remap(nblocks, logical)) return;
     const cfloat_p tblk = (cfloat_p)(uintptr_t)tblk_g;
@@ -145,9 +145,7 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_normals_kernel(
     float* kd2 = s_d2[wid];
 
     const int pkt = (int)logical * kWaves + wid;
-    int32_t* kidx;
-    if constexpr (knn_idx_in_global(KCAP)) kidx = idx_slab + (size_t)pkt * (KCAP * 64);
-    else kidx = s_idx[wid];
+    int32_t* kidx = idx_slab + (size_t)pkt * (KCAP * 64);
     const int leaf0 = pkt * 8;
     if (leaf0 >= nleaf) return;  // whole wave out of range (no block barriers below)
     const int64_t i = (int64_t)pkt * 64 + lane;
@@ -318,15 +316,12 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
         int32_t* __restrict__ idx_slab) {
     constexpr int kWaves = knn_waves(KCAP);
     __shared__ float s_d2[kWaves][KCAP * 64];
-    __shared__ int32_t s_idx[kWaves][knn_idx_in_global(KCAP) ? 1 : KCAP * 64];
     uint32_t logical;
     if (!xcd_remap(nblocks, logical)) return;
     const cfloat_p tblk = (cfloat_p)(uintptr_t)tblk_g;
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
     float* kd2 = s_d2[wid];
-    int32_t* kidx;
-    if constexpr (knn_idx_in_global(KCAP)) kidx = idx_slab + ((size_t)logical * kWaves + wid) * (KCAP * 64);
-    else kidx = s_idx[wid];
+    int32_t* kidx = idx_slab + ((size_t)logical * kWaves + wid) * (KCAP * 64);
     const int64_t i = ((int64_t)logical * kWaves + wid) * 64 + lane;
     if (i - lane >= nq) return;  // whole wave out of range (no block barriers below)
     const bool valid = i < nq;
@@ -448,31 +443,32 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
     if (!valid) return;
     const int64_t row = (int64_t)qperm[i] * k;
     if constexpr (KCAP > kMaxKnn) {
-        // ---- the big lists are sorted where they are: original indices first, then a lane-private
-        // insertion sort of its LDS column by (d2, original index)
+        // ---- the big lists: every entry goes to the row position of its RANK by (d2, original index) --
+        // the number of entries with a smaller distance, read from the lane's LDS column; the indices
+        // (global memory) are compared only between entries whose distances are equal
         for (int t = 0; t < st.count; ++t) {
             const int32_t j = kidx[t * 64 + lane];
             kidx[t * 64 + lane] = __float_as_int(tblk_g[(int64_t)(j >> 3) * kLeafFloats + 24 + (j & 7)]);
         }
-        for (int a = 1; a < st.count; ++a) {
+        for (int a = 0; a < st.count; ++a) {
             const float dv = kd2[a * 64 + lane];
-            const int32_t iv = kidx[a * 64 + lane];
-            int b = a - 1;
-            while (b >= 0) {
+            int rank = 0, same = 0;
+            for (int b = 0; b < st.count; ++b) {
                 const float db = kd2[b * 64 + lane];
-                const int32_t ib = kidx[b * 64 + lane];
-                if (!(db > dv || (db == dv && ib > iv))) break;
-                kd2[(b + 1) * 64 + lane] = db;
-                kidx[(b + 1) * 64 + lane] = ib;
-                --b;
+                rank += (db < dv) ? 1 : 0;
+                same += (db == dv) ? 1 : 0;
             }
-            kd2[(b + 1) * 64 + lane] = dv;
-            kidx[(b + 1) * 64 + lane] = iv;
+            const int32_t iv = kidx[a * 64 + lane];
+            if (same > 1) {
+                for (int b = 0; b < st.count; ++b)
+                    if (b != a && kd2[b * 64 + lane] == dv && kidx[b * 64 + lane] < iv) ++rank;
+            }
+            idx_out[row + rank] = iv;
+            d2_out[row + rank] = dv;
         }
-        for (int t = 0; t < k; ++t) {
-            const bool have = t < st.count;
-            idx_out[row + t] = have ? kidx[t * 64 + lane] : -1;
-            d2_out[row + t] = have ? kd2[t * 64 + lane] : INFINITY;
+        for (int t = st.count; t < k; ++t) {
+            idx_out[row + t] = -1;
+            d2_out[row + t] = INFINITY;
         }
     } else {
     // ---- sort (d2, original index) ascending in registers, unused slots last

@@ -2509,19 +2509,17 @@ static int estimate_normals_impl(mi_icp_ctx* c, const float* xyz, int64_t n, int
         TRY(mi_icp_set_target(a, xyz, nullptr, nullptr, n, mem_kind));
         float* dn = normals;
         if (mem_kind == MI_ICP_HOST) TRY(ensure(a, a->stage[1], (size_t)n * 3, &dn));
-        const int waves = knn_waves(knn <= kMaxKnn ? kMaxKnn : kMaxKnnBig);
+        const int cap = knn_capacity(knn), waves = knn_waves(cap);
         const uint32_t nblocks = (uint32_t)((a->nleaf + waves * 8 - 1) / (waves * 8));
         const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
-        int32_t* slab = nullptr;
-        if (knn <= kMaxKnn) TRY(ensure(a, a->knn_idx, (size_t)nblocks * waves * kMaxKnn * 64, &slab));
-        if (knn <= kMaxKnn)
-            knn_normals_kernel<0, kMaxKnn><<<grid, waves * 64, 0, a->stream>>>(
-                    (const float*)a->nodes.p, (const float*)a->tblk.p, a->leaf_first, a->nts, a->nleaf, knn, r2, nblocks,
-                    dn, nullptr, nullptr, slab);
-        else
-            knn_normals_kernel<0, kMaxKnnBig><<<grid, waves * 64, 0, a->stream>>>(
-                    (const float*)a->nodes.p, (const float*)a->tblk.p, a->leaf_first, a->nts, a->nleaf, knn, r2, nblocks,
-                    dn, nullptr, nullptr, nullptr);
+        int32_t* slab;
+        TRY(ensure(a, a->knn_idx, (size_t)nblocks * waves * cap * 64, &slab));
+#define MI_NRM_ARGS (const float*)a->nodes.p, (const float*)a->tblk.p, a->leaf_first, a->nts, a->nleaf, knn, r2, nblocks, \
+                    dn, nullptr, nullptr, slab
+        if (cap == kMaxKnn) knn_normals_kernel<0, kMaxKnn><<<grid, waves * 64, 0, a->stream>>>(MI_NRM_ARGS);
+        else if (cap == kMaxKnnMid) knn_normals_kernel<0, kMaxKnnMid><<<grid, waves * 64, 0, a->stream>>>(MI_NRM_ARGS);
+        else knn_normals_kernel<0, kMaxKnnBig><<<grid, waves * 64, 0, a->stream>>>(MI_NRM_ARGS);
+#undef MI_NRM_ARGS
         KCHK(a);
         if (mem_kind == MI_ICP_HOST) TRY(from_device(a, (const float*)dn, normals, (size_t)n * 3, mem_kind));
         HIPCHK(a, hipStreamSynchronize(a->stream));
@@ -2565,15 +2563,16 @@ int mi_icp_search_knn(mi_icp_ctx* c, const float* queries, int64_t nq, int knn, 
     TRY(ensure(c, c->flags, 8, (unsigned long long**)&cnt));
     HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(unsigned long long), c->stream));
     const uint32_t npackets = (uint32_t)((nq + 63) / 64);
-    const int waves = knn_waves(knn <= kMaxKnn ? kMaxKnn : kMaxKnnBig);
+    const int cap = knn_capacity(knn), waves = knn_waves(cap);
     const uint32_t nblocks = (npackets + waves - 1) / waves;
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
-    int32_t* slab = nullptr;
-    if (knn <= kMaxKnn) TRY(ensure(c, c->knn_idx, (size_t)nblocks * waves * kMaxKnn * 64, &slab));
+    int32_t* slab;
+    TRY(ensure(c, c->knn_idx, (size_t)nblocks * waves * cap * 64, &slab));
 #define MI_KNN_ARGS (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, (const float*)c->sx.p, \
                     (const float*)c->sy.p, (const float*)c->sz.p, (const int32_t*)c->sperm.p, (int)nq, c->nleaf, knn, \
                     radius > 0.0f ? radius * radius : INFINITY, nblocks, d_idx, d_d2, cnt, slab
-    if (knn <= kMaxKnn) knn_search_kernel<kMaxKnn><<<grid, waves * 64, 0, c->stream>>>(MI_KNN_ARGS);
+    if (cap == kMaxKnn) knn_search_kernel<kMaxKnn><<<grid, waves * 64, 0, c->stream>>>(MI_KNN_ARGS);
+    else if (cap == kMaxKnnMid) knn_search_kernel<kMaxKnnMid><<<grid, waves * 64, 0, c->stream>>>(MI_KNN_ARGS);
     else knn_search_kernel<kMaxKnnBig><<<grid, waves * 64, 0, c->stream>>>(MI_KNN_ARGS);
 #undef MI_KNN_ARGS
     KCHK(c);
@@ -2638,19 +2637,17 @@ int mi_icp_compute_color_gradients(mi_icp_ctx* c, float radius, int max_nn, floa
     TRY(ensure(c, c->tgrad, (size_t)c->nts, &tgrad));
     float* dg = gradients_out;
     if (gradients_out && mem_kind == MI_ICP_HOST) TRY(ensure(c, c->stage[1], (size_t)n * 3, &dg));
-    const int waves = knn_waves(max_nn <= kMaxKnn ? kMaxKnn : kMaxKnnBig);
+    const int cap = knn_capacity(max_nn), waves = knn_waves(cap);
     const uint32_t nblocks = (uint32_t)((c->nleaf + waves * 8 - 1) / (waves * 8));
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
-    int32_t* slab = nullptr;
-    if (max_nn <= kMaxKnn) TRY(ensure(c, c->knn_idx, (size_t)nblocks * waves * kMaxKnn * 64, &slab));
-    if (max_nn <= kMaxKnn)
-        knn_normals_kernel<1, kMaxKnn><<<grid, waves * 64, 0, c->stream>>>(
-                (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, c->nts, c->nleaf, max_nn,
-                radius * radius, nblocks, dg, (const float4*)c->tnrm.p, tgrad, slab);
-    else
-        knn_normals_kernel<1, kMaxKnnBig><<<grid, waves * 64, 0, c->stream>>>(
-                (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, c->nts, c->nleaf, max_nn,
-                radius * radius, nblocks, dg, (const float4*)c->tnrm.p, tgrad, nullptr);
+    int32_t* slab;
+    TRY(ensure(c, c->knn_idx, (size_t)nblocks * waves * cap * 64, &slab));
+#define MI_GRAD_ARGS (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, c->nts, c->nleaf, max_nn, \
+                     radius * radius, nblocks, dg, (const float4*)c->tnrm.p, tgrad, slab
+    if (cap == kMaxKnn) knn_normals_kernel<1, kMaxKnn><<<grid, waves * 64, 0, c->stream>>>(MI_GRAD_ARGS);
+    else if (cap == kMaxKnnMid) knn_normals_kernel<1, kMaxKnnMid><<<grid, waves * 64, 0, c->stream>>>(MI_GRAD_ARGS);
+    else knn_normals_kernel<1, kMaxKnnBig><<<grid, waves * 64, 0, c->stream>>>(MI_GRAD_ARGS);
+#undef MI_GRAD_ARGS
     KCHK(c);
     c->t_has_grad = true;
     if (gradients_out) {

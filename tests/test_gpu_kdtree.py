@@ -102,6 +102,20 @@ def test_errors_and_limits(eng):
     eng.set_target(tgt)
     found, idx, d2 = eng.search_knn(np.array([[0.5, 0.5, 0.6]], np.float32), 8)
     assert found == 8 and len(set(idx[0].tolist())) == 8 and np.all(d2[0] == d2[0, 0])
+    # the longer lists (64 and 104 slots) place every entry at its rank by (distance, index): equal
+    # distances everywhere, and two distance classes with the row ending inside the second
+    tgt = np.concatenate([np.tile(np.array([[0.5, 0.5, 0.5]], np.float32), (90, 1)),
+                          np.tile(np.array([[0.5, 0.5, 0.25]], np.float32), (90, 1))])
+    eng.set_target(tgt)
+    for k in (40, 64, 70, 100):
+        found, idx, d2 = eng.search_knn(np.array([[0.5, 0.5, 0.6], [0.5, 0.5, 0.2]], np.float32), k)
+        assert found == 2 * k
+        for r, near in ((0, 0), (1, 90)):
+            row = idx[r].tolist()
+            assert len(set(row)) == k and np.all(np.diff(d2[r]) >= 0)
+            first = [j for j in row if near <= j < near + 90]
+            assert row[:len(first)] == first and len(first) == min(k, 90)       # the nearer class first ...
+            assert first == sorted(first) and row[len(first):] == sorted(row[len(first):])   # ... ascending in index
 
 
 def test_sparse_and_clustered_targets_stay_exact_and_fast(eng):
