@@ -65,6 +65,31 @@ struct KnnStateT {
 };
 typedef KnnStateT<kMaxKnn> KnnState;
 
+// The 24 coordinates of leaf L (wave-uniform) through the scalar unit: three s_load_dwordx8 issued together,
+// one wait -- left to the compiler they became one load per coordinate, each waited for just before its use
+// (the stores of the list updates in between may alias for all it knows): eight round trips per leaf.
+typedef float f8v __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) f8v* cf8_p;
+struct LeafXYZ {
+    f8v x, y, z;
+};
+__device__ __forceinline__ LeafXYZ load_leaf(cfloat_p tblk, int L) {
+    const cf8_p line = (cf8_p)(tblk + (size_t)L * kLeafFloats);
+    LeafXYZ r;
+    r.x = line[0];
+    r.y = line[1];
+    r.z = line[2];
+    return r;
+}
+
+// Every slot of the lane's distance column starts at -1: the search for a group's largest entry reads
+// all 8 slots of the group without asking which of them are in use.
+template <int KCAP>
+__device__ __forceinline__ void knn_clear(float* kd2, int lane) {
+#pragma unroll
+    for (int t = 0; t < KCAP; ++t) kd2[t * 64 + lane] = -1.0f;
+}
+
 // Offer candidate (d2, j) to this lane's list of the k nearest (LDS columns kd2 / kidx, slot
 // t of lane l at [t * 64 + l]).  A full list replaces its largest entry; the new largest is
 // found in two steps -- the replaced slot's group of 8 is re-read, then the 4 group maxima
@@ -95,10 +120,11 @@ __device__ __forceinline__ bool knn_offer(float* kd2, int32_t* kidx, int lane, i
         } else {  // the list's largest entry (in group g) was replaced: re-read that group
             float m = -1.0f;
             int mp = g * 8;
+            const float* grp = kd2 + g * (8 * 64) + lane;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int slot = g * 8 + u;
-                const float v = (slot < k) ? kd2[slot * 64 + lane] : -1.0f;  // unused slots never win (d2 >= 0)
+                const float v = grp[u * 64];  // slots >= k hold -1 (knn_clear): they never win (d2 >= 0)
                 const bool hi = v > m;
                 m = hi ? v : m;
                 mp = hi ? slot : mp;
@@ -144,7 +170,7 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_normals_kernel(
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
     float* kd2 = s_d2[wid];
 
-    const int pkt = (int)logical * kWaves + wid;
+    const int pkt = __builtin_amdgcn_readfirstlane((int)logical * kWaves + wid);
     int32_t* kidx = idx_slab + (size_t)pkt * (KCAP * 64);
     const int leaf0 = pkt * 8;
     if (leaf0 >= nleaf) return;  // whole wave out of range (no block barriers below)
@@ -162,15 +188,16 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_normals_kernel(
     KnnStateT<KCAP> st;
     // r2 = +inf: plain k-NN; finite: the k nearest with d2 < r2 (KDTreeSearchParamRadius)
     st.init((valid && k > 0) ? r2 : -1.0f);
+    knn_clear<KCAP>(kd2, lane);
 
     // ---- A: seed from the Morton neighbourhood ---------------------------------
     const int seed_lo = max(0, leaf0 - kKnnSeedBefore);
     const int seed_hi = min(nleaf, leaf0 + kKnnSeedAfter);
     for (int L = seed_lo; L < seed_hi; ++L) {
-        const cfloat_p line = tblk + (size_t)L * kLeafFloats;
+        const LeafXYZ p = load_leaf(tblk, L);
 #pragma unroll
         for (int t = 0; t < kLeaf; ++t) {
-            const float d2 = sq3(qx - line[t], qy - line[8 + t], qz - line[16 + t]);
+            const float d2 = sq3(qx - p.x[t], qy - p.y[t], qz - p.z[t]);
             knn_offer(kd2, kidx, lane, k, st, d2, L * kLeaf + t);  // padding points have d2 = +inf
         }
     }
@@ -179,13 +206,13 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_normals_kernel(
 
     // ---- B: traversal -------------------------------------------------------------
     traverse_wide(records_g, leaf_first, cube, [&](uint32_t Lu) {
-        const int L = (int)Lu;
+        const int L = __builtin_amdgcn_readfirstlane((int)Lu);  // (wave-uniform by construction)
         if (L >= seed_lo && L < seed_hi) return;
-        const cfloat_p line = tblk + (size_t)L * kLeafFloats;
+        const LeafXYZ p = load_leaf(tblk, L);
         bool shrunk = false;
 #pragma unroll
         for (int t = 0; t < kLeaf; ++t) {
-            const float d2 = sq3(qx - line[t], qy - line[8 + t], qz - line[16 + t]);
+            const float d2 = sq3(qx - p.x[t], qy - p.y[t], qz - p.z[t]);
             shrunk |= knn_offer(kd2, kidx, lane, k, st, d2, L * kLeaf + t);
         }
         if (shrunk) set_cube(cube, qx, qy, qz, st.worst);
@@ -333,6 +360,7 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
     }
     KnnStateT<KCAP> st;
     st.init((valid && k > 0) ? r2 : -1.0f);  // r2 = +inf: plain k-NN
+    knn_clear<KCAP>(kd2, lane);
 
     // ---- A: a first bound.  A plain k-NN query starts with an infinite search cube, and a
     // depth-first walk in child order would wade through the whole tree before the k-th
@@ -430,12 +458,12 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
     // ---- B: the exact walk
     traverse_wide(records_g, leaf_first, cube, [&](uint32_t Lu) {
         const bool seeded = Lu >= seed_lo && Lu < seed_hi;  // this lane has these points already
-        const int L = (int)Lu;
-        const cfloat_p line = tblk + (size_t)L * kLeafFloats;
+        const int L = __builtin_amdgcn_readfirstlane((int)Lu);
+        const LeafXYZ p = load_leaf(tblk, L);
         bool shrunk = false;
 #pragma unroll
         for (int t = 0; t < kLeaf; ++t) {
-            const float d2 = seeded ? INFINITY : sq3(qx - line[t], qy - line[8 + t], qz - line[16 + t]);
+            const float d2 = seeded ? INFINITY : sq3(qx - p.x[t], qy - p.y[t], qz - p.z[t]);
             shrunk |= knn_offer(kd2, kidx, lane, k, st, d2, L * kLeaf + t);  // padding points: d2 = +inf
         }
         if (shrunk) set_cube(cube, qx, qy, qz, st.worst);
