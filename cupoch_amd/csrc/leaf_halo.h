@@ -187,35 +187,42 @@ __device__ __forceinline__ void halo_sort64_merges(uint32_t& key, int lane) {
 }
 __device__ __forceinline__ void halo_sort64(uint32_t& key, int lane) { halo_sort64_merges<64>(key, lane); }
 
-constexpr int kHaloWaves = 4;                    // waves per workgroup = per tile of 64 leaves
+constexpr int kHaloTile = 16;                    // leaves per wave = per workgroup
 constexpr uint32_t kHaloDistMask = 0xfffffe00u;  // key: 23 bits of the distance | 9 of the point's index
 constexpr float kHaloShrink = 0.999999f;         // reaches are reported a little short, the overhang a little long
 
-// One workgroup per tile of 64 leaves, a wave per leaf (16 leaves each).  halo: [nleaf][8] lines of 32 floats;
-// lreg[L][3], [7] <- the rings' reaches, packed (halo_pack_reaches; both 0: no halo).
-__global__ __launch_bounds__(64 * kHaloWaves) void leaf_halo_build(float* __restrict__ lreg, int nleaf,
-                                                                   const uint2* __restrict__ cand,
-                                                                   const float* __restrict__ tblk,
-                                                                   float* __restrict__ halo) {
-    __shared__ uint32_t s_ids[64 * 65];           // [leaf of the tile][candidate], row stride 65: conflict-free both ways
-    __shared__ uint32_t s_keys[kHaloWaves][128];  // a wave's in-bound keys, compacted
-    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint32_t tile = blockIdx.x;
-    // the tile's candidate ids: coalesced rows of the scratch tile -> LDS, transposed
+// One wave per 16 consecutive leaves (a quarter of a scratch tile), a leaf at a time; no workgroup barrier and
+// 4.7 KB of LDS per wave, so the kernel's occupancy is what its registers allow (with four waves sharing a
+// tile's 17 KB of candidate ids it held 13.6 waves per CU).  halo: [nleaf][8] lines of 32 floats; lreg[L][3], [7] <-
+// the rings' reaches, packed (halo_pack_reaches; both 0: no halo).
+__global__ __launch_bounds__(64) void leaf_halo_build(float* __restrict__ lreg, int nleaf,
+                                                      const uint2* __restrict__ cand,
+                                                      const float* __restrict__ tblk,
+                                                      float* __restrict__ halo) {
+    __shared__ uint32_t s_ids[kHaloTile * 65];  // [leaf of the wave's 16][candidate], row stride 65: conflict-free both ways
+    __shared__ uint32_t s_keys[128];            // the in-bound keys, compacted
+    const int lane = (int)threadIdx.x;
+    const uint32_t base = blockIdx.x * (uint32_t)kHaloTile;  // first leaf
+    const uint32_t tile = base >> 6, sub = base & 63u;        // scratch tile, first leaf inside it
+    // the candidate ids of the 16 leaves: rows of the scratch tile -> LDS, transposed (lane = (row of 4, leaf))
     int cnt_mine = 0;
     {
-        const uint32_t Lm = tile * 64u + (uint32_t)lane;
+        const uint32_t Lm = base + (uint32_t)(lane & 15);
         if (Lm < (uint32_t)nleaf) cnt_mine = __float_as_int(lreg[(size_t)Lm * kLeafRegFloats + 7]);
         int cmax = cnt_mine;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o, 64));
-        for (int t = wid; t < cmax; t += kHaloWaves)
-            s_ids[lane * 65 + t] = cand[((size_t)tile * kLinkCand + (size_t)t) * 64u + (size_t)lane].x;
+        for (int o = 8; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o, 64));
+        cmax = __builtin_amdgcn_readfirstlane(cmax);
+        for (int t0 = 0; t0 < cmax; t0 += 4) {
+            const int t = t0 + (lane >> 4);
+            if (t < cmax)
+                s_ids[(lane & 15) * 65 + t] = cand[((size_t)tile * kLinkCand + (size_t)t) * 64u + sub + (uint32_t)(lane & 15)].x;
+        }
     }
-    __syncthreads();
-    uint32_t* keys = s_keys[wid];
-    for (int li = wid; li < 64; li += kHaloWaves) {
-        const uint32_t L = tile * 64u + (uint32_t)li;  // wave-uniform
+    __builtin_amdgcn_wave_barrier();
+    uint32_t* keys = s_keys;
+    for (int li = 0; li < kHaloTile; ++li) {
+        const uint32_t L = base + (uint32_t)li;  // wave-uniform
         if (L >= (uint32_t)nleaf) break;
         const int count = __shfl(cnt_mine, li, 64);
         float* lines = halo + (size_t)L * (kHaloLines * kHaloLineFloats);

@@ -489,7 +489,7 @@ int build_links(mi_icp_ctx* c, hipStream_t st) {
     leaf_halo_collect<<<((lblocks + 7u) / 8u) * 8u, 64, 0, st>>>(
             (const float*)c->nodes.p, c->leaf_first, c->nleaf, lblocks, (float*)c->tlreg.p, cand);
     KCHK(c);
-    leaf_halo_build<<<(unsigned)ntiles, 64 * kHaloWaves, 0, st>>>((float*)c->tlreg.p, c->nleaf, cand, (const float*)c->tblk.p, halo);
+    leaf_halo_build<<<(unsigned)(((size_t)c->nleaf + kHaloTile - 1) / kHaloTile), 64, 0, st>>>((float*)c->tlreg.p, c->nleaf, cand, (const float*)c->tblk.p, halo);
     KCHK(c);
     return MI_ICP_OK;
 }
