@@ -1785,7 +1785,11 @@ static int loop_run(mi_icp_ctx* c, int budget) {
         if (c->links_inflight && !c->halo_declined) TRY(ensure_links(c));
         // (a short remainder rides along: one host synchronisation less than it would cost)
         int n = (budget <= kChunk + kChunk / 2) ? budget : kChunk;
-        if (undecided && c->ns >= kLarge) n = 1;
+        // (with several ranks the chunking must not depend on anything a rank sees alone: every rank has to
+        // enqueue the same number of evaluations -- an in-library RCCL all-reduce is a host-side call per
+        // evaluation, and a rank that stops at `done` after fewer of them would leave its peers' calls unmatched)
+        const bool several_ranks = c->comm != nullptr || c->mail_dev != nullptr;
+        if (undecided && c->ns >= kLarge && !several_ranks) n = 1;
         const int passes_before = c->loop_host->passes;
         c->halo_use = halo_poll(c);
         for (int i = 0; i < n; ++i) TRY(loop_enqueue_evaluation(c, true));
