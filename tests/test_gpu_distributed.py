@@ -172,6 +172,54 @@ def test_mailbox_exchange_two_processes_on_one_gpu(tmp_path, mode):
     assert m0["eval"][0] == pytest.approx(ev.fitness, abs=1e-6) and m0["eval"][1] == pytest.approx(ev.inlier_rmse, rel=1e-5)
 
 
+def _worker_big(rank, world, job, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cupoch_amd import distributed as D
+    from cupoch_amd.engine import Engine
+    torch.cuda.set_device(0)
+    d = make_pair(N_BIG, seed=29, noise=0.2)
+    eng = Engine(0)
+    src_dev = torch.from_numpy(d["src"]).cuda()
+    mine = D.device_shard_source(eng, src_dev, rank, world)
+    eng.set_target(torch.from_numpy(d["tgt"]).cuda(), torch.from_numpy(d["tgt_nrm"]).cuda())
+    eng.set_source(src_dev[torch.from_numpy(mine).cuda()])
+    eng.comm_init_local(job, world, rank)
+    eng.set_global_source_count(N_BIG)
+    res = eng.registration_icp(PT2PL, d["max_dist"], None, 1e-6, 1e-6, 30, -1.0)   # stops by its criteria
+    np.savez(os.path.join(out_dir, "big_%d.npz" % rank), T=np.array(res.transformation, np.float32),
+             stat=np.array([res.fitness, res.inlier_rmse, res.iterations]))
+    eng.comm_destroy()
+    eng.close()
+
+
+N_BIG = 1_100_000
+
+
+def test_sharded_loop_with_halo_decisions_of_its_own_on_every_rank(tmp_path):
+    """Shards of more than 500k noisy points: every rank's loop looks at ITS lanes' requests for halos and
+    builds them (or not) when it sees fit, and the loop ends by its convergence criteria, not its budget.  The
+    ranks must still take identical steps, stop at the same iteration, and end where the single-process loop ends
+    (the number of evaluations a rank enqueues must not depend on what it decides: mi_icp.hip loop_run)."""
+    from cupoch_amd.engine import Engine
+    world = 2
+    job = "testbig_%d_%d" % (os.getpid(), _free_port())
+    mp.spawn(_worker_big, args=(world, job, str(tmp_path)), nprocs=world, join=True)
+    d = make_pair(N_BIG, seed=29, noise=0.2)
+    eng = Engine(0)
+    eng.set_target(d["tgt"], d["tgt_nrm"])
+    eng.set_source(d["src"])
+    ref = eng.registration_icp(PT2PL, d["max_dist"], None, 1e-6, 1e-6, 30, -1.0)
+    eng.close()
+    m0, m1 = np.load(tmp_path / "big_0.npz"), np.load(tmp_path / "big_1.npz")
+    np.testing.assert_array_equal(m0["T"], m1["T"])
+    np.testing.assert_array_equal(m0["stat"], m1["stat"])
+    assert int(m0["stat"][2]) == ref.iterations and ref.iterations < 30
+    assert np.linalg.norm(m0["T"] - np.array(ref.transformation, np.float32)) <= 1e-6
+    assert m0["stat"][0] == pytest.approx(ref.fitness, abs=1e-6) and m0["stat"][1] == pytest.approx(ref.inlier_rmse, rel=1e-5)
+
+
 def _worker_lonely(rank, job, out_dir):
     import sys
     import time
