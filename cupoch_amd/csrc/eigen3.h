@@ -166,6 +166,28 @@ __device__ __forceinline__ void sqrt_matrix3x3(const M3& A, M3& W) {
             W.m[r][c] = e[0][r] * s0 * e[0][c] + e[1][r] * s1 * e[1][c] + e[2][r] * s2 * e[2][c];
 }
 
+// S = W W for W = SqrtMatrix3x3(A), without the eigen-decomposition: FastEigen3x3 (eigenvalue.inl:93-154) divides
+// its input by its largest coefficient (signed maximum, starting from A[0][0]), returns the eigenvalues of THAT
+// matrix -- they are never scaled back -- and reads the upper triangle only; an input without off-diagonal entries
+// gets eval = its diagonal, unscaled, and the identity as eigenvectors; an all-non-positive one (max_coeff == 0) zeros.
+__device__ __forceinline__ void gicp_weight(const M3& A, float (&S)[3][3]) {
+    float mx = A.m[0][0];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) mx = (A.m[r][c] > mx) ? A.m[r][c] : mx;
+    const float s00 = A.m[0][0] / mx, s11 = A.m[1][1] / mx, s22 = A.m[2][2] / mx;
+    const float s01 = A.m[0][1] / mx, s02 = A.m[0][2] / mx, s12 = A.m[1][2] / mx;
+    const float norm = s01 * s01 + s02 * s02 + s12 * s12;
+    const bool zero = mx == 0.0f, diag = !(norm > 0.0f);
+    S[0][0] = zero ? 0.0f : (diag ? A.m[0][0] : s00);
+    S[1][1] = zero ? 0.0f : (diag ? A.m[1][1] : s11);
+    S[2][2] = zero ? 0.0f : (diag ? A.m[2][2] : s22);
+    S[0][1] = S[1][0] = (zero || diag) ? 0.0f : s01;
+    S[0][2] = S[2][0] = (zero || diag) ? 0.0f : s02;
+    S[1][2] = S[2][1] = (zero || diag) ? 0.0f : s12;
+}
+
 // Eigen 3x3 inverse by cofactors (generalized_icp.cu:91)
 __device__ __forceinline__ void inverse3(const M3& M, M3& I) {
     const float c00 = M.m[1][1] * M.m[2][2] - M.m[1][2] * M.m[2][1];

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_kernel(ReduceArgs a, Xf
                 acc[27] += (double)(r0 * r0 + r1 * r1);
             }
         } else if (EST == kEstGICP) {
-            M3 Cs, M, Mi, W;
+            M3 Cs, M, Mi;
             rotate_cov(T, a.scov + i * 9, Cs);
             const float* Ct = a.tcov + (int64_t)j * 9;
 #pragma unroll
@@ -362,22 +362,53 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_kernel(ReduceArgs a, Xf
 #pragma unroll
                 for (int c = 0; c < 3; ++c) M.m[r][c] = Ct[c * 3 + r] + Cs.m[r][c];
             inverse3(M, Mi);
-            sqrt_matrix3x3(Mi, W);
+            // The reference's three rows are J = [W A | W], r = W d with W = SqrtMatrix3x3(Mi) symmetric
+            // (generalized_icp.cu:88-104), so what they add to the system is
+            //   J^T J = [A^T S A, A^T S; S A, S],  J^T r = [A^T S d; S d],  r^T r = d^T S d   with S = W W:
+            // no square root of a matrix is needed -- only what SqrtMatrix3x3 takes the root OF (gicp_weight:
+            // FastEigen3x3 scales its input by its largest coefficient and never scales back).  The closed-form
+            // eigen-solver (acosf / cosf, ten divisions) was two thirds of this functor's instructions, and the
+            // three rows' 81 fp64 multiply-adds become 28 additions.  S differs from the reference's W W by that
+            // solver's own rounding (~1e-6 of the largest entry); the parity tests hold GICP's system to 2e-5.
             if (MODE == 0) {
-                const float A[3][3] = {{0.0f, vs[2], -vs[1]}, {-vs[2], 0.0f, vs[0]}, {vs[1], -vs[0], 0.0f}};
+                float S[3][3];
+                gicp_weight(Mi, S);
+                const float x = vs[0], y = vs[1], z = vs[2];
+                const float Sd[3] = {S[0][0] * d[0] + S[0][1] * d[1] + S[0][2] * d[2],
+                                     S[1][0] * d[0] + S[1][1] * d[1] + S[1][2] * d[2],
+                                     S[2][0] * d[0] + S[2][1] * d[1] + S[2][2] * d[2]};
+                // P = S A, A = [0 z -y; -z 0 x; y -x 0];  Q = A^T P (symmetric)
+                float P[3][3], Q[3][3];
 #pragma unroll
-                for (int row = 0; row < 3; ++row) {
-                    float J[6];
-#pragma unroll
-                    for (int col = 0; col < 3; ++col) {
-                        J[col] = W.m[row][0] * A[0][col] + W.m[row][1] * A[1][col] +
-                                 W.m[row][2] * A[2][col];
-                        J[3 + col] = W.m[row][col];
-                    }
-                    const float r = W.m[row][0] * d[0] + W.m[row][1] * d[1] + W.m[row][2] * d[2];
-                    accum_row(acc, J, r);
+                for (int r = 0; r < 3; ++r) {
+                    P[r][0] = S[r][2] * y - S[r][1] * z;
+                    P[r][1] = S[r][0] * z - S[r][2] * x;
+                    P[r][2] = S[r][1] * x - S[r][0] * y;
                 }
-            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    Q[0][c] = y * P[2][c] - z * P[1][c];
+                    Q[1][c] = z * P[0][c] - x * P[2][c];
+                    Q[2][c] = x * P[1][c] - y * P[0][c];
+                }
+                const float g[3] = {y * Sd[2] - z * Sd[1], z * Sd[0] - x * Sd[2], x * Sd[1] - y * Sd[0]};
+                int k = 0;
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int q = p; q < 6; ++q, ++k) {
+                        const float v = (q < 3) ? Q[p][q] : ((p < 3) ? P[q - 3][p] : S[p - 3][q - 3]);
+                        acc[k] += (double)v;
+                    }
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    acc[21 + p] += (double)g[p];
+                    acc[24 + p] += (double)Sd[p];
+                }
+                acc[27] += (double)dot3(d, Sd);
+            } else {  // ComputeRMSE (generalized_icp.cu:121-130): d^T W d -- the root itself; not on the loop's path
+                M3 W;
+                sqrt_matrix3x3(Mi, W);
                 float Wd[3];
 #pragma unroll
                 for (int r = 0; r < 3; ++r) Wd[r] = W.m[r][0] * d[0] + W.m[r][1] * d[1] + W.m[r][2] * d[2];

@@ -17,7 +17,7 @@ fi
 if has bench; then
   timeout 900 python bench.py 2>&1 | grep '^{"metric' | tee $O/bench_10m.json | python scripts/benchline.py
   timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | grep '^{"metric' | tee $O/bench_10m_steps20_warmup5.json | python scripts/benchline.py
-  for n in 100000 1000000 5000000 20000000; do timeout 600 python bench.py --points $n --no-cpu-baseline --no-secondary 2>&1 | grep '^{"metric'; done > $O/bench_by_size.jsonl
+  for n in 100000 1000000 5000000 20000000 50000000 100000000; do timeout 600 python bench.py --points $n --no-cpu-baseline --no-secondary 2>&1 | grep '^{"metric'; done > $O/bench_by_size.jsonl
   MI_ICP_FORCE_COMM=1 timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 20 2>&1 | grep '^{"metric' | tee $O/bench_10m_rccl_1rank.json | python scripts/benchline.py
   MI_ICP_FORCE_COMM=2 timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 20 2>&1 | grep '^{"metric' | tee $O/bench_10m_mailbox_1rank.json | python scripts/benchline.py
 fi
