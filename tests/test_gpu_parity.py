@@ -169,6 +169,36 @@ def test_compute_system_matches_oracle(eng, est):
     np.testing.assert_allclose(U, Uref, atol=3e-6)
 
 
+def test_gicp_system_on_covariances_the_eigen_solver_special_cases(eng):
+    """GICP's rows are accumulated from S = W W without taking W (reduce.h, eigen3.h gicp_weight), which restates how
+    FastEigen3x3 treats its input: scaled by its largest coefficient in general, taken as is when it has no
+    off-diagonal entries, zero when nothing in it is positive.  Axis-aligned normals under a pure translation give
+    exactly diagonal (Ct + Cs)^-1 (the unscaled branch), alone and mixed with general ones: against the oracle's
+    row-by-row form."""
+    n = 20000
+    rng = np.random.default_rng(17)
+    tgt = rng.random((n, 3), dtype=np.float32)
+    src = (tgt + np.float32(0.004) * rng.standard_normal((n, 3)).astype(np.float32) + np.array([0.003, -0.002, 0.001], np.float32)).astype(np.float32)
+    axes = np.eye(3, dtype=np.float32)
+    nrm = axes[rng.integers(0, 3, n)]                               # axis-aligned: diagonal covariances
+    gen = rng.standard_normal((n, 3)).astype(np.float32)
+    gen /= np.linalg.norm(gen, axis=1, keepdims=True)
+    mixed = np.where((np.arange(n) % 3 == 0)[:, None], gen, nrm).astype(np.float32)
+    for normals in (nrm, mixed):
+        cov = orc.covariances_from_normals(normals)
+        T = np.eye(4, dtype=np.float32)
+        T[:3, 3] = [0.001, 0.0005, -0.002]                          # no rotation: diagonal stays diagonal
+        eng.set_target(cuda(tgt), cuda(normals), cuda(cov))
+        eng.set_source(cuda(src), cuda(normals), cuda(cov))
+        eng.search_radius_1nn(0.05, T)
+        got = eng.compute_system(GICP, T)
+        cor = eng.get_correspondences()
+        ref = orc.compute_system(GICP, orc.transform_points(T, src), tgt, cor, orc.transform_normals(T, normals), normals,
+                                 orc.rotate_covariances(T, cov), cov)
+        assert np.isfinite(ref).all() and len(cor) > n // 2
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+
+
 def test_explicit_correspondence_set(eng):
     d = _systems_inputs(5000, seed=2)
     eng.set_target(d["tgt"], d["tgt_nrm"])
