@@ -186,6 +186,25 @@ __device__ __forceinline__ bool cubes_inside(const Cube& c, uint64_t full_exec, 
     return all != 0u;
 }
 
+// The hit child (bit of `hit`, wave-uniform) that the most lanes' cubes overlap (vm: this lane's 8 bits); the lowest
+// such child among equals.
+__device__ __forceinline__ uint32_t most_wanted_child(uint32_t vm, uint32_t hit) {
+    uint32_t first = (uint32_t)__builtin_ctz(hit);
+    if ((hit & (hit - 1u)) != 0u) {
+        uint32_t most = 0u;
+#pragma unroll
+        for (uint32_t c = 0; c < 8u; ++c) {
+            if (((hit >> c) & 1u) == 0u) continue;  // wave-uniform
+            const uint32_t n = (uint32_t)__popcll(__ballot(((vm >> c) & 1u) != 0u));
+            if (n > most) {
+                most = n;
+                first = c;
+            }
+        }
+    }
+    return first;
+}
+
 template <class LeafRecFn>
 __device__ __forceinline__ uint32_t traverse_from(const float* records_g, uint32_t leaf_first, uint32_t start,
                                                   const Cube& cube, LeafRecFn&& leaf_rec) {
@@ -240,9 +259,14 @@ __device__ __forceinline__ uint32_t traverse_from(const float* records_g, uint32
         uint32_t hit = wave_or_mask(vm);
         if (id == top && skip < 8u) hit &= ~(1u << skip);  // climbing: that child's subtree is done
         if (id < leaf_first) {
-            if (hit) {  // descend into the first hit child, remember the others
-                pend = (pend << 8) | (uint64_t)(hit & (hit - 1u));
-                id = id * 8u + (uint32_t)__builtin_ctz(hit);
+            if (hit) {
+                // Descend into the hit child that the MOST lanes' cubes overlap -- the one the packet's queries sit
+                // in -- and remember the others: what is found there shrinks the cubes, and a sibling that was hit
+                // by the large cubes costs one record when its turn comes instead of its subtree.  (In child order
+                // the walk from the root went through half of the far subtrees before the near one.)
+                const uint32_t first = most_wanted_child(vm, hit);
+                pend = (pend << 8) | (uint64_t)(hit & ~(1u << first));
+                id = id * 8u + first;
                 off = off * 8 + 1;
                 continue;
             }
@@ -363,7 +387,8 @@ __device__ __forceinline__ uint32_t traverse_seeded(const float* records_g, uint
             if (dpar1 == id) hit &= dmask1;
         }
         if (id < leaf_first) {
-            if (hit) {
+            if (hit) {  // (in child order: the walk starts at the seed's node, where the lanes' answers mostly are --
+                        // most_wanted_child here measured nothing on the noisy passes and the transient)
                 pend = (pend << 8) | (uint64_t)(hit & (hit - 1u));
                 id = id * 8u + (uint32_t)__builtin_ctz(hit);
                 off = off * 8 + 1;
