@@ -153,6 +153,145 @@ __device__ __forceinline__ bool knn_offer(float* kd2, int32_t* kidx, int lane, i
     return shrunk;
 }
 
+// ---- lanes that do not belong to their packet ---------------------------------------------------------------
+// The walk is wave-uniform: a packet enters every box that ANY of its lanes' cubes overlaps, and every lane is
+// offered every point found there.  That is cheap while the 64 queries are neighbours with similar bounds -- and
+// ruinous for an outlier: a point far from the rest of the cloud has its k-th neighbour at that distance, its cube
+// swallows the dense part whole, and its packet went through 2M candidates (EstimateNormals of 2M points + 1000
+// points scattered around them: 177 ms instead of 3).  Such lanes -- a bound several times the packet's typical one,
+// or a packet whose queries lie further apart than their bounds reach -- leave the packet: they take no part in the
+// wave's walk (nothing is offered to them there, their cube is empty) and walk ON THEIR OWN afterwards
+// (knn_solo_walk): per-lane descent, nearest child first, boxes pruned by their exact L2 distance instead of
+// the cube, so that a far query facing a dense cloud looks at the leaves its ball touches, not at the cloud.
+__device__ __forceinline__ float wave_all_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_all_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_all_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+constexpr float kSoloBound = 4.0f;    // a lane whose bound radius exceeds this many typical ones walks alone
+constexpr float kSoloSpread = 16.0f;  // a packet whose queries span more than this many typical bounds is dissolved
+
+// bound2: the lane's current bound on the squared k-th distance (+inf: none yet)
+__device__ __forceinline__ bool knn_walks_alone(bool valid, float qx, float qy, float qz, float bound2) {
+    const float r = __builtin_amdgcn_sqrtf(fmaxf(bound2, 0.0f));
+    const bool fin = valid && r < INFINITY;
+    // the typical bound: mean of the finite ones, then of those within kSoloBound of that mean (one lane with a
+    // bound a thousand times the others' must not set the scale it is judged by)
+    float n = wave_all_sum(fin ? 1.0f : 0.0f);
+    float mean = wave_all_sum(fin ? r : 0.0f) / fmaxf(n, 1.0f);
+    const bool in = fin && r <= kSoloBound * mean;
+    n = wave_all_sum(in ? 1.0f : 0.0f);
+    mean = wave_all_sum(in ? r : 0.0f) / fmaxf(n, 1.0f);
+    if (!(n > 0.0f)) return valid;  // nobody has a bound: everybody for himself
+    const float ex = wave_all_max(valid ? qx : -INFINITY) - wave_all_min(valid ? qx : INFINITY);
+    const float ey = wave_all_max(valid ? qy : -INFINITY) - wave_all_min(valid ? qy : INFINITY);
+    const float ez = wave_all_max(valid ? qz : -INFINITY) - wave_all_min(valid ? qz : INFINITY);
+    const bool spread = fmaxf(ex, fmaxf(ey, ez)) > kSoloSpread * mean;
+    return valid && (spread || !(r <= kSoloBound * mean));
+}
+
+// ... and packets whose cubes, alike as they may be, reach into a part of the cloud far denser than their own (sparse
+// points around a dense scan: their k-th neighbours are at the distance of the scan, the cubes hold all of it).  Nothing
+// local tells; the upper levels of the tree do: a probe walks them with the packet's cubes down to the nodes of 512
+// points and counts the ones it would enter -- about a dozen for a packet among its likes (2-3 % of its walk), and when
+// the count passes kSoloNodes the probe stops and every lane of the packet walks alone.
+constexpr uint32_t kSoloNodes = 96u;
+__device__ __forceinline__ bool knn_packet_reaches_too_far(const float* records_g, uint32_t leaf_first, const Cube& cube) {
+    if (leaf_first < 512u) return false;  // (a tree this small is walked in no time either way)
+    uint32_t nodes = 0u;
+    Cube probe = cube;
+    traverse_from(records_g, leaf_first >> 6, 1u, probe, [&](uint32_t, uint32_t, uint32_t hit) {
+        nodes += (uint32_t)__builtin_popcount(hit);
+        if (nodes > kSoloNodes) {  // enough seen: with empty cubes the probe ends at once
+            probe.lox = probe.loy = probe.loz = INFINITY;
+            probe.hix = probe.hiy = probe.hiz = -INFINITY;
+        }
+    });
+    return nodes > kSoloNodes;
+}
+
+// The per-lane walk.  Every lane with `solo` set searches the whole tree for itself: its own node id and stack of
+// pending siblings (the wave-uniform walk's scheme, in vector registers), records and leaves fetched by the lane,
+// a box entered when its L2 distance from the query -- formed with the same rounding as the points' distances, so
+// never larger than any of them -- is below the lane's bound, the nearest hit child first.  offer(L): the lane's
+// leaf L to its list (called in divergent code: per-lane work only).
+template <class BoundFn, class OfferFn>
+__device__ __forceinline__ void knn_solo_walk(const float* __restrict__ records_g, uint32_t leaf_first, bool solo,
+                                              float qx, float qy, float qz, BoundFn&& bound2, OfferFn&& offer) {
+    uint32_t id = 1u;
+    int32_t off = -1;
+    uint64_t pend = 0ull;
+    bool on = solo;
+    while (__ballot(on) != 0ull) {
+        uint32_t hit = 0u, nearest = 0u;
+        float dnear = INFINITY;
+        if (on) {
+            const float4* rec = reinterpret_cast<const float4*>(records_g + ((size_t)(id + (uint32_t)off) << 6));
+            const float w2 = bound2();
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float4 a = rec[3 * p], b = rec[3 * p + 1], c = rec[3 * p + 2];
+                // {Amin.x,Bmin.x,Amin.y,Bmin.y} {Amin.z,Bmin.z,Amax.x,Bmax.x} {Amax.y,Bmax.y,Amax.z,Bmax.z}
+                const float gax = fmaxf(fmaxf(a.x - qx, qx - b.z), 0.0f), gay = fmaxf(fmaxf(a.z - qy, qy - c.x), 0.0f);
+                const float gaz = fmaxf(fmaxf(b.x - qz, qz - c.z), 0.0f);
+                const float gbx = fmaxf(fmaxf(a.y - qx, qx - b.w), 0.0f), gby = fmaxf(fmaxf(a.w - qy, qy - c.y), 0.0f);
+                const float gbz = fmaxf(fmaxf(b.y - qz, qz - c.w), 0.0f);
+                const float da = sq3(gax, gay, gaz), db = sq3(gbx, gby, gbz);  // (an empty slot's inverted box: +inf)
+                if (da < w2) {
+                    hit |= 1u << (2 * p);
+                    if (da < dnear) {
+                        dnear = da;
+                        nearest = 2u * p;
+                    }
+                }
+                if (db < w2) {
+                    hit |= 2u << (2 * p);
+                    if (db < dnear) {
+                        dnear = db;
+                        nearest = 2u * p + 1u;
+                    }
+                }
+            }
+        }
+        const bool inner = on && id < leaf_first;
+        if (on && !inner) {  // a leaf-level record: its hit leaves, one after the other (the lanes that are at one)
+            const uint32_t lbase = (id - leaf_first) * 8u;
+            while (hit != 0u) {
+                const uint32_t c = (uint32_t)__builtin_ctz(hit);
+                hit &= hit - 1u;
+                offer(lbase + c);
+            }
+        }
+        if (inner && hit != 0u) {
+            pend = (pend << 8) | (uint64_t)(hit & ~(1u << nearest));
+            id = id * 8u + nearest;
+            off = off * 8 + 1;
+        } else if (on) {
+            if (pend == 0ull) {
+                on = false;
+            } else {
+                const uint32_t z = (uint32_t)__builtin_ctzll(pend);
+                const uint32_t j3 = (z >> 3) * 3u;
+                pend >>= (z & 56u);
+                id = ((id >> j3) & ~7u) | (z & 7u);
+                off >>= j3;
+                const uint32_t lo = (uint32_t)pend;
+                pend = (pend & 0xffffffff00000000ull) | (uint64_t)(lo & (lo - 1u));
+            }
+        }
+    }
+}
+
 // OUT 0: normals_out[orig] (3 floats).  OUT 1: tgrad[sorted] (float4, w = 0) and, when
 // not null, normals_out[orig] receives the gradient for inspection; tnrm = sorted target
 // normals with the intensity in .w.
@@ -201,8 +340,16 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_normals_kernel(
             knn_offer(kd2, kidx, lane, k, st, d2, L * kLeaf + t);  // padding points have d2 = +inf
         }
     }
+    // lanes that would drag the packet through the tree walk alone, after the others (knn_walks_alone)
+    bool solo = knn_walks_alone(valid && k > 0, qx, qy, qz, st.worst);
+    const float solo_bound = st.worst;
     Cube cube;
-    set_cube(cube, qx, qy, qz, st.worst);
+    set_cube(cube, qx, qy, qz, solo ? -1.0f : st.worst);
+    if (knn_packet_reaches_too_far(records_g, leaf_first, cube)) {
+        solo = valid && k > 0;
+        set_cube(cube, qx, qy, qz, -1.0f);
+    }
+    if (solo) st.worst = -1.0f;  // (nothing is below that: the wave's walk offers them nothing)
 
     // ---- B: traversal -------------------------------------------------------------
     traverse_wide(records_g, leaf_first, cube, [&](uint32_t Lu) {
@@ -217,6 +364,25 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_normals_kernel(
         }
         if (shrunk) set_cube(cube, qx, qy, qz, st.worst);
     });
+    if (__ballot(solo) != 0ull) {  // (rare: wave-uniform)
+        if (solo) st.worst = solo_bound;
+        knn_solo_walk(records_g, leaf_first, solo, qx, qy, qz, [&]() { return st.worst; }, [&](uint32_t L) {
+            if ((int)L >= seed_lo && (int)L < seed_hi) return;
+            const float4* line = reinterpret_cast<const float4*>(tblk_g + (size_t)L * kLeafFloats);
+            float c[24];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                const float4 f = line[e];
+                c[4 * e] = f.x;
+                c[4 * e + 1] = f.y;
+                c[4 * e + 2] = f.z;
+                c[4 * e + 3] = f.w;
+            }
+#pragma unroll
+            for (int t = 0; t < kLeaf; ++t)
+                knn_offer(kd2, kidx, lane, k, st, sq3(qx - c[t], qy - c[8 + t], qz - c[16 + t]), (int32_t)(L * kLeaf) + t);
+        });
+    }
 
     if (!valid) return;
     if (OUT == 1) {
@@ -453,8 +619,15 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
             }
         }
     }
+    bool solo = knn_walks_alone(valid && k > 0, qx, qy, qz, st.worst);  // (see there)
+    const float solo_bound = st.worst;
     Cube cube;
-    set_cube(cube, qx, qy, qz, st.worst);
+    set_cube(cube, qx, qy, qz, solo ? -1.0f : st.worst);
+    if (knn_packet_reaches_too_far(records_g, leaf_first, cube)) {
+        solo = valid && k > 0;
+        set_cube(cube, qx, qy, qz, -1.0f);
+    }
+    if (solo) st.worst = -1.0f;
     // ---- B: the exact walk
     traverse_wide(records_g, leaf_first, cube, [&](uint32_t Lu) {
         const bool seeded = Lu >= seed_lo && Lu < seed_hi;  // this lane has these points already
@@ -468,6 +641,25 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
         }
         if (shrunk) set_cube(cube, qx, qy, qz, st.worst);
     });
+    if (__ballot(solo) != 0ull) {
+        if (solo) st.worst = solo_bound;
+        knn_solo_walk(records_g, leaf_first, solo, qx, qy, qz, [&]() { return st.worst; }, [&](uint32_t L) {
+            if (L >= seed_lo && L < seed_hi) return;
+            const float4* line = reinterpret_cast<const float4*>(tblk_g + (size_t)L * kLeafFloats);
+            float c[24];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                const float4 f = line[e];
+                c[4 * e] = f.x;
+                c[4 * e + 1] = f.y;
+                c[4 * e + 2] = f.z;
+                c[4 * e + 3] = f.w;
+            }
+#pragma unroll
+            for (int u = 0; u < kLeaf; ++u)
+                knn_offer(kd2, kidx, lane, k, st, sq3(qx - c[u], qy - c[8 + u], qz - c[16 + u]), (int32_t)(L * kLeaf) + u);
+        });
+    }
     if (!valid) return;
     const int64_t row = (int64_t)qperm[i] * k;
     if constexpr (KCAP > kMaxKnn) {

@@ -153,3 +153,41 @@ def test_sparse_and_clustered_targets_stay_exact_and_fast(eng):
         eng.search_knn(q, k, r)
         torch.cuda.synchronize()
         assert time.perf_counter() - t0 < 0.5, (k, r)
+
+
+def test_outliers_around_a_dense_cloud_walk_alone(eng):
+    """A few points scattered far around a dense cloud have their k-th neighbours at the distance of the cloud: in
+    the wave-uniform walk their cubes hold all of it and their packets were offered every point (EstimateNormals of
+    2M + 1000 such points: 177 ms).  They leave their packets -- by their bounds (knn_walks_alone) or, where whole
+    packets are like that, by the probe of the tree's upper levels (knn_packet_reaches_too_far) -- and walk alone
+    with L2 pruning (knn_normals.h knn_solo_walk): same rows as the oracle's, in a time of the usual order."""
+    import time
+    rng = np.random.default_rng(123)
+    dense = (rng.random((300_000, 3), dtype=np.float32) * np.float32(0.1)).astype(np.float32)
+    far = (rng.random((400, 3), dtype=np.float32) * np.float32(100.0) - np.float32(50.0)).astype(np.float32)
+    tgt = np.concatenate([dense, far])
+    # queries: every outlier itself, points next to outliers, points inside the cloud, points in between
+    qry = np.concatenate([far, far[:200] + np.float32(0.5), dense[:3000] + np.float32(1e-4),
+                          (rng.random((500, 3), dtype=np.float32) * np.float32(4.0) - np.float32(2.0)).astype(np.float32)])
+    eng.set_target(tgt)
+    for k in (1, 8, 30, 70):
+        found, idx, d2 = eng.search_knn(qry, k)
+        ret, oi, od = orc.search_knn(tgt, qry, k)
+        assert found == ret
+        rows_equal_up_to_ties(idx, d2, oi, od, tgt, qry)
+    found, idx, d2 = eng.search_knn(qry, 30, 20.0)                   # a radius that reaches the cloud from many outliers
+    ret, oi, od = orc.search_radius(tgt, qry, 20.0, 30)
+    assert found == ret
+    rows_equal_up_to_ties(idx, d2, oi, od, tgt, qry)
+    # EstimateNormals of the whole cloud (queries = its own points), against the neighbour sets just verified
+    nrm = eng.estimate_normals_knn(tgt, 30)
+    assert np.isfinite(nrm).all() and np.allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-4)
+    big = np.concatenate([(rng.random((2_000_000, 3), dtype=np.float32) * np.float32(0.1)).astype(np.float32),
+                          (rng.random((1000, 3), dtype=np.float32) * np.float32(100.0)).astype(np.float32)])
+    d = torch.from_numpy(big).cuda()
+    eng.estimate_normals_knn(d, 30)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.estimate_normals_knn(d, 30)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.05          # (3 ms; 177 ms with every lane in the wave's walk)
