@@ -287,4 +287,65 @@ __global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     }
 }
 
+// THE WALK'S CAP (nn_search.h): 1.5 x the geometric mean of the diagonals of the leaf-level nodes' boxes (64 slots
+// each; nodes without an extent -- one point, or copies of one -- do not count), into the root record's padding,
+// floats kRecordCap / kRecordCap2 (its square); +inf when no node has an extent.  The geometric mean: a handful of
+// nodes that hold far-away outliers have boxes thousands of times the others' and must not set the scale.
+// scratch: {sum of log2(diagonal), count, ticket, -}, zeroed by the caller.
+constexpr float kCapDiagonals = 1.5f;
+__global__ __launch_bounds__(256) void tree_scale(float* __restrict__ records, uint32_t leaf_first, uint32_t used_last,
+                                                  float* __restrict__ scratch) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    float lg = 0.0f, one = 0.0f;
+    if (t < used_last) {
+        const float4* rec = reinterpret_cast<const float4*>(records + ((size_t)(full_levels_below(leaf_first) + t) << 6));
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float4 a = rec[3 * p], b = rec[3 * p + 1], c = rec[3 * p + 2];
+            // {Amin.x,Bmin.x,Amin.y,Bmin.y} {Amin.z,Bmin.z,Amax.x,Bmax.x} {Amax.y,Bmax.y,Amax.z,Bmax.z}; empty: (+inf, -inf)
+            lo[0] = fminf(lo[0], fminf(a.x, a.y));
+            lo[1] = fminf(lo[1], fminf(a.z, a.w));
+            lo[2] = fminf(lo[2], fminf(b.x, b.y));
+            hi[0] = fmaxf(hi[0], fmaxf(b.z, b.w));
+            hi[1] = fmaxf(hi[1], fmaxf(c.x, c.y));
+            hi[2] = fmaxf(hi[2], fmaxf(c.z, c.w));
+        }
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        const float diag = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+        if (diag > 0.0f && diag < INFINITY) {  // (NaN, empty and point-like nodes: no)
+            lg = __builtin_log2f(diag);
+            one = 1.0f;
+        }
+    }
+    __shared__ float s_lg[4], s_one[4];
+    __shared__ uint32_t s_last;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lg += __shfl_xor(lg, o, 64);
+        one += __shfl_xor(one, o, 64);
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        s_lg[threadIdx.x >> 6] = lg;
+        s_one[threadIdx.x >> 6] = one;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        atomicAdd(scratch + 0, s_lg[0] + s_lg[1] + s_lg[2] + s_lg[3]);
+        atomicAdd(scratch + 1, s_one[0] + s_one[1] + s_one[2] + s_one[3]);
+        __threadfence();
+        s_last = atomicAdd(reinterpret_cast<uint32_t*>(scratch) + 2, 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last != 0u && threadIdx.x == 0u) {
+        __threadfence();
+        const float sum = __hip_atomic_load(scratch + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float cnt = __hip_atomic_load(scratch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float cap = (cnt > 0.0f) ? kCapDiagonals * __builtin_exp2f(sum / cnt) : INFINITY;
+        records[kRecordCap] = cap;
+        records[kRecordCap2] = cap * cap;  // (overflow: +inf, i.e. no cap)
+    }
+}
+
+
 }  // namespace mi

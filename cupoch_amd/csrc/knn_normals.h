@@ -161,7 +161,7 @@ __device__ __forceinline__ bool knn_offer(float* kd2, int32_t* kidx, int lane, i
 // points scattered around them: 177 ms instead of 3).  Such lanes -- a bound several times the packet's typical one,
 // or a packet whose queries lie further apart than their bounds reach -- leave the packet: they take no part in the
 // wave's walk (nothing is offered to them there, their cube is empty) and walk ON THEIR OWN afterwards
-// (knn_solo_walk): per-lane descent, nearest child first, boxes pruned by their exact L2 distance instead of
+// (traverse.h solo_walk): per-lane descent, nearest child first, boxes pruned by their exact L2 distance instead of
 // the cube, so that a far query facing a dense cloud looks at the leaves its ball touches, not at the cloud.
 __device__ __forceinline__ float wave_all_sum(float v) {
 #pragma unroll
@@ -218,78 +218,6 @@ __device__ __forceinline__ bool knn_packet_reaches_too_far(const float* records_
         }
     });
     return nodes > kSoloNodes;
-}
-
-// The per-lane walk.  Every lane with `solo` set searches the whole tree for itself: its own node id and stack of
-// pending siblings (the wave-uniform walk's scheme, in vector registers), records and leaves fetched by the lane,
-// a box entered when its L2 distance from the query -- formed with the same rounding as the points' distances, so
-// never larger than any of them -- is below the lane's bound, the nearest hit child first.  offer(L): the lane's
-// leaf L to its list (called in divergent code: per-lane work only).
-template <class BoundFn, class OfferFn>
-__device__ __forceinline__ void knn_solo_walk(const float* __restrict__ records_g, uint32_t leaf_first, bool solo,
-                                              float qx, float qy, float qz, BoundFn&& bound2, OfferFn&& offer) {
-    uint32_t id = 1u;
-    int32_t off = -1;
-    uint64_t pend = 0ull;
-    bool on = solo;
-    while (__ballot(on) != 0ull) {
-        uint32_t hit = 0u, nearest = 0u;
-        float dnear = INFINITY;
-        if (on) {
-            const float4* rec = reinterpret_cast<const float4*>(records_g + ((size_t)(id + (uint32_t)off) << 6));
-            const float w2 = bound2();
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const float4 a = rec[3 * p], b = rec[3 * p + 1], c = rec[3 * p + 2];
-                // {Amin.x,Bmin.x,Amin.y,Bmin.y} {Amin.z,Bmin.z,Amax.x,Bmax.x} {Amax.y,Bmax.y,Amax.z,Bmax.z}
-                const float gax = fmaxf(fmaxf(a.x - qx, qx - b.z), 0.0f), gay = fmaxf(fmaxf(a.z - qy, qy - c.x), 0.0f);
-                const float gaz = fmaxf(fmaxf(b.x - qz, qz - c.z), 0.0f);
-                const float gbx = fmaxf(fmaxf(a.y - qx, qx - b.w), 0.0f), gby = fmaxf(fmaxf(a.w - qy, qy - c.y), 0.0f);
-                const float gbz = fmaxf(fmaxf(b.y - qz, qz - c.w), 0.0f);
-                const float da = sq3(gax, gay, gaz), db = sq3(gbx, gby, gbz);  // (an empty slot's inverted box: +inf)
-                if (da < w2) {
-                    hit |= 1u << (2 * p);
-                    if (da < dnear) {
-                        dnear = da;
-                        nearest = 2u * p;
-                    }
-                }
-                if (db < w2) {
-                    hit |= 2u << (2 * p);
-                    if (db < dnear) {
-                        dnear = db;
-                        nearest = 2u * p + 1u;
-                    }
-                }
-            }
-        }
-        const bool inner = on && id < leaf_first;
-        if (on && !inner) {  // a leaf-level record: its hit leaves, one after the other (the lanes that are at one)
-            const uint32_t lbase = (id - leaf_first) * 8u;
-            while (hit != 0u) {
-                const uint32_t c = (uint32_t)__builtin_ctz(hit);
-                hit &= hit - 1u;
-                offer(lbase + c);
-            }
-        }
-        if (inner && hit != 0u) {
-            pend = (pend << 8) | (uint64_t)(hit & ~(1u << nearest));
-            id = id * 8u + nearest;
-            off = off * 8 + 1;
-        } else if (on) {
-            if (pend == 0ull) {
-                on = false;
-            } else {
-                const uint32_t z = (uint32_t)__builtin_ctzll(pend);
-                const uint32_t j3 = (z >> 3) * 3u;
-                pend >>= (z & 56u);
-                id = ((id >> j3) & ~7u) | (z & 7u);
-                off >>= j3;
-                const uint32_t lo = (uint32_t)pend;
-                pend = (pend & 0xffffffff00000000ull) | (uint64_t)(lo & (lo - 1u));
-            }
-        }
-    }
 }
 
 // OUT 0: normals_out[orig] (3 floats).  OUT 1: tgrad[sorted] (float4, w = 0) and, when
@@ -366,7 +294,7 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_normals_kernel(
     });
     if (__ballot(solo) != 0ull) {  // (rare: wave-uniform)
         if (solo) st.worst = solo_bound;
-        knn_solo_walk(records_g, leaf_first, solo, qx, qy, qz, [&]() { return st.worst; }, [&](uint32_t L) {
+        solo_walk(records_g, leaf_first, solo, qx, qy, qz, [&]() { return st.worst; }, [&](uint32_t L) {
             if ((int)L >= seed_lo && (int)L < seed_hi) return;
             const float4* line = reinterpret_cast<const float4*>(tblk_g + (size_t)L * kLeafFloats);
             float c[24];
@@ -643,7 +571,7 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
     });
     if (__ballot(solo) != 0ull) {
         if (solo) st.worst = solo_bound;
-        knn_solo_walk(records_g, leaf_first, solo, qx, qy, qz, [&]() { return st.worst; }, [&](uint32_t L) {
+        solo_walk(records_g, leaf_first, solo, qx, qy, qz, [&]() { return st.worst; }, [&](uint32_t L) {
             if (L >= seed_lo && L < seed_hi) return;
             const float4* line = reinterpret_cast<const float4*>(tblk_g + (size_t)L * kLeafFloats);
             float c[24];

@@ -135,6 +135,7 @@ struct mi_icp_ctx {
     DevBuf keys0, keys1, vals0, vals1, hist, scan_tmp, bounds_part, bounds;
     DevBuf partial, sys_dev, dense_idx, flags, pairs_out, seg_start;
     DevBuf stage[6];
+    DevBuf tscale;   // scratch of kd_build.h tree_scale
     DevBuf knn_idx;  // candidate indices of the small k-NN lists, [packet][slot][lane] (knn_normals.h)
     double* sys_host = nullptr;  // pinned, 32 doubles + spare
     float* f_host = nullptr;     // pinned, 16 floats
@@ -1158,7 +1159,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
                      &c->scan_tmp, &c->bounds_part, &c->bounds, &c->partial, &c->sys_dev,
                      &c->dense_idx, &c->flags, &c->pairs_out, &c->seg_start, &c->loop_dev, &c->ticket, &c->mail_state, &c->alt[0],
                      &c->alt[1], &c->alt[2], &c->alt[3], &c->alt[4], &c->alt[5], &c->alt[6], &c->alt[7], &c->alt[8], &c->stage[0],
-                     &c->stage[1], &c->stage[2], &c->stage[3], &c->stage[4], &c->stage[5], &c->knn_idx};
+                     &c->stage[1], &c->stage[2], &c->stage[3], &c->stage[4], &c->stage[5], &c->knn_idx, &c->tscale};
     for (DevBuf* b : all) release(*b);
     if (c->sys_host) (void)hipHostFree(c->sys_host);
     if (c->cell_total_host) (void)hipHostFree(c->cell_total_host);
@@ -1328,6 +1329,13 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
                                                               lay.levels, lay.levels - 3 * above_groups);
         KCHK(c);
         used = (used + 7u) / 8u;
+    }
+    {   // the cap of the wave-uniform walks' cubes, from the leaf-level nodes' sizes (kd_build.h tree_scale)
+        float* ts;
+        TRY(ensure(c, c->tscale, 4, &ts));
+        HIPCHK(c, hipMemsetAsync(ts, 0, 16, c->stream));
+        tree_scale<<<(used_last + 255u) / 256u, 256, 0, c->stream>>>(nodes, leaf_first, used_last, ts);
+        KCHK(c);
     }
     c->links_ready = false;  // (the leaves' halos: started below, or by the registration loop / the first seeded search)
     c->halo_iters = c->halo_asked = 0;

@@ -206,6 +206,7 @@ __device__ __forceinline__ bool nn_packet_body(
     int32_t seed_j = -1;
     if (SEED) seed_j = nn_idx[ic];
     const float rx = sx[ic], ry = sy[ic], rz = sz[ic];
+    const float cap2 = ((cfloat_p)(uintptr_t)records_g)[kRecordCap2];  // the walk's cap, squared (THE CAP, below)
     Xform T = Tv;
     if (loop) {
         if (loop->done) return false;
@@ -355,13 +356,25 @@ __device__ __forceinline__ bool nn_packet_body(
             }
         }
     }
+    // THE CAP.  The walk is wave-uniform: the packet enters every box that any lane's cube overlaps.  A query far from
+    // the target whose correspondence radius still reaches it -- an outlier of the source under a generous
+    // max_correspondence_distance -- has a cube that holds the target whole, and its packet looked at all of it
+    // (1M points, 500 such queries: 86 ms per iteration instead of 0.06).  So the wave's cubes are capped at a radius
+    // read from the tree (kd_build.h tree_scale: 1.5 geometric-mean diagonals of a 64-point node, ~10 point spacings;
+    // in the root record's padding), and a lane that has found nothing within the cap although more was asked for
+    // finishes ON ITS OWN afterwards (traverse.h solo_walk: L2 pruning).  With the usual radii (a few spacings) no
+    // cube is ever capped.
+    const bool any_walk = SEED ? (__ballot(!retired) != 0ull) : true;  // wave-uniform
+    const uint64_t done_before = __ballot(retired);
+    // (cap2: requested with the prologue's other scalar loads -- fetched here it was a round trip of its own in front
+    // of every walk)
     // the search cube of the lanes that go on (an empty one takes no part in box tests; invalid lanes: best = -1 -> empty)
     Cube cube;
     if (retired) {
         cube.lox = cube.loy = cube.loz = INFINITY;
         cube.hix = cube.hiy = cube.hiz = -INFINITY;
     } else {
-        set_cube(cube, qx, qy, qz, best);
+        set_cube(cube, qx, qy, qz, fminf(best, cap2));
     }
     constexpr uint32_t kNoItem = 0xffffffffu;
     uint32_t held = kNoItem;             // this lane's one pending leaf while no lane has had a second
@@ -373,7 +386,7 @@ __device__ __forceinline__ bool nn_packet_body(
         if (valid && (int32_t)(uint32_t)b != bidx) {
             best = nb;
             bidx = (int32_t)(uint32_t)b;
-            if (!retired) set_cube(cube, qx, qy, qz, best);  // a retired lane's cube stays empty
+            if (!retired) set_cube(cube, qx, qy, qz, fminf(best, cap2));  // a retired lane's cube stays empty
         }
     };
     auto drain = [&](uint32_t first, uint32_t count) {
@@ -450,6 +463,22 @@ __device__ __forceinline__ bool nn_packet_body(
         }
     } else if (queued) {
         drain(0u, queued);
+    }
+    if (any_walk && r2 > cap2) {  // (wave-uniform; never with a radius of a few spacings)
+        // unfinished: not complete before the walk, nothing found within the cap (the capped walk has seen every point
+        // that near), and the radius asked for reaches further
+        const bool alone = valid && ((done_before >> lane) & 1ull) == 0ull && !(best < cap2);
+        if (__ballot(alone) != 0ull) {
+            solo_walk(records_g, leaf_first, alone, qx, qy, qz, [&]() { return best; }, [&](uint32_t L) {
+                const float4* line = reinterpret_cast<const float4*>(tblk_g + (size_t)L * kLeafFloats);
+                const LineMin w = line_min(line[0], line[1], line[2], line[3], line[4], line[5], qx, qy, qz);
+                const int32_t j = (int32_t)(L * (uint32_t)kLeaf + (uint32_t)w.k);
+                if (w.m < best || (w.m == best && bidx >= 0 && j < bidx)) {  // (strict radius: best starts at r2; NaN: never)
+                    best = w.m;
+                    bidx = j;
+                }
+            });
+        }
     }
 
     if (valid) {

@@ -55,6 +55,7 @@ typedef const __attribute__((address_space(4))) f16v* cf16_p;
 constexpr int kRecordFloats = 64;  // 256 B: 4 sibling pairs of 12 floats + 16 floats of padding
 constexpr int kPairStride = 12;
 constexpr int kMaxLevels = 9;      // 8-bit masks in a 64-bit stack: 8 pushes
+constexpr int kRecordCap = 56, kRecordCap2 = 57;  // floats of the ROOT record's padding: the walk's cap and its square (kd_build.h tree_scale)
 
 // (h - 1) / 7 for h = 8^k, exact via the inverse of 7 modulo 2^32
 __host__ __device__ __forceinline__ uint32_t full_levels_below(uint32_t h) {
@@ -456,6 +457,80 @@ __device__ __forceinline__ uint32_t traverse_seeded(const float* records_g, uint
     }
     return steps;
 }
+
+// THE PER-LANE WALK (for queries that do not belong to their packet: knn_normals.h knn_walks_alone, nn_search.h
+// kCapped).  Every lane with `solo` set searches the whole tree for itself: its own node id and stack of
+// pending siblings (the wave-uniform walk's scheme, in vector registers), records and leaves fetched by the lane,
+// a box entered when its L2 distance from the query -- formed with the same rounding as the points' distances, so
+// never larger than any of them -- is below the lane's bound, the nearest hit child first.  offer(L): the lane's
+// leaf L to its list (called in divergent code: per-lane work only).
+template <class BoundFn, class OfferFn>
+__device__ __forceinline__ void solo_walk(const float* __restrict__ records_g, uint32_t leaf_first, bool solo,
+                                              float qx, float qy, float qz, BoundFn&& bound2, OfferFn&& offer) {
+    uint32_t id = 1u;
+    int32_t off = -1;
+    uint64_t pend = 0ull;
+    bool on = solo;
+    while (__ballot(on) != 0ull) {
+        uint32_t hit = 0u, nearest = 0u;
+        float dnear = INFINITY;
+        if (on) {
+            const float4* rec = reinterpret_cast<const float4*>(records_g + ((size_t)(id + (uint32_t)off) << 6));
+            const float w2 = bound2();
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float4 a = rec[3 * p], b = rec[3 * p + 1], c = rec[3 * p + 2];
+                // {Amin.x,Bmin.x,Amin.y,Bmin.y} {Amin.z,Bmin.z,Amax.x,Bmax.x} {Amax.y,Bmax.y,Amax.z,Bmax.z}
+                const float gax = fmaxf(fmaxf(a.x - qx, qx - b.z), 0.0f), gay = fmaxf(fmaxf(a.z - qy, qy - c.x), 0.0f);
+                const float gaz = fmaxf(fmaxf(b.x - qz, qz - c.z), 0.0f);
+                const float gbx = fmaxf(fmaxf(a.y - qx, qx - b.w), 0.0f), gby = fmaxf(fmaxf(a.w - qy, qy - c.y), 0.0f);
+                const float gbz = fmaxf(fmaxf(b.y - qz, qz - c.w), 0.0f);
+                const float da = sq3(gax, gay, gaz), db = sq3(gbx, gby, gbz);  // (an empty slot's inverted box: +inf)
+                if (da < w2) {
+                    hit |= 1u << (2 * p);
+                    if (da < dnear) {
+                        dnear = da;
+                        nearest = 2u * p;
+                    }
+                }
+                if (db < w2) {
+                    hit |= 2u << (2 * p);
+                    if (db < dnear) {
+                        dnear = db;
+                        nearest = 2u * p + 1u;
+                    }
+                }
+            }
+        }
+        const bool inner = on && id < leaf_first;
+        if (on && !inner) {  // a leaf-level record: its hit leaves, one after the other (the lanes that are at one)
+            const uint32_t lbase = (id - leaf_first) * 8u;
+            while (hit != 0u) {
+                const uint32_t c = (uint32_t)__builtin_ctz(hit);
+                hit &= hit - 1u;
+                offer(lbase + c);
+            }
+        }
+        if (inner && hit != 0u) {
+            pend = (pend << 8) | (uint64_t)(hit & ~(1u << nearest));
+            id = id * 8u + nearest;
+            off = off * 8 + 1;
+        } else if (on) {
+            if (pend == 0ull) {
+                on = false;
+            } else {
+                const uint32_t z = (uint32_t)__builtin_ctzll(pend);
+                const uint32_t j3 = (z >> 3) * 3u;
+                pend >>= (z & 56u);
+                id = ((id >> j3) & ~7u) | (z & 7u);
+                off >>= j3;
+                const uint32_t lo = (uint32_t)pend;
+                pend = (pend & 0xffffffff00000000ull) | (uint64_t)(lo & (lo - 1u));
+            }
+        }
+    }
+}
+
 
 template <class LeafRecFn>
 __device__ __forceinline__ uint32_t traverse_records(const float* records_g, uint32_t leaf_first,
