@@ -18,6 +18,7 @@ cpif $S/odometry.jsonl $P/r03_odometry_measured.jsonl
 cpif $S/knn_search.jsonl $P/r03_knn_search_measured.jsonl
 cpif $S/normals_10m.txt $P/r03_normals_10m.txt
 cpif $S/config1_cpu_p2p_100k.json $P/r03_config1_cpu_p2p_100k.json
+cpif $S/non_uniform_clouds.txt $P/r03_non_uniform_clouds.txt
 for k in head cold noisy configs knn transient; do
   f=$(find $S/st_$k -name 's_kernel_stats.csv' | head -1)
   case $k in head) n=r03_rocprofv3_kernel_stats.csv;; cold) n=r03_cold_call_rocprofv3_kernel_stats.csv;; *) n=r03_${k}_rocprofv3_kernel_stats.csv;; esac

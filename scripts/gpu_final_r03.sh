@@ -35,6 +35,7 @@ if has rows; then
   timeout 600 python scripts/measure_knn.py 1,0.0 8,0.0 30,0.0 30,0.01 64,0.0 100,0.0 2>&1 | grep '^{' > $O/knn_search.jsonl
   timeout 600 python scripts/measure_normals_10m.py 2>&1 | grep normals > $O/normals_10m.txt
   timeout 900 python scripts/measure_config1.py > $O/config1_cpu_p2p_100k.json 2>/dev/null; cut -c1-300 $O/config1_cpu_p2p_100k.json
+  { timeout 300 python scripts/dev/normals_clustered.py; timeout 300 python scripts/dev/icp_outliers.py; timeout 300 python scripts/dev/first_pass_stats.py; } 2>&1 | grep -v amdgpu.ids > $O/non_uniform_clouds.txt; cat $O/non_uniform_clouds.txt
 fi
 if has stats; then
   prof --kernel-trace --stats --output-format csv -d $R/$O/st_head -o s -- python $R/bench.py --no-cpu-baseline --no-secondary > $O/st_head.log 2>&1; echo "stats head rc=$?"
