@@ -293,6 +293,7 @@ __global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_eu(8, 8
 // nodes that hold far-away outliers have boxes thousands of times the others' and must not set the scale.
 // scratch: {sum of log2(diagonal), count, ticket, -}, zeroed by the caller.
 constexpr float kCapDiagonals = 1.5f;
+constexpr float kNearDiagonals = 0.18f;  // a first round from the root: ~1.25 point spacings on volumetric data
 __global__ __launch_bounds__(256) void tree_scale(float* __restrict__ records, uint32_t leaf_first, uint32_t used_last,
                                                   float* __restrict__ scratch) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
@@ -344,6 +345,8 @@ __global__ __launch_bounds__(256) void tree_scale(float* __restrict__ records, u
         const float cap = (cnt > 0.0f) ? kCapDiagonals * __builtin_exp2f(sum / cnt) : INFINITY;
         records[kRecordCap] = cap;
         records[kRecordCap2] = cap * cap;  // (overflow: +inf, i.e. no cap)
+        const float nearr = (cnt > 0.0f) ? kNearDiagonals * __builtin_exp2f(sum / cnt) : INFINITY;
+        records[kRecordNear2] = nearr * nearr;
     }
 }
 

@@ -368,13 +368,21 @@ __device__ __forceinline__ bool nn_packet_body(
     const uint64_t done_before = __ballot(retired);
     // (cap2: requested with the prologue's other scalar loads -- fetched here it was a round trip of its own in front
     // of every walk)
+    // TWO ROUNDS FROM THE ROOT.  A pass without previous matches starts every lane at the correspondence radius, and
+    // a packet's 64 cubes of that size reach into ~20 leaf-level nodes (34 records, 9 batches of 64 leaf evaluations
+    // per packet at a radius of 2 spacings) although nearly every query's answer lies within a spacing.  So the first
+    // round walks with the cubes cut to ~1.25 spacings (kRecordNear2: 0.18 of the tree's node diagonal) -- what it finds
+    // within that radius is final -- and only the lanes that found nothing so near walk again, at the radius asked for
+    // (still under the cap).
+    float wcap2 = cap2;  // (wave-uniform) the radius, squared, the wave's cubes are cut to in this round
+    if (!SEED) wcap2 = fminf(cap2, ((cfloat_p)(uintptr_t)records_g)[kRecordNear2]);
     // the search cube of the lanes that go on (an empty one takes no part in box tests; invalid lanes: best = -1 -> empty)
     Cube cube;
     if (retired) {
         cube.lox = cube.loy = cube.loz = INFINITY;
         cube.hix = cube.hiy = cube.hiz = -INFINITY;
     } else {
-        set_cube(cube, qx, qy, qz, fminf(best, cap2));
+        set_cube(cube, qx, qy, qz, fminf(best, wcap2));
     }
     constexpr uint32_t kNoItem = 0xffffffffu;
     uint32_t held = kNoItem;             // this lane's one pending leaf while no lane has had a second
@@ -386,7 +394,7 @@ __device__ __forceinline__ bool nn_packet_body(
         if (valid && (int32_t)(uint32_t)b != bidx) {
             best = nb;
             bidx = (int32_t)(uint32_t)b;
-            if (!retired) set_cube(cube, qx, qy, qz, fminf(best, cap2));  // a retired lane's cube stays empty
+            if (!retired) set_cube(cube, qx, qy, qz, fminf(best, wcap2));  // a retired lane's cube stays empty
         }
     };
     auto drain = [&](uint32_t first, uint32_t count) {
@@ -450,19 +458,36 @@ __device__ __forceinline__ bool nn_packet_body(
             if (lane == 0 && nw) atomicAdd(stats + 8 + w, (unsigned long long)nw);
         }
     }
-    if (!SEED) steps = traverse_from(records_g, leaf_first, 1u, cube, on_leaf_record);
-    else if (__builtin_expect(__ballot(!retired) != 0ull, 0)) {
-        const uint32_t my_node = (seed_j >= 0) ? leaf_first + ((uint32_t)seed_j >> 6) : 0u;  // leaf-level node of the previous match
-        steps = traverse_seeded(records_g, leaf_first, my_node, cube, retired, on_leaf_record);
-    }
-    if (!spilled) {  // one item per lane at most: each lane evaluates its own
-        if (__ballot(held != kNoItem) != 0ull) {
-            if (STATS) ++batches;
-            eval_item(sh, tblk_g, held != kNoItem, lane, held, qx, qy, qz, r2);
-            take_results();
+    for (;;) {  // (once; twice for a pass from the root with lanes that found nothing near)
+        if (!SEED) steps += traverse_from(records_g, leaf_first, 1u, cube, on_leaf_record);
+        else if (__builtin_expect(__ballot(!retired) != 0ull, 0)) {
+            const uint32_t my_node = (seed_j >= 0) ? leaf_first + ((uint32_t)seed_j >> 6) : 0u;  // leaf-level node of the previous match
+            steps = traverse_seeded(records_g, leaf_first, my_node, cube, retired, on_leaf_record);
         }
-    } else if (queued) {
-        drain(0u, queued);
+        if (!spilled) {  // one item per lane at most: each lane evaluates its own
+            if (__ballot(held != kNoItem) != 0ull) {
+                if (STATS) ++batches;
+                eval_item(sh, tblk_g, held != kNoItem, lane, held, qx, qy, qz, r2);
+                take_results();
+            }
+        } else if (queued) {
+            drain(0u, queued);
+        }
+        if (SEED || !(wcap2 < cap2) || !(r2 > wcap2)) break;  // (wave-uniform) not a first round, or nothing was cut
+        // the second round: the lanes with nothing within the first round's radius, at min(the radius asked for, the cap)
+        const bool again = valid && !(best < wcap2);
+        if (__ballot(again) == 0ull) break;
+        wcap2 = cap2;
+        retired = !again;
+        if (retired) {
+            cube.lox = cube.loy = cube.loz = INFINITY;
+            cube.hix = cube.hiy = cube.hiz = -INFINITY;
+        } else {
+            set_cube(cube, qx, qy, qz, fminf(best, wcap2));
+        }
+        held = kNoItem;
+        spilled = false;
+        queued = 0u;
     }
     if (any_walk && r2 > cap2) {  // (wave-uniform; never with a radius of a few spacings)
         // unfinished: not complete before the walk, nothing found within the cap (the capped walk has seen every point

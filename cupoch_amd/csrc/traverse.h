@@ -56,6 +56,7 @@ constexpr int kRecordFloats = 64;  // 256 B: 4 sibling pairs of 12 floats + 16 f
 constexpr int kPairStride = 12;
 constexpr int kMaxLevels = 9;      // 8-bit masks in a 64-bit stack: 8 pushes
 constexpr int kRecordCap = 56, kRecordCap2 = 57;  // floats of the ROOT record's padding: the walk's cap and its square (kd_build.h tree_scale)
+constexpr int kRecordNear2 = 58;                  // ... and the squared radius of a first round from the root (nn_search.h)
 
 // (h - 1) / 7 for h = 8^k, exact via the inverse of 7 modulo 2^32
 __host__ __device__ __forceinline__ uint32_t full_levels_below(uint32_t h) {
