@@ -1,16 +1,17 @@
 // knn_normals.h -- PointCloud::EstimateNormals(KDTreeSearchParamKNN(k)) on the
-// LBVH (geometry/estimate_normals.cu:38-127, geometry_functor.h:35-55).
+// target tree (geometry/estimate_normals.cu:38-127, geometry_functor.h:35-55).
 //
 // The reference runs FLANN's k-NN with the per-query heap in global memory
 // (N*k indices + distances written out), then a reduce_by_key over N*k
 // cumulant tuples.  Here a wave owns the 64 points of 8 consecutive leaves
-// (queries are the cloud's own points, already in Morton order), keeps each
-// lane's k candidates in LDS ([slot][lane], conflict-free for any slot), and
-// never materialises the neighbour lists:
+// (queries are the cloud's own points, already in kd order), keeps each
+// lane's k candidate DISTANCES in LDS ([slot][lane], conflict-free for any slot)
+// and their indices in a slab of global memory, and never hands the lists out:
 //   A. seed every lane's candidate set from the leaves around its own leaf in
-//      Morton order (spatially close, so the k-th distance is already tight);
+//      kd order (spatially close, so the k-th distance is already tight);
 //   B. wave-uniform tree traversal as in nn_search.h with the lane's current
-//      k-th distance as its bound (seed leaves are skipped);
+//      k-th distance as its bound (seed leaves are skipped) -- for the lanes that
+//      belong to their packet; the others walk on their own (knn_walks_alone);
 //   C. fp32 cumulants over the lane's k neighbours, closed-form eigenvector
 //      (FastEigen3x3MinMaxVec), written to the point's ORIGINAL index.
 // Neighbours include the point itself; fewer than 3 neighbours or a zero
