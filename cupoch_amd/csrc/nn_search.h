@@ -535,8 +535,10 @@ __device__ __forceinline__ bool nn_packet_body(
 
 // The search as a kernel of its own: one packet per workgroup (the dispatcher refills wave slots one at a
 // time: 3 % faster than 4 packets per workgroup), 8 waves per SIMD.
+// (the pass from the root may take 72 registers -- 7 waves per SIMD: with 64 its two rounds spilled 20 bytes per lane,
+// 150 MB of scratch writes per 10M-query launch, and it is bound by its vector instructions, not by its occupancy)
 template <bool SEED, bool STATS>
-__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_packet_kernel(
+__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SEED ? 8 : 7, 8))) void nn_packet_kernel(
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
         int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
         const float* __restrict__ lreg_g, const float* __restrict__ halo_g, uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, uint32_t nblocks, int32_t* __restrict__ nn_idx,
