@@ -127,7 +127,7 @@ __device__ __forceinline__ uint32_t loop_state_word(const DevLoop* st_g) {
 // finishes the loop with its error flag set.
 __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys_in, int resume, DevLoop& st_s,
                                                 const StepPre pre = StepPre{false, 0u, 0.0, 0u},
-                                                const MailArgs mail = MailArgs{nullptr, nullptr, 0, 1, 0u}) {
+                                                const MailArgs mail = MailArgs{nullptr, nullptr, 0, 1, 0u, nullptr, nullptr}) {
     constexpr int kWords = (int)(sizeof(DevLoop) / 4);
     constexpr int kSysWord0 = (int)(offsetof(DevLoop, sys) / 4);
     static_assert(sizeof(DevLoop) % 4 == 0 && kWords <= kStepThreads, "DevLoop is copied a word per thread");

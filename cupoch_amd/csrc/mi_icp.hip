@@ -735,7 +735,7 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, DevLoop* loop
         const int g2 = std::min(grid, 512);
         static const bool no_fused_step = std::getenv("MI_ICP_NO_FUSED_STEP") != nullptr;  // A/B switch
         EvTimer t(c, 1, loop != nullptr);
-        const MailArgs no_mail = {nullptr, nullptr, 0, 1, 0u};
+        const MailArgs no_mail = {nullptr, nullptr, 0, 1, 0u, nullptr, nullptr};
         const bool mail = c->mail_dev != nullptr;
         if (fuse_step && loop && mail && !no_fused_step) {  // N ranks on one node: exchange + step in the finishing block
             reduce_pt2pl_kernel<4, 2><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, mail_args(c));
@@ -1765,7 +1765,7 @@ static int loop_enqueue_evaluation(mi_icp_ctx* c, bool seed) {
     if (stepped) return MI_ICP_OK;  // (point-to-plane: the reduction's last block exchanged the sums, if need be, and took the step)
     const bool mail = c->mail_dev != nullptr;
     if (!mail) TRY(allreduce_system(c));  // (with a mailbox the step kernel starts with the exchange)
-    const MailArgs no_mail = {nullptr, nullptr, 0, 1, 0u};
+    const MailArgs no_mail = {nullptr, nullptr, 0, 1, 0u, nullptr, nullptr};
     loop_step_kernel<<<1, kStepThreads, 0, c->stream>>>(d, (double*)c->sys_dev.p, 0, mail ? mail_args(c) : no_mail);
     KCHK(c);
     return MI_ICP_OK;
@@ -1914,7 +1914,7 @@ int mi_icp_icp_iterate(mi_icp_ctx* c, int n_iterations, mi_icp_result* out) {
         // re-open the loop for n more updates: the update for the next iteration is formed
         // from the system of the last evaluation (resume = step without stats/test)
         DevLoop* d = (DevLoop*)c->loop_dev.p;
-        loop_step_kernel<<<1, kStepThreads, 0, c->stream>>>(d, (double*)c->sys_dev.p, n_iterations, MailArgs{nullptr, nullptr, 0, 1, 0u});
+        loop_step_kernel<<<1, kStepThreads, 0, c->stream>>>(d, (double*)c->sys_dev.p, n_iterations, MailArgs{nullptr, nullptr, 0, 1, 0u, nullptr, nullptr});
         KCHK(c);
         TRY(loop_run(c, n_iterations));
     }

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_pt2pl_kernel(ReduceArgs
                                    (STEP == 2) ? mail.seq_dev : nullptr);
     if (STEP && last) {
         __shared__ DevLoop st_s;
-        loop_step_block(loop, out32, 0, st_s, pre, (STEP == 2) ? mail : MailArgs{nullptr, nullptr, 0, 1, 0u});
+        loop_step_block(loop, out32, 0, st_s, pre, (STEP == 2) ? mail : MailArgs{nullptr, nullptr, 0, 1, 0u, nullptr, nullptr});
     }
 }
 
