@@ -9,6 +9,7 @@
 #pragma once
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "cupoch/geometry/pointcloud.h"
 
@@ -28,6 +29,14 @@ bool ReadPointCloud(const std::string& filename, geometry::PointCloud& pointclou
 /// The general entrance for writing a PointCloud to a file (extension decides).
 bool WritePointCloud(const std::string& filename, const geometry::PointCloud& pointcloud, bool write_ascii = false,
                      bool compressed = false, bool print_progress = false);
+
+/// The parse alone, into host arrays (what ReadPointCloud uploads): for callers that stage the cloud themselves, and
+/// for checking the readers where there is no device (tests/cpp/test_io_malformed.cpp).  normals / colors come back
+/// empty when the file has none.
+bool ReadPointCloudToHost(const std::string& filename, std::vector<Eigen::Vector3f>& points,
+                          std::vector<Eigen::Vector3f>& normals, std::vector<Eigen::Vector3f>& colors,
+                          const std::string& format = "auto", bool remove_nan_points = true,
+                          bool remove_infinite_points = true);
 
 bool ReadPointCloudFromPLY(const std::string& filename, geometry::PointCloud& pointcloud, bool print_progress = false);
 bool WritePointCloudToPLY(const std::string& filename, const geometry::PointCloud& pointcloud, bool write_ascii = false,

@@ -157,8 +157,14 @@ bool ReadPcdHeader(std::istream& in, PcdHeader& h) {
     if (h.points > kMaxPoints) return false;
     long long off = 0, el = 0;
     for (auto& f : h.fields) {
-        // untrusted input: a size the record decoder has no case for would overrun its 8-byte buffer
-        if (!ValidScalar(f.type, f.size) || f.count <= 0 || f.count > 4096) return false;
+        // untrusted input: a size beyond 8 would overrun the record decoder's 8-byte buffer.  Only the fields the
+        // reader DECODES (x y z, normal_*, rgb[a]) must be a (type, size) pair it has a case for; any other field
+        // -- a lidar's `timestamp U 8`, an `intensity I 8` -- is skipped by its size alone, as the reference skips
+        // it (io/file_format/file_pcd.cu: UnpackBinaryPCDElement returns 0 for sizes it does not know and
+        // CheckHeader asks for x, y, z only)
+        const bool decoded = f.name == "x" || f.name == "y" || f.name == "z" || f.name == "normal_x" || f.name == "normal_y" ||
+                             f.name == "normal_z" || f.name == "rgb" || f.name == "rgba";
+        if (f.size < 1 || f.size > 8 || (decoded && !ValidScalar(f.type, f.size)) || f.count <= 0 || f.count > 4096) return false;
         f.offset = (int)off;
         f.element = (int)el;
         off += (long long)f.size * f.count;
@@ -491,6 +497,26 @@ bool ReadPointCloud(const std::string& filename, geometry::PointCloud& pointclou
         Upload(h, pointcloud);
     }
     return ok;
+}
+
+bool ReadPointCloudToHost(const std::string& filename, std::vector<Eigen::Vector3f>& points,
+                          std::vector<Eigen::Vector3f>& normals, std::vector<Eigen::Vector3f>& colors,
+                          const std::string& format, bool remove_nan_points, bool remove_infinite_points) {
+    points.clear();
+    normals.clear();
+    colors.clear();
+    const std::string ext = (format == "auto") ? LowerExtension(filename) : format;
+    if (ext.empty()) {
+        LogWarning("Read geometry::PointCloud failed: unknown file extension.");
+        return false;
+    }
+    HostCloud h;
+    if (!ReadHost(filename, ext, h)) return false;
+    RemoveNonFinite(h, remove_nan_points, remove_infinite_points);
+    points.swap(h.points);
+    if (h.normals.size() == points.size()) normals.swap(h.normals);
+    if (h.colors.size() == points.size()) colors.swap(h.colors);
+    return true;
 }
 
 bool ReadPointCloudFromPCD(const std::string& filename, geometry::PointCloud& pointcloud, bool) {

@@ -53,9 +53,19 @@ def read_pcd_arrays(path):
         n = int(header["POINTS"][0]) if "POINTS" in header else int(header["WIDTH"][0]) * int(header["HEIGHT"][0])
         mode = header["DATA"][0].lower()
         dt = []
+        decoded = ("x", "y", "z", "normal_x", "normal_y", "normal_z", "rgb", "rgba")
+        known = {("F", 4): "<f4", ("F", 8): "<f8", ("U", 1): "u1", ("U", 2): "<u2", ("U", 4): "<u4",
+                 ("I", 1): "i1", ("I", 2): "<i2", ("I", 4): "<i4"}
         for name, sz, ty, cnt in zip(fields, sizes, types, counts):
-            base = {("F", 4): "<f4", ("F", 8): "<f8", ("U", 1): "u1", ("U", 2): "<u2", ("U", 4): "<u4",
-                    ("I", 1): "i1", ("I", 2): "<i2", ("I", 4): "<i4"}[(ty.upper(), sz)]
+            base = known.get((ty.upper(), sz))
+            if base is None:
+                # a field the reader does not decode (a lidar's `timestamp U 8`) is skipped by its size alone, as the
+                # reference skips it (file_pcd.cu: UnpackBinaryPCDElement knows no such size, CheckHeader asks for x y z)
+                if name in decoded or not 1 <= sz <= 8:
+                    raise ValueError("PCD: field %s has no decodable type/size (%s %d)" % (name, ty, sz))
+                base = {1: "u1", 2: "<u2", 4: "<u4", 8: "<u8"}.get(sz, "V%d" % sz)
+                if mode == "ascii" and base.startswith("V"):
+                    base = "<f8"
             dt.append((name, base) if cnt == 1 else (name, base, (cnt,)))
         dt = np.dtype(dt)
         if mode == "binary":

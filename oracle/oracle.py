@@ -260,8 +260,10 @@ def evaluate_registration(src, tgt, max_dist, T=None):
 
 def registration_icp(src, tgt, max_dist, init=None, est=EST_P2P, det_thresh=None,
                      relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=30,
-                     src_nrm=None, tgt_nrm=None, src_cov=None, tgt_cov=None):
-    """Restatement of registration::RegistrationICP (registration.cu:121-172)."""
+                     src_nrm=None, tgt_nrm=None, src_cov=None, tgt_cov=None, composed=False):
+    """Restatement of registration::RegistrationICP (registration.cu:121-172).
+    composed=True: DESIGN.md deviation 1 restated -- the composed transformation applied to the pristine
+    source every iteration (what the engine does) instead of the reference's incremental fp32 transforms."""
     src, tgt = _f32(src, (-1, 3)), _f32(tgt, (-1, 3))
     sn, tn = _f32(src_nrm, (-1, 3)), _f32(tgt_nrm, (-1, 3))
     sc, tc = _cov_cm(src_cov), _cov_cm(tgt_cov)
@@ -270,11 +272,15 @@ def registration_icp(src, tgt, max_dist, init=None, est=EST_P2P, det_thresh=None
         det_thresh = 1e-6 if est in (EST_PT2PL, EST_SYM) else -1.0
     cor = np.empty((max(len(src), 1), 2), np.int32)
     res = _Result()
-    lib().oracle_registration_icp(
-        _p(src), _p(sn), _p(sc), C.c_int64(len(src)), _p(tgt), _p(tn), _p(tc),
-        C.c_int64(len(tgt)), C.c_float(max_dist), _p(_T_in(init)), C.c_int(est),
-        C.c_float(det_thresh), C.c_float(relative_fitness), C.c_float(relative_rmse),
-        C.c_int(max_iteration), _p(cor), C.byref(res))
+    lib().oracle_set_composed(C.c_int(1 if composed else 0))
+    try:
+        lib().oracle_registration_icp(
+            _p(src), _p(sn), _p(sc), C.c_int64(len(src)), _p(tgt), _p(tn), _p(tc),
+            C.c_int64(len(tgt)), C.c_float(max_dist), _p(_T_in(init)), C.c_int(est),
+            C.c_float(det_thresh), C.c_float(relative_fitness), C.c_float(relative_rmse),
+            C.c_int(max_iteration), _p(cor), C.byref(res))
+    finally:
+        lib().oracle_set_composed(C.c_int(0))
     return RegistrationResult(res, cor)
 
 

@@ -30,6 +30,23 @@ static void expect_rejected(const std::string& path, const char* what) {
     }
 }
 
+// a file the readers must TAKE (parsed on the host only: there is no device here), with its first point checked
+static void expect_points(const std::string& path, const char* what, size_t n, float x0, float y0, float z0) {
+    std::vector<Eigen::Vector3f> p, nr, c;
+    bool ok = false;
+    try {
+        ok = io::ReadPointCloudToHost(path, p, nr, c);
+    } catch (...) {
+        std::fprintf(stderr, "EXCEPTION escaped for %s\n", what);
+        ++failures;
+        return;
+    }
+    if (!ok || p.size() != n || (n > 0 && (p[0][0] != x0 || p[0][1] != y0 || p[0][2] != z0))) {
+        std::fprintf(stderr, "REJECTED or misread: %s (ok %d, %zu points)\n", what, (int)ok, p.size());
+        ++failures;
+    }
+}
+
 static void write_file(const std::string& path, const std::string& header, const std::vector<unsigned char>& body = {}) {
     FILE* f = std::fopen(path.c_str(), "wb");
     std::fwrite(header.data(), 1, header.size(), f);
@@ -48,6 +65,27 @@ int main(int argc, char** argv) {
     expect_rejected(dir + "/size3.pcd", "SIZE 3 for a float");
     write_file(dir + "/type.pcd", std::string(pcd) + "SIZE 4 4 4\nTYPE Q F F\nCOUNT 1 1 1\nWIDTH 4\nHEIGHT 1\nPOINTS 4\nDATA binary\n", some);
     expect_rejected(dir + "/type.pcd", "unknown TYPE");
+    {   // fields the reader does not decode are skipped by their size, whatever it is (a lidar's `timestamp U 8`
+        // used to make the whole file unreadable; the reference reads it -- file_pcd.cu UnpackBinaryPCDElement / CheckHeader)
+        std::vector<unsigned char> body;
+        for (int i = 0; i < 3; ++i) {
+            const float xyz[3] = {1.0f + (float)i, 2.0f, 3.0f};
+            const uint64_t stamp = 0x1122334455667788ull + (uint64_t)i;
+            const unsigned char odd[3] = {9, 9, 9};
+            body.insert(body.end(), (const unsigned char*)xyz, (const unsigned char*)xyz + 12);
+            body.insert(body.end(), (const unsigned char*)&stamp, (const unsigned char*)&stamp + 8);
+            body.insert(body.end(), odd, odd + 3);
+        }
+        write_file(dir + "/aux.pcd", "# .PCD v0.7\nVERSION 0.7\nFIELDS x y z timestamp ring\nSIZE 4 4 4 8 3\nTYPE F F F U I\nCOUNT 1 1 1 1 1\nWIDTH 3\nHEIGHT 1\nPOINTS 3\nDATA binary\n", body);
+        expect_points(dir + "/aux.pcd", "auxiliary U 8 / I 3 fields next to x y z", 3, 1.0f, 2.0f, 3.0f);
+        write_file(dir + "/aux_ascii.pcd", "VERSION 0.7\nFIELDS x y z timestamp\nSIZE 4 4 4 8\nTYPE F F F U\nCOUNT 1 1 1 1\nWIDTH 2\nHEIGHT 1\nPOINTS 2\nDATA ascii\n1 2 3 1234567890123\n4 5 6 1234567890124\n");
+        expect_points(dir + "/aux_ascii.pcd", "auxiliary U 8 field, ascii", 2, 1.0f, 2.0f, 3.0f);
+        // ... but not beyond the decoder's 8-byte buffer, and the decoded fields stay strict
+        write_file(dir + "/aux9.pcd", "VERSION 0.7\nFIELDS x y z blob\nSIZE 4 4 4 9\nTYPE F F F U\nCOUNT 1 1 1 1\nWIDTH 3\nHEIGHT 1\nPOINTS 3\nDATA binary\n", some);
+        expect_rejected(dir + "/aux9.pcd", "SIZE 9 for an auxiliary field");
+        write_file(dir + "/x8int.pcd", "VERSION 0.7\nFIELDS x y z\nSIZE 8 4 4\nTYPE I F F\nCOUNT 1 1 1\nWIDTH 3\nHEIGHT 1\nPOINTS 3\nDATA binary\n", some);
+        expect_rejected(dir + "/x8int.pcd", "x as I 8 (no such case in the decoder)");
+    }
     // counts the file cannot back
     write_file(dir + "/huge.pcd", std::string(pcd) + "SIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 999999999\nHEIGHT 1\nPOINTS 999999999\nDATA binary\n", some);
     expect_rejected(dir + "/huge.pcd", "POINTS beyond the file (binary)");

@@ -45,6 +45,33 @@ def test_pcd_reader_roundtrip(tmp_path):
     assert a["normals"] is None and a["colors"] is None
 
 
+def test_pcd_reader_skips_auxiliary_fields_of_any_size(tmp_path):
+    """a lidar file with `timestamp U 8` next to x y z must load (the reference skips what it does not
+    decode: file_pcd.cu UnpackBinaryPCDElement / CheckHeader); the decoded fields themselves stay strict."""
+    from cupoch_amd.io import read_pcd_arrays
+    rec = np.zeros(5, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("timestamp", "<u8"), ("ring", "V3")])
+    rec["x"], rec["y"], rec["z"] = np.arange(5), 2.0, 3.0
+    rec["timestamp"] = 0x1122334455667788 + np.arange(5, dtype=np.uint64)
+    hdr = ("VERSION 0.7\nFIELDS x y z timestamp ring\nSIZE 4 4 4 8 3\nTYPE F F F U I\nCOUNT 1 1 1 1 1\nWIDTH 5\nHEIGHT 1\n"
+           "POINTS 5\nDATA binary\n")
+    p = tmp_path / "aux.pcd"
+    p.write_bytes(hdr.encode() + rec.tobytes())
+    a = read_pcd_arrays(str(p))
+    np.testing.assert_array_equal(a["points"], np.stack([np.arange(5), np.full(5, 2.0), np.full(5, 3.0)], 1).astype(np.float32))
+    asc = tmp_path / "aux_ascii.pcd"
+    asc.write_text("VERSION 0.7\nFIELDS x y z timestamp\nSIZE 4 4 4 8\nTYPE F F F U\nCOUNT 1 1 1 1\nWIDTH 2\nHEIGHT 1\nPOINTS 2\n"
+                   "DATA ascii\n1 2 3 1234567890123\n4 5 6 1234567890124\n")
+    np.testing.assert_array_equal(read_pcd_arrays(str(asc))["points"], [[1, 2, 3], [4, 5, 6]])
+    bad = tmp_path / "x8.pcd"
+    bad.write_bytes(b"VERSION 0.7\nFIELDS x y z\nSIZE 8 4 4\nTYPE I F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA binary\n" + bytes(16))
+    with pytest.raises(ValueError):
+        read_pcd_arrays(str(bad))
+    big = tmp_path / "aux9.pcd"
+    big.write_bytes(b"VERSION 0.7\nFIELDS x y z blob\nSIZE 4 4 4 9\nTYPE F F F U\nCOUNT 1 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA binary\n" + bytes(21))
+    with pytest.raises(ValueError):
+        read_pcd_arrays(str(big))
+
+
 def test_lzf_format_vectors_and_roundtrip():
     """PCD's binary_compressed carries an LZF stream (mi_icp_lzf_*, host helpers of the C ABI).  liblzf is
     an absent third-party dependency of the reference, so the decoder is pinned on streams written out
