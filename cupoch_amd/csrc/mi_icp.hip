@@ -139,7 +139,7 @@ struct mi_icp_ctx {
     DevBuf knn_idx;  // candidate indices of the small k-NN lists, [packet][slot][lane] (knn_normals.h)
     double* sys_host = nullptr;  // pinned, 32 doubles + spare
     float* f_host = nullptr;     // pinned, 16 floats
-    uint32_t* u_host = nullptr;  // pinned, 4 words
+    uint32_t* u_host = nullptr;  // pinned, 16 words ([0]: counts read back by the one-shot entry points, [8]: the halo_want counter)
     void* od_host = nullptr;     // pinned OdState mirror (odometry), allocated on first use
 
     // ---- registration loop (device-resident, loop.h) ----
@@ -508,6 +508,14 @@ int ensure_links(mi_icp_ctx* c) {
     TRY(build_links(c, c->stream));
     c->links_ready = true;
     return MI_ICP_OK;
+}
+
+// The build's candidate scratch (512 B per leaf: 0.9 GB for a 10M-point target) is dead once the halos are complete.
+// Called where the device is idle anyway (the end of a registration call): hipFree synchronises.  Small targets keep
+// theirs -- frame-to-frame callers would pay an allocation per frame.
+void release_links_scratch(mi_icp_ctx* c) {
+    constexpr size_t kKeepBelow = (size_t)64 << 20;
+    if (c->links_ready && !c->links_inflight && c->tlinks_tmp.p && c->tlinks_tmp.bytes >= kKeepBelow) release(c->tlinks_tmp);
 }
 
 // Are they there?  Never waits: a build in flight counts once its event has completed.
@@ -990,12 +998,32 @@ int mailbox_open(mi_icp_ctx* c, const std::string& name, int nranks, int rank) {
                 return fail(c, MI_ICP_ERR_COMM, "mailbox: hipHostRegister failed");
             }
             (void)__atomic_fetch_add(&box->attached, 1u, __ATOMIC_ACQ_REL);
-            while (__atomic_load_n(&box->go, __ATOMIC_ACQUIRE) != 1u) {
-                if (late()) {  // (e.g. the box was a crashed job's, caught between its `ready` and its `go`)
+            // While waiting for `go`: is the NAME still this box?  A crashed job's leftover (ready, never started) under a
+            // reused name looks like ours; rank 0 replaces it (unlink + create), after which the name leads to another
+            // inode -- this mapping is then dropped and the name opened again (the wait used to run into the
+            // attach time-out, and rank 0's with it).
+            bool replaced = false;
+            for (int polls = 0; __atomic_load_n(&box->go, __ATOMIC_ACQUIRE) != 1u; ++polls) {
+                if (late()) {  // (e.g. the box was a crashed job's and rank 0 never came)
                     drop(p);
                     return fail(c, MI_ICP_ERR_COMM, "mailbox: rank 0 did not start %s in time", name.c_str());
                 }
+                if (polls % 100 == 99) {
+                    struct stat now;
+                    const int fd2 = shm_open(name.c_str(), O_RDWR, 0600);
+                    const bool other = fd2 >= 0 && fstat(fd2, &now) == 0 && (now.st_ino != st.st_ino || now.st_dev != st.st_dev);
+                    if (fd2 >= 0) close(fd2);
+                    if (other && __atomic_load_n(&box->go, __ATOMIC_ACQUIRE) != 1u) {
+                        replaced = true;
+                        break;
+                    }
+                }
                 std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+            if (replaced) {
+                drop(p);
+                box = nullptr;
+                continue;
             }
             break;
         }
@@ -1808,7 +1836,9 @@ static int loop_run(mi_icp_ctx* c, int budget) {
         budget -= n;
         c->halo_iters += executed;
         if (no_halo) {
-            const int64_t asked = (int64_t)c->u_host[8] - c->halo_want_seen;  // by this chunk's iterations
+            // (a 32-bit device counter that keeps counting through a long stepping loop: the difference is taken
+            // modulo 2^32, so a wrap between two looks costs nothing)
+            const int64_t asked = (int64_t)(uint32_t)(c->u_host[8] - (uint32_t)c->halo_want_seen);  // by this chunk's iterations
             c->halo_want_seen = (int64_t)c->u_host[8];
             c->halo_asked += asked;
             if (undecided) {
@@ -1938,6 +1968,8 @@ int mi_icp_registration_icp(mi_icp_ctx* c, int est, float max_distance, const fl
         TRY(loop_pull(c));
         collect_pooled(c, 1);
         if (!c->loop_host->done) TRY(loop_run(c, std::max(p.max_iteration, 0)));
+        (void)halo_poll(c);
+        release_links_scratch(c);
     }
     std::memset(out, 0, sizeof(*out));
     fill_result(c, out);

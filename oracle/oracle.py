@@ -542,6 +542,20 @@ def ref_rand_vec4i(n, vmin, vmax, seed):
     return out
 
 
+def ref_lzf():
+    """The reference's vendored liblzf (third_party/liblzf/lzf_c.c, lzf_d.c compiled in place into
+    oracle/_ref/libref_lzf.so) or None where it was not built."""
+    path = os.path.join(_HERE, "_ref", "libref_lzf.so")
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    L.lzf_compress.restype = C.c_uint
+    L.lzf_compress.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint]
+    L.lzf_decompress.restype = C.c_uint
+    L.lzf_decompress.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint]
+    return L
+
+
 def ref_flann_available():
     return os.path.exists(os.path.join(_HERE, "_ref", "libref_flann.so"))
 

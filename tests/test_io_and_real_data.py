@@ -73,9 +73,9 @@ def test_pcd_reader_skips_auxiliary_fields_of_any_size(tmp_path):
 
 
 def test_lzf_format_vectors_and_roundtrip():
-    """PCD's binary_compressed carries an LZF stream (mi_icp_lzf_*, host helpers of the C ABI).  liblzf is
-    an absent third-party dependency of the reference, so the decoder is pinned on streams written out
-    by hand from the published format: literal runs (ctrl < 32: ctrl + 1 bytes follow) and back
+    """PCD's binary_compressed carries an LZF stream (mi_icp_lzf_*, host helpers of the C ABI).  The decoder
+    on streams written out by hand from the published format (the reference's own liblzf: the next test):
+    literal runs (ctrl < 32: ctrl + 1 bytes follow) and back
     references (len = (ctrl >> 5) + 2, 7 -> + next byte; distance = ((ctrl & 31) << 8 | next) + 1)."""
     from cupoch_amd.io import lzf_compress, lzf_decompress
     # "abc" literal, then 6 bytes from 3 back (overlapping copy): abcabcabc
@@ -96,6 +96,38 @@ def test_lzf_format_vectors_and_roundtrip():
         assert lzf_decompress(comp, len(data)) == data
         if len(data) > 20000:
             assert len(comp) < len(data) // 4
+
+
+def test_lzf_against_the_references_vendored_liblzf():
+    """csrc/lzf.h restates the LZF format; the reference's PCD reader / writer call the liblzf vendored under
+    third_party/liblzf (file_pcd.cu:218,461,690).  Both ways: streams THAT compressor writes decode here to the
+    input, streams this compressor writes decode THERE -- what a file exchanged with the reference needs.  (The two
+    compressors' byte streams need not be equal: the format leaves the match search to the writer.)"""
+    import ctypes as C
+    from cupoch_amd.io import lzf_compress, lzf_decompress
+    L = orc.ref_lzf()
+    if L is None:
+        pytest.skip("oracle/_ref/libref_lzf.so not built (needs /root/reference)")
+    rng = np.random.default_rng(3)
+    pts = rng.random((4000, 3), dtype=np.float32)
+    cases = [b"a" * 5, bytes(rng.integers(0, 256, 20000, dtype=np.uint8)), np.repeat(rng.random(700, dtype=np.float32), 5).tobytes(),
+             bytes(70000), b"0123456789" * 2500, np.ascontiguousarray(pts.T).tobytes(),          # field-major floats: a PCD payload
+             np.round(pts * 64).astype(np.float32).T.tobytes()]
+    for data in cases:
+        # the reference compresses, the engine decodes
+        cap = len(data) * 2 + 64
+        buf = C.create_string_buffer(cap)
+        n = L.lzf_compress(data, len(data), buf, cap)
+        assert n > 0
+        assert lzf_decompress(buf.raw[:n], len(data)) == data
+        # the engine compresses, the reference decodes
+        comp = lzf_compress(data)
+        out = C.create_string_buffer(len(data) + 16)
+        m = L.lzf_decompress(comp, len(comp), out, len(data) + 16)
+        assert m == len(data) and out.raw[:m] == data
+        # and neither writer is much worse than the other on compressible data
+        if n < len(data) // 2:
+            assert len(comp) <= 1.25 * n + 64
 
 
 @pytest.mark.parametrize("mode", ["binary", "ascii", "binary_compressed"])
