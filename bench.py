@@ -195,6 +195,76 @@ def secondary(eng, src, tgt, nrm, d_tgt, d_nrm, d_src, max_dist, n, torch, _lib)
     return out
 
 
+def strong_big(eng, n_big, steps, warmup, rank, world, local, torch, dist, D, _lib):
+    """The same strong-scaling bench at a size where an 8-way shard is still a large cloud:
+    n_big-vs-n_big point-to-plane, BASELINE.md section 3's construction.  Generated on rank 0's GPU with torch's
+    generator and broadcast (host memory and numpy would take minutes at 100M), sharded like the headline, timed the
+    same way (3 windows of `steps`, median, max over ranks)."""
+    dev = torch.device("cuda", local)
+    s = float(n_big) ** (-1.0 / 3.0)
+    if rank == 0:
+        g = torch.Generator(device=dev)
+        g.manual_seed(4242)
+        tgt = torch.rand((n_big, 3), generator=g, device=dev, dtype=torch.float32)
+        nrm = torch.randn((n_big, 3), generator=g, device=dev, dtype=torch.float32)
+        nrm /= torch.linalg.norm(nrm, dim=1, keepdim=True)
+        ang = 0.2 * s
+        ax = np.array([1.0, 2.0, 3.0]) / np.sqrt(14.0)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+        t = 0.2 * s * np.array([1.0, -1.0, 1.0]) / np.sqrt(3.0)
+        Rinv = torch.from_numpy(R.T.copy()).to(dev)
+        tinv = torch.from_numpy(-R.T @ t).to(dev)
+        src = torch.empty((n_big, 3), device=dev, dtype=torch.float32)
+        for lo in range(0, n_big, 1 << 24):        # (in slices: the fp64 intermediate of the whole cloud is 2.4 GB)
+            hi = min(n_big, lo + (1 << 24))
+            src[lo:hi] = (tgt[lo:hi].double() @ Rinv.T + tinv).float()
+        src = src[torch.randperm(n_big, generator=g, device=dev)]
+    else:
+        tgt = torch.empty((n_big, 3), device=dev, dtype=torch.float32)
+        nrm = torch.empty((n_big, 3), device=dev, dtype=torch.float32)
+        src = torch.empty((n_big, 3), device=dev, dtype=torch.float32)
+    if world > 1:
+        for x in (tgt, nrm, src):
+            dist.broadcast(x, src=0)
+        mine = D.device_shard_source(eng, src, rank, world)
+        src = src[torch.from_numpy(mine).to(dev)].contiguous()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.set_target(tgt, nrm)
+    eng.set_source(src)
+    eng.synchronize()
+    build_ms = (time.perf_counter() - t0) * 1e3
+    if world > 1:
+        eng.set_global_source_count(n_big)
+    eng.set_profiling(False)
+    eng.icp_begin(_lib.EST_POINT_TO_PLANE, 2.0 * s, None, -1.0)
+    eng.icp_iterate(warmup)
+    windows = []
+    for _ in range(3):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = eng.icp_iterate(steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        w = time.perf_counter() - t0
+        if world > 1:
+            tw = torch.tensor([w], dtype=torch.float64, device=dev)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            w = float(tw.item())
+        windows.append(w)
+    el = float(np.median(windows))
+    return {"points": n_big, "n_gpus": world, "steps": steps, "value": round(steps / el, 2), "unit": "iterations/s",
+            "ms_per_step": round(el / steps * 1e3, 4), "source_points_this_rank": int(len(src)), "build_ms": round(build_ms, 1),
+            "final_fitness": round(float(res.fitness), 6),
+            "note": "same bench, same sharding and exchange, %d-vs-%d points: the size at which one rank's share of an "
+                    "8-way shard (%.1fM points) is still bandwidth-bound; compare with the N = 1 line's figure"
+                    % (n_big, n_big, n_big / 8e6)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,6 +274,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=7, help="timed windows of --steps iterations; value = median")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--big-points", type=int, default=100_000_000,
+                    help="size of secondary.strong_100M (the strong-scaling bench again at a size an 8-way shard still fills); 0: skip")
     args = ap.parse_args()
 
     import torch
@@ -252,19 +324,22 @@ def main():
     build_ms = (time.perf_counter() - t0) * 1e3
     host_allreduce = False
     begun = False
+    exchange = None
     if world > 1:
-        # The exchange, best first: the node's shared-memory mailbox (the kernels exchange the 32 sums
-        # themselves, csrc/mailbox.h), the in-library ncclAllReduce, a host-driven loop over
-        # torch.distributed.  A way counts only if the warm-up iterations ran on EVERY rank.
-        for attempt in ("rccl+mailbox", "mailbox", "rccl"):
-            ok, why = 1, ""
+        # How the ranks exchange the 32 sums is MEASURED (mi_icp_comm_autotune): the node's shared-memory mailbox
+        # (host-memory words), device inboxes over HIP IPC and the in-library ncclAllReduce each run 200 exchanges of a
+        # known vector, checked exactly and timed (max over ranks); the fastest that passed on every rank is used, one
+        # that fails is skipped.  Set-ups, best first: RCCL communicator + mailbox, the mailbox alone, and -- should
+        # neither come up on every rank -- a host-driven loop over torch.distributed.
+        tried = []
+        for attempt in (("mailbox",) if one_device else ("rccl+mailbox", "mailbox")):
+            ok, why, tune = 1, "", None
             try:
                 if attempt == "mailbox":
                     D.init_engine_comm_local(eng, n)       # no RCCL in the library at all
                 else:
-                    if attempt == "rccl":
-                        os.environ["MI_ICP_NO_MAILBOX"] = "1"
                     D.init_engine_comm(eng, n)
+                tune = eng.comm_autotune(200)
                 eng.set_profiling(False)
                 eng.icp_begin(_lib.EST_POINT_TO_PLANE, max_dist, None, -1.0)
                 eng.icp_iterate(args.warmup)
@@ -272,8 +347,10 @@ def main():
                 ok, why = 0, str(e)
             t = torch.tensor([ok], dtype=torch.int32, device=("cpu" if one_device else "cuda"))
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            tried.append({"setup": attempt, "ok": bool(int(t.item())), "why_not": why or None})
             if int(t.item()) == 1:
                 begun = True
+                exchange = dict(tune, setup=attempt)
                 break
             if rank == 0:
                 print("bench: exchange via %s unavailable (%s)" % (attempt, why or "failed on another rank"), file=sys.stderr)
@@ -283,9 +360,11 @@ def main():
                 pass
         if not begun:
             host_allreduce = True
+            exchange = {"chosen": "host-driven torch.distributed all-reduce", "setup": "none"}
             eng.set_global_source_count(n)
             if rank == 0:
                 print("bench: falling back to a host-driven loop with torch.distributed all-reduce", file=sys.stderr)
+        exchange["tried"] = tried
     elif os.environ.get("MI_ICP_BENCH_HOST_LOOP") == "1":
         host_allreduce = True      # exercises the fallback loop on one rank
     elif os.environ.get("MI_ICP_FORCE_COMM") == "2":
@@ -398,11 +477,13 @@ def main():
             "config": {"workload": "%s-vs-%s point-to-plane ICP, radius 1-NN on an 8-ary kd-cell tree, r=2*N^(-1/3), "
                                    "uniform random clouds (BASELINE.md section 3)" % (_fmt(n), _fmt(n)),
                        "points": n, "max_correspondence_distance": max_dist, "det_thresh": -1.0,
-                       "parallelism": ("source sharded x%d, target+tree replicated, %s all-reduce of 32 f64/iter"
-                                       % (world, "host-driven torch.distributed" if host_allreduce else
-                                          ("shared-memory mailbox (inside the reduction kernel), no collective launch:"
-                                           if eng.comm_kind() == 2 else "in-library RCCL")))
+                       "parallelism": ("source sharded x%d (Morton-contiguous), target + tree replicated; 32 f64 summed over the "
+                                       "ranks per iteration via %s -- chosen by a timed known-answer self-test of every "
+                                       "available path, us per exchange (max over ranks): %s; RCCL communicator of %s ranks"
+                                       % (world, exchange.get("chosen"), json.dumps(exchange.get("latency_us")),
+                                          exchange.get("rccl_comm_count")))
                        if world > 1 else "single GPU",
+                       "exchange": exchange,
                        "accumulate": "f64", "build_ms": round(build_ms, 2),
                        "final_fitness": round(float(res.fitness), 6),
                        "final_rmse": float(res.inlier_rmse),
@@ -427,6 +508,16 @@ def main():
             eng.drop_seeds()
             gi, gd, _ = eng.search_radius_1nn(max_dist)        # the engine's neighbours under the identity
             out["cpu_baseline"] = cpu_baseline(src, tgt, nrm, max_dist, n, (gi, gd))
+    # the strong-scaling bench once more at a size where an 8-way shard is still a large cloud (every rank takes part)
+    big = None
+    if args.big_points > 0 and n == 10_000_000 and not args.no_secondary and not host_allreduce and not one_device:
+        try:
+            big = strong_big(eng, args.big_points, args.steps, args.warmup, rank, world, local, torch, dist, D, _lib)
+        except Exception as e:   # noqa: BLE001 -- a secondary figure must not cost the headline
+            big = {"error": str(e)}
+    if rank == 0:
+        if big is not None:
+            out["config"].setdefault("secondary", {})["strong_100M" if args.big_points == 100_000_000 else "strong_big"] = big
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -124,6 +124,7 @@ SIGNATURES = {
     "mi_icp_comm_init": (_I, [_P, _P, _I, _I]),
     "mi_icp_comm_init_local": (_I, [_P, C.c_char_p, _I, _I]),
     "mi_icp_comm_kind": (_I, [_P]),
+    "mi_icp_comm_autotune": (_I, [_P, _I, _P, _P]),
     "mi_icp_comm_destroy": (_I, [_P]),
     "mi_icp_set_global_source_count": (_I, [_P, _L]),
     "mi_icp_spatial_order": (_I, [_P, _P, _L, _P, _I]),

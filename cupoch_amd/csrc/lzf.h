@@ -1,8 +1,8 @@
 // lzf.h -- the LZF byte format that PCD's DATA binary_compressed carries (reference:
 // io/file_format/file_pcd.cu:218,461,690 call lzf_decompress / lzf_compress of the liblzf vendored under
 // third_party/liblzf).  Written from the published format, not from those sources; pinned against them both ways --
-// their compressor's streams decode here, this compressor's streams decode there (oracle/_ref/libref_lzf.so is
-// third_party/liblzf/lzf_{c,d}.c compiled in place; tests/test_io_and_real_data.py).  Host code.
+// their compressor's streams decode here, this compressor's streams decode there (the test side compiles
+// third_party/liblzf/lzf_{c,d}.c in place for that; tests/test_io_and_real_data.py).  Host code.
 //
 // Stream = a sequence of chunks, each starting with a control byte c:
 //   c < 32       literal run: the next c + 1 bytes are copied to the output;

@@ -542,6 +542,19 @@ class Engine:
         """0: none, 1: RCCL all-reduce, 2: shared-memory mailbox"""
         return int(self._L.mi_icp_comm_kind(self._ctx))
 
+    def comm_autotune(self, exchanges=200):
+        """Collective: self-test (known-answer) and time every available exchange path, keep the fastest that passed on
+        every rank (mi_icp_comm_autotune).  Returns a dict: chosen ("host mailbox" / "device inboxes" / "rccl" / "none"),
+        latency_us per path (None: not available, "failed": did not pass), rccl_comm_count, exchanges, verified."""
+        lat = (C.c_double * 3)()
+        info = (C.c_int * 4)()
+        self._chk(self._L.mi_icp_comm_autotune(self._ctx, int(exchanges), lat, info))
+        names = ("host mailbox", "device inboxes", "rccl")
+        show = lambda v: None if v == -1.0 else ("failed" if v < 0 else round(float(v), 3))
+        return {"chosen": names[info[0] - 1] if 1 <= info[0] <= 3 else "none",
+                "latency_us": {n: show(lat[i]) for i, n in enumerate(names)},
+                "rccl_comm_count": int(info[1]), "exchanges": int(info[2]), "verified": bool(info[3])}
+
     def comm_destroy(self):
         self._chk(self._L.mi_icp_comm_destroy(self._ctx))
 

@@ -389,9 +389,10 @@ MI_ICP_API int mi_icp_registration_colored_icp(mi_icp_ctx* ctx, float max_distan
  * mi_icp_comm_init: RCCL communicator from a shared ncclUniqueId + the mailbox (named after
  * the id).  mi_icp_comm_init_local: the mailbox alone, no RCCL -- all ranks pass the same
  * job_name (letters, digits, '_', '-'), one node only.  mi_icp_comm_kind: 0 none, 1 RCCL
- * all-reduce, 2 mailbox, 3 mailbox with device inboxes (MI_ICP_MAILBOX=device on rank 0: every rank keeps an
- * inbox in fine-grained device memory that its peers open through HIP IPC and write their posts into -- GPU to
- * GPU, polls stay local; any rank failing to set that up keeps all of them on the host-memory box).  Set-up: rank 0 makes the box and waits (MI_ICP_MAIL_ATTACH_MS, default 30 s)
+ * all-reduce, 2 mailbox, 3 mailbox with device inboxes (every rank keeps an inbox in fine-grained device memory
+ * that its peers open through HIP IPC and write their posts into -- GPU to GPU, polls stay local; any rank failing
+ * to set that up keeps all of them on the host-memory box; USED when MI_ICP_MAILBOX=device is set or
+ * mi_icp_comm_autotune below measured them faster; MI_ICP_MAILBOX=host: not even set up).  Set-up: rank 0 makes the box and waits (MI_ICP_MAIL_ATTACH_MS, default 30 s)
  * until every other rank has mapped and registered it; mi_icp_comm_init then lets the ranks agree over the
  * RCCL communicator whether ALL of them have it (else none uses it).  A peer that does not post within ~10 s
  * fails the call with MI_ICP_ERR_COMM; the communicator is void from then on (the ranks' exchange counters
@@ -402,6 +403,20 @@ MI_ICP_API int mi_icp_comm_init(mi_icp_ctx* ctx, const char* id128, int nranks, 
 MI_ICP_API int mi_icp_comm_init_local(mi_icp_ctx* ctx, const char* job_name, int nranks, int rank);
 MI_ICP_API int mi_icp_comm_kind(const mi_icp_ctx* ctx);
 MI_ICP_API int mi_icp_comm_destroy(mi_icp_ctx* ctx);
+/* Which way the ranks exchange is MEASURED, not assumed (collective: every rank calls it, right after
+ * mi_icp_comm_init[_local] and before any registration).  Each available path -- [0] the box's host-memory words,
+ * [1] device inboxes over HIP IPC (set up next to the box unless MI_ICP_MAILBOX=host), [2] the in-library
+ * ncclAllReduce followed by a one-block kernel, as the loop's step kernel follows it -- performs `exchanges`
+ * (<= 0: 200) all-reduces of a KNOWN vector that changes with every exchange; every total is checked exactly on the
+ * device, the run is timed with events on the context's stream, and the ranks' CPUs gather the figures through the
+ * shared-memory box (through the communicator when there is no box).  lat_us3[p]: microseconds per exchange, the
+ * maximum over the ranks; -1: path not available, -2: it failed its self-test (timed out or summed wrongly) on some
+ * rank -- such a path is skipped, never fatal, and the ranks' exchange counters are re-aligned behind it.  The
+ * fastest path that passed everywhere becomes the one the loops use (identical on every rank: all decide on the same
+ * gathered figures).  info4 = {chosen path (1 host words, 2 device inboxes, 3 RCCL; 0: single rank), ncclCommCount
+ * of the communicator (0: none), exchanges timed per path, 1 if every path that was tried passed}.
+ * MI_ICP_ERR_COMM when no path passed or the ranks did not meet (the communicator is void then). */
+MI_ICP_API int mi_icp_comm_autotune(mi_icp_ctx* ctx, int exchanges, double* lat_us3, int* info4);
 /* total source size over all ranks (fitness denominator, registration.cu:76) */
 MI_ICP_API int mi_icp_set_global_source_count(mi_icp_ctx* ctx, int64_t n_total);
 /* The order in which a source cloud is cut into per-rank shards: order_out[s] = original index

@@ -361,3 +361,92 @@ def test_mailbox_exchange_eight_processes_on_one_gpu(tmp_path, mode):
     assert m[0]["stat"][0] == pytest.approx(ref.fitness, abs=1e-6) and int(m[0]["stat"][2]) == ref.iterations
     assert m[0]["eval"][0] == pytest.approx(ev.fitness, abs=1e-6) and m[0]["eval"][1] == pytest.approx(ev.inlier_rmse, rel=1e-5)
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("mi_icp_eight_")]     # the name went once all had attached
+
+
+def _worker_autotune(rank, world, job, out_dir, broken):
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.pop("MI_ICP_MAILBOX", None)                 # the default set-up: the box AND device inboxes
+    if broken:
+        os.environ["MI_ICP_SELFTEST_BREAK"] = broken
+    from cupoch_amd import distributed as D
+    from cupoch_amd.engine import Engine
+    torch.cuda.set_device(0)
+    d = make_pair(N8, seed=21, noise=0.03)
+    eng = Engine(0)
+    src_dev = torch.from_numpy(d["src"]).cuda()
+    mine = D.device_shard_source(eng, src_dev, rank, world)
+    eng.set_target(torch.from_numpy(d["tgt"]).cuda(), torch.from_numpy(d["tgt_nrm"]).cuda())
+    eng.set_source(src_dev[torch.from_numpy(mine).cuda()])
+    eng.comm_init_local(job, world, rank)
+    assert eng.comm_kind() == 2                            # until measured otherwise: the host-memory words
+    tune = eng.comm_autotune(64)
+    tune["kind_after"] = eng.comm_kind()
+    eng.set_global_source_count(N8)
+    res = eng.registration_icp(PT2PL, d["max_dist"], None, 0.0, 0.0, ITER8, -1.0)
+    tune["T"] = np.array(res.transformation, np.float32).tolist()
+    tune["stat"] = [res.fitness, res.inlier_rmse, res.iterations]
+    with open(os.path.join(out_dir, "tune_%d.json" % rank), "w") as f:
+        json.dump(tune, f)
+    eng.comm_destroy()
+    eng.close()
+
+
+@pytest.mark.parametrize("broken", ["", "wrong:2", "mute:1"])
+def test_exchange_paths_are_self_tested_timed_and_chosen_alike_on_every_rank(tmp_path, broken):
+    """mi_icp_comm_autotune, rehearsed with eight processes on one GPU: every available path --
+    the box's host-memory words, device inboxes over HIP IPC (RCCL cannot put two ranks on one device) -- runs its
+    exchanges of a known vector, checked exactly on the device and timed; the ranks gather the figures through the box
+    and ALL keep the same, fastest path that passed everywhere.  A path on which one rank posts a wrong vector
+    ("wrong:2": the device inboxes) or nothing at all ("mute:1": the host words; its peers' kernels time out after
+    ~2 s) is reported as failed on every rank, skipped, and the exchange counters are re-aligned behind it: the loop
+    that follows runs on the other path and still equals the single-process loop."""
+    import json
+    from cupoch_amd.engine import Engine
+    world = 8
+    job = "tune_%d_%d" % (os.getpid(), _free_port())
+    mp.spawn(_worker_autotune, args=(world, job, str(tmp_path), broken), nprocs=world, join=True)
+    t = [json.load(open(tmp_path / ("tune_%d.json" % r))) for r in range(world)]
+    for r in range(1, world):
+        assert t[r] == t[0], (r, t[r], t[0])                  # figures, choice and results identical on every rank
+    lat = t[0]["latency_us"]
+    assert lat["rccl"] is None and t[0]["rccl_comm_count"] == 0 and t[0]["exchanges"] == 64
+    if not broken:
+        assert t[0]["verified"] and all(isinstance(lat[k], float) and 0.0 < lat[k] < 1e5 for k in ("host mailbox", "device inboxes"))
+        best = min(("host mailbox", "device inboxes"), key=lambda k: lat[k])
+        assert t[0]["chosen"] == best and t[0]["kind_after"] == (2 if best == "host mailbox" else 3)
+    elif broken == "wrong:2":
+        assert not t[0]["verified"] and lat["device inboxes"] == "failed" and t[0]["chosen"] == "host mailbox"
+    else:
+        assert not t[0]["verified"] and lat["host mailbox"] == "failed" and t[0]["chosen"] == "device inboxes"
+        assert t[0]["kind_after"] == 3
+    d = make_pair(N8, seed=21, noise=0.03)
+    eng = Engine(0)
+    eng.set_target(d["tgt"], d["tgt_nrm"])
+    eng.set_source(d["src"])
+    ref = eng.registration_icp(PT2PL, d["max_dist"], None, 0.0, 0.0, ITER8, -1.0)
+    eng.close()
+    assert np.linalg.norm(np.array(t[0]["T"], np.float32) - np.array(ref.transformation, np.float32)) <= 1e-6
+    assert t[0]["stat"][0] == pytest.approx(ref.fitness, abs=1e-6) and int(t[0]["stat"][2]) == ref.iterations
+
+
+def test_autotune_on_a_one_rank_rccl_communicator_reports_the_collective():
+    """... and the third path where a one-GPU box can run it: a one-rank RCCL communicator (no box: the figure travels
+    through the communicator itself); ncclCommCount is reported, the choice is RCCL, the loop unchanged."""
+    from cupoch_amd.engine import Engine, comm_unique_id
+    d = make_pair(40000, seed=5, noise=0.02)
+    eng = Engine(0)
+    eng.set_target(d["tgt"], d["tgt_nrm"])
+    eng.set_source(d["src"])
+    ref = eng.registration_icp(PT2PL, d["max_dist"], None, 0.0, 0.0, 6, -1.0)
+    eng.comm_init(comm_unique_id(), 1, 0)
+    tune = eng.comm_autotune(32)
+    assert tune["chosen"] == "rccl" and tune["rccl_comm_count"] == 1 and tune["verified"]
+    assert tune["latency_us"]["host mailbox"] is None and 0.0 < tune["latency_us"]["rccl"] < 1e5
+    eng.set_global_source_count(len(d["src"]))
+    got = eng.registration_icp(PT2PL, d["max_dist"], None, 0.0, 0.0, 6, -1.0)
+    np.testing.assert_array_equal(np.array(got.transformation), np.array(ref.transformation))
+    eng.comm_destroy()
+    eng.close()
