@@ -4,6 +4,7 @@
 //   covariances<-normals registration/generalized_icp.cu:18-30,52-59
 #pragma once
 #include "device_utils.h"
+#include "primitives.h"
 
 namespace mi {
 
@@ -293,6 +294,176 @@ __global__ __launch_bounds__(256) void voxel_means(
         if (col) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) out_col[seg * 3 + d] = (float)(ac[d] / cnt);
+        }
+    }
+}
+
+// ---- VoxelDownSample, the path for grids whose packed key fits 32 bits (round 4) ----------------------------------
+// The first form above sorts (64-bit key, index) pairs and then gathers every point through the sorted indices:
+// 10M random 12-byte reads each pull a 128-byte line (2.2 GB of line traffic for 240 MB of payload, 0.77 ms), behind
+// three or four 64-bit radix passes of 0.18 ms.  Here:
+//  * the key is 32 bits (a pass moves a third less);
+//  * the PAYLOAD travels with the key through the passes (rs_scatter_pay: a tile-local gather and run-wise writes
+//    instead of one cloud-wide random gather at the end), no index array at all;
+//  * the passes sort on the key's bits ABOVE the lowest L <= 5 only, L chosen so that a pass is saved (21 bits:
+//    2 passes instead of 3): points of one voxel are then not contiguous but lie in one RUN of equal key >> L with at
+//    most 2^L voxels in it; vox_run_masks notes which of them occur (a 32-bit mask per run), a scan of the counts
+//    gives every voxel its output position -- still the lexicographic (x, y, z) order of down_sample.cu:200-203 --
+//    and voxel_means_runs lets 8 lanes per voxel walk their run and add up the points whose low bits match.
+// Sums are fp64 in a fixed order (input order inside a run: the sort is stable), so the means are reproducible.
+__global__ __launch_bounds__(256) void voxel_keys32(const float* __restrict__ pts, int64_t n, VoxelGrid g,
+                                                    uint32_t* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int32_t k[3];
+    voxel_key3(g, pts + i * 3, k);
+    keys[i] = ((uint32_t)k[0] << (g.bits_y + g.bits_z)) | ((uint32_t)k[1] << g.bits_z) | (uint32_t)k[2];
+}
+
+// head(i) = sorted element i opens a new run (its key >> L differs from its predecessor's).  Tile sums of the head
+// flags (the scan's first step, primitives.h) straight from the keys ...
+__global__ __launch_bounds__(kScanThreads) void vox_head_sums(const uint32_t* __restrict__ keys, int n, int L,
+                                                               uint32_t* __restrict__ tile_sums) {
+    __shared__ uint32_t lds4[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    uint32_t s = 0;
+    uint32_t prev = (base > 0 && base - 1 < n) ? (keys[base - 1] >> L) : 0u;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+        if (base + k < n) {
+            const uint32_t cur = keys[base + k] >> L;
+            s += (base + k == 0 || cur != prev) ? 1u : 0u;
+            prev = cur;
+        }
+    uint32_t tot;
+    block_exclusive_scan(s, &tot, lds4);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+// ... and, with the tiles' offsets (scan_tile_offsets), run_start[rank of head i] = i; run_start[R] = n
+__global__ __launch_bounds__(kScanThreads) void vox_head_apply(const uint32_t* __restrict__ keys, int n, int L,
+                                                                const uint32_t* __restrict__ tile_offs, int ntiles,
+                                                                uint32_t* __restrict__ run_start) {
+    __shared__ uint32_t lds4[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    uint32_t h[kScanItems];
+    uint32_t s = 0;
+    uint32_t prev = (base > 0 && base - 1 < n) ? (keys[base - 1] >> L) : 0u;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        h[k] = 0u;
+        if (base + k < n) {
+            const uint32_t cur = keys[base + k] >> L;
+            h[k] = (base + k == 0 || cur != prev) ? 1u : 0u;
+            prev = cur;
+        }
+        s += h[k];
+    }
+    uint32_t tot;
+    uint32_t off = tile_offs[blockIdx.x] + block_exclusive_scan(s, &tot, lds4);
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (h[k]) run_start[off] = (uint32_t)(base + k);
+        off += h[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) run_start[tile_offs[ntiles]] = (uint32_t)n;  // (tile_offs[ntiles] = R)
+}
+
+// 16 lanes per run: which of the run's 2^L voxels occur.  mask[r], cnt[r] = popcount; runs past the end (the grid
+// covers an upper bound, R itself stays on the device: *nruns) get cnt 0.
+__global__ __launch_bounds__(256) void vox_run_masks(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ run_start,
+                                                     const uint32_t* __restrict__ nruns, int64_t rmax, int L,
+                                                     uint32_t* __restrict__ mask, uint32_t* __restrict__ cnt) {
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int sub = (int)(threadIdx.x & 15u);
+    const bool live = r < rmax && r < (int64_t)*nruns;
+    uint32_t m = 0u;
+    if (live) {
+        const uint32_t s = run_start[r], e = run_start[r + 1];
+        const uint32_t low = (1u << L) - 1u;
+        for (uint32_t t = s + (uint32_t)sub; t < e; t += 16u) m |= 1u << (keys[t] & low);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m |= (uint32_t)__shfl_xor((int)m, o, 16);
+    if (r < rmax && sub == 0) {
+        mask[r] = m;
+        cnt[r] = (uint32_t)__popc(m);
+    }
+}
+
+// 8 lanes per OUTPUT voxel v: its run r (the last one whose first voxel voff[r] is <= v) and the low bits f of its
+// key (the (v - voff[r])-th set bit of the run's mask); fp64 sums over the run's elements with those low bits, in
+// input order per lane, an 8-lane tree on top; means, normals normalised after averaging (down_sample.cu:77-90).
+// L == 0: a run IS a voxel (voff / mask are not read).
+__global__ __launch_bounds__(256) void voxel_means_runs(
+        const uint32_t* __restrict__ keys, const Pay3* __restrict__ pts, const Pay3* __restrict__ nrm, const Pay3* __restrict__ col,
+        const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ voff, const uint32_t* __restrict__ mask,
+        const uint32_t* __restrict__ nruns_p, int L, int64_t m, float* __restrict__ out_pts, float* __restrict__ out_nrm,
+        float* __restrict__ out_col) {
+    const int64_t v = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int sub = (int)(threadIdx.x & 7u);
+    double ap[3] = {0, 0, 0}, an[3] = {0, 0, 0}, ac[3] = {0, 0, 0}, cnt = 0.0;
+    uint32_t s = 0, e = 0, f = 0;
+    const uint32_t low = (L > 0) ? ((1u << L) - 1u) : 0u;
+    if (v < m) {
+        uint32_t r = (uint32_t)v;
+        if (L > 0) {
+            uint32_t lo = 0u, hi = *nruns_p;  // the last r in [0, R) with voff[r] <= v
+            while (hi - lo > 1u) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (voff[mid] <= (uint32_t)v) lo = mid;
+                else hi = mid;
+            }
+            r = lo;
+            uint32_t mm = mask[r];
+            for (uint32_t j = (uint32_t)v - voff[r]; j > 0u; --j) mm &= mm - 1u;
+            f = (uint32_t)__builtin_ctz(mm);
+        }
+        s = run_start[r];
+        e = run_start[r + 1];
+    }
+    for (uint32_t t = s + (uint32_t)sub; t < e; t += 8u) {
+        if (L > 0 && (keys[t] & low) != f) continue;
+        const Pay3 p = pts[t];
+        ap[0] += (double)p.x;
+        ap[1] += (double)p.y;
+        ap[2] += (double)p.z;
+        cnt += 1.0;
+        if (nrm) {
+            const Pay3 q = nrm[t];
+            an[0] += (double)q.x;
+            an[1] += (double)q.y;
+            an[2] += (double)q.z;
+        }
+        if (col) {
+            const Pay3 q = col[t];
+            ac[0] += (double)q.x;
+            ac[1] += (double)q.y;
+            ac[2] += (double)q.z;
+        }
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) {
+        cnt += __shfl_down(cnt, off, 8);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            ap[d] += __shfl_down(ap[d], off, 8);
+            an[d] += __shfl_down(an[d], off, 8);
+            ac[d] += __shfl_down(ac[d], off, 8);
+        }
+    }
+    if (v < m && sub == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) out_pts[v * 3 + d] = (float)(ap[d] / cnt);
+        if (nrm) {
+            const float w[3] = {(float)(an[0] / cnt), (float)(an[1] / cnt), (float)(an[2] / cnt)};
+            const float l = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) out_nrm[v * 3 + d] = w[d] / l;
+        }
+        if (col) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) out_col[v * 3 + d] = (float)(ac[d] / cnt);
         }
     }
 }

@@ -139,6 +139,7 @@ struct mi_icp_ctx {
     DevBuf stage[6];
     DevBuf tscale;   // scratch of kd_build.h tree_scale
     DevBuf knn_idx;  // candidate indices of the small k-NN lists, [packet][slot][lane] (knn_normals.h)
+    DevBuf vpay[6];  // VoxelDownSample: two sets of payload arrays (points, normals, colours) the radix passes alternate between
     double* sys_host = nullptr;  // pinned, 32 doubles + spare
     float* f_host = nullptr;     // pinned, 16 floats
     uint32_t* u_host = nullptr;  // pinned, 16 words ([0]: counts read back by the one-shot entry points, [8]: the halo_want counter)
@@ -1204,7 +1205,8 @@ void mi_icp_destroy(mi_icp_ctx* c) {
                      &c->scan_tmp, &c->bounds_part, &c->bounds, &c->partial, &c->sys_dev,
                      &c->dense_idx, &c->flags, &c->pairs_out, &c->seg_start, &c->loop_dev, &c->ticket, &c->mail_state, &c->alt[0],
                      &c->alt[1], &c->alt[2], &c->alt[3], &c->alt[4], &c->alt[5], &c->alt[6], &c->alt[7], &c->alt[8], &c->stage[0],
-                     &c->stage[1], &c->stage[2], &c->stage[3], &c->stage[4], &c->stage[5], &c->knn_idx, &c->tscale};
+                     &c->stage[1], &c->stage[2], &c->stage[3], &c->stage[4], &c->stage[5], &c->knn_idx, &c->tscale, &c->vpay[0], &c->vpay[1],
+                     &c->vpay[2], &c->vpay[3], &c->vpay[4], &c->vpay[5]};
     for (DevBuf* b : all) release(*b);
     if (c->sys_host) (void)hipHostFree(c->sys_host);
     if (c->cell_total_host) (void)hipHostFree(c->cell_total_host);
@@ -2101,6 +2103,73 @@ int mi_icp_covariances_from_normals(mi_icp_ctx* c, const float* normals, int64_t
     return MI_ICP_OK;
 }
 
+// VoxelDownSample for grids whose packed (x, y, z) key fits 32 bits (geometry_kernels.h, "the path for grids ..."):
+// keys -> radix passes on the bits above the lowest L that carry the payload -> runs of equal key >> L -> which voxels
+// occur in each run -> their output positions -> means.  Two host synchronisations in the whole call (the bounds that
+// place the grid, the voxel count that sizes the output), as before.
+static int voxel_downsample_keys32(mi_icp_ctx* c, const float* dp, const float* dn, const float* dcol, int64_t n,
+                                   const VoxelGrid& g, int bits, float* out_xyz, float* out_normals, float* out_colors,
+                                   int64_t* m, int mem_kind) {
+    SortBuffers sb;
+    TRY(sort_buffers(c, n, &sb));
+    uint32_t* const keys[2] = {reinterpret_cast<uint32_t*>(sb.keys[0]), reinterpret_cast<uint32_t*>(sb.keys[1])};
+    voxel_keys32<<<blocks_for(n), 256, 0, c->stream>>>(dp, n, g, keys[0]);
+    KCHK(c);
+    // the lowest L <= 5 key bits stay unsorted where that saves a pass (21 bits: 2 passes, L = 5; 24 bits: 3, L = 0)
+    const int passes = std::max(0, (bits - 5 + 7) / 8);
+    const int L = std::min(5, std::max(0, bits - 8 * passes));
+    const Pay3* first[3] = {reinterpret_cast<const Pay3*>(dp), reinterpret_cast<const Pay3*>(dn), reinterpret_cast<const Pay3*>(dcol)};
+    Pay3* scratch[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    for (int set = 0; set < std::min(passes, 2); ++set)
+        for (int a = 0; a < 3; ++a)
+            if (first[a]) TRY(ensure(c, c->vpay[set * 3 + a], (size_t)n, &scratch[set][a]));
+    const Pay3* pay[3];
+    const int cur = radix_sort_payload32(c->stream, keys, first, scratch, sb.hist, sb.scan_tmp, n, L, bits, pay);
+    KCHK(c);
+    const uint32_t* skeys = keys[cur];
+    // runs of equal key >> L
+    const int ntiles = scan_num_tiles(n);
+    uint32_t *run_start, *mask = nullptr, *voff = nullptr, *tmp = sb.scan_tmp;
+    TRY(ensure(c, c->seg_start, (size_t)n + 4, &run_start));
+    vox_head_sums<<<ntiles, kScanThreads, 0, c->stream>>>(skeys, (int)n, L, tmp);
+    scan_tile_offsets<<<1, kScanThreads, 0, c->stream>>>(tmp, ntiles);
+    vox_head_apply<<<ntiles, kScanThreads, 0, c->stream>>>(skeys, (int)n, L, tmp, ntiles, run_start);
+    KCHK(c);
+    uint32_t* nruns = run_start + n + 2;  // (kept apart: the scan below reuses tmp)
+    HIPCHK(c, hipMemcpyAsync(nruns, tmp + ntiles, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    const uint32_t* total = nruns;
+    if (L > 0) {
+        const int64_t rmax = (bits - L >= 31) ? n : std::min<int64_t>(n, (int64_t)1 << (bits - L));
+        TRY(ensure(c, c->flags, (size_t)n, &mask));
+        TRY(ensure(c, c->dense_idx, (size_t)n, &voff));
+        vox_run_masks<<<blocks_for(rmax * 16), 256, 0, c->stream>>>(skeys, run_start, nruns, rmax, L, mask, voff);
+        KCHK(c);
+        exclusive_scan_u32(c->stream, voff, voff, rmax, tmp);
+        KCHK(c);
+        total = tmp + scan_num_tiles(rmax);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->u_host, total, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int64_t nvox = (int64_t)c->u_host[0];
+    float *op = out_xyz, *on = out_normals, *oc = out_colors;
+    if (mem_kind == MI_ICP_HOST) {
+        TRY(ensure(c, c->stage[3], (size_t)nvox * 3, &op));
+        if (dn) TRY(ensure(c, c->stage[4], (size_t)nvox * 3, &on));
+        if (dcol) TRY(ensure(c, c->stage[5], (size_t)nvox * 3, &oc));
+    }
+    voxel_means_runs<<<blocks_for(nvox * 8), 256, 0, c->stream>>>(skeys, pay[0], pay[1], pay[2], run_start, voff, mask, nruns, L,
+                                                                 nvox, op, dn ? on : nullptr, dcol ? oc : nullptr);
+    KCHK(c);
+    if (mem_kind == MI_ICP_HOST) {
+        TRY(from_device(c, (const float*)op, out_xyz, (size_t)nvox * 3, mem_kind));
+        if (dn) TRY(from_device(c, (const float*)on, out_normals, (size_t)nvox * 3, mem_kind));
+        if (dcol) TRY(from_device(c, (const float*)oc, out_colors, (size_t)nvox * 3, mem_kind));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *m = nvox;
+    return MI_ICP_OK;
+}
+
 int mi_icp_voxel_downsample(mi_icp_ctx* c, const float* xyz, const float* normals,
                             const float* colors, int64_t n, float voxel, float* out_xyz,
                             float* out_normals, float* out_colors, int64_t* m, int mem_kind) {
@@ -2142,6 +2211,11 @@ int mi_icp_voxel_downsample(mi_icp_ctx* c, const float* xyz, const float* normal
         g.bits_y = bits[1];
         g.bits_z = bits[2];
     }
+
+    static const bool old_voxel = std::getenv("MI_ICP_VOXEL_OLD") != nullptr;  // A/B switch: the (64-bit key, index) sort + gather
+    if (bits[0] + bits[1] + bits[2] <= 32 && !old_voxel)
+        return voxel_downsample_keys32(c, dp, dn, dcol, n, g, bits[0] + bits[1] + bits[2], out_xyz, out_normals, out_colors, m,
+                                       mem_kind);
 
     SortBuffers sb;
     TRY(sort_buffers(c, n, &sb));

@@ -267,6 +267,113 @@ __global__ __launch_bounds__(kSortThreads) void rs_scatter(const K* __restrict__
     }
 }
 
+// The same scatter for 32-bit keys that carry up to three float3 PAYLOAD arrays instead of an index (VoxelDownSample:
+// points, normals, colours travel with their voxel key; a null array is skipped).  The reads are a gather inside
+// the workgroup's own tile (8192 elements: 96 KB per array, cache-resident), the writes go out run by run.
+struct __attribute__((packed, aligned(4))) Pay3 {
+    float x, y, z;
+};
+struct PayArrays {
+    const Pay3* in[3];
+    Pay3* out[3];
+};
+
+template <int kSortChunks>
+__global__ __launch_bounds__(kSortThreads) void rs_scatter_pay(const uint32_t* __restrict__ keys_in,
+                                                               uint32_t* __restrict__ keys_out, PayArrays pay,
+                                                               const uint32_t* __restrict__ offs, int n, int nseg,
+                                                               int shift) {
+    constexpr int kSortWaveSeg = 64 * kSortChunks;
+    constexpr int kSortSeg = kSortWaveSeg * kSortWaves;
+    __shared__ uint32_t wcnt[kSortWaves][256];
+    __shared__ uint32_t tile_start[256];
+    __shared__ int32_t gdelta[256];
+    __shared__ uint32_t wtot[kSortThreads / 64];
+    __shared__ uint16_t perm[kSortSeg];
+    const int tid = (int)threadIdx.x;
+    const int lane = lane_id();
+    const int wid = tid >> 6;
+    const int seg = (int)blockIdx.x;
+    const int64_t tbase = (int64_t)seg * kSortSeg;
+    const int tile_n = (int)min((int64_t)kSortSeg, (int64_t)n - tbase);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wcnt[wid][lane + 64 * k] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t packed[kSortChunks];
+#pragma unroll
+    for (int c = 0; c < kSortChunks; ++c) {
+        const int e = wid * kSortWaveSeg + c * 64 + lane;
+        const bool valid = e < tile_n;
+        const uint32_t key = valid ? keys_in[tbase + e] : 0u;
+        const uint32_t digit = (key >> shift) & 255u;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (digit >> b) & 1u;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+        const uint32_t cnt = (uint32_t)__popcll(peers);
+        uint32_t pos = 0;
+        if (valid) pos = wcnt[wid][digit] + rank;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) wcnt[wid][digit] = pos + cnt;
+        __builtin_amdgcn_wave_barrier();
+        packed[c] = (digit << 16) | pos;
+    }
+    __syncthreads();
+    uint32_t total = 0;
+    if (tid < 256) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) {
+            const uint32_t k = wcnt[w][tid];
+            wcnt[w][tid] = run;
+            run += k;
+        }
+        total = run;
+    }
+    {
+        uint32_t x = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wtot[wid] = x;
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t woff = 0;
+            for (int w = 0; w < wid; ++w) woff += wtot[w];
+            const uint32_t start = woff + x - total;
+            tile_start[tid] = start;
+            gdelta[tid] = (int32_t)(offs[(int64_t)tid * nseg + seg] - start);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kSortChunks; ++c) {
+        const int e = wid * kSortWaveSeg + c * 64 + lane;
+        if (e < tile_n) {
+            const uint32_t digit = packed[c] >> 16;
+            perm[tile_start[digit] + wcnt[wid][digit] + (packed[c] & 0xffffu)] = (uint16_t)e;
+        }
+    }
+    __syncthreads();
+    for (int p = tid; p < tile_n; p += kSortThreads) {
+        const int e = (int)perm[p];
+        const uint32_t key = keys_in[tbase + e];
+        const uint32_t digit = (key >> shift) & 255u;
+        const uint32_t pos = (uint32_t)(gdelta[digit] + (int32_t)p);
+        keys_out[pos] = key;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            if (pay.in[a]) pay.out[a][pos] = pay.in[a][tbase + e];  // (wave-uniform)
+    }
+}
+
 struct SortBuffers {
     uint64_t* keys[2];
     uint32_t* vals[2];
@@ -309,6 +416,41 @@ static inline int radix_sort_pairs_t(hipStream_t st, K* const keys[2], uint32_t*
 
 static inline int radix_sort_pairs(hipStream_t st, const SortBuffers& b, int64_t n, int key_bits) {
     return radix_sort_pairs_t<uint64_t>(st, b.keys, b.vals, b.hist, b.scan_tmp, n, key_bits);
+}
+
+// 32-bit keys with float3 payload arrays, sorted on the key bits [lo_bit, hi_bit).  first_in: the caller's arrays (read
+// by the first pass only), scratch[2][3]: two sets of arrays the passes alternate between.  Returns the key buffer's
+// index (0 / 1) and through *result the arrays that hold the sorted payload (first_in itself when there is no pass).
+static inline int radix_sort_payload32(hipStream_t st, uint32_t* const keys[2], const Pay3* const first_in[3],
+                                       Pay3* const scratch[2][3], uint32_t* hist, uint32_t* scan_tmp, int64_t n,
+                                       int lo_bit, int hi_bit, const Pay3* result[3]) {
+    for (int a = 0; a < 3; ++a) result[a] = first_in[a];
+    if (n <= 0) return 0;
+    const int nseg = sort_num_segments(n);
+    const int chunks = sort_chunks_for(n);
+    int cur = 0, set = 0;
+    for (int shift = lo_bit; shift < hi_bit; shift += 8) {
+        switch (chunks) {
+            case 16: rs_histogram<uint32_t, 16><<<nseg, kSortThreads, 0, st>>>(keys[cur], hist, (int)n, nseg, shift); break;
+            case 4: rs_histogram<uint32_t, 4><<<nseg, kSortThreads, 0, st>>>(keys[cur], hist, (int)n, nseg, shift); break;
+            default: rs_histogram<uint32_t, 1><<<nseg, kSortThreads, 0, st>>>(keys[cur], hist, (int)n, nseg, shift); break;
+        }
+        exclusive_scan_u32(st, hist, hist, (int64_t)256 * nseg, scan_tmp);
+        PayArrays pay;
+        for (int a = 0; a < 3; ++a) {
+            pay.in[a] = result[a];
+            pay.out[a] = result[a] ? scratch[set][a] : nullptr;
+        }
+        switch (chunks) {
+            case 16: rs_scatter_pay<16><<<nseg, kSortThreads, 0, st>>>(keys[cur], keys[cur ^ 1], pay, hist, (int)n, nseg, shift); break;
+            case 4: rs_scatter_pay<4><<<nseg, kSortThreads, 0, st>>>(keys[cur], keys[cur ^ 1], pay, hist, (int)n, nseg, shift); break;
+            default: rs_scatter_pay<1><<<nseg, kSortThreads, 0, st>>>(keys[cur], keys[cur ^ 1], pay, hist, (int)n, nseg, shift); break;
+        }
+        for (int a = 0; a < 3; ++a) result[a] = pay.out[a];
+        cur ^= 1;
+        set ^= 1;
+    }
+    return cur;
 }
 
 // the same buffers holding 32-bit keys

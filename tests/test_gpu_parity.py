@@ -378,7 +378,11 @@ def test_voxel_downsample_golden(eng, golden):
     np.testing.assert_allclose(_rows(c), _rows(g["ref_colors"]), atol=g["tol"])
 
 
-@pytest.mark.parametrize("n,voxel", [(1000, 0.1), (200000, 0.02), (200000, 1e-4), (5000, 10.0)])
+# (the grid's packed key: 12 / 18 / 42 / 3 bits -- one pass with 4 unsorted low bits, two with 2, the 64-bit fallback,
+# no pass at all -- then 21 bits (two passes, 5 low bits: the 10M bench's shape), 24 (three, none), 30 (four, none),
+# 15 (two, ... ) and a grid that is long in one axis only)
+@pytest.mark.parametrize("n,voxel", [(1000, 0.1), (200000, 0.02), (200000, 1e-4), (5000, 10.0), (300000, 0.01),
+                                     (300000, 0.004), (100000, 0.001), (50000, 0.04), (70001, 0.3)])
 def test_voxel_downsample_matches_oracle(eng, n, voxel):
     rng = np.random.default_rng(n)
     pts = rng.random((n, 3), dtype=np.float32)
@@ -395,6 +399,38 @@ def test_voxel_downsample_matches_oracle(eng, n, voxel):
     p1, n1, c1 = eng.voxel_downsample(pts, voxel)             # no normals / colors path
     np.testing.assert_allclose(p1, rp, atol=1e-6)
     assert n1 is None and c1 is None
+    if n == 70001:                                            # a slab: 12 bits along x, 1 along y and z
+        slab = pts * np.array([50.0, 0.2, 0.2], np.float32)
+        ps, _, cs = eng.voxel_downsample(cuda(slab), 0.02, None, cuda(col))
+        rs, _, rcs = orc.voxel_downsample(slab, 0.02, None, col)
+        assert len(ps) == len(rs)
+        np.testing.assert_allclose(ps.cpu().numpy(), rs, atol=4e-6)
+        np.testing.assert_allclose(cs.cpu().numpy(), rcs, atol=1e-6)
+
+
+def test_voxel_downsample_both_forms_agree_to_the_last_bit_or_two(tmp_path):
+    """The 32-bit-key path with the payload carried through the radix passes (round 4) against the first form (64-bit
+    keys, indices, one gather; MI_ICP_VOXEL_OLD=1 in a child process -- the library reads its switches once): the same
+    voxels in the same order, and values that differ at most in the last bit or two -- both add a voxel's points in
+    fp64, but deal them to their 8 lanes differently, so an fp64 sum may round the other way once in a long while."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from cupoch_amd.engine import Engine; e = Engine(0);"
+            "rng = np.random.default_rng(9); pts = rng.random((400000, 3), dtype=np.float32);"
+            "nrm = rng.standard_normal((400000, 3)).astype(np.float32); col = rng.random((400000, 3), dtype=np.float32);"
+            "out = []\n"
+            "for v in (0.5, 0.05, 0.011, 0.003):\n"
+            "    out += [np.asarray(a) for a in e.voxel_downsample(pts, v, nrm, col)]\n"
+            "np.savez(sys.argv[1], *out)") % os.path.dirname(here)
+    for name, env in (("new", {}), ("old", {"MI_ICP_VOXEL_OLD": "1"})):
+        subprocess.run([sys.executable, "-c", code, str(tmp_path / (name + ".npz"))], check=True, env=dict(os.environ, **env), timeout=600)
+    a, b = np.load(tmp_path / "new.npz"), np.load(tmp_path / "old.npz")
+    assert len(a.files) == 12
+    for k in a.files:
+        assert a[k].shape == b[k].shape, k
+        np.testing.assert_array_max_ulp(a[k], b[k], maxulp=2)
 
 
 def test_covariances_from_normals_matches_oracle(eng):
