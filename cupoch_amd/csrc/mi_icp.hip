@@ -1801,10 +1801,71 @@ static int launch_fused_iteration(mi_icp_ctx* c, DevLoop* d) {
     return MI_ICP_OK;
 }
 
+// Mid-sized sources (a rank's share of a sharded registration): search + rows + reduction + exchange + step in ONE
+// launch with the sums kept in registers across a wave's packets (fused_small.h, icp_mid_iteration_kernel).
+// MI_ICP_MID_MAX: the largest source that takes it (0: never).
+constexpr int64_t kMidMax = 0;  // (set from the measurements: DESIGN section 5 / EXPERIMENTS.md)
+static bool mid_iteration_applies(const mi_icp_ctx* c, bool seed) {
+    static const int64_t limit = [] { const char* e = std::getenv("MI_ICP_MID_MAX"); return e ? std::atoll(e) : kMidMax; }();
+    static const int64_t fused_limit = [] { const char* e = std::getenv("MI_ICP_FUSED_MAX"); return e ? std::atoll(e) : kFusedMax; }();
+    return limit > 0 && seed && c->nn_valid && c->loop_est == kEstPt2Pl && estimator_ready(c, kEstPt2Pl) && c->t_has_rec &&
+           c->trec.p != nullptr && c->n_user_pairs < 0 && c->ns > fused_limit && c->ns <= limit && c->nt > 0;
+}
+
+static int launch_mid_iteration(mi_icp_ctx* c, DevLoop* d, bool* stepped) {
+    const bool have_halo = c->halo_use;
+    uint32_t* want = (!have_halo && !c->links_inflight && c->links_allowed) ? (uint32_t*)c->halo_want.p : nullptr;
+    const uint32_t npackets = (uint32_t)((c->ns + 63) / 64);
+    // one round of waves at the kernel's occupancy: 4 per SIMD, 16 per CU (MI_ICP_MID_WAVES: waves per CU aimed at)
+    static const uint32_t waves_per_cu = [] { const char* e = std::getenv("MI_ICP_MID_WAVES"); const int v = e ? std::atoi(e) : 0; return (uint32_t)(v > 0 ? v : 16); }();
+    static const uint32_t ncu = [] { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); return (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? (uint32_t)p.multiProcessorCount : 256u; }();
+    const uint32_t target_waves = waves_per_cu * ncu;
+    const uint32_t ppw = std::max(1u, (npackets + target_waves - 1) / target_waves);
+    const uint32_t nwaves = (npackets + ppw - 1) / ppw;
+    const uint32_t nblocks = (nwaves + kFusedPackets - 1) / kFusedPackets;
+    const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
+    double *partial, *sys;
+    TRY(ensure(c, c->partial, (size_t)std::max<uint32_t>(kReduceBlocks, grid) * kSysSize, &partial));
+    TRY(ensure(c, c->sys_dev, kSysSize, &sys));
+    if (!c->ticket.p) {
+        uint32_t* ticket;
+        TRY(ensure(c, c->ticket, 64, &ticket));
+        HIPCHK(c, hipMemsetAsync(ticket, 0, 256, c->stream));
+    }
+    const MailArgs no_mail = {nullptr, nullptr, 0, 1, 0u, nullptr, nullptr};
+    EvTimer t(c, 0, true);
+#define MI_MID_ARGS (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns, (const float*)c->nodes.p, \
+            (const float*)c->tblk.p, (const float*)c->tlreg.p, have_halo ? (const float*)c->thalo.p : nullptr, c->leaf_first, \
+            c->loop_r2, npackets, ppw, nblocks, (int32_t*)c->nn_idx.p, want, (const float*)c->trec.p, d, partial, (uint32_t*)c->ticket.p, sys
+    if (mail_on(c)) {
+        icp_mid_iteration_kernel<2><<<grid, kReduceThreads, 0, c->stream>>>(MI_MID_ARGS, mail_args(c));
+        *stepped = true;
+    } else if (!c->comm && !c->mail_dev) {
+        icp_mid_iteration_kernel<1><<<grid, kReduceThreads, 0, c->stream>>>(MI_MID_ARGS, no_mail);
+        *stepped = true;
+    } else {
+        icp_mid_iteration_kernel<0><<<grid, kReduceThreads, 0, c->stream>>>(MI_MID_ARGS, no_mail);
+        *stepped = false;
+    }
+#undef MI_MID_ARGS
+    KCHK(c);
+    c->last_search_kind = 1;
+    return MI_ICP_OK;
+}
+
 // one evaluation: search under the loop's transform, reduction, all-reduce, step kernel
 static int loop_enqueue_evaluation(mi_icp_ctx* c, bool seed) {
     DevLoop* d = (DevLoop*)c->loop_dev.p;
     if (fused_iteration_applies(c, seed)) return launch_fused_iteration(c, d);
+    if (mid_iteration_applies(c, seed)) {
+        bool mid_stepped = false;
+        TRY(launch_mid_iteration(c, d, &mid_stepped));
+        if (mid_stepped) return MI_ICP_OK;
+        TRY(allreduce_system(c));  // (RCCL between the sums and the step)
+        loop_step_kernel<<<1, kStepThreads, 0, c->stream>>>(d, (double*)c->sys_dev.p, 0, MailArgs{nullptr, nullptr, 0, 1, 0u, nullptr, nullptr});
+        KCHK(c);
+        return MI_ICP_OK;
+    }
     const Mat4 I = host::identity4();
     TRY(launch_nn(c, I, c->loop_r2, seed, nullptr, d));
     bool stepped = false;
@@ -1932,7 +1993,20 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
         HIPCHK(c, hipMemsetAsync(want, 0, sizeof(uint32_t), c->stream));
     }
     c->halo_use = halo_poll(c);
-    if (c->halo_sticky && !c->halo_use) TRY(start_links_async(c));
+    // A context whose loops have asked for halos before builds them NOW, on the loop's own stream, ahead of the first
+    // pass -- which then starts from the queries' own seeds (launch_nn).  (Round 3 started the build on the private
+    // stream next to the first pass and the match-order re-sort: the 2.5-ms build and those streaming kernels fought
+    // for the memory system -- match_order_keys 28 us alone, 1.7 ms beside leaf_halo_build; leaf_halo_collect 0.73 ->
+    // 1.7 ms -- and the loop waited for the build at its first seeded iteration anyway.  MI_ICP_LINKS_ASYNC=1: that form.)
+    if (c->halo_sticky && !c->halo_use) {
+        static const bool links_async = std::getenv("MI_ICP_LINKS_ASYNC") != nullptr;  // A/B switch
+        if (links_async || c->links_inflight) {
+            TRY(start_links_async(c));
+        } else {
+            TRY(ensure_links(c));
+            c->halo_use = halo_poll(c);
+        }
+    }
     TRY(loop_enqueue_evaluation(c, false));
     // from here on the packets follow the target's order (pays for itself in ~4 iterations)
     static const bool no_resort = std::getenv("MI_ICP_NO_RESORT") != nullptr;  // A/B switch for tuning
