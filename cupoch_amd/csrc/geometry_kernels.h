@@ -322,16 +322,31 @@ __global__ __launch_bounds__(256) void voxel_keys32(const float* __restrict__ pt
 
 // head(i) = sorted element i opens a new run (its key >> L differs from its predecessor's).  Tile sums of the head
 // flags (the scan's first step, primitives.h) straight from the keys ...
+// (a thread's 8 consecutive keys come as two 16-byte loads where the tile is whole)
+__device__ __forceinline__ void vox_load8(const uint32_t* __restrict__ keys, int64_t base, int n, uint32_t (&k)[kScanItems]) {
+    static_assert(kScanItems == 8, "two uint4 per thread");
+    if (base + kScanItems <= n) {
+        const uint4 a = *reinterpret_cast<const uint4*>(keys + base), b = *reinterpret_cast<const uint4*>(keys + base + 4);
+        k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w;
+        k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < kScanItems; ++j) k[j] = (base + j < n) ? keys[base + j] : 0u;
+    }
+}
+
 __global__ __launch_bounds__(kScanThreads) void vox_head_sums(const uint32_t* __restrict__ keys, int n, int L,
                                                                uint32_t* __restrict__ tile_sums) {
     __shared__ uint32_t lds4[4];
     const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
     uint32_t s = 0;
     uint32_t prev = (base > 0 && base - 1 < n) ? (keys[base - 1] >> L) : 0u;
+    uint32_t k8[kScanItems];
+    vox_load8(keys, base, n, k8);
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k)
         if (base + k < n) {
-            const uint32_t cur = keys[base + k] >> L;
+            const uint32_t cur = k8[k] >> L;
             s += (base + k == 0 || cur != prev) ? 1u : 0u;
             prev = cur;
         }
@@ -349,11 +364,13 @@ __global__ __launch_bounds__(kScanThreads) void vox_head_apply(const uint32_t* _
     uint32_t h[kScanItems];
     uint32_t s = 0;
     uint32_t prev = (base > 0 && base - 1 < n) ? (keys[base - 1] >> L) : 0u;
+    uint32_t k8[kScanItems];
+    vox_load8(keys, base, n, k8);
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         h[k] = 0u;
         if (base + k < n) {
-            const uint32_t cur = keys[base + k] >> L;
+            const uint32_t cur = k8[k] >> L;
             h[k] = (base + k == 0 || cur != prev) ? 1u : 0u;
             prev = cur;
         }
@@ -366,7 +383,10 @@ __global__ __launch_bounds__(kScanThreads) void vox_head_apply(const uint32_t* _
         if (h[k]) run_start[off] = (uint32_t)(base + k);
         off += h[k];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) run_start[tile_offs[ntiles]] = (uint32_t)n;  // (tile_offs[ntiles] = R)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        run_start[tile_offs[ntiles]] = (uint32_t)n;  // (tile_offs[ntiles] = R)
+        run_start[n + 2] = tile_offs[ntiles];        // R itself, kept where later scans do not reach
+    }
 }
 
 // 16 lanes per run: which of the run's 2^L voxels occur.  mask[r], cnt[r] = popcount; runs past the end (the grid
@@ -464,6 +484,107 @@ __global__ __launch_bounds__(256) void voxel_means_runs(
         if (col) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) out_col[v * 3 + d] = (float)(ac[d] / cnt);
+        }
+    }
+}
+
+// L > 0: a WAVE per run.  The run's elements are read 64 at a time, one per lane (coalesced); the lanes of a chunk
+// that share a voxel (equal low key bits: L ballots) are added up by the lowest of them, in lane order, through the LDS
+// crossbar; the chunk's group totals go into per-voxel fp64 accumulators in LDS, chunk after chunk -- a fixed order,
+// so the means are reproducible.  Then lane f writes voxel f's means at the run's output offset + its rank in the mask.
+// (8 lanes per output voxel, each walking its whole run and picking its own points -- voxel_means_runs with L > 0 -- took
+// 0.57-0.70 ms at 10M points: 16 voxels of a run each re-read the run's keys and fetch their points line by line.)
+__global__ __launch_bounds__(64) void voxel_means_wave(
+        const uint32_t* __restrict__ keys, const Pay3* __restrict__ pts, const Pay3* __restrict__ nrm, const Pay3* __restrict__ col,
+        const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ voff, const uint32_t* __restrict__ mask,
+        const uint32_t* __restrict__ nruns_p, int64_t rmax, int L, float* __restrict__ out_pts, float* __restrict__ out_nrm,
+        float* __restrict__ out_col) {
+    __shared__ double s_acc[32][10];  // [voxel of the run][x y z | nx ny nz | r g b | count]
+    const int lane = lane_id();
+    const int64_t r = (int64_t)blockIdx.x;  // (one wave per workgroup: runs differ in length, the dispatcher refills wave slots one at a time)
+    if (r >= rmax || r >= (int64_t)*nruns_p) return;
+    const uint32_t s = run_start[r], e = run_start[r + 1];
+    const uint32_t low = (1u << L) - 1u;
+    double(*acc)[10] = s_acc;
+    if (lane < 32) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[lane][k] = 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int nv = 3 + (nrm ? 3 : 0) + (col ? 3 : 0);  // (wave-uniform)
+    for (uint32_t c0 = s; c0 < e; c0 += 64u) {
+        // (issuing the next chunk's loads ahead of this chunk's work was tried: 11 registers more, an occupancy step
+        // down, 140 against 132 us)
+        const uint32_t t = c0 + (uint32_t)lane;
+        const bool valid = t < e;
+        const uint32_t tc = valid ? t : s;
+        const uint32_t f = keys[tc] & low;
+        float v[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        {
+            const Pay3 p = pts[tc];
+            v[0] = p.x; v[1] = p.y; v[2] = p.z;
+        }
+        if (nrm) {
+            const Pay3 q = nrm[tc];
+            v[3] = q.x; v[4] = q.y; v[5] = q.z;
+            if (col) {
+                const Pay3 c = col[tc];
+                v[6] = c.x; v[7] = c.y; v[8] = c.z;
+            }
+        } else if (col) {
+            const Pay3 c = col[tc];
+            v[3] = c.x; v[4] = c.y; v[5] = c.z;
+        }
+        // the lanes of this chunk with my voxel
+        uint64_t eq = __ballot(valid);
+        for (int b = 0; b < L; ++b) {
+            const bool bit = (f >> b) & 1u;
+            const uint64_t m = __ballot(valid && bit);
+            eq &= bit ? m : ~m;
+        }
+        const bool leader = valid && (uint32_t)__builtin_ctzll(eq) == (uint32_t)lane;
+        double sum[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sum[k] = (double)v[k];
+        uint64_t rest = leader ? (eq & (eq - 1ull)) : 0ull;  // the group's other lanes, ascending
+        while (__ballot(rest != 0ull) != 0ull) {
+            const bool take = rest != 0ull;
+            const int src = take ? (int)__builtin_ctzll(rest) : lane;
+            rest &= rest - 1ull;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                if (k < nv) {  // (uniform)
+                    const float o = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v[k])));
+                    if (take) sum[k] += (double)o;
+                }
+            }
+        }
+        if (leader) {
+            double* a = acc[f];
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (k < nv) a[k] += sum[k];
+            a[9] += (double)__popcll(eq);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t m = mask[r];
+    if (lane < 32 && ((m >> lane) & 1u)) {
+        const int64_t v = (int64_t)voff[r] + (int64_t)__popc(m & ((1u << lane) - 1u));
+        const double* a = acc[lane];
+        const double cnt = a[9];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) out_pts[v * 3 + d] = (float)(a[d] / cnt);
+        if (nrm) {
+            const float w[3] = {(float)(a[3] / cnt), (float)(a[4] / cnt), (float)(a[5] / cnt)};
+            const float l = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) out_nrm[v * 3 + d] = w[d] / l;
+        }
+        if (col) {
+            const int o = nrm ? 6 : 3;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) out_col[v * 3 + d] = (float)(a[o + d] / cnt);
         }
     }
 }

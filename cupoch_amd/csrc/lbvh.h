@@ -20,20 +20,38 @@
 namespace mi {
 
 // ---- bounds ---------------------------------------------------------------
-constexpr int kBoundsBlocks = 512;
+constexpr int kBoundsBlocks = 1024;
 
+// (four points in flight per thread, each one 12-byte load: with one point per iteration and 512 blocks the kernel sat
+// on its load latency -- 45 us for the 120 MB of a 10M-point cloud)
 __global__ __launch_bounds__(256) void bounds_partial(const float* __restrict__ pts, int n,
                                                       float* __restrict__ partial /*[blocks][6]*/) {
+    struct __attribute__((packed, aligned(4))) P {
+        float x, y, z;
+    };
+    const P* __restrict__ p3 = reinterpret_cast<const P*>(pts);
     __shared__ float red[4][6];
     float mn[3] = {INFINITY, INFINITY, INFINITY};
     float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float v = pts[i * 3 + d];
-            mn[d] = fminf(mn[d], v);
-            mx[d] = fmaxf(mx[d], v);
-        }
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const P a = p3[i], b = p3[i + stride], c = p3[i + 2 * stride], d = p3[i + 3 * stride];
+        mn[0] = fminf(fminf(mn[0], fminf(a.x, b.x)), fminf(c.x, d.x));
+        mn[1] = fminf(fminf(mn[1], fminf(a.y, b.y)), fminf(c.y, d.y));
+        mn[2] = fminf(fminf(mn[2], fminf(a.z, b.z)), fminf(c.z, d.z));
+        mx[0] = fmaxf(fmaxf(mx[0], fmaxf(a.x, b.x)), fmaxf(c.x, d.x));
+        mx[1] = fmaxf(fmaxf(mx[1], fmaxf(a.y, b.y)), fmaxf(c.y, d.y));
+        mx[2] = fmaxf(fmaxf(mx[2], fmaxf(a.z, b.z)), fmaxf(c.z, d.z));
+    }
+    for (; i < n; i += stride) {
+        const P a = p3[i];
+        mn[0] = fminf(mn[0], a.x);
+        mn[1] = fminf(mn[1], a.y);
+        mn[2] = fminf(mn[2], a.z);
+        mx[0] = fmaxf(mx[0], a.x);
+        mx[1] = fmaxf(mx[1], a.y);
+        mx[2] = fmaxf(mx[2], a.z);
     }
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
 #pragma unroll

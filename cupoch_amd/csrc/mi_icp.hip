@@ -316,6 +316,10 @@ int sort_buffers(mi_icp_ctx* c, int64_t n, SortBuffers* sb) {
     int nseg = sort_num_segments(n);
     nseg = std::max(nseg, sort_num_segments(std::min<int64_t>(n, (1 << 21) - 1)));
     nseg = std::max(nseg, sort_num_segments(std::min<int64_t>(n, (1 << 18) - 1)));
+    // (the payload-carrying sort of VoxelDownSample works on tiles of at most 4096 elements)
+    nseg = std::max(nseg, sort_pay_num_segments(n));
+    nseg = std::max(nseg, sort_pay_num_segments(std::min<int64_t>(n, (1 << 20) - 1)));
+    nseg = std::max(nseg, sort_pay_num_segments(std::min<int64_t>(n, (1 << 18) - 1)));
     TRY(ensure(c, c->keys0, (size_t)n, &sb->keys[0]));
     TRY(ensure(c, c->keys1, (size_t)n, &sb->keys[1]));
     TRY(ensure(c, c->vals0, (size_t)n, &sb->vals[0]));
@@ -1381,7 +1385,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
         float* ts;
         TRY(ensure(c, c->tscale, 4, &ts));
         HIPCHK(c, hipMemsetAsync(ts, 0, 16, c->stream));
-        tree_scale<<<(used_last + 255u) / 256u, 256, 0, c->stream>>>(nodes, leaf_first, used_last, ts);
+        tree_scale<<<std::min(256u, (used_last + 255u) / 256u), 256, 0, c->stream>>>(nodes, leaf_first, used_last, ts);
         KCHK(c);
     }
     c->links_ready = false;  // (the leaves' halos: started below, or by the registration loop / the first seeded search)
@@ -2209,8 +2213,7 @@ static int voxel_downsample_keys32(mi_icp_ctx* c, const float* dp, const float* 
     scan_tile_offsets<<<1, kScanThreads, 0, c->stream>>>(tmp, ntiles);
     vox_head_apply<<<ntiles, kScanThreads, 0, c->stream>>>(skeys, (int)n, L, tmp, ntiles, run_start);
     KCHK(c);
-    uint32_t* nruns = run_start + n + 2;  // (kept apart: the scan below reuses tmp)
-    HIPCHK(c, hipMemcpyAsync(nruns, tmp + ntiles, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    uint32_t* nruns = run_start + n + 2;  // (R, written by vox_head_apply; kept apart: the scan below reuses tmp)
     const uint32_t* total = nruns;
     if (L > 0) {
         const int64_t rmax = (bits - L >= 31) ? n : std::min<int64_t>(n, (int64_t)1 << (bits - L));
@@ -2231,8 +2234,14 @@ static int voxel_downsample_keys32(mi_icp_ctx* c, const float* dp, const float* 
         if (dn) TRY(ensure(c, c->stage[4], (size_t)nvox * 3, &on));
         if (dcol) TRY(ensure(c, c->stage[5], (size_t)nvox * 3, &oc));
     }
-    voxel_means_runs<<<blocks_for(nvox * 8), 256, 0, c->stream>>>(skeys, pay[0], pay[1], pay[2], run_start, voff, mask, nruns, L,
-                                                                 nvox, op, dn ? on : nullptr, dcol ? oc : nullptr);
+    if (L > 0) {  // a wave per run
+        const int64_t rmax = (bits - L >= 31) ? n : std::min<int64_t>(n, (int64_t)1 << (bits - L));
+        voxel_means_wave<<<(unsigned)rmax, 64, 0, c->stream>>>(skeys, pay[0], pay[1], pay[2], run_start, voff, mask, nruns, rmax, L,
+                                                                      op, dn ? on : nullptr, dcol ? oc : nullptr);
+    } else {      // a run is a voxel: 8 lanes each
+        voxel_means_runs<<<blocks_for(nvox * 8), 256, 0, c->stream>>>(skeys, pay[0], pay[1], pay[2], run_start, voff, mask, nruns, L,
+                                                                     nvox, op, dn ? on : nullptr, dcol ? oc : nullptr);
+    }
     KCHK(c);
     if (mem_kind == MI_ICP_HOST) {
         TRY(from_device(c, (const float*)op, out_xyz, (size_t)nvox * 3, mem_kind));
@@ -3240,6 +3249,23 @@ int mi_icp_debug_get_leaf_halos(mi_icp_ctx* c, float* halos_out) {
 }
 
 int mi_icp_debug_last_search_kind(const mi_icp_ctx* c) { return c ? c->last_search_kind : -1; }
+
+int mi_icp_debug_occupancy(int which) {
+    int blocks = -1;
+    hipError_t e = hipErrorInvalidValue;
+    switch (which) {
+        case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kd_build_groups, kKdThreads, 0); break;
+        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, nn_packet_kernel<true, false>, kNNThreads, 0); break;
+        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, nn_packet_kernel<false, false>, kNNThreads, 0); break;
+        case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reduce_pt2pl_kernel<4, 1>, kReduceThreads, 0); break;
+        case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, leaf_halo_build, 64, 0); break;
+        case 5: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, rs_scatter_pay<8>, kSortThreads, 0); break;
+        case 6: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, voxel_means_wave, 64, 0); break;
+        case 7: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, icp_mid_iteration_kernel<1>, kReduceThreads, 0); break;
+        default: return -1;
+    }
+    return e == hipSuccess ? blocks : -2;
+}
 
 int mi_icp_debug_solve_both(int device, const double* systems, int n, float det_thresh, float* out_serial,
                             float* out_wave, int32_t* ok_serial, int32_t* ok_wave) {
