@@ -104,10 +104,15 @@ MI_ICP_API int mi_icp_synchronize(mi_icp_ctx* ctx);
  * Synchronous (the tree's size is read back once); at most ~3e8 points.
  * The leaves' HALOS (what a loop's seeded searches use once the matches are no
  * longer exact; csrc/leaf_halo.h) are built on demand, on a private low-priority
- * stream: when a registration loop's searches ask for them, with the loop on a
- * context whose loops have asked before, and -- for a target below 2M points on a
- * context that has registered before -- right behind the tree, next to whatever
- * the caller enqueues next.
+ * stream: when a registration loop's searches ask for them (ahead of the loop's first
+ * pass, on the loop's own stream, on a context whose loops have asked before), and --
+ * for a target below 2M points on a context that has registered before -- right behind
+ * the tree, next to whatever the caller enqueues next.
+ * Device memory a context keeps per target point: ~75 B of tree (leaf lines, regions,
+ * records; 1.67 slots per point at 10M), + 40 B with normals, + 60 B with covariances;
+ * the halos add 1 KB per LEAF (~215 B per point) once built, and their build 0.5 KB per
+ * leaf of candidate scratch that is released at the end of the registration call that
+ * built them (targets whose scratch is below 64 MB keep it: frame-to-frame callers).
  * mi_icp_set_source replaces `geometry::PointCloud pcd = source`
  * (registration/registration.cu:147): the engine keeps a Morton-sorted SoA
  * copy and never mutates the caller's cloud.  Stream-ordered. */
@@ -321,7 +326,13 @@ MI_ICP_API int mi_icp_covariances_from_normals(mi_icp_ctx* ctx, const float* nor
                                                int mem_kind);
 /* PointCloud::EstimateNormals(KDTreeSearchParamKNN(knn))
  * (geometry/estimate_normals.cu:82-127), knn <= 100 (knn::NUM_MAX_NN,
- * knn/kdtree_search_param.h:26; lists of up to 32 neighbours take the faster kernel). */
+ * knn/kdtree_search_param.h:26; lists of up to 32 neighbours take the faster kernel).
+ * Workspace: the k-NN kernels (this call, mi_icp_search_knn, the colour gradients) keep
+ * their candidates' INDICES in a device slab of 128 B per point / query for k <= 32
+ * (256 B up to 64, 416 B up to 100: 1.3 / 2.6 / 4.2 GB per 10M), allocated by the first
+ * such call of a context and reused by the later ones; EstimateNormals builds the cloud's
+ * tree in a private scratch context of its own (the caller's target / source / loop
+ * state survive the call). */
 MI_ICP_API int mi_icp_estimate_normals_knn(mi_icp_ctx* ctx, const float* xyz, int64_t n,
                                            int knn, float* normals, int mem_kind);
 /* PointCloud::EstimateNormals(KDTreeSearchParamRadius(radius, max_nn)): the max_nn

@@ -243,6 +243,58 @@ def test_gicp_system_on_covariances_the_eigen_solver_special_cases(eng):
         np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
 
 
+def test_gicp_system_on_singular_and_indefinite_covariances(eng):
+    """ADVICE r3 / DESIGN deviation 6, pinned.  (a) A correspondence whose Ct + Cs is SINGULAR (both covariances zero)
+    poisons the whole system in the reference's form -- (Ct+Cs)^-1 is not finite -- and here alike.  (b) One whose
+    Ct + Cs is INDEFINITE (not a covariance: a negative eigenvalue) gives NaN rows in the reference (cwiseSqrt of a negative
+    eigenvalue, eigenvalue.inl SqrtMatrix3x3) but a finite contribution here, because the rows are accumulated from
+    S = W W without taking the root: the one place where the two can part on finite inputs, and only on inputs that
+    are not covariances."""
+    n = 3000
+    rng = np.random.default_rng(23)
+    tgt = rng.random((n, 3), dtype=np.float32)
+    src = (tgt + np.float32(0.002) * rng.standard_normal((n, 3)).astype(np.float32)).astype(np.float32)
+    nrm = rng.standard_normal((n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    cov = orc.covariances_from_normals(nrm)
+    T = np.eye(4, dtype=np.float32)
+
+    def systems(cs, ct):
+        eng.set_target(cuda(tgt), cuda(nrm), cuda(ct))
+        eng.set_source(cuda(src), cuda(nrm), cuda(cs))
+        eng.search_radius_1nn(0.05, T)
+        got = eng.compute_system(GICP, T)
+        cor = eng.get_correspondences()
+        ref = orc.compute_system(GICP, src, tgt, cor, nrm, nrm, cs, ct)
+        return got, ref, cor
+
+    got, ref, cor = systems(cov, cov)                                   # sane covariances: finite and equal
+    assert np.isfinite(ref).all() and np.isfinite(got).all() and len(cor) == n
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+    # (a) one point with zero covariance on both sides (source i matches target i here)
+    cs, ct = cov.copy(), cov.copy()
+    cs[7] = 0.0
+    ct[7] = 0.0
+    got, ref, cor = systems(cs, ct)
+    assert (cor[7] == [7, 7]).all()
+    assert not np.isfinite(ref[:27]).all() and not np.isfinite(got[:27]).all()
+    assert got[29] == ref[29] == n and np.isfinite(got[28])            # the statistics do not go through the weights
+    # (b) one point whose summed covariance is indefinite
+    cs, ct = cov.copy(), cov.copy()
+    cs[11] = np.diag([1.0, 1.0, -0.8]).astype(np.float32)
+    ct[11] = np.diag([0.1, 0.1, 0.1]).astype(np.float32)
+    got, ref, cor = systems(cs, ct)
+    assert not np.isfinite(ref[:27]).all()                              # the reference's form: NaN rows
+    assert np.isfinite(got).all()                                       # here: a finite S = (Ct + Cs)^-1 (scaled)
+    # ... and the finite system is the sane one plus that one correspondence's rows: removing the point restores parity
+    keep = np.arange(n) != 11
+    cor_wo = cor[keep]
+    ref_wo = orc.compute_system(GICP, src, tgt, cor_wo, nrm, nrm, cs, ct)
+    eng.set_correspondences(cor_wo)
+    got_wo = eng.compute_system(GICP, T)
+    np.testing.assert_allclose(got_wo, ref_wo, rtol=2e-5, atol=2e-5 * np.abs(ref_wo).max())
+
+
 def test_explicit_correspondence_set(eng):
     d = _systems_inputs(5000, seed=2)
     eng.set_target(d["tgt"], d["tgt_nrm"])
