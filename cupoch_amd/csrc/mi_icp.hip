@@ -633,6 +633,18 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
         self_seeded = true;
     }
     c->last_search_kind = use_seed ? 1 : (self_seeded ? 2 : 0);
+    static const bool first_solo = std::getenv("MI_ICP_FIRST_SOLO") != nullptr;  // experiment: every lane walks on its own
+    if (first_solo && !use_seed && !self_seeded && !stats && c->leaf_first >= 1u) {
+        const uint32_t npackets = (uint32_t)((c->ns + 63) / 64);
+        const uint32_t grid = ((npackets + 7u) / 8u) * 8u;
+        nn_solo_kernel<<<grid, kNNThreads, 0, c->stream>>>((const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns,
+                                                          (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, X, loop, r2,
+                                                          npackets, idx, loop ? nullptr : d2);
+        KCHK(c);
+        c->nn_valid = true;
+        c->n_user_pairs = -1;
+        return MI_ICP_OK;
+    }
     launch(use_seed || self_seeded, (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, c->ns, idx,
            loop ? nullptr : d2);
     KCHK(c);

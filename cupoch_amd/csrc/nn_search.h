@@ -551,6 +551,43 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SEED
                                       r2, nn_idx, nn_d2, stats, want, unused);
 }
 
+// EXPERIMENT (MI_ICP_FIRST_SOLO=1; EXPERIMENTS.md round 4): a pass without previous matches in which every lane walks
+// the tree ON ITS OWN (traverse.h solo_walk: per-lane node id and sibling stack, nearest child first, L2 pruning
+// against the lane's own bound) instead of the wave walking once for its 64 queries.  Same exact answers.
+__global__ __launch_bounds__(kNNThreads) void nn_solo_kernel(
+        const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int ns,
+        const float* __restrict__ records_g, const float* __restrict__ tblk_g, uint32_t leaf_first, Xform Tv,
+        const DevLoop* __restrict__ loop, float r2, uint32_t nblocks, int32_t* __restrict__ nn_idx, float* __restrict__ nn_d2) {
+    uint32_t logical;
+    if (!xcd_remap(nblocks, logical)) return;
+    const int lane = lane_id();
+    const int i = (int)(logical * 64u) + lane;
+    const bool valid = i < ns;
+    const int ic = valid ? i : 0;
+    Xform T = Tv;
+    if (loop) {
+        if (loop->done) return;
+        T = loop->X;
+    }
+    float qx, qy, qz;
+    xform_point(T, sx[ic], sy[ic], sz[ic], qx, qy, qz);
+    float best = r2;
+    int32_t bidx = -1;
+    solo_walk(records_g, leaf_first, valid, qx, qy, qz, [&]() { return best; }, [&](uint32_t L) {
+        const float4* line = reinterpret_cast<const float4*>(tblk_g + (size_t)L * kLeafFloats);
+        const LineMin w = line_min(line[0], line[1], line[2], line[3], line[4], line[5], qx, qy, qz);
+        const int32_t j = (int32_t)(L * (uint32_t)kLeaf + (uint32_t)w.k);
+        if (w.m < best || (w.m == best && bidx >= 0 && j < bidx)) {
+            best = w.m;
+            bidx = j;
+        }
+    });
+    if (valid) {
+        nn_idx[i] = bidx;
+        if (nn_d2) nn_d2[i] = (bidx >= 0) ? best : INFINITY;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Result export in the reference's layout.
 // ---------------------------------------------------------------------------

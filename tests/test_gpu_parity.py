@@ -460,6 +460,33 @@ def test_voxel_downsample_matches_oracle(eng, n, voxel):
         np.testing.assert_allclose(cs.cpu().numpy(), rcs, atol=1e-6)
 
 
+def test_voxel_downsample_edge_shapes(eng):
+    """The run-wise mean kernel's corners: one point; a voxel that holds 50k copies of one point next to sparse ones (a
+    run of hundreds of 64-element chunks); colours without normals; every point in ONE voxel; a cloud smaller than a
+    wave -- each against the oracle (same voxels, same lexicographic order)."""
+    rng = np.random.default_rng(77)
+    one = np.array([[0.3, -0.2, 0.9]], np.float32)
+    p, _, _ = eng.voxel_downsample(one, 0.05)
+    np.testing.assert_array_equal(p, one)
+    heavy = np.concatenate([np.repeat(np.array([[0.5, 0.5, 0.5]], np.float32), 50000, 0),
+                            rng.random((3000, 3), dtype=np.float32)])[rng.permutation(53000)]
+    col = rng.random((53000, 3), dtype=np.float32)
+    for voxel in (0.01, 0.11):
+        p, nn, c = eng.voxel_downsample(cuda(heavy), voxel, None, cuda(col))
+        rp, _, rc = orc.voxel_downsample(heavy, voxel, None, col)
+        assert nn is None and len(p) == len(rp)
+        np.testing.assert_allclose(p.cpu().numpy(), rp, atol=1e-6)
+        np.testing.assert_allclose(c.cpu().numpy(), rc, atol=2e-6)
+    small = rng.random((37, 3), dtype=np.float32)
+    nrm = rng.standard_normal((37, 3)).astype(np.float32)
+    for voxel in (0.2, 5.0):                                   # 5.0: every point in one voxel
+        p, nn, _ = eng.voxel_downsample(small, voxel, nrm)
+        rp, rn, _ = orc.voxel_downsample(small, voxel, nrm)
+        assert len(p) == len(rp) and (voxel < 1.0 or len(p) == 1)
+        np.testing.assert_allclose(p, rp, atol=1e-6)
+        np.testing.assert_allclose(nn, rn, atol=2e-5)
+
+
 def test_voxel_downsample_both_forms_agree_to_the_last_bit_or_two(tmp_path):
     """The 32-bit-key path with the payload carried through the radix passes (round 4) against the first form (64-bit
     keys, indices, one gather; MI_ICP_VOXEL_OLD=1 in a child process -- the library reads its switches once): the same
