@@ -2206,8 +2206,14 @@ static int voxel_downsample_keys32(mi_icp_ctx* c, const float* dp, const float* 
     voxel_keys32<<<blocks_for(n), 256, 0, c->stream>>>(dp, n, g, keys[0]);
     KCHK(c);
     // the lowest L <= 5 key bits stay unsorted where that saves a pass (21 bits: 2 passes, L = 5; 24 bits: 3, L = 0)
-    const int passes = std::max(0, (bits - 5 + 7) / 8);
-    const int L = std::min(5, std::max(0, bits - 8 * passes));
+    int passes = std::max(0, (bits - 5 + 7) / 8);
+    int L = std::min(5, std::max(0, bits - 8 * passes));
+    // ... but only where runs are long enough to give a wave work: with more possible runs than an eighth of the points
+    // (a fine grid over a sparse cloud: most runs a point or two) the key is sorted whole and 8 lanes take a voxel
+    if (L > 0 && (bits - L >= 31 || ((int64_t)1 << (bits - L)) > n / 8)) {
+        L = 0;
+        passes = (bits + 7) / 8;
+    }
     const Pay3* first[3] = {reinterpret_cast<const Pay3*>(dp), reinterpret_cast<const Pay3*>(dn), reinterpret_cast<const Pay3*>(dcol)};
     Pay3* scratch[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     for (int set = 0; set < std::min(passes, 2); ++set)

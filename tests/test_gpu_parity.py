@@ -431,10 +431,11 @@ def test_voxel_downsample_golden(eng, golden):
 
 
 # (the grid's packed key: 12 / 18 / 42 / 3 bits -- one pass with 4 unsorted low bits, two with 2, the 64-bit fallback,
-# no pass at all -- then 21 bits (two passes, 5 low bits: the 10M bench's shape), 24 (three, none), 30 (four, none),
-# 15 (two, ... ) and a grid that is long in one axis only)
+# no pass at all -- then 21 bits, 24, 30, 15 and a grid that is long in one axis only; the last one is the 10M bench's
+# shape with runs long enough for the run-wise means: 21 bits, two passes, 5 low bits left to the means kernel.  Where a
+# grid has more possible runs than an eighth of the points the key is sorted whole instead)
 @pytest.mark.parametrize("n,voxel", [(1000, 0.1), (200000, 0.02), (200000, 1e-4), (5000, 10.0), (300000, 0.01),
-                                     (300000, 0.004), (100000, 0.001), (50000, 0.04), (70001, 0.3)])
+                                     (300000, 0.004), (100000, 0.001), (50000, 0.04), (70001, 0.3), (800000, 0.01)])
 def test_voxel_downsample_matches_oracle(eng, n, voxel):
     rng = np.random.default_rng(n)
     pts = rng.random((n, 3), dtype=np.float32)
