@@ -183,10 +183,19 @@ __device__ __forceinline__ void kd_median_partition(KdShared& s, const uint32_t 
     __syncthreads();
     for (int shift = 24; shift >= 0; shift -= 8) {
         const uint32_t pre = prefix[seg];
+        // (padding -- 40 % of a 10M-point target's slots, whole waves of it -- shares its upper 20 bits: in the two upper
+        // bytes' passes all of it lands in bin 255, 64 lanes on one LDS address.  Counted per wave instead; a wave's 256
+        // positions lie in one segment.)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (shift == 24 || ((v[c] ^ pre) >> (shift + 8)) == 0u)
-                atomicAdd(&hist[seg * 256 + (int)((v[c] >> shift) & 255u)], 1u);
+        for (int c = 0; c < 4; ++c) {
+            const bool in = shift == 24 || ((v[c] ^ pre) >> (shift + 8)) == 0u;
+            const bool pad = shift >= 16 && v[c] >= 0xfffff000u;
+            if (in && !pad) atomicAdd(&hist[seg * 256 + (int)((v[c] >> shift) & 255u)], 1u);
+            if (shift >= 16) {
+                const uint64_t m = __ballot(in && pad);
+                if (m != 0ull && lane == 0) atomicAdd(&hist[seg * 256 + 255], (uint32_t)__popcll(m));
+            }
+        }
         __syncthreads();
         if (wid < nseg) {  // wave `wid` owns segment `wid`: lane l looks at bins 4l .. 4l+3 and clears them
             uint4* h = reinterpret_cast<uint4*>(hist + wid * 256);
@@ -456,6 +465,10 @@ __device__ __forceinline__ void kd_sort_levels(KdShared& s, int levels, float2* 
                 }
         }
         kd_box_allreduce(mn, mx, S >> 2);  // the segment's S / 4 lanes
+        // A wave that holds nothing but padding (a 10M-point target fills its 4096-slot groups to 60 %: six of a
+        // group's sixteen waves) has nothing to order -- any arrangement of padding is as good as any other.  It
+        // takes part in the siblings' exchange below (with +-inf: no cut) and leaves.
+        const bool idle = !PLANES && lS == 8 && !(mn[0] < INFINITY) && !(mn[1] < INFINITY) && !(mn[2] < INFINITY);
         if (SAFE && lS >= 6) {
             // the sibling half's extreme along the axis the parent was split along
             const bool left = ((4 * tid) & S) == 0;
@@ -478,6 +491,13 @@ __device__ __forceinline__ void kd_sort_levels(KdShared& s, int levels, float2* 
 #pragma unroll
                 for (int e = 0; e < 6; ++e) s.safe[e * 64 + (tid >> 4)] = P[e];
             }
+        }
+        if (idle) {  // (wave-uniform; past the round's only barrier)
+            if (SAFE && (tid & 15) == 0) {  // its four 64-slot nodes: empty regions
+#pragma unroll
+                for (int e = 0; e < 6; ++e) s.safe[e * 64 + (tid >> 4)] = (e < 3) ? INFINITY : -INFINITY;
+            }
+            break;
         }
         int ax;
         float lo, sc;
