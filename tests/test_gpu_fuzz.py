@@ -143,6 +143,37 @@ def test_registration_matches_oracle_on_random_configurations(eng, case):
 _RULES = []
 
 
+@pytest.mark.parametrize("case", range(N_REG))
+def test_voxel_downsample_matches_oracle_on_random_configurations(eng, case):
+    """Random cloud kinds (volume, noisy sheet, clusters of very different density, lattice with duplicates), sizes from
+    one point to 400k, voxel sizes from 'every point alone' to 'one voxel', offsets far from the origin, with and
+    without normals / colours: the grid's key width, the number of radix passes, the bits left to the means kernel and
+    the run lengths all follow from these (geometry_kernels.h) -- same voxels, same order, same means as the oracle."""
+    rng = np.random.default_rng(9000 + case)
+    n = int(10 ** rng.uniform(0, 5.6))
+    pts = random_cloud(rng, n)
+    pts = (pts * np.float32(10.0 ** rng.uniform(-1, 1.5)) + rng.normal(0, 10.0 ** rng.uniform(-1, 2), 3).astype(np.float32)).astype(np.float32)
+    ext = float(np.ptp(pts, axis=0).max()) or 1.0
+    voxel = ext * 10.0 ** rng.uniform(-3.0, 0.5)
+    if ext / voxel > 5e5:                       # (keep the oracle's and the engine's grid inside what float32 indices resolve)
+        voxel = ext / 5e5
+    nrm = rng.standard_normal((n, 3)).astype(np.float32) if rng.random() < 0.6 else None
+    col = rng.random((n, 3), dtype=np.float32) if rng.random() < 0.5 else None
+    p, nn, c = eng.voxel_downsample(pts, voxel, nrm, col)
+    rp, rn, rc = orc.voxel_downsample(pts, voxel, nrm, col)
+    assert len(p) == len(rp), (case, n, voxel, len(p), len(rp))
+    scale = float(np.abs(pts).max()) or 1.0
+    np.testing.assert_allclose(p, rp, atol=2e-6 * scale)
+    if nrm is None:
+        assert nn is None
+    else:
+        np.testing.assert_allclose(nn, rn, atol=4e-5)
+    if col is None:
+        assert c is None
+    else:
+        np.testing.assert_allclose(c, rc, atol=2e-6)
+
+
 @pytest.mark.skipif(os.environ.get("MI_ICP_WAIT_LINKS") is not None, reason="this IS the forced run")
 def test_the_same_cases_with_every_first_pass_from_its_own_seeds():
     """The loops normally get their target's halos on demand and start a first pass from the queries' own

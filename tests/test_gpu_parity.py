@@ -51,7 +51,10 @@ def check_nn(idx, d2, oi, od, src_t, tgt):
         dd = src_t[diff] - tgt[idx[diff]]
         d_alt = (dd[:, 2] * dd[:, 2] + (dd[:, 1] * dd[:, 1] + dd[:, 0] * dd[:, 0])).astype(np.float32)
         assert np.allclose(d_alt, od[diff], rtol=1e-6), "index mismatch that is not a tie"
-        assert len(diff) <= max(2, len(idx) // 1000)
+        # (in general position ties are rare; on a lattice or among duplicated points -- the fuzz test's fourth
+        # cloud kind -- equidistant targets are the rule, and every one of them has just been checked)
+        if len(np.unique(tgt[:, 0])) > 0.9 * len(tgt):
+            assert len(diff) <= max(2, len(idx) // 1000)
 
 
 # --------------------------------------------------------------------------- search
