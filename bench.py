@@ -265,6 +265,53 @@ def strong_big(eng, n_big, steps, warmup, rank, world, local, torch, dist, D, _l
                     % (n_big, n_big, n_big / 8e6)}
 
 
+_ABANDONED = []   # contexts whose RCCL call never returned: never closed (closing would wait for them)
+
+
+def rccl_beside(D, Engine, local, rank, world, timeout_s=180.0):
+    """The in-library RCCL path with `world` ranks -- ncclCommInitRank, the known-answer self-test and 200 timed
+    ncclAllReduce of the 32 sums (mi_icp_comm_autotune) -- on a SCRATCH context and a helper thread, while the
+    engine that runs the bench keeps its mailbox.  A communicator that does not form (or a collective that does not
+    finish) within `timeout_s` is reported and left behind; the bench goes on, and leaves through os._exit at the end."""
+    import threading
+    from cupoch_amd.engine import comm_unique_id
+    try:
+        uid = D.exchange_unique_id(comm_unique_id, rank)   # (torch.distributed broadcast: on the main thread, every rank)
+    except Exception as e:   # noqa: BLE001
+        return {"error": "unique id: %s" % e}
+    box = {}
+
+    def work():
+        try:
+            e2 = Engine(local)
+            box["engine"] = e2
+            e2.comm_init(uid, world, rank)
+            box["tune"] = e2.comm_autotune(200)
+            e2.comm_destroy()
+            e2.close()
+            box["closed"] = True
+        except Exception as e:   # noqa: BLE001
+            box["error"] = str(e)
+
+    os.environ["MI_ICP_NO_MAILBOX"] = "1"   # (read by mi_icp_comm_init at every call: RCCL alone on the scratch context)
+    th = threading.Thread(target=work, daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        _ABANDONED.append((th, box))
+        return {"error": "no answer from RCCL within %.0f s (communicator or collective): left behind" % timeout_s}
+    os.environ.pop("MI_ICP_NO_MAILBOX", None)
+    if "error" in box:
+        if not box.get("closed") and "engine" in box:
+            _ABANDONED.append((th, box))
+        return {"error": box["error"]}
+    tune = box["tune"]
+    return {"latency_us": tune["latency_us"].get("rccl"), "comm_ranks": tune["rccl_comm_count"],
+            "verified": tune["verified"], "exchanges": tune["exchanges"], "set_up_and_test_s": round(time.perf_counter() - t0, 2),
+            "note": "ncclCommInitRank + known-answer self-test + timed ncclAllReduce of the 32 sums, in-library, on a scratch context"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -327,12 +374,18 @@ def main():
     exchange = None
     if world > 1:
         # How the ranks exchange the 32 sums is MEASURED (mi_icp_comm_autotune): the node's shared-memory mailbox
-        # (host-memory words), device inboxes over HIP IPC and the in-library ncclAllReduce each run 200 exchanges of a
-        # known vector, checked exactly and timed (max over ranks); the fastest that passed on every rank is used, one
-        # that fails is skipped.  Set-ups, best first: RCCL communicator + mailbox, the mailbox alone, and -- should
-        # neither come up on every rank -- a host-driven loop over torch.distributed.
+        # (host-memory words) and device inboxes over HIP IPC each run 200 exchanges of a known vector, checked exactly
+        # and timed (max over ranks); the fastest that passed on every rank is used, one that fails is skipped.
+        # Set-ups, in this order: the mailbox alone (shared memory + HIP IPC: nothing that can block on a network),
+        # RCCL communicator + mailbox, and -- should neither come up on every rank -- a host-driven loop over
+        # torch.distributed.  The in-library ncclAllReduce is self-tested and timed BESIDE the first one, on a scratch
+        # context and under a watchdog (rccl_beside, below): its figure is reported, and a communicator that never
+        # forms cannot hold the run.  MI_ICP_BENCH_RCCL_FIRST=1: the communicator on the engine itself, first.
         tried = []
-        for attempt in (("mailbox",) if one_device else ("rccl+mailbox", "mailbox")):
+        order = ("mailbox",) if one_device else ("mailbox", "rccl+mailbox")
+        if os.environ.get("MI_ICP_BENCH_RCCL_FIRST") == "1" and not one_device:
+            order = ("rccl+mailbox", "mailbox")
+        for attempt in order:
             ok, why, tune = 1, "", None
             try:
                 if attempt == "mailbox":
@@ -364,6 +417,14 @@ def main():
             eng.set_global_source_count(n)
             if rank == 0:
                 print("bench: falling back to a host-driven loop with torch.distributed all-reduce", file=sys.stderr)
+        elif (exchange.get("setup") == "mailbox" and os.environ.get("MI_ICP_BENCH_NO_RCCL") != "1" and
+              (not one_device or os.environ.get("MI_ICP_BENCH_RCCL_BESIDE") == "1")):
+            # (MI_ICP_BENCH_RCCL_BESIDE=1 in a one-device rehearsal: RCCL refuses several ranks on one GPU -- the error path)
+            exchange["rccl_in_library"] = rccl_beside(D, Engine, local, rank, world,
+                                                      float(os.environ.get("MI_ICP_BENCH_RCCL_TIMEOUT_S", "180")))
+            if exchange["rccl_in_library"].get("latency_us") is not None:
+                exchange["latency_us"]["rccl"] = exchange["rccl_in_library"]["latency_us"]
+                exchange["rccl_comm_count"] = exchange["rccl_in_library"].get("comm_ranks")
         exchange["tried"] = tried
     elif os.environ.get("MI_ICP_BENCH_HOST_LOOP") == "1":
         host_allreduce = True      # exercises the fallback loop on one rank
@@ -479,7 +540,7 @@ def main():
                        "points": n, "max_correspondence_distance": max_dist, "det_thresh": -1.0,
                        "parallelism": ("source sharded x%d (Morton-contiguous), target + tree replicated; 32 f64 summed over the "
                                        "ranks per iteration via %s -- chosen by a timed known-answer self-test of every "
-                                       "available path, us per exchange (max over ranks): %s; RCCL communicator of %s ranks"
+                                       "available path, us per exchange (max over ranks): %s; in-library RCCL communicator of %s ranks"
                                        % (world, exchange.get("chosen"), json.dumps(exchange.get("latency_us")),
                                           exchange.get("rccl_comm_count")))
                        if world > 1 else "single GPU",
@@ -518,9 +579,13 @@ def main():
     if rank == 0:
         if big is not None:
             out["config"].setdefault("secondary", {})["strong_100M" if args.big_points == 100_000_000 else "strong_big"] = big
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if _ABANDONED:   # a helper thread is still inside RCCL: no teardown that could wait for it
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         eng.comm_destroy()
         dist.destroy_process_group()
     eng.close()

@@ -20,6 +20,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <cctype>
 #include <cstring>
 #include <functional>
@@ -2924,7 +2927,44 @@ int mi_icp_comm_init(mi_icp_ctx* c, const char* id128, int nranks, int rank) {
         g_rccl.CommDestroy(c->comm);
         c->comm = nullptr;
     }
-    ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+    // ncclCommInitRank blocks until EVERY rank has joined; one that never does (a crashed peer, a bootstrap socket the
+    // container's network does not route) would hold the caller forever -- and a scaling run with it, although the
+    // node's mailbox needs no RCCL at all.  So the call runs on a helper thread that owns nothing but its result, and
+    // the caller waits MI_ICP_COMM_INIT_MS (default 120 s; <= 0: for ever) for it: past that the communicator is given
+    // up (the thread is left behind, blocked; it touches nothing of this context), the call fails with
+    // MI_ICP_ERR_COMM and the caller may go on with mi_icp_comm_init_local.
+    struct InitResult {
+        std::mutex m;
+        std::condition_variable cv;
+        bool done = false;
+        ncclResult_t r = ncclSuccess;
+        ncclComm_t comm = nullptr;
+    };
+    static const long init_ms = [] { const char* e = std::getenv("MI_ICP_COMM_INIT_MS"); return e ? std::atol(e) : 120000L; }();
+    auto res = std::make_shared<InitResult>();
+    {
+        const int device = c->device;
+        std::thread([res, device, nranks, id, rank] {
+            ncclComm_t comm = nullptr;
+            ncclResult_t r = (hipSetDevice(device) == hipSuccess) ? g_rccl.CommInitRank(&comm, nranks, id, rank) : ncclUnhandledCudaError;
+            std::lock_guard<std::mutex> g(res->m);
+            res->r = r;
+            res->comm = comm;
+            res->done = true;
+            res->cv.notify_all();
+        }).detach();
+    }
+    {
+        std::unique_lock<std::mutex> g(res->m);
+        if (init_ms > 0) {
+            if (!res->cv.wait_for(g, std::chrono::milliseconds(init_ms), [&] { return res->done; }))
+                return fail(c, MI_ICP_ERR_COMM, "ncclCommInitRank did not return within %ld ms (MI_ICP_COMM_INIT_MS): given up", init_ms);
+        } else {
+            res->cv.wait(g, [&] { return res->done; });
+        }
+    }
+    const ncclResult_t r = res->r;
+    c->comm = res->comm;
     if (r != ncclSuccess) {
         c->comm = nullptr;
         return fail(c, MI_ICP_ERR_COMM, "ncclCommInitRank failed (%d)", (int)r);

@@ -398,7 +398,8 @@ MI_ICP_API int mi_icp_registration_colored_icp(mi_icp_ctx* ctx, float max_distan
  *  - otherwise (MI_ICP_NO_MAILBOX=1, more ranks, mailbox set-up failed) one
  *    ncclAllReduce(double, 32) on the context's stream, then the step kernel.
  * mi_icp_comm_init: RCCL communicator from a shared ncclUniqueId + the mailbox (named after
- * the id).  mi_icp_comm_init_local: the mailbox alone, no RCCL -- all ranks pass the same
+ * the id); ncclCommInitRank blocks until every rank has joined -- the call waits MI_ICP_COMM_INIT_MS (default 120000;
+ * <= 0: for ever) for it and fails with MI_ICP_ERR_COMM past that.  mi_icp_comm_init_local: the mailbox alone, no RCCL -- all ranks pass the same
  * job_name (letters, digits, '_', '-'), one node only.  mi_icp_comm_kind: 0 none, 1 RCCL
  * all-reduce, 2 mailbox, 3 mailbox with device inboxes (every rank keeps an inbox in fine-grained device memory
  * that its peers open through HIP IPC and write their posts into -- GPU to GPU, polls stay local; any rank failing
