@@ -49,7 +49,10 @@ if has rehearsal; then
   for w in 2 8; do
     MI_ICP_BENCH_ONE_DEVICE=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $w --master-addr 127.0.0.1 --master-port 2951$w bench.py --gpus $w --steps 10 --warmup 3 --repeats 2 > $O/rehearsal$w.log 2>&1; echo "rehearsal $w rc=$?"
     grep '^{"metric' $O/rehearsal$w.log
-  done > $O/bench_rehearsal_one_device.jsonl
+  done | grep "^{" > $O/bench_rehearsal_one_device.jsonl
+  # ... and with the in-library RCCL measured beside the mailbox: RCCL refuses a second rank on one device -- the error path
+  MI_ICP_BENCH_ONE_DEVICE=1 MI_ICP_BENCH_RCCL_BESIDE=1 MI_ICP_COMM_INIT_MS=20000 MI_ICP_BENCH_RCCL_TIMEOUT_S=40 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 3 --repeats 2 > $O/rehearsal2b.log 2>&1; echo "rehearsal 2 + rccl beside rc=$?"
+  grep '^{"metric' $O/rehearsal2b.log >> $O/bench_rehearsal_one_device.jsonl
   cut -c1-400 $O/bench_rehearsal_one_device.jsonl
 fi
 if has stats; then
