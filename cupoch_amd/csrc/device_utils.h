@@ -13,8 +13,14 @@ namespace mi {
 
 constexpr int kWave = 64;
 constexpr int kLeaf = 8;          // points per LBVH leaf
-constexpr int kLeafFloats = 32;   // x[8] y[8] z[8] orig_idx[8] = one 128-B line
-constexpr int kLeafRegFloats = 8; // per leaf: region lo.xyz, A | hi.xyz, B (kd_build.h); A, B: the reaches of its halo lines (leaf_halo.h)
+constexpr int kLeafFloats = 32;   // x[8] y[8] z[8] region[8] = one 128-B line
+// The fourth row of a leaf line is the leaf's REGION record: lo.xyz, A | hi.xyz, B (kd_build.h); A, B: the reaches of its
+// halo lines (leaf_halo.h).  (Up to round 3 it held the points' original indices and the regions had an array of their
+// own: the seeded search then touched two cache lines per leaf -- 160 bytes of HBM traffic instead of 128.  The indices,
+// needed only where results leave the library, are an array indexed by slot now: tidx.)
+constexpr int kLeafRegFloats = 8;            // floats of a region record
+constexpr int kLeafRegOffset = 24;           // its place inside the leaf line
+constexpr int kLeafRegStride = kLeafFloats;  // from one leaf's record to the next: `lreg` pointers are tblk + kLeafRegOffset
 
 // Row-major 3x4 rigid transform passed by value as a kernel argument (SGPRs).
 struct Xform {

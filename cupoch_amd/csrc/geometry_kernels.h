@@ -596,12 +596,12 @@ __device__ __forceinline__ float intensity_of(const float* rgb) {
     return (float)((double)((rgb[0] + rgb[1]) + rgb[2]) / 3.0);
 }
 
-__global__ __launch_bounds__(256) void target_intensity(const float* __restrict__ tblk,
+__global__ __launch_bounds__(256) void target_intensity(const int32_t* __restrict__ tidx,
                                                         const float* __restrict__ rgb, int n,
                                                         float4* __restrict__ tnrm) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
-    const int32_t orig = __float_as_int(tblk[(s >> 3) * kLeafFloats + 24 + (s & 7)]);
+    const int32_t orig = tidx[s];
     if (orig >= 0) tnrm[s].w = intensity_of(rgb + (int64_t)orig * 3);  // n counts padding slots too
 }
 

@@ -29,7 +29,8 @@ struct GroupBuildArgs {
     float* trec;              // [ngroups * 4096][6] {x, y, z, nx, ny, nz} or null: what the point-to-plane reduction gathers
     float* tcov;              // [ngroups * 4096 * 9] or null
     float* records;
-    float* lreg;              // [ngroups * 512][8] leaf regions (below)
+    float* lreg;              // tblk + kLeafRegOffset: the leaf lines' fourth rows, [ngroups * 512] region records (below)
+    int32_t* tidx;            // [ngroups * 4096] original index of every slot (-1: padding)
     float link_delta;         // bound of the halos (leaf_halo.h) as a fraction of the leaf-level node's extent
     float region_margin;      // a leaf's region is kept within this many bounds of its own box
 };
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_eu(8, 8
         line[0] = s.cx[li];
         line[8] = s.cy[li];
         line[16] = s.cz[li];
-        line[24] = __int_as_float((int)o);
+        a.tidx[slot0 + p] = (int32_t)o;
         if (a.tnrm) {
             const float4 n4 = real ? make_float4(a.nrm[o * 3], a.nrm[o * 3 + 1], a.nrm[o * 3 + 2], 0.0f)
                                    : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_eu(8, 8
                 reg[3 + d] = fminf(reg[3 + d], s.bb[(3 + d) * kKdChunks + tid] + margin);
             }
         }
-        float4* out = reinterpret_cast<float4*>(a.lreg + ((size_t)g * kKdChunks + (size_t)tid) * kLeafRegFloats);
+        float4* out = reinterpret_cast<float4*>(a.lreg + ((size_t)g * kKdChunks + (size_t)tid) * kLeafRegStride);
         out[0] = make_float4(reg[0], reg[1], reg[2], 0.0f);
         out[1] = make_float4(reg[3], reg[4], reg[5], delta0);
     }

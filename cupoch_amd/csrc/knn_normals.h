@@ -226,8 +226,8 @@ __device__ __forceinline__ bool knn_packet_reaches_too_far(const float* records_
 // normals with the intensity in .w.
 template <int OUT, int KCAP = kMaxKnn>
 __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_normals_kernel(
-        const float* __restrict__ records_g, const float* __restrict__ tblk_g, uint32_t leaf_first, int64_t n,
-        int nleaf,
+        const float* __restrict__ records_g, const float* __restrict__ tblk_g, const int32_t* __restrict__ tidx_g,
+        uint32_t leaf_first, int64_t n, int nleaf,
         int k, float r2, uint32_t nblocks, float* __restrict__ normals_out,
         const float4* __restrict__ tnrm, float4* __restrict__ tgrad, int32_t* __restrict__ idx_slab) {
     constexpr int kWaves = knn_waves(KCAP);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_normals_kernel(
         qx = line[0];
         qy = line[8];
         qz = line[16];
-        orig = __float_as_int(line[24]);
+        orig = tidx_g[i];
     }
     const bool valid = orig >= 0;
     KnnStateT<KCAP> st;
@@ -431,8 +431,8 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_normals_kernel(
 // [k] of indices / squared distances, padded with -1 / +inf, at the query's ORIGINAL index.
 template <int KCAP = kMaxKnn>
 __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
-        const float* __restrict__ records_g, const float* __restrict__ tblk_g, uint32_t leaf_first,
-        const float* __restrict__ qx_g, const float* __restrict__ qy_g, const float* __restrict__ qz_g,
+        const float* __restrict__ records_g, const float* __restrict__ tblk_g, const int32_t* __restrict__ tidx_g,
+        uint32_t leaf_first, const float* __restrict__ qx_g, const float* __restrict__ qy_g, const float* __restrict__ qz_g,
         const int32_t* __restrict__ qperm, int nq, int nleaf, int k, float r2, uint32_t nblocks,
         int32_t* __restrict__ idx_out, float* __restrict__ d2_out, unsigned long long* __restrict__ found,
         int32_t* __restrict__ idx_slab) {
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
         // (global memory) are compared only between entries whose distances are equal
         for (int t = 0; t < st.count; ++t) {
             const int32_t j = kidx[t * 64 + lane];
-            kidx[t * 64 + lane] = __float_as_int(tblk_g[(int64_t)(j >> 3) * kLeafFloats + 24 + (j & 7)]);
+            kidx[t * 64 + lane] = tidx_g[j];
         }
         for (int a = 0; a < st.count; ++a) {
             const float dv = kd2[a * 64 + lane];
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
         if (t < st.count) {
             const int32_t j = kidx[t * 64 + lane];
             v[t] = kd2[t * 64 + lane];
-            p[t] = __float_as_int(tblk_g[(int64_t)(j >> 3) * kLeafFloats + 24 + (j & 7)]);
+            p[t] = tidx_g[j];
         }
     }
 #pragma unroll

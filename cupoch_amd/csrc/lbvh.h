@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void build_leaves(
         const uint32_t* __restrict__ order, const float* __restrict__ pts,
         const float* __restrict__ nrm, const float* __restrict__ cov, int64_t n, int nleaf, int nslots,
         uint32_t leaf_first, float* __restrict__ tblk, float4* __restrict__ tnrm,
-        float* __restrict__ tcov, float* __restrict__ records, float* __restrict__ trec) {
+        float* __restrict__ tcov, float* __restrict__ records, float* __restrict__ trec, int32_t* __restrict__ tidx) {
     const int L = (int)(blockIdx.x * 256 + threadIdx.x);
     if (L >= nslots) return;
     float mn[3] = {INFINITY, INFINITY, INFINITY};
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void build_leaves(
             line[k] = p[0];
             line[8 + k] = p[1];
             line[16 + k] = p[2];
-            line[24 + k] = __int_as_float(o);
+            tidx[s] = o;
         }
     }
     // the leaf is child (L & 7) of last-level node leaf_first + (L >> 3)
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void build_level(float* __restrict__ records, 
 __global__ __launch_bounds__(256) void fill_invalid_leaf_regions(float* __restrict__ lreg, int nleaf) {
     const int L = (int)(blockIdx.x * 256 + threadIdx.x);
     if (L >= nleaf) return;
-    float4* out = reinterpret_cast<float4*>(lreg + (size_t)L * kLeafRegFloats);
+    float4* out = reinterpret_cast<float4*>(lreg + (size_t)L * kLeafRegStride);
     out[0] = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);
     out[1] = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
 }

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const bool valid = L < (uint32_t)nleaf;
     float4 g0 = make_float4(INFINITY, INFINITY, INFINITY, 0.0f), g1 = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
     if (valid) {
-        const float4* rg = reinterpret_cast<const float4*>(lreg + (size_t)L * kLeafRegFloats);
+        const float4* rg = reinterpret_cast<const float4*>(lreg + (size_t)L * kLeafRegStride);
         g0 = rg[0];
         g1 = rg[1];
     }
@@ -120,8 +120,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                       });
     }
     if (!valid) return;
-    lreg[(size_t)L * kLeafRegFloats + 3] = usable ? bound : 0.0f;
-    lreg[(size_t)L * kLeafRegFloats + 7] = __int_as_float(count);
+    lreg[(size_t)L * kLeafRegStride + 3] = usable ? bound : 0.0f;
+    lreg[(size_t)L * kLeafRegStride + 7] = __int_as_float(count);
 }
 
 // inclusive prefix sum over the wave on the DPP network (row_shr 1, 2, 4, 8 scan each row of 16 lanes,
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64) void leaf_halo_build(float* __restrict__ lreg, 
     int cnt_mine = 0;
     {
         const uint32_t Lm = base + (uint32_t)(lane & 15);
-        if (Lm < (uint32_t)nleaf) cnt_mine = __float_as_int(lreg[(size_t)Lm * kLeafRegFloats + 7]);
+        if (Lm < (uint32_t)nleaf) cnt_mine = __float_as_int(lreg[(size_t)Lm * kLeafRegStride + 7]);
         int cmax = cnt_mine;
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o, 64));
@@ -226,14 +226,14 @@ __global__ __launch_bounds__(64) void leaf_halo_build(float* __restrict__ lreg, 
         if (L >= (uint32_t)nleaf) break;
         const int count = __shfl(cnt_mine, li, 64);
         float* lines = halo + (size_t)L * (kHaloLines * kHaloLineFloats);
-        const float4* rg = reinterpret_cast<const float4*>(lreg + (size_t)L * kLeafRegFloats);
+        const float4* rg = reinterpret_cast<const float4*>(lreg + (size_t)L * kLeafRegStride);
         const float4 g0 = rg[0], g1 = rg[1];
         float bound = g0.w;  // (collect's final bound; 0: not usable)
         if (count <= 0 || !(bound > 0.0f)) {
             // no halo: the search never reads the lines (reaches 0)
             if (lane == 0) {
-                lreg[(size_t)L * kLeafRegFloats + 3] = 0.0f;
-                lreg[(size_t)L * kLeafRegFloats + 7] = 0.0f;
+                lreg[(size_t)L * kLeafRegStride + 3] = 0.0f;
+                lreg[(size_t)L * kLeafRegStride + 7] = 0.0f;
             }
             continue;
         }
@@ -374,8 +374,8 @@ __global__ __launch_bounds__(64) void leaf_halo_build(float* __restrict__ lreg, 
         const uint32_t wa = (uint32_t)__builtin_amdgcn_readlane((int)pa, 7);
         const uint32_t wb = bbits | (uint32_t)__builtin_amdgcn_readlane((int)pb, 7);
         if (lane == 0) {
-            lreg[(size_t)L * kLeafRegFloats + 3] = __uint_as_float(wa);
-            lreg[(size_t)L * kLeafRegFloats + 7] = (unit > 0.0f) ? __uint_as_float(wb) : 0.0f;
+            lreg[(size_t)L * kLeafRegStride + 3] = __uint_as_float(wa);
+            lreg[(size_t)L * kLeafRegStride + 7] = (unit > 0.0f) ? __uint_as_float(wb) : 0.0f;
         }
         __builtin_amdgcn_wave_barrier();  // (keys are rewritten by the next leaf)
     }

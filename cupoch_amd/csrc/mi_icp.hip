@@ -101,7 +101,7 @@ struct mi_icp_ctx {
     int64_t nts = 0;  // sorted positions of the target incl. padding slots (kd_cells.h)
     uint32_t leaf_first = 1, nrecords = 0;  // 8-ary tree: first last-level node id, record count
     bool t_has_nrm = false, t_has_cov = false, t_has_int = false, t_has_grad = false, t_has_rec = false;
-    DevBuf tblk, tnrm, trec, tcov, tgrad, nodes, inv_t, tlreg, thalo, tlinks_tmp;
+    DevBuf tblk, tnrm, trec, tcov, tgrad, nodes, inv_t, tidx, thalo, tlinks_tmp;  // (leaf regions: the leaf lines' fourth rows, lreg_of)
     DevBuf cell_planes, cell_samples, cell_cstart, cell_gstart;
     uint32_t* cell_total_host = nullptr;  // pinned
     bool inv_t_valid = false;
@@ -193,6 +193,9 @@ struct mi_icp_ctx {
     bool ev_pending_nn = false, ev_pending_red = false;
     double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
+
+// the leaves' region records: the fourth row of every leaf line (device_utils.h: kLeafRegOffset, kLeafRegStride)
+static inline float* lreg_of(const mi_icp_ctx* c) { return c->tblk.p ? (float*)c->tblk.p + mi::kLeafRegOffset : nullptr; }
 
 namespace {
 
@@ -502,9 +505,9 @@ int build_links(mi_icp_ctx* c, hipStream_t st) {
     TRY(ensure(c, c->tlinks_tmp, ntiles * 64 * kLinkCand, &cand));
     const uint32_t lblocks = (uint32_t)ntiles;
     leaf_halo_collect<<<((lblocks + 7u) / 8u) * 8u, 64, 0, st>>>(
-            (const float*)c->nodes.p, c->leaf_first, c->nleaf, lblocks, (float*)c->tlreg.p, cand);
+            (const float*)c->nodes.p, c->leaf_first, c->nleaf, lblocks, lreg_of(c), cand);
     KCHK(c);
-    leaf_halo_build<<<(unsigned)(((size_t)c->nleaf + kHaloTile - 1) / kHaloTile), 64, 0, st>>>((float*)c->tlreg.p, c->nleaf, cand, (const float*)c->tblk.p, halo);
+    leaf_halo_build<<<(unsigned)(((size_t)c->nleaf + kHaloTile - 1) / kHaloTile), 64, 0, st>>>(lreg_of(c), c->nleaf, cand, (const float*)c->tblk.p, halo);
     KCHK(c);
     return MI_ICP_OK;
 }
@@ -612,7 +615,7 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
         const uint32_t npackets = (uint32_t)((ns + 63) / 64);
         const uint32_t nblocks = (npackets + kNNPacketsPerBlock - 1) / kNNPacketsPerBlock;
         const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
-#define MI_NN_ARGS sx, sy, sz, (int)ns, (const float*)c->nodes.p, (const float*)c->tblk.p, (const float*)c->tlreg.p, \
+#define MI_NN_ARGS sx, sy, sz, (int)ns, (const float*)c->nodes.p, (const float*)c->tblk.p, (const float*)lreg_of(c), \
                    links, c->leaf_first, X, loop, r2, nblocks, out_idx, out_d2, stats, want
         if (stats) {
             if (seeded) nn_packet_kernel<true, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
@@ -668,7 +671,7 @@ int ensure_inverse_maps(mi_icp_ctx* c) {
         int32_t* inv;
         TRY(ensure(c, c->inv_t, (size_t)c->nt, &inv));
         HIPCHK(c, hipMemsetAsync(inv, 0xff, sizeof(int32_t) * (size_t)c->nt, c->stream));
-        invert_perm_target<<<blocks_for(c->nts), 256, 0, c->stream>>>((const float*)c->tblk.p, (int)c->nts, inv);
+        invert_perm_target<<<blocks_for(c->nts), 256, 0, c->stream>>>((const int32_t*)c->tidx.p, (int)c->nts, inv);
         KCHK(c);
         c->inv_t_valid = true;
     }
@@ -1217,7 +1220,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
     if (c->ev_links) (void)hipEventDestroy(c->ev_links);
     mailbox_close(c);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    DevBuf* all[] = {&c->trec, &c->tlreg, &c->thalo, &c->tlinks_tmp, &c->halo_want, &c->loop_hist, &c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
+    DevBuf* all[] = {&c->trec, &c->tidx, &c->thalo, &c->tlinks_tmp, &c->halo_want, &c->loop_hist, &c->tblk, &c->tnrm, &c->tcov, &c->tgrad, &c->sint, &c->nodes, &c->inv_t, &c->cell_planes, &c->cell_samples, &c->cell_cstart,
                      &c->cell_gstart, &c->sx, &c->sy, &c->sz,
                      &c->sperm, &c->snrm, &c->scov, &c->nn_idx, &c->nn_d2, &c->inv_s,
                      &c->user_pairs, &c->keys0, &c->keys1, &c->vals0, &c->vals1, &c->hist,
@@ -1338,8 +1341,9 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     float* nodes;
     TRY(ensure(c, c->tblk, (size_t)nleaf * kLeafFloats, &tblk));
     TRY(ensure(c, c->nodes, (size_t)nrecords * kRecordFloats, &nodes));
-    float* lreg;
-    TRY(ensure(c, c->tlreg, (size_t)nleaf * kLeafRegFloats, &lreg));
+    float* lreg = tblk + kLeafRegOffset;  // the region records: fourth row of every leaf line (device_utils.h)
+    int32_t* tidx;
+    TRY(ensure(c, c->tidx, (size_t)nleaf * kLeaf, &tidx));
     float* trec = nullptr;
     static const bool no_trec = std::getenv("MI_ICP_NO_TREC") != nullptr;  // A/B switch
     if (d_nrm) TRY(ensure(c, c->tnrm, (size_t)nts, &tnrm));
@@ -1356,7 +1360,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
         KCHK(c);
         const int nslots = (int)used_last * 8;
         build_leaves<<<blocks_for(nslots), 256, 0, c->stream>>>(order, d_pts, d_nrm, d_cov, nts, nleaf, nslots,
-                                                                leaf_first, tblk, tnrm, tcov, nodes, trec);
+                                                                leaf_first, tblk, tnrm, tcov, nodes, trec, tidx);
         KCHK(c);
         first = leaf_first;
         used = used_last;
@@ -1379,6 +1383,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
         ga.tcov = tcov;
         ga.records = nodes;
         ga.lreg = lreg;
+        ga.tidx = tidx;
         static const float link_delta = [] { const char* e = std::getenv("MI_ICP_LINK_DELTA"); const float v = e ? (float)std::atof(e) : 0.0f; return v > 0.0f ? v : 0.25f; }();
         ga.link_delta = link_delta;
         static const float region_margin = [] { const char* e = std::getenv("MI_ICP_REGION_MARGIN"); const float v = e ? (float)std::atof(e) : 0.0f; return v > 0.0f ? v : 0.5f; }();
@@ -1496,7 +1501,7 @@ static int export_dense_idx(mi_icp_ctx* c, int32_t** dense_out) {
     if (c->ns > 0) {
         export_dense<<<blocks_for(c->ns), 256, 0, c->stream>>>(
                 (const int32_t*)c->nn_idx.p, (const float*)c->nn_d2.p, (const int32_t*)c->sperm.p,
-                (const float*)c->tblk.p, (int)c->ns, dense, nullptr);
+                (const int32_t*)c->tidx.p, (int)c->ns, dense, nullptr);
         KCHK(c);
     }
     *dense_out = dense;
@@ -1522,7 +1527,7 @@ int mi_icp_search_radius_1nn(mi_icp_ctx* c, const float* T, float radius, int32_
         if (d2_out) TRY(ensure(c, c->flags, (size_t)c->ns, (float**)&dense_d2));
         export_dense<<<blocks_for(c->ns), 256, 0, c->stream>>>(
                 (const int32_t*)c->nn_idx.p, (const float*)c->nn_d2.p, (const int32_t*)c->sperm.p,
-                (const float*)c->tblk.p, (int)c->ns, dense, dense_d2);
+                (const int32_t*)c->tidx.p, (int)c->ns, dense, dense_d2);
         KCHK(c);
         TRY(from_device(c, dense, idx_out, (size_t)c->ns, mem_kind));
         if (d2_out) TRY(from_device(c, dense_d2, d2_out, (size_t)c->ns, mem_kind));
@@ -1813,7 +1818,7 @@ static int launch_fused_iteration(mi_icp_ctx* c, DevLoop* d) {
     EvTimer t(c, 0, true);
     icp_small_iteration_kernel<<<grid, kReduceThreads, 0, c->stream>>>(
             (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns, (const float*)c->nodes.p,
-            (const float*)c->tblk.p, (const float*)c->tlreg.p, have_halo ? (const float*)c->thalo.p : nullptr, c->leaf_first,
+            (const float*)c->tblk.p, (const float*)lreg_of(c), have_halo ? (const float*)c->thalo.p : nullptr, c->leaf_first,
             c->loop_r2, npackets, nblocks, (int32_t*)c->nn_idx.p, want, (const float*)c->trec.p, d, partial, (uint32_t*)c->ticket.p, sys);
     KCHK(c);
     c->last_search_kind = 1;
@@ -1854,7 +1859,7 @@ static int launch_mid_iteration(mi_icp_ctx* c, DevLoop* d, bool* stepped) {
     const MailArgs no_mail = {nullptr, nullptr, 0, 1, 0u, nullptr, nullptr};
     EvTimer t(c, 0, true);
 #define MI_MID_ARGS (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns, (const float*)c->nodes.p, \
-            (const float*)c->tblk.p, (const float*)c->tlreg.p, have_halo ? (const float*)c->thalo.p : nullptr, c->leaf_first, \
+            (const float*)c->tblk.p, (const float*)lreg_of(c), have_halo ? (const float*)c->thalo.p : nullptr, c->leaf_first, \
             c->loop_r2, npackets, ppw, nblocks, (int32_t*)c->nn_idx.p, want, (const float*)c->trec.p, d, partial, (uint32_t*)c->ticket.p, sys
     if (mail_on(c)) {
         icp_mid_iteration_kernel<2><<<grid, kReduceThreads, 0, c->stream>>>(MI_MID_ARGS, mail_args(c));
@@ -2753,7 +2758,7 @@ static int estimate_normals_impl(mi_icp_ctx* c, const float* xyz, int64_t n, int
         const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
         int32_t* slab;
         TRY(ensure(a, a->knn_idx, (size_t)nblocks * waves * cap * 64, &slab));
-#define MI_NRM_ARGS (const float*)a->nodes.p, (const float*)a->tblk.p, a->leaf_first, a->nts, a->nleaf, knn, r2, nblocks, \
+#define MI_NRM_ARGS (const float*)a->nodes.p, (const float*)a->tblk.p, (const int32_t*)a->tidx.p, a->leaf_first, a->nts, a->nleaf, knn, r2, nblocks, \
                     dn, nullptr, nullptr, slab
         if (cap == kMaxKnn) knn_normals_kernel<0, kMaxKnn><<<grid, waves * 64, 0, a->stream>>>(MI_NRM_ARGS);
         else if (cap == kMaxKnnMid) knn_normals_kernel<0, kMaxKnnMid><<<grid, waves * 64, 0, a->stream>>>(MI_NRM_ARGS);
@@ -2807,7 +2812,7 @@ int mi_icp_search_knn(mi_icp_ctx* c, const float* queries, int64_t nq, int knn, 
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
     int32_t* slab;
     TRY(ensure(c, c->knn_idx, (size_t)nblocks * waves * cap * 64, &slab));
-#define MI_KNN_ARGS (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, (const float*)c->sx.p, \
+#define MI_KNN_ARGS (const float*)c->nodes.p, (const float*)c->tblk.p, (const int32_t*)c->tidx.p, c->leaf_first, (const float*)c->sx.p, \
                     (const float*)c->sy.p, (const float*)c->sz.p, (const int32_t*)c->sperm.p, (int)nq, c->nleaf, knn, \
                     radius > 0.0f ? radius * radius : INFINITY, nblocks, d_idx, d_d2, cnt, slab
     if (cap == kMaxKnn) knn_search_kernel<kMaxKnn><<<grid, waves * 64, 0, c->stream>>>(MI_KNN_ARGS);
@@ -2835,7 +2840,7 @@ int mi_icp_set_target_colors(mi_icp_ctx* c, const float* rgb, int mem_kind) {
         return fail(c, MI_ICP_ERR_STATE, "set_target_colors: the target has no normals");
     const float* d_rgb;
     TRY(to_device(c, rgb, (size_t)c->nt * 3, mem_kind, c->stage[1], &d_rgb));
-    target_intensity<<<blocks_for(c->nts), 256, 0, c->stream>>>((const float*)c->tblk.p, d_rgb, (int)c->nts,
+    target_intensity<<<blocks_for(c->nts), 256, 0, c->stream>>>((const int32_t*)c->tidx.p, d_rgb, (int)c->nts,
                                                               (float4*)c->tnrm.p);
     KCHK(c);
     c->t_has_int = true;
@@ -2881,7 +2886,7 @@ int mi_icp_compute_color_gradients(mi_icp_ctx* c, float radius, int max_nn, floa
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
     int32_t* slab;
     TRY(ensure(c, c->knn_idx, (size_t)nblocks * waves * cap * 64, &slab));
-#define MI_GRAD_ARGS (const float*)c->nodes.p, (const float*)c->tblk.p, c->leaf_first, c->nts, c->nleaf, max_nn, \
+#define MI_GRAD_ARGS (const float*)c->nodes.p, (const float*)c->tblk.p, (const int32_t*)c->tidx.p, c->leaf_first, c->nts, c->nleaf, max_nn, \
                      radius * radius, nblocks, dg, (const float4*)c->tnrm.p, tgrad, slab
     if (cap == kMaxKnn) knn_normals_kernel<1, kMaxKnn><<<grid, waves * 64, 0, c->stream>>>(MI_GRAD_ARGS);
     else if (cap == kMaxKnnMid) knn_normals_kernel<1, kMaxKnnMid><<<grid, waves * 64, 0, c->stream>>>(MI_GRAD_ARGS);
@@ -3286,8 +3291,8 @@ int mi_icp_debug_nn_stats(mi_icp_ctx* c, const float* T, float radius, int use_s
 int mi_icp_debug_get_leaf_regions(mi_icp_ctx* c, float* regions_out) {
     TRY(check_ctx(c));
     if (!regions_out || c->nt <= 0) return fail(c, MI_ICP_ERR_INVALID, "debug_get_leaf_regions: no target / bad arguments");
-    HIPCHK(c, hipMemcpyAsync(regions_out, c->tlreg.p, (size_t)c->nleaf * kLeafRegFloats * sizeof(float),
-                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(regions_out, kLeafRegFloats * sizeof(float), lreg_of(c), kLeafRegStride * sizeof(float),
+                               kLeafRegFloats * sizeof(float), (size_t)c->nleaf, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MI_ICP_OK;
 }
@@ -3368,9 +3373,14 @@ int mi_icp_debug_get_tree(mi_icp_ctx* c, int64_t* info5, float* records_out, flo
     if (records_out)
         HIPCHK(c, hipMemcpyAsync(records_out, c->nodes.p, (size_t)c->nrecords * kRecordFloats * sizeof(float),
                                  hipMemcpyDeviceToHost, c->stream));
-    if (leaf_lines_out)
+    // (handed out in the form x[8] y[8] z[8] orig_idx[8]: the indices have an array of their own on the device, the
+    // lines' fourth rows hold the regions -- mi_icp_debug_get_leaf_regions)
+    if (leaf_lines_out) {
         HIPCHK(c, hipMemcpyAsync(leaf_lines_out, c->tblk.p, (size_t)c->nleaf * kLeafFloats * sizeof(float),
                                  hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(leaf_lines_out + kLeafRegOffset, kLeafFloats * sizeof(float), c->tidx.p, kLeaf * sizeof(int32_t),
+                                   kLeaf * sizeof(int32_t), (size_t)c->nleaf, hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MI_ICP_OK;
 }

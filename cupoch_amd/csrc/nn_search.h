@@ -236,7 +236,7 @@ __device__ __forceinline__ bool nn_packet_body(
         // (lanes without a previous match read leaf 0: no branch between the index and its loads)
         const uint32_t Lc = (j >= 0) ? ((uint32_t)j >> 3) : 0u;
         const float4* line = reinterpret_cast<const float4*>(tblk_g + (size_t)Lc * kLeafFloats);
-        const float4* rg = reinterpret_cast<const float4*>(lreg_g + (size_t)Lc * kLeafRegFloats);
+        const float4* rg = reinterpret_cast<const float4*>(lreg_g + (size_t)Lc * kLeafRegStride);
         const float4 x0 = line[0], x1 = line[1], y0 = line[2], y1 = line[3], z0 = line[4], z1 = line[5];
         const float4 g0 = rg[0], g1 = rg[1];
         if (j >= 0) {
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void locate_leaves(const float* __restrict__ s
 __global__ __launch_bounds__(256) void export_dense(const int32_t* __restrict__ nn_idx,
                                                     const float* __restrict__ nn_d2,
                                                     const int32_t* __restrict__ sperm,
-                                                    const float* __restrict__ tblk, int ns,
+                                                    const int32_t* __restrict__ tidx, int ns,
                                                     int32_t* __restrict__ idx_out,
                                                     float* __restrict__ d2_out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256) void export_dense(const int32_t* __restrict__ 
     const int32_t j = nn_idx[i];
     const int32_t o = sperm[i];
     int32_t tj = -1;
-    if (j >= 0) tj = __float_as_int(tblk[(int64_t)(j >> 3) * kLeafFloats + 24 + (j & 7)]);
+    if (j >= 0) tj = tidx[j];
     if (idx_out) idx_out[o] = tj;
     if (d2_out) d2_out[o] = nn_d2[i];
 }
@@ -723,11 +723,11 @@ __global__ __launch_bounds__(256) void invert_perm_source(const int32_t* __restr
     if (s < ns) inv[sperm[s]] = (int32_t)s;
 }
 
-__global__ __launch_bounds__(256) void invert_perm_target(const float* __restrict__ tblk, int nt,
+__global__ __launch_bounds__(256) void invert_perm_target(const int32_t* __restrict__ tidx, int nt,
                                                           int32_t* __restrict__ inv) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s < nt) {  // nt = sorted positions incl. padding slots (original index -1)
-        const int32_t o = __float_as_int(tblk[(s >> 3) * kLeafFloats + 24 + (s & 7)]);
+        const int32_t o = tidx[s];
         if (o >= 0) inv[o] = (int32_t)s;
     }
 }

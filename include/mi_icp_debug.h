@@ -54,8 +54,9 @@ MI_ICP_API int mi_icp_debug_solve_both(int device, const double* systems, int n,
  * (padded sorted positions), leaves, leaf_first (id of the first leaf-level node), records,
  * points}.  records_out (records * 64 floats: 8 child boxes as 4 sibling pairs of 12,
  * floats 48..53 the node's region, 54 its validity flag) and leaf_lines_out (leaves * 32
- * floats: x[8] y[8] z[8] original index[8], padding = +inf / -1) may be NULL to query the
- * sizes only. */
+ * floats: x[8] y[8] z[8] original index[8], padding = +inf / -1; on the device a line's fourth
+ * row holds the leaf's region record and the indices are an array of their own -- the export
+ * puts the indices there) may be NULL to query the sizes only. */
 MI_ICP_API int mi_icp_debug_get_tree(mi_icp_ctx* ctx, int64_t* info5, float* records_out,
                                      float* leaf_lines_out);
 /* Per leaf (mi_icp_debug_get_tree's info5[1] leaves) 8 floats: region lo.xyz, word A, region hi.xyz,
