@@ -2,12 +2,12 @@
 # Round 4: the validation + every measurement that goes into profiles/r04_* -- ONE pass on the code as committed
 # (gpurun -- scripts/gpu_final_r04.sh [sections]).  Everything lands under gpurun_out/r04/; scripts/collect_profiles_r04.sh
 # copies it into profiles/ under the names profiles/README.md lists.
-# sections (default: all): tests bench rows rehearsal stats pmc traffic pmcrows
+# sections (default: all): tests traffic bench rows rehearsal stats pmc pmcrows
 O=gpurun_out/r04
 mkdir -p $O
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-S=${*:-tests bench rows rehearsal stats pmc traffic pmcrows}
+S=${*:-tests traffic bench rows rehearsal stats pmc pmcrows}
 has() { [[ " $S " == *" $1 "* ]]; }
 prof() { (cd /tmp && timeout 300 rocprofv3 "$@"); }
 if has tests; then
@@ -16,6 +16,16 @@ if has tests; then
   timeout 300 python __graft_entry__.py smoke 2>&1 | grep -v amdgpu.ids | tail -2 | tee $O/smoke.log
   cp gpurun_out/fuzz_registration_rules.json $O/ 2>/dev/null
   python scripts/dev/occupancy.py 2>&1 | grep occupancy > $O/occupancy.txt
+fi
+# (the traffic section runs ahead of the bench: bench.py quotes profiles/nn_traffic.json, which this section writes)
+if has traffic; then
+  scripts/gpu_traffic.sh > $O/traffic.log 2>&1; tail -6 $O/traffic.log
+  [ -s gpurun_out/nn_traffic.json ] && cp gpurun_out/nn_traffic.json profiles/nn_traffic.json   # (this box's copy: what the bench section quotes)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    prof --kernel-trace --pmc $c --output-format csv -d $R/$O/pmc_noisy_$c -o p -- python $R/scripts/dev/noisy_one.py 0.15 > $O/pmc_noisy_$c.log 2>&1; echo "pmc noisy $c rc=$?"
+  done
+  { echo "# FETCH_SIZE / WRITE_SIZE (KB per launch as reported: vector loads count at half their bytes, profiles/r04_fetch_calibration.txt) on the noisy workload"
+    python scripts/pmc_kernels.py "$O/pmc_noisy_*SIZE/p_counter_collection.csv" "nn_packet_kernel<true" leaf_halo; } | tee $O/pmc_noisy_traffic.txt
 fi
 if has bench; then
   timeout 900 python bench.py 2>&1 | grep '^{"metric' | tee $O/bench_10m.json | python scripts/benchline.py
@@ -75,14 +85,6 @@ if has pmc; then
     python scripts/pmc_kernels.py "$O/pmc_head*/p_counter_collection.csv" "nn_packet_kernel<true" reduce_pt2pl
     echo "# the same counters on the noisy workload (scripts/dev/noisy_one.py 0.15: 10M target, 6M noisy source, sigma = 0.15 spacings, converged iterations with halos)"
     python scripts/pmc_kernels.py "$O/pmc_noisy*/p_counter_collection.csv" "nn_packet_kernel<true" leaf_halo; } | tee $O/pmc_summary.txt
-fi
-if has traffic; then
-  scripts/gpu_traffic.sh > $O/traffic.log 2>&1; tail -6 $O/traffic.log
-  for c in FETCH_SIZE WRITE_SIZE; do
-    prof --kernel-trace --pmc $c --output-format csv -d $R/$O/pmc_noisy_$c -o p -- python $R/scripts/dev/noisy_one.py 0.15 > $O/pmc_noisy_$c.log 2>&1; echo "pmc noisy $c rc=$?"
-  done
-  { echo "# FETCH_SIZE / WRITE_SIZE (KB per launch as reported: vector loads count at half their bytes, profiles/r04_fetch_calibration.txt) on the noisy workload"
-    python scripts/pmc_kernels.py "$O/pmc_noisy_*SIZE/p_counter_collection.csv" "nn_packet_kernel<true" leaf_halo; } | tee $O/pmc_noisy_traffic.txt
 fi
 if has pmcrows; then
   i=0
