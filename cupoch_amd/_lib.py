@@ -16,8 +16,10 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmi_icp.so")
 INCLUDE = os.path.join(ROOT, "include")
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-               "-shared", "-I/opt/rocm/include"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-I/opt/rocm/include"]
+# the library's translation units (csrc/ctx.h says what each holds); compiled side by side, then linked
+UNITS = ["mi_icp", "mi_build", "mi_geometry", "mi_knn", "mi_comm", "mi_debug"]
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 
 MI_ICP_HOST, MI_ICP_DEVICE = 0, 1
 EST_POINT_TO_POINT, EST_POINT_TO_PLANE, EST_SYMMETRIC, EST_GENERALIZED = 1, 2, 3, 5
@@ -42,16 +44,33 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 ... -o cupoch_amd/lib/libmi_icp.so"""
+    """hipcc --offload-arch=gfx950 -c csrc/<unit>.hip for every unit (in parallel; a unit whose object is newer than
+    every source is kept), then hipcc -shared ... -o cupoch_amd/lib/libmi_icp.so"""
     if not force and not needs_build():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise MiIcpError("hipcc not found; cannot build libmi_icp.so")
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, "mi_icp.hip"), "-o", LIB_PATH + ".tmp"]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    headers = [s for s in _sources() if s.endswith(".h")]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+
+    def compile_unit(u):
+        src, obj = os.path.join(CSRC, u + ".hip"), os.path.join(OBJ_DIR, u + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(newest_header, os.path.getmtime(src)):
+            return obj
+        cmd = [hipcc] + HIPCC_FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(UNITS)) as pool:
+        objs = list(pool.map(compile_unit, UNITS))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH + ".tmp"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH

@@ -70,7 +70,7 @@ __device__ __forceinline__ void strided_pixel(const DepthArgs& a, int64_t idx, i
     col = (int)(idx % sw) * a.stride;
 }
 
-__global__ __launch_bounds__(256) void depth_valid_flags(DepthArgs a, int64_t count, uint32_t* __restrict__ flags) {
+static __global__ __launch_bounds__(256) void depth_valid_flags(DepthArgs a, int64_t count, uint32_t* __restrict__ flags) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= count) return;
     int row, col;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void depth_valid_flags(DepthArgs a, int64_t co
 }
 
 // pos == null: every pixel is written at its own index (project_valid_depth_only = false)
-__global__ __launch_bounds__(256) void depth_emit(DepthArgs a, int64_t count, const uint32_t* __restrict__ pos,
+static __global__ __launch_bounds__(256) void depth_emit(DepthArgs a, int64_t count, const uint32_t* __restrict__ pos,
                                                   float* __restrict__ out_xyz, float* __restrict__ out_nrm,
                                                   float* __restrict__ out_rgb) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;

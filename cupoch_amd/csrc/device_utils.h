@@ -9,6 +9,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The hand-offs that replace a release fence by "returnless atomics drained with s_waitcnt vmcnt(0) before the ticket"
+// (kd_build.h tree_scale, reduce.h) rely on the gfx9 family's counters: stores and returnless atomics are tracked by
+// vmcnt there (gfx10+ has a separate vscnt).  This library is written for gfx950 only; anything else must not compile.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libmi_icp is written for gfx950 (CDNA4) only: wave64, gfx9 vmcnt semantics, 160 KB LDS"
+#endif
+
 namespace mi {
 
 constexpr int kWave = 64;

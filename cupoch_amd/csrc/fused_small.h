@@ -20,7 +20,7 @@ namespace mi {
 
 constexpr int kFusedPackets = kReduceThreads / 64;  // packets per workgroup
 
-__global__ __launch_bounds__(kReduceThreads) void icp_small_iteration_kernel(
+static __global__ __launch_bounds__(kReduceThreads) void icp_small_iteration_kernel(
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int ns,
         const float* __restrict__ records_g, const float* __restrict__ tblk_g, const float* __restrict__ lreg_g,
         const float* __restrict__ halo_g, uint32_t leaf_first, float r2, uint32_t npackets, uint32_t nblocks,
@@ -105,65 +105,6 @@ __global__ __launch_bounds__(kReduceThreads) void icp_small_iteration_kernel(
     if (last) {
         __shared__ DevLoop st_s;
         loop_step_block(loop, out32, 0, st_s, pre);
-    }
-}
-
-// ---- the same for MID-SIZED sources (a rank's share of a sharded registration, clouds of 0.2M-3M points; round 4) ----
-// Past ~170k points the kernel above loses to two launches: it totals one set of 30 sums per PACKET (64 rows out of
-// LDS).  Here a wave takes `ppw` consecutive packets and keeps the 30 sums of all its rows in fp64 REGISTERS across
-// them -- 40 instructions per packet instead of a 64-step LDS loop -- and only then goes through the reduction's finish
-// (wave sums on the DPP network, block row, ticket; the last block totals the rows, exchanges them with the other
-// ranks if there are any, and takes the loop's step).  The price is the search body's 63 registers PLUS 60 for the
-// sums: 4 waves per SIMD instead of 8, so that the grid is sized to fill the chip once (16 waves per CU) and every
-// wave walks its packets one after the other.  What it saves an 8-way shard of the 10M bench: the second launch's ramp
-// and tail, the match index's round trip through memory and the second read of the source (measured: DESIGN section 5).
-// STEP as in reduce_pt2pl_kernel: 0 the sums only, 1 + the loop's step, 2 + the ranks' exchange before it.
-template <int STEP>
-__global__ __launch_bounds__(kReduceThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void icp_mid_iteration_kernel(
-        const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int ns,
-        const float* __restrict__ records_g, const float* __restrict__ tblk_g, const float* __restrict__ lreg_g,
-        const float* __restrict__ halo_g, uint32_t leaf_first, float r2, uint32_t npackets, uint32_t ppw, uint32_t nblocks,
-        int32_t* __restrict__ nn_idx, uint32_t* __restrict__ want, const float* __restrict__ trec, DevLoop* __restrict__ loop,
-        double* __restrict__ partial, uint32_t* __restrict__ ticket, double* __restrict__ out32, MailArgs mail) {
-    __shared__ PacketShared s_pk[kFusedPackets];
-    if (loop->done) return;  // (every wave of every workgroup alike)
-    const int wid = (int)(threadIdx.x >> 6);
-    uint32_t logical;
-    const bool in_range = xcd_remap(nblocks, logical);
-    double acc[30];
-#pragma unroll
-    for (int k = 0; k < 30; ++k) acc[k] = 0.0;
-    const uint32_t first = (logical * (uint32_t)kFusedPackets + (uint32_t)wid) * ppw;
-    for (uint32_t p = 0; in_range && p < ppw; ++p) {
-        const uint32_t packet = first + p;
-        if (packet >= npackets) break;  // (wave-uniform)
-        PacketResult r;
-        const Xform none = {};
-        (void)nn_packet_body<true, false>(s_pk[wid], packet, sx, sy, sz, ns, records_g, tblk_g, lreg_g, halo_g, leaf_first,
-                                          none, loop, r2, nn_idx, nullptr, nullptr, want, r);
-        // this lane's row (reduce_pt2pl_kernel's arithmetic on the search's own transformed point)
-        const bool have = r.valid && r.bidx >= 0;
-        const F3* rec = reinterpret_cast<const F3*>(trec + (int64_t)(have ? r.bidx : 0) * 6);
-        const F3 tp = rec[0], tn = rec[1];
-        if (have) {
-            const float vs[3] = {r.qx, r.qy, r.qz};
-            const float nt[3] = {tn.x, tn.y, tn.z};
-            const float d[3] = {vs[0] - tp.x, vs[1] - tp.y, vs[2] - tp.z};
-            acc[28] += (double)sq3(d[0], d[1], d[2]);
-            acc[29] += 1.0;
-            float J[6];
-            cross3(vs, nt, J);
-            J[3] = nt[0];
-            J[4] = nt[1];
-            J[5] = nt[2];
-            accum_row(acc, J, dot3(d, nt));
-        }
-    }
-    StepPre pre{STEP != 0, 0u, 0.0, 0u};
-    const bool last = block_finish(acc, partial, ticket, out32, &pre, STEP ? loop : nullptr, (STEP == 2) ? mail.seq_dev : nullptr);
-    if (STEP && last) {
-        __shared__ DevLoop st_s;
-        loop_step_block(loop, out32, 0, st_s, pre, (STEP == 2) ? mail : MailArgs{nullptr, nullptr, 0, 1, 0u, nullptr, nullptr});
     }
 }
 

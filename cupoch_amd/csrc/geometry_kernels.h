@@ -9,7 +9,7 @@
 namespace mi {
 
 // ---- Transform (in place on the caller's AoS arrays) --------------------------
-__global__ __launch_bounds__(256) void transform_cloud(Xform T, float* __restrict__ pts,
+static __global__ __launch_bounds__(256) void transform_cloud(Xform T, float* __restrict__ pts,
                                                        float* __restrict__ nrm,
                                                        float* __restrict__ cov, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -60,7 +60,7 @@ struct Affine {
     int use_r, use_s, use_c, use_t;
 };
 
-__global__ __launch_bounds__(256) void affine_cloud(Affine A, float* __restrict__ pts, float* __restrict__ nrm,
+static __global__ __launch_bounds__(256) void affine_cloud(Affine A, float* __restrict__ pts, float* __restrict__ nrm,
                                                     float* __restrict__ cov, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void affine_cloud(Affine A, float* __restrict_
 
 // ---- utility::ComputeCenter (utility/eigen.inl:223-232): per-block fp64 sums, one more block totals them
 constexpr int kCenterBlocks = 512;
-__global__ __launch_bounds__(256) void center_partial(const float* __restrict__ pts, int64_t n,
+static __global__ __launch_bounds__(256) void center_partial(const float* __restrict__ pts, int64_t n,
                                                       double* __restrict__ partial /*[blocks][4]*/) {
     __shared__ double red[4][3];
     double s[3] = {0.0, 0.0, 0.0};
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void center_partial(const float* __restrict__ 
 }
 
 // out[7..9] = sum / n as floats (out = the bounds record: min[3], max[3], extent, center[3])
-__global__ void center_final(const double* __restrict__ partial, int nblocks, int64_t n, float* __restrict__ out) {
+static __global__ void center_final(const double* __restrict__ partial, int nblocks, int64_t n, float* __restrict__ out) {
     const int d = (int)threadIdx.x;
     if (d >= 3) return;
     double t = 0.0;
@@ -150,7 +150,7 @@ __global__ void center_final(const double* __restrict__ partial, int nblocks, in
 }
 
 // ---- GICP: covariance from a normal, C = Rx diag(eps,1,1) Rx^T ----------------
-__global__ __launch_bounds__(256) void cov_from_normals(const float* __restrict__ nrm, int64_t n,
+static __global__ __launch_bounds__(256) void cov_from_normals(const float* __restrict__ nrm, int64_t n,
                                                         float eps, float* __restrict__ cov) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -194,7 +194,7 @@ __device__ __forceinline__ void voxel_key3(const VoxelGrid& g, const float* p, i
 
 // axis < 0: packed lexicographic key of element i; axis 0..2: that axis' cell
 // index of element order[i] (one pass of the three-sort fallback)
-__global__ __launch_bounds__(256) void voxel_keys(const float* __restrict__ pts, int64_t n,
+static __global__ __launch_bounds__(256) void voxel_keys(const float* __restrict__ pts, int64_t n,
                                                   VoxelGrid g, int axis,
                                                   const uint32_t* __restrict__ order,
                                                   uint64_t* __restrict__ keys,
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void voxel_keys(const float* __restrict__ pts,
 }
 
 // head[i] = 1 when sorted element i opens a new voxel
-__global__ __launch_bounds__(256) void voxel_heads(const float* __restrict__ pts, int64_t n,
+static __global__ __launch_bounds__(256) void voxel_heads(const float* __restrict__ pts, int64_t n,
                                                    VoxelGrid g,
                                                    const uint32_t* __restrict__ order,
                                                    uint32_t* __restrict__ head) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void voxel_heads(const float* __restrict__ pts
 }
 
 // the same from the sorted PACKED keys (one key = one voxel): no gathers
-__global__ __launch_bounds__(256) void voxel_heads_keys(const uint64_t* __restrict__ keys, int64_t n,
+static __global__ __launch_bounds__(256) void voxel_heads_keys(const uint64_t* __restrict__ keys, int64_t n,
                                                         uint32_t* __restrict__ head) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void voxel_heads_keys(const uint64_t* __restri
 }
 
 // seg_start[rank of head i] = i ; seg_start[m] = n is written by the host side
-__global__ __launch_bounds__(256) void voxel_seg_starts(const uint32_t* __restrict__ head,
+static __global__ __launch_bounds__(256) void voxel_seg_starts(const uint32_t* __restrict__ head,
                                                         const uint32_t* __restrict__ pos,
                                                         int64_t n,
                                                         uint32_t* __restrict__ seg_start) {
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void voxel_seg_starts(const uint32_t* __restri
 
 // 8 lanes per voxel: fp64 sums of points / normals / colors over the run, mean,
 // normals normalised after averaging (down_sample.cu:77-90)
-__global__ __launch_bounds__(256) void voxel_means(
+static __global__ __launch_bounds__(256) void voxel_means(
         const float* __restrict__ pts, const float* __restrict__ nrm,
         const float* __restrict__ col, const uint32_t* __restrict__ order,
         const uint32_t* __restrict__ seg_start, int64_t m, int64_t n,
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void voxel_means(
 //    gives every voxel its output position -- still the lexicographic (x, y, z) order of down_sample.cu:200-203 --
 //    and voxel_means_runs lets 8 lanes per voxel walk their run and add up the points whose low bits match.
 // Sums are fp64 in a fixed order (input order inside a run: the sort is stable), so the means are reproducible.
-__global__ __launch_bounds__(256) void voxel_keys32(const float* __restrict__ pts, int64_t n, VoxelGrid g,
+static __global__ __launch_bounds__(256) void voxel_keys32(const float* __restrict__ pts, int64_t n, VoxelGrid g,
                                                     uint32_t* __restrict__ keys) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -335,7 +335,7 @@ __device__ __forceinline__ void vox_load8(const uint32_t* __restrict__ keys, int
     }
 }
 
-__global__ __launch_bounds__(kScanThreads) void vox_head_sums(const uint32_t* __restrict__ keys, int n, int L,
+static __global__ __launch_bounds__(kScanThreads) void vox_head_sums(const uint32_t* __restrict__ keys, int n, int L,
                                                                uint32_t* __restrict__ tile_sums) {
     __shared__ uint32_t lds4[4];
     const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kScanThreads) void vox_head_sums(const uint32_t* __
 }
 
 // ... and, with the tiles' offsets (scan_tile_offsets), run_start[rank of head i] = i; run_start[R] = n
-__global__ __launch_bounds__(kScanThreads) void vox_head_apply(const uint32_t* __restrict__ keys, int n, int L,
+static __global__ __launch_bounds__(kScanThreads) void vox_head_apply(const uint32_t* __restrict__ keys, int n, int L,
                                                                 const uint32_t* __restrict__ tile_offs, int ntiles,
                                                                 uint32_t* __restrict__ run_start) {
     __shared__ uint32_t lds4[4];
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(kScanThreads) void vox_head_apply(const uint32_t* _
 
 // 16 lanes per run: which of the run's 2^L voxels occur.  mask[r], cnt[r] = popcount; runs past the end (the grid
 // covers an upper bound, R itself stays on the device: *nruns) get cnt 0.
-__global__ __launch_bounds__(256) void vox_run_masks(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ run_start,
+static __global__ __launch_bounds__(256) void vox_run_masks(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ run_start,
                                                      const uint32_t* __restrict__ nruns, int64_t rmax, int L,
                                                      uint32_t* __restrict__ mask, uint32_t* __restrict__ cnt) {
     const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void vox_run_masks(const uint32_t* __restrict_
 // key (the (v - voff[r])-th set bit of the run's mask); fp64 sums over the run's elements with those low bits, in
 // input order per lane, an 8-lane tree on top; means, normals normalised after averaging (down_sample.cu:77-90).
 // L == 0: a run IS a voxel (voff / mask are not read).
-__global__ __launch_bounds__(256) void voxel_means_runs(
+static __global__ __launch_bounds__(256) void voxel_means_runs(
         const uint32_t* __restrict__ keys, const Pay3* __restrict__ pts, const Pay3* __restrict__ nrm, const Pay3* __restrict__ col,
         const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ voff, const uint32_t* __restrict__ mask,
         const uint32_t* __restrict__ nruns_p, int L, int64_t m, float* __restrict__ out_pts, float* __restrict__ out_nrm,
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void voxel_means_runs(
 // so the means are reproducible.  Then lane f writes voxel f's means at the run's output offset + its rank in the mask.
 // (8 lanes per output voxel, each walking its whole run and picking its own points -- voxel_means_runs with L > 0 -- took
 // 0.57-0.70 ms at 10M points: 16 voxels of a run each re-read the run's keys and fetch their points line by line.)
-__global__ __launch_bounds__(64) void voxel_means_wave(
+static __global__ __launch_bounds__(64) void voxel_means_wave(
         const uint32_t* __restrict__ keys, const Pay3* __restrict__ pts, const Pay3* __restrict__ nrm, const Pay3* __restrict__ col,
         const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ voff, const uint32_t* __restrict__ mask,
         const uint32_t* __restrict__ nruns_p, int64_t rmax, int L, float* __restrict__ out_pts, float* __restrict__ out_nrm,
@@ -596,7 +596,7 @@ __device__ __forceinline__ float intensity_of(const float* rgb) {
     return (float)((double)((rgb[0] + rgb[1]) + rgb[2]) / 3.0);
 }
 
-__global__ __launch_bounds__(256) void target_intensity(const int32_t* __restrict__ tidx,
+static __global__ __launch_bounds__(256) void target_intensity(const int32_t* __restrict__ tidx,
                                                         const float* __restrict__ rgb, int n,
                                                         float4* __restrict__ tnrm) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void target_intensity(const int32_t* __restric
     if (orig >= 0) tnrm[s].w = intensity_of(rgb + (int64_t)orig * 3);  // n counts padding slots too
 }
 
-__global__ __launch_bounds__(256) void source_intensity(const int32_t* __restrict__ sperm,
+static __global__ __launch_bounds__(256) void source_intensity(const int32_t* __restrict__ sperm,
                                                         const float* __restrict__ rgb, int n,
                                                         float* __restrict__ sint) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -48,7 +48,7 @@ struct GroupBuildArgs {
 
 
 // (two 1024-thread workgroups per CU = 8 waves per SIMD: at most 64 VGPRs)
-__global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void kd_build_groups(GroupBuildArgs a) {
+static __global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void kd_build_groups(GroupBuildArgs a) {
     __shared__ KdShared s;
     __shared__ uint32_t s_src[3];  // first sorted position, number of points of this group, groups of its cell
     __shared__ float s_region[6];
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_eu(8, 8
 // scratch: {sum of log2(diagonal), count, ticket, -}, zeroed by the caller.
 constexpr float kCapDiagonals = 1.5f;
 constexpr float kNearDiagonals = 0.18f;  // a first round from the root: ~1.25 point spacings on volumetric data
-__global__ __launch_bounds__(256) void tree_scale(float* __restrict__ records, uint32_t leaf_first, uint32_t used_last,
+static __global__ __launch_bounds__(256) void tree_scale(float* __restrict__ records, uint32_t leaf_first, uint32_t used_last,
                                                   float* __restrict__ scratch) {
     float lg = 0.0f, one = 0.0f;
     // (a grid-stride loop over the nodes on at most 256 workgroups, and the hand-off the reduction uses -- atomics that

@@ -46,7 +46,7 @@ static inline int cell_levels_for(int64_t n) {
 }
 
 // sample j = point floor(j * n / S)
-__global__ __launch_bounds__(256) void cells_sample_gather(const float* __restrict__ pts, int64_t n,
+static __global__ __launch_bounds__(256) void cells_sample_gather(const float* __restrict__ pts, int64_t n,
                                                            int64_t S, float* __restrict__ samp) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= S) return;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void cells_starts(const K* __restrict__ keys, 
 
 // One block: groups per cell = max(1, ceil(count / 4096)), their exclusive prefix gstart,
 // and the total number of groups in total[0].
-__global__ __launch_bounds__(1024) void cells_layout(const uint32_t* __restrict__ cstart, int ncells,
+static __global__ __launch_bounds__(1024) void cells_layout(const uint32_t* __restrict__ cstart, int ncells,
                                                      uint32_t* __restrict__ gstart, uint32_t* __restrict__ total) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t s_carry;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(1024) void cells_layout(const uint32_t* __restrict_
 // stride subsample when it has more, wrapped around when fewer) and resolves `levels`
 // more levels.  keys/vals: the samples sorted by their depth-base_level cell (vals =
 // sample index); base_level == 0: all S samples in order.
-__global__ __launch_bounds__(kKdThreads) void cells_planes(const float* __restrict__ samp, int64_t S,
+static __global__ __launch_bounds__(kKdThreads) void cells_planes(const float* __restrict__ samp, int64_t S,
                                                            const uint64_t* __restrict__ keys,
                                                            const uint32_t* __restrict__ vals, int base_level,
                                                            int levels, float2* __restrict__ planes) {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kKdThreads) void cells_planes(const float* __restri
 }
 
 // sorted position p (cell-major, stable) -> slot gstart[cell] * 4096 + rank within the cell
-__global__ __launch_bounds__(256) void cells_scatter(const uint64_t* __restrict__ keys,
+static __global__ __launch_bounds__(256) void cells_scatter(const uint64_t* __restrict__ keys,
                                                      const uint32_t* __restrict__ vals,
                                                      const uint32_t* __restrict__ cstart,
                                                      const uint32_t* __restrict__ gstart, int64_t n,
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void cells_scatter(const uint64_t* __restrict_
     order_padded[slot] = vals[p];
 }
 
-__global__ __launch_bounds__(256) void fill_u32(uint32_t* __restrict__ a, int64_t n, uint32_t v) {
+static __global__ __launch_bounds__(256) void fill_u32(uint32_t* __restrict__ a, int64_t n, uint32_t v) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) a[i] = v;
 }

@@ -528,7 +528,7 @@ constexpr uint32_t kNoPoint = 0xffffffffu;  // order[] entry of a padding slot
 // order_in / order_out: sorted position -> original index (distinct buffers); n = number
 // of positions (a multiple of 4096 when the layout is padded); kNoPoint entries are
 // padding and end up behind the group's points.
-__global__ __launch_bounds__(kKdThreads) void kd_refine_groups(const float* __restrict__ pts,
+static __global__ __launch_bounds__(kKdThreads) void kd_refine_groups(const float* __restrict__ pts,
                                                                const uint32_t* __restrict__ order_in,
                                                                uint32_t* __restrict__ order_out, int64_t n) {
     __shared__ KdShared s;

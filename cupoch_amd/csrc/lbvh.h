@@ -24,7 +24,7 @@ constexpr int kBoundsBlocks = 1024;
 
 // (four points in flight per thread, each one 12-byte load: with one point per iteration and 512 blocks the kernel sat
 // on its load latency -- 45 us for the 120 MB of a 10M-point cloud)
-__global__ __launch_bounds__(256) void bounds_partial(const float* __restrict__ pts, int n,
+static __global__ __launch_bounds__(256) void bounds_partial(const float* __restrict__ pts, int n,
                                                       float* __restrict__ partial /*[blocks][6]*/) {
     struct __attribute__((packed, aligned(4))) P {
         float x, y, z;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void bounds_partial(const float* __restrict__ 
 }
 
 // one block of 64 threads: out[0..2] = min, out[3..5] = max, out[6] = max extent
-__global__ void bounds_final(const float* __restrict__ partial, int nblocks,
+static __global__ void bounds_final(const float* __restrict__ partial, int nblocks,
                              float* __restrict__ out) {
     const int lane = lane_id();
     float mn[3] = {INFINITY, INFINITY, INFINITY};
@@ -170,7 +170,7 @@ __device__ __forceinline__ void store_own(float* __restrict__ records, uint32_t 
 // to them, and writes the leaf box into its parent's record.  Slots past nleaf
 // get the inverted box.  n = number of sorted positions; order[] entries equal to
 // kNoPoint are padding (kd_cells.h): +inf coordinates, original index -1.
-__global__ __launch_bounds__(256) void build_leaves(
+static __global__ __launch_bounds__(256) void build_leaves(
         const uint32_t* __restrict__ order, const float* __restrict__ pts,
         const float* __restrict__ nrm, const float* __restrict__ cov, int64_t n, int nleaf, int nslots,
         uint32_t leaf_first, float* __restrict__ tblk, float4* __restrict__ tnrm,
@@ -250,7 +250,7 @@ __device__ __forceinline__ void cell_region(const float2* __restrict__ planes, i
 // own_flag: the nodes are kd subtrees of the cells' plane tree (every cell has one group):
 // node t of this level is the plane tree's node (region_depth, t), and its REGION
 // (kd_cells.h cell_region) is stored as the own box instead of the points' box.
-__global__ __launch_bounds__(256) void build_level(float* __restrict__ records, uint32_t first,
+static __global__ __launch_bounds__(256) void build_level(float* __restrict__ records, uint32_t first,
                                                    uint32_t used, uint32_t count, uint32_t own_flag,
                                                    const float2* __restrict__ planes, int cell_levels,
                                                    int region_depth) {
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void build_level(float* __restrict__ records, 
 }
 
 // leaf regions of a tree that has none (Morton-run fallback): nothing is inside, no halo
-__global__ __launch_bounds__(256) void fill_invalid_leaf_regions(float* __restrict__ lreg, int nleaf) {
+static __global__ __launch_bounds__(256) void fill_invalid_leaf_regions(float* __restrict__ lreg, int nleaf) {
     const int L = (int)(blockIdx.x * 256 + threadIdx.x);
     if (L >= nleaf) return;
     float4* out = reinterpret_cast<float4*>(lreg + (size_t)L * kLeafRegStride);
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void fill_invalid_leaf_regions(float* __restri
 }
 
 // ---- source: Morton-ordered SoA copy ---------------------------------------
-__global__ __launch_bounds__(256) void gather_source(
+static __global__ __launch_bounds__(256) void gather_source(
         const uint32_t* __restrict__ order, const float* __restrict__ pts,
         const float* __restrict__ nrm, const float* __restrict__ cov, int n,
         float* __restrict__ sx, float* __restrict__ sy, float* __restrict__ sz,
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void gather_source(
 // one or two bottom records instead of the ~18 leaves a geometrically compact but
 // unaligned packet touches.  Any source order is correct; this one is just cheaper
 // to search for as long as the clouds stay roughly where they are (ICP iterations).
-__global__ __launch_bounds__(256) void match_order_keys(const int32_t* __restrict__ nn_idx, int ns,
+static __global__ __launch_bounds__(256) void match_order_keys(const int32_t* __restrict__ nn_idx, int ns,
                                                         uint32_t unmatched_key,
                                                         uint32_t* __restrict__ keys,
                                                         uint32_t* __restrict__ vals) {
@@ -337,7 +337,7 @@ struct SourceArrays {
     float* nn_d2;
 };
 
-__global__ __launch_bounds__(256) void permute_source(const uint32_t* __restrict__ ord, int ns,
+static __global__ __launch_bounds__(256) void permute_source(const uint32_t* __restrict__ ord, int ns,
                                                       SourceArrays in, SourceArrays out) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= ns) return;

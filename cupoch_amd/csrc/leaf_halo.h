@@ -42,7 +42,7 @@
 // entry l % 8 of line l / 8.
 #pragma once
 #include "device_utils.h"
-#include "nn_search.h"
+#include "halo_format.h"
 #include "traverse.h"
 
 namespace mi {
@@ -59,7 +59,7 @@ __host__ __device__ __forceinline__ size_t link_temp_index(uint32_t L, int t) { 
 
 // lreg[L][3] <- bound, lreg[L][7] <- number of candidates (as an integer's bits), cand[L][0..count) unsorted;
 // candidate = {leaf id | direction mask << 26, distance bits}
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void leaf_halo_collect(
+static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void leaf_halo_collect(
         const float* __restrict__ records_g, uint32_t leaf_first, int nleaf, uint32_t nblocks,
         float* __restrict__ lreg, uint2* __restrict__ cand) {
     uint32_t logical;
@@ -195,7 +195,7 @@ constexpr float kHaloShrink = 0.999999f;         // reaches are reported a littl
 // 4.7 KB of LDS per wave, so the kernel's occupancy is what its registers allow (with four waves sharing a
 // tile's 17 KB of candidate ids it held 13.6 waves per CU).  halo: [nleaf][8] lines of 32 floats; lreg[L][3], [7] <-
 // the rings' reaches, packed (halo_pack_reaches; both 0: no halo).
-__global__ __launch_bounds__(64) void leaf_halo_build(float* __restrict__ lreg, int nleaf,
+static __global__ __launch_bounds__(64) void leaf_halo_build(float* __restrict__ lreg, int nleaf,
                                                       const uint2* __restrict__ cand,
                                                       const float* __restrict__ tblk,
                                                       float* __restrict__ halo) {

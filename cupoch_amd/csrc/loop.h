@@ -18,6 +18,9 @@
 
 namespace mi {
 
+constexpr int kSysSize = 32;  // the reduced system: 21 + 6 sums, r^2, d^2, count, two spare (reduce.h)
+constexpr int kEstP2P = 1, kEstPt2Pl = 2, kEstSym = 3, kEstColored = 4, kEstGICP = 5;  // MI_ICP_EST_* (include/mi_icp.h)
+
 struct DevLoop {
     Xform X;             // what the source points see (row-major 3x4), read by the kernels
     int32_t done;        // != 0: loop finished (converged or iteration budget spent)
@@ -211,11 +214,6 @@ __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys
     }
     __syncthreads();
     if (tid < kWords) reinterpret_cast<uint32_t*>(st_g)[tid] = dst[tid];
-}
-
-__global__ __launch_bounds__(kStepThreads) void loop_step_kernel(DevLoop* st_g, double* sys_in, int resume, MailArgs mail) {
-    __shared__ DevLoop st_s;
-    loop_step_block(st_g, sys_in, resume, st_s, StepPre{false, 0u, 0.0, 0u}, mail);
 }
 
 }  // namespace mi

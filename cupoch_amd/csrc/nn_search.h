@@ -21,6 +21,7 @@
 // target's order (FLANN keeps the first visited).
 #pragma once
 #include "device_utils.h"
+#include "halo_format.h"
 #include "loop.h"
 #include "traverse.h"
 
@@ -37,28 +38,7 @@ constexpr int kNNPacketsPerBlock = kNNThreads / 64;
 // item's query comes over ds_bpermute, the leaf's 8 points over per-lane vector loads, the
 // result goes back with an LDS atomic min on (d2 bits << 32 | slot) -- d2 >= 0, so the
 // integer order is the float order and equal distances resolve to the lowest slot.
-constexpr int kHaloLines = 8;            // halo lines per leaf (leaf_halo.h): the 64 nearest points of other leaves, 8 per line, in rings
-constexpr int kHaloLineFloats = 32;      // x[8] y[8] z[8] slot[8]: a leaf line with the points' slots in its fourth row
-constexpr float kHaloUnit = 1.0f / 64.0f;
 constexpr int kItemQueue = 64 + 8 * 64;  // tree walk: a drain leaves < 64 behind, one record adds <= 512; halo phase: 16-bit items, <= 8 per lane
-
-// The reaches of a leaf's eight halo lines travel in the two spare words of its region record, as 6-bit
-// fractions q_k of the bound (the reach a line has when no point lies behind it): word A = q0 .. q4 from bit 0,
-// the low two bits of q7 on top; word B = q5, q6 from bit 0, the high four bits of q7 from bit 12, the bound
-// -- the upper 16 bits of an fp32, rounded down -- on top; reach k = bound / 64 * q_k, rounded down when packed.
-__host__ __device__ __forceinline__ uint32_t halo_reach_fraction(uint32_t wa, uint32_t wb, int k) {
-    return (k < 5) ? ((wa >> (6 * k)) & 63u) : ((k < 7) ? ((wb >> (6 * (k - 5))) & 63u) : ((wa >> 30) | (((wb >> 12) & 15u) << 2)));
-}
-// How many lines a cube that pokes out of the region by `over` has to read: 1 .. 8, or 9: beyond them all.
-__device__ __forceinline__ uint32_t halo_lines_needed(float wa_f, float wb_f, float over) {
-    const uint32_t wa = __float_as_uint(wa_f), wb = __float_as_uint(wb_f);
-    const float unit = __uint_as_float(wb & 0xffff0000u) * kHaloUnit;
-    uint32_t n = 1u;
-#pragma unroll
-    for (int k = 0; k < kHaloLines; ++k)
-        n += (over < unit * (float)halo_reach_fraction(wa, wb, k)) ? 0u : 1u;  // (NaN: every line and then the walk)
-    return n;
-}
 
 struct PacketShared {
     unsigned long long best[64];  // per lane: d2 bits << 32 | slot
@@ -551,43 +531,6 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SEED
                                       r2, nn_idx, nn_d2, stats, want, unused);
 }
 
-// EXPERIMENT (MI_ICP_FIRST_SOLO=1; EXPERIMENTS.md round 4): a pass without previous matches in which every lane walks
-// the tree ON ITS OWN (traverse.h solo_walk: per-lane node id and sibling stack, nearest child first, L2 pruning
-// against the lane's own bound) instead of the wave walking once for its 64 queries.  Same exact answers.
-__global__ __launch_bounds__(kNNThreads) void nn_solo_kernel(
-        const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int ns,
-        const float* __restrict__ records_g, const float* __restrict__ tblk_g, uint32_t leaf_first, Xform Tv,
-        const DevLoop* __restrict__ loop, float r2, uint32_t nblocks, int32_t* __restrict__ nn_idx, float* __restrict__ nn_d2) {
-    uint32_t logical;
-    if (!xcd_remap(nblocks, logical)) return;
-    const int lane = lane_id();
-    const int i = (int)(logical * 64u) + lane;
-    const bool valid = i < ns;
-    const int ic = valid ? i : 0;
-    Xform T = Tv;
-    if (loop) {
-        if (loop->done) return;
-        T = loop->X;
-    }
-    float qx, qy, qz;
-    xform_point(T, sx[ic], sy[ic], sz[ic], qx, qy, qz);
-    float best = r2;
-    int32_t bidx = -1;
-    solo_walk(records_g, leaf_first, valid, qx, qy, qz, [&]() { return best; }, [&](uint32_t L) {
-        const float4* line = reinterpret_cast<const float4*>(tblk_g + (size_t)L * kLeafFloats);
-        const LineMin w = line_min(line[0], line[1], line[2], line[3], line[4], line[5], qx, qy, qz);
-        const int32_t j = (int32_t)(L * (uint32_t)kLeaf + (uint32_t)w.k);
-        if (w.m < best || (w.m == best && bidx >= 0 && j < bidx)) {
-            best = w.m;
-            bidx = j;
-        }
-    });
-    if (valid) {
-        nn_idx[i] = bidx;
-        if (nn_d2) nn_d2[i] = (bidx >= 0) ? best : INFINITY;
-    }
-}
-
 // ---------------------------------------------------------------------------
 // Result export in the reference's layout.
 // ---------------------------------------------------------------------------
@@ -620,7 +563,7 @@ __device__ __forceinline__ uint32_t nearest_child(const float (&w)[48], float qx
     return c;
 }
 
-__global__ __launch_bounds__(256) void locate_leaves(const float* __restrict__ sx, const float* __restrict__ sy,
+static __global__ __launch_bounds__(256) void locate_leaves(const float* __restrict__ sx, const float* __restrict__ sy,
                                                      const float* __restrict__ sz, int ns,
                                                      const float* __restrict__ records_g, uint32_t leaf_first,
                                                      uint32_t nleaf, Xform Tv, const DevLoop* __restrict__ loop,
@@ -670,7 +613,7 @@ __global__ __launch_bounds__(256) void locate_leaves(const float* __restrict__ s
     if (i < ns) nn_idx[i] = (int32_t)(leaf * (uint32_t)kLeaf);
 }
 
-__global__ __launch_bounds__(256) void export_dense(const int32_t* __restrict__ nn_idx,
+static __global__ __launch_bounds__(256) void export_dense(const int32_t* __restrict__ nn_idx,
                                                     const float* __restrict__ nn_d2,
                                                     const int32_t* __restrict__ sperm,
                                                     const int32_t* __restrict__ tidx, int ns,
@@ -687,7 +630,7 @@ __global__ __launch_bounds__(256) void export_dense(const int32_t* __restrict__ 
 }
 
 // flags[o] = 1 when original source point o has a match
-__global__ __launch_bounds__(256) void corr_flags(const int32_t* __restrict__ dense_idx, int ns,
+static __global__ __launch_bounds__(256) void corr_flags(const int32_t* __restrict__ dense_idx, int ns,
                                                   uint32_t* __restrict__ flags) {
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= ns) return;
@@ -696,7 +639,7 @@ __global__ __launch_bounds__(256) void corr_flags(const int32_t* __restrict__ de
 
 // stable compaction into (source, target) pairs, ascending in source index
 // (thrust::remove_if at registration/registration.cu:62-69)
-__global__ __launch_bounds__(256) void corr_compact(const int32_t* __restrict__ dense_idx,
+static __global__ __launch_bounds__(256) void corr_compact(const int32_t* __restrict__ dense_idx,
                                                     const uint32_t* __restrict__ pos, int ns,
                                                     int32_t* __restrict__ pairs) {
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -712,18 +655,18 @@ __global__ __launch_bounds__(256) void corr_compact(const int32_t* __restrict__ 
 // explicit CorrespondenceSet -> the engine's internal form: nn_idx[sorted
 // source position] = sorted target position.  inv_s / inv_t map original ->
 // sorted index.  Source points absent from the set get -1.
-__global__ __launch_bounds__(256) void fill_i32(int32_t* __restrict__ a, int64_t n, int32_t v) {
+static __global__ __launch_bounds__(256) void fill_i32(int32_t* __restrict__ a, int64_t n, int32_t v) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) a[i] = v;
 }
 
-__global__ __launch_bounds__(256) void invert_perm_source(const int32_t* __restrict__ sperm, int ns,
+static __global__ __launch_bounds__(256) void invert_perm_source(const int32_t* __restrict__ sperm, int ns,
                                                           int32_t* __restrict__ inv) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s < ns) inv[sperm[s]] = (int32_t)s;
 }
 
-__global__ __launch_bounds__(256) void invert_perm_target(const int32_t* __restrict__ tidx, int nt,
+static __global__ __launch_bounds__(256) void invert_perm_target(const int32_t* __restrict__ tidx, int nt,
                                                           int32_t* __restrict__ inv) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s < nt) {  // nt = sorted positions incl. padding slots (original index -1)
@@ -732,7 +675,7 @@ __global__ __launch_bounds__(256) void invert_perm_target(const int32_t* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void import_pairs(const int32_t* __restrict__ pairs, int64_t c,
+static __global__ __launch_bounds__(256) void import_pairs(const int32_t* __restrict__ pairs, int64_t c,
                                                     const int32_t* __restrict__ inv_s,
                                                     const int32_t* __restrict__ inv_t, int ns,
                                                     int nt, int32_t* __restrict__ nn_idx) {

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kOdThreads) void od_filter3(const float* __restrict
 }
 
 // Image::Downsample, float (image.cu:121-145): 2x2 mean into floor(w/2) x floor(h/2)
-__global__ __launch_bounds__(kOdThreads) void od_downsample(const float* __restrict__ src, int w, int h,
+static __global__ __launch_bounds__(kOdThreads) void od_downsample(const float* __restrict__ src, int w, int h,
                                                             float* __restrict__ dst) {
     const int hw = w / 2, hh = h / 2;
     const int64_t idx = (int64_t)blockIdx.x * kOdThreads + threadIdx.x;
@@ -323,7 +323,7 @@ __host__ __device__ inline void od_matrix4_to_vector6(const host::Mat4& T, float
 // update: 0 derive the terms only, 1 plain iteration, 2 weighted iteration (the system gets the
 // motion prior first, the velocity and sigma2 are advanced; DoSingleIterationWeighted :690-705,
 // ComputeMultiscaleWeighted :806-818), 3 the weighted variant's half step: w_sum <- sums[0].
-__global__ __launch_bounds__(64) void od_step(OdState* st, double* sums, OdCamera cam, int update) {
+static __global__ __launch_bounds__(64) void od_step(OdState* st, double* sums, OdCamera cam, int update) {
     __shared__ double sys[32];
     if (threadIdx.x < 32) sys[threadIdx.x] = sums[threadIdx.x];
     __syncthreads();
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64) void od_step(OdState* st, double* sums, OdCamer
 
 // NormalizeIntensity's Image::LinearTransform(0.5 / mean, 0) (odometry.cu:431-435), the mean
 // taken from the kOdMeans sums on the device: which = 0 source, 1 target.
-__global__ __launch_bounds__(kOdThreads) void od_scale_by_mean(float* __restrict__ img, int64_t n,
+static __global__ __launch_bounds__(kOdThreads) void od_scale_by_mean(float* __restrict__ img, int64_t n,
                                                                const double* __restrict__ sums, int which) {
     const float mean = (float)sums[which] / (float)sums[29];
     const float scale = (float)(0.5 / (double)mean);

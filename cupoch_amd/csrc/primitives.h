@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* t
     return woff + x - v;
 }
 
-__global__ __launch_bounds__(kScanThreads) void scan_tile_sums(const uint32_t* __restrict__ in,
+static __global__ __launch_bounds__(kScanThreads) void scan_tile_sums(const uint32_t* __restrict__ in,
                                                                uint32_t* __restrict__ tile_sums,
                                                                int n) {
     __shared__ uint32_t lds4[4];
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_tile_sums(const uint32_t* _
 }
 
 // one block; in-place exclusive scan of tile_sums[0..ntiles), total -> [ntiles]
-__global__ __launch_bounds__(kScanThreads) void scan_tile_offsets(uint32_t* __restrict__ tile_sums,
+static __global__ __launch_bounds__(kScanThreads) void scan_tile_offsets(uint32_t* __restrict__ tile_sums,
                                                                   int ntiles) {
     __shared__ uint32_t lds4[4];
     uint32_t carry = 0;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_tile_offsets(uint32_t* __re
     if (threadIdx.x == 0) tile_sums[ntiles] = carry;
 }
 
-__global__ __launch_bounds__(kScanThreads) void scan_apply(const uint32_t* in, uint32_t* out,
+static __global__ __launch_bounds__(kScanThreads) void scan_apply(const uint32_t* in, uint32_t* out,
                                                            const uint32_t* __restrict__ tile_offs,
                                                            int n) {
     __shared__ uint32_t lds4[4];

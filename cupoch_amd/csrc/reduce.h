@@ -22,8 +22,6 @@
 
 namespace mi {
 
-constexpr int kEstP2P = 1, kEstPt2Pl = 2, kEstSym = 3, kEstColored = 4, kEstGICP = 5;
-constexpr int kSysSize = 32;
 constexpr int kReduceThreads = 256;
 constexpr int kReduceBlocks = 1024;  // the generic reduction's grid limit (4 per CU); the last block to arrive totals the rows (block_finish_rows)
 

@@ -403,8 +403,9 @@ MI_ICP_API int mi_icp_registration_colored_icp(mi_icp_ctx* ctx, float max_distan
  * job_name (letters, digits, '_', '-'), one node only.  mi_icp_comm_kind: 0 none, 1 RCCL
  * all-reduce, 2 mailbox, 3 mailbox with device inboxes (every rank keeps an inbox in fine-grained device memory
  * that its peers open through HIP IPC and write their posts into -- GPU to GPU, polls stay local; any rank failing
- * to set that up keeps all of them on the host-memory box; USED when MI_ICP_MAILBOX=device is set or
- * mi_icp_comm_autotune below measured them faster; MI_ICP_MAILBOX=host: not even set up).  Set-up: rank 0 makes the box and waits (MI_ICP_MAIL_ATTACH_MS, default 30 s)
+ * to set that up keeps all of them on the host-memory box; USED when MI_ICP_MAILBOX=device is set ON RANK 0
+ * (published through the box: the peers' own environment is not consulted) or
+ * mi_icp_comm_autotune below measured them faster; MI_ICP_MAILBOX=host on rank 0: not even set up).  Set-up: rank 0 makes the box and waits (MI_ICP_MAIL_ATTACH_MS, default 30 s)
  * until every other rank has mapped and registered it; mi_icp_comm_init then lets the ranks agree over the
  * RCCL communicator whether ALL of them have it (else none uses it).  A peer that does not post within ~10 s
  * fails the call with MI_ICP_ERR_COMM; the communicator is void from then on (the ranks' exchange counters

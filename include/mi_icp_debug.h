@@ -41,7 +41,7 @@ MI_ICP_API int mi_icp_debug_drop_seeds(mi_icp_ctx* ctx);
 MI_ICP_API int mi_icp_debug_last_search_kind(const mi_icp_ctx* ctx);
 /* Resident workgroups per CU the runtime grants a kernel at its launch shape (hipOccupancyMaxActiveBlocksPerMultiprocessor):
  * which = 0 kd_build_groups, 1 nn_packet_kernel<seeded>, 2 nn_packet_kernel<from the root>, 3 reduce_pt2pl_kernel<4,1>,
- * 4 leaf_halo_build, 5 rs_scatter_pay<8>, 6 voxel_means_wave, 7 icp_mid_iteration_kernel<1>.  Returns the count, < 0 on error. */
+ * 4 leaf_halo_build, 5 rs_scatter_pay<8>, 6 voxel_means_wave.  Returns the count, < 0 on error. */
 MI_ICP_API int mi_icp_debug_occupancy(int which);
 /* The loop step's two forms of utility::SolveJacobianSystemAndObtainExtrinsicMatrix side by side, on the
  * device: n systems of 32 doubles each (host memory; the reduction's layout: 21 upper-triangle sums of

@@ -7,6 +7,6 @@ from cupoch_amd import _lib
 L = _lib.load()
 torch.cuda.init()
 names = ["kd_build_groups (1024 threads)", "nn_packet_kernel<seeded> (64)", "nn_packet_kernel<root> (64)", "reduce_pt2pl_kernel<4,1> (256)",
-         "leaf_halo_build (64)", "rs_scatter_pay<8> (512)", "voxel_means_wave (64)", "icp_mid_iteration_kernel<1> (256)"]
+         "leaf_halo_build (64)", "rs_scatter_pay<8> (512)", "voxel_means_wave (64)"]
 for i, n in enumerate(names):
     print("occupancy: %-40s %d workgroups per CU" % (n, L.mi_icp_debug_occupancy(i)))

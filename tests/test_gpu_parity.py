@@ -491,29 +491,26 @@ def test_voxel_downsample_edge_shapes(eng):
         np.testing.assert_allclose(nn, rn, atol=2e-5)
 
 
-def test_voxel_downsample_both_forms_agree_to_the_last_bit_or_two(tmp_path):
-    """The 32-bit-key path with the payload carried through the radix passes (round 4) against the first form (64-bit
-    keys, indices, one gather; MI_ICP_VOXEL_OLD=1 in a child process -- the library reads its switches once): the same
-    voxels in the same order, and values that differ at most in the last bit or two -- both add a voxel's points in
-    fp64, but deal them to their 8 lanes differently, so an fp64 sum may round the other way once in a long while."""
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    code = ("import sys, numpy as np; sys.path.insert(0, %r); from cupoch_amd.engine import Engine; e = Engine(0);"
-            "rng = np.random.default_rng(9); pts = rng.random((400000, 3), dtype=np.float32);"
-            "nrm = rng.standard_normal((400000, 3)).astype(np.float32); col = rng.random((400000, 3), dtype=np.float32);"
-            "out = []\n"
-            "for v in (0.5, 0.05, 0.011, 0.003):\n"
-            "    out += [np.asarray(a) for a in e.voxel_downsample(pts, v, nrm, col)]\n"
-            "np.savez(sys.argv[1], *out)") % os.path.dirname(here)
-    for name, env in (("new", {}), ("old", {"MI_ICP_VOXEL_OLD": "1"})):
-        subprocess.run([sys.executable, "-c", code, str(tmp_path / (name + ".npz"))], check=True, env=dict(os.environ, **env), timeout=600)
-    a, b = np.load(tmp_path / "new.npz"), np.load(tmp_path / "old.npz")
-    assert len(a.files) == 12
-    for k in a.files:
-        assert a[k].shape == b[k].shape, k
-        np.testing.assert_array_max_ulp(a[k], b[k], maxulp=2)
+def test_voxel_downsample_both_forms_agree_to_the_last_bit_or_two(eng):
+    """The 32-bit-key path with the payload carried through the radix passes against the first form (64-bit keys,
+    indices, one gather), which now serves only grids whose packed key needs more than 32 bits: ONE far point at
+    large positive coordinates leaves the grid's origin where it was (the minimum bound) but stretches the grid to
+    3 x 21 bits -- every other voxel must come out in the same place with values that differ at most in the last bit
+    or two (both add a voxel's points in fp64, but deal them to their lanes differently)."""
+    rng = np.random.default_rng(9)
+    n = 400000
+    pts = rng.random((n, 3), dtype=np.float32)
+    nrm = rng.standard_normal((n, 3)).astype(np.float32)
+    col = rng.random((n, 3), dtype=np.float32)
+    far = np.full((1, 3), 3000.0, np.float32)
+    for v in (0.5, 0.05, 0.011, 0.003):
+        a = [np.asarray(x) for x in eng.voxel_downsample(pts, v, nrm, col)]
+        b = [np.asarray(x) for x in eng.voxel_downsample(np.vstack([pts, far]), v, np.vstack([nrm, nrm[:1]]),
+                                                         np.vstack([col, col[:1]]))]
+        for x, y in zip(a, b):
+            assert y.shape[0] == x.shape[0] + 1, v          # (the far point's voxel: the largest key, last)
+            np.testing.assert_array_max_ulp(x, y[:-1], maxulp=2)
+        np.testing.assert_array_equal(b[0][-1], far[0])
 
 
 def test_covariances_from_normals_matches_oracle(eng):
