@@ -202,7 +202,30 @@ def strong_big(eng, n_big, steps, warmup, rank, world, local, torch, dist, D, _l
     same way (3 windows of `steps`, median, max over ranks)."""
     dev = torch.device("cuda", local)
     s = float(n_big) ** (-1.0 / 3.0)
-    if rank == 0:
+
+    class _StageFailed(Exception):
+        pass
+
+    def stage(name, fn):
+        """Run one fallible stage; with several ranks AGREE on its outcome before anybody enters the next collective
+        (a rank that ran out of memory here used to leave its peers waiting in a broadcast: ADVICE r4)."""
+        err, val = "", None
+        try:
+            val = fn()
+        except Exception as e:   # noqa: BLE001
+            err = "%s: %s" % (name, e)
+        if world > 1:
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                raise _StageFailed(err or "%s failed on another rank" % name)
+        elif err:
+            raise _StageFailed(err)
+        return val
+
+    def generate():
+        if rank != 0:
+            return tuple(torch.empty((n_big, 3), device=dev, dtype=torch.float32) for _ in range(3))
         g = torch.Generator(device=dev)
         g.manual_seed(4242)
         tgt = torch.rand((n_big, 3), generator=g, device=dev, dtype=torch.float32)
@@ -220,26 +243,38 @@ def strong_big(eng, n_big, steps, warmup, rank, world, local, torch, dist, D, _l
             hi = min(n_big, lo + (1 << 24))
             src[lo:hi] = (tgt[lo:hi].double() @ Rinv.T + tinv).float()
         src = src[torch.randperm(n_big, generator=g, device=dev)]
-    else:
-        tgt = torch.empty((n_big, 3), device=dev, dtype=torch.float32)
-        nrm = torch.empty((n_big, 3), device=dev, dtype=torch.float32)
-        src = torch.empty((n_big, 3), device=dev, dtype=torch.float32)
-    if world > 1:
-        for x in (tgt, nrm, src):
-            dist.broadcast(x, src=0)
-        mine = D.device_shard_source(eng, src, rank, world)
-        src = src[torch.from_numpy(mine).to(dev)].contiguous()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.set_target(tgt, nrm)
-    eng.set_source(src)
-    eng.synchronize()
-    build_ms = (time.perf_counter() - t0) * 1e3
-    if world > 1:
-        eng.set_global_source_count(n_big)
-    eng.set_profiling(False)
-    eng.icp_begin(_lib.EST_POINT_TO_PLANE, 2.0 * s, None, -1.0)
-    eng.icp_iterate(warmup)
+        return tgt, nrm, src
+
+    try:
+        tgt, nrm, src = stage("generate", generate)
+        if world > 1:
+            for x in (tgt, nrm, src):
+                dist.broadcast(x, src=0)
+
+        def load():
+            nonlocal src
+            if world > 1:
+                mine = D.device_shard_source(eng, src, rank, world)
+                src = src[torch.from_numpy(mine).to(dev)].contiguous()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.set_target(tgt, nrm)
+            eng.set_source(src)
+            eng.synchronize()
+            return (time.perf_counter() - t0) * 1e3
+
+        build_ms = stage("build", load)
+
+        def begin():
+            if world > 1:
+                eng.set_global_source_count(n_big)
+            eng.set_profiling(False)
+            eng.icp_begin(_lib.EST_POINT_TO_PLANE, 2.0 * s, None, -1.0)
+            eng.icp_iterate(warmup)
+
+        stage("begin", begin)
+    except _StageFailed as e:
+        return {"error": str(e)}
     windows = []
     for _ in range(3):
         if world > 1:

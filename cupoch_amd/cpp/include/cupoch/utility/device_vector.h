@@ -4,6 +4,7 @@
 // host vector.  thrust::host_vector is std::vector here.
 #pragma once
 #include <cstddef>
+#include <memory>
 #include <utility>
 #include <vector>
 
@@ -35,7 +36,6 @@ public:
     device_vector(const device_vector& o) { assign_device(o.data_, o.size_); }
     device_vector(device_vector&& o) noexcept { swap(o); }
     device_vector(const std::vector<T>& h) { assign_host(h.data(), h.size()); }
-    ~device_vector() { device_free(data_); }
     device_vector& operator=(const device_vector& o) {
         if (this != &o) assign_device(o.data_, o.size_);
         return *this;
@@ -63,13 +63,19 @@ public:
         if (n > cap_) {
             T* p = (T*)device_alloc(n * sizeof(T));
             if (size_) copy_d2d(p, data_, size_ * sizeof(T));
-            device_free(data_);
+            store_.reset(p, [](void* q) { device_free(q); });  // (the former block goes when its last holder does)
             data_ = p;
             cap_ = n;
         }
         size_ = n;
     }
+    /// The block behind data(), shared: whoever holds it keeps the memory alive -- the zero-copy DLPack export
+    /// (the reference's handle, utility/dl_converter.cu:60-69).  The vector itself never shares on copy (copies are
+    /// deep, as thrust's); a later resize beyond the capacity moves the VECTOR to a new block and leaves this one
+    /// to its holders.
+    std::shared_ptr<void> share() const { return store_; }
     void swap(device_vector& o) noexcept {
+        std::swap(store_, o.store_);
         std::swap(data_, o.data_);
         std::swap(size_, o.size_);
         std::swap(cap_, o.cap_);
@@ -86,6 +92,7 @@ private:
         resize(n);
         if (n) copy_d2d(data_, d, n * sizeof(T));
     }
+    std::shared_ptr<void> store_;  // owns the block data_ points to
     T* data_ = nullptr;
     size_t size_ = 0, cap_ = 0;
 };

@@ -185,8 +185,10 @@ private:
 // DLPack (geometry/pointcloud.cpp:82-100, utility/dl_converter.cu:42-118, cupoch_pybind/dl_converter.inl of the
 // reference; its third_party/dlpack is an empty submodule here, so the ABI structs of DLPack's stable v0.x
 // `DLManagedTensor` -- what a capsule named "dltensor" carries -- are restated).  Export: an (n, 3) float32 tensor on
-// kDLROCM that OWNS a device copy of the vector (the reference also copies the vector into the tensor's context but then
-// publishes the cloud's own pointer, dl_converter.cu:64-69: the tensor dies with the cloud; here it does not).  Import:
+// kDLROCM over the cloud's OWN buffer -- zero-copy, as the reference publishes it (dl_converter.cu:60-86) -- kept alive
+// by a shared handle on the block (utility::device_vector::share): the tensor stays valid when the cloud is destroyed
+// or re-allocated, sees what the cloud's in-place operations (Transform, ...) write until then, and costs nothing
+// (the reference's handle is a thrust copy of the vector, 120 MB for a 10M-point cloud, that nothing reads).  Import:
 // host (kDLCPU / pinned) or device (kDLROCM, or kDLCUDA as PyTorch-ROCm builds before 2.x labelled it) memory is COPIED
 // into the cloud's vector; the capsule is left to its owner, as in the reference.
 extern "C" {
@@ -211,20 +213,20 @@ enum { kMiDLCPU = 1, kMiDLCUDA = 2, kMiDLCUDAHost = 3, kMiDLROCM = 10, kMiDLROCM
 enum { kMiDLFloat = 2 };
 
 struct Vec3Export {
-    utility::device_vector<Eigen::Vector3f> handle;
+    std::shared_ptr<void> handle;  // the cloud's block, shared
     int64_t shape[2];
     MiDLManagedTensor tensor;
 };
 
 py::capsule to_dlpack_capsule(const utility::device_vector<Eigen::Vector3f>& src) {
     Vec3Export* e = new Vec3Export();
-    e->handle = src;  // a device copy the tensor owns
+    e->handle = src.share();  // no copy: the tensor and the cloud hold the same block
     int dev = 0;
     (void)hipGetDevice(&dev);
-    e->shape[0] = (int64_t)e->handle.size();
+    e->shape[0] = (int64_t)src.size();
     e->shape[1] = 3;
     MiDLTensor& t = e->tensor.dl_tensor;
-    t.data = (void*)e->handle.data();
+    t.data = (void*)src.data();
     t.device.device_type = kMiDLROCM;
     t.device.device_id = dev;
     t.ndim = 2;

@@ -135,6 +135,8 @@ struct mi_icp_ctx {
     mi_icp_ctx* aux = nullptr;
 
     // ---- instrumentation ----
+    mi::eng::DevBuf stamps;    // loop.h "where an iteration's time goes" (mi_icp_debug_set_step_stamps)
+    bool stamps_on = false;
     bool profiling = false;
     static constexpr int kEvPairs = 16;   // per kind: one pair per launch of a chunk
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -34,6 +34,7 @@ struct DevLoop {
     float fitness, rmse, prev_fitness, prev_rmse;
     int64_t n_source_global;
     uint64_t history;    // device address of float2[kLoopHistory] or 0: (fitness, rmse) an update started from, by iteration
+    uint64_t stamps;     // device address of uint64[kStampWords] or 0: where an iteration's time goes (mi_icp_debug_set_step_stamps)
     int32_t ready;       // estimator inputs present (normals / covariances)
     int32_t error;       // != 0: the ranks' exchange failed (mailbox.h); the loop is finished, its result void
     host::Mat4 T;        // reported transformation (column-major)
@@ -88,6 +89,32 @@ __device__ __forceinline__ float select16(const float* m, int i) {
     return v;
 }
 
+// WHERE AN ITERATION'S TIME GOES (include/mi_icp_debug.h mi_icp_debug_set_step_stamps; kernels instantiated with STAMP
+// only): s_memrealtime stamps -- one clock for the whole device, 100 MHz -- of
+//   [0] the search's earliest wave start (atomic min)   [1] its latest wave end (atomic max)
+//   [2] the reduction's earliest block start (min)      [3] the last block has taken the ticket
+//   [4] rows totalled   [5] ranks' exchange done   [6] solve + compose done   [7] state written
+// The finishing block then adds the eight spans between them -- [0]-[7 of the iteration before], [1]-[0], ... [7]-[6]
+// -- to [16 .. 23], counts the iteration in [24], keeps [7] in [8] and re-arms [0 .. 2].
+constexpr int kStampWords = 32;
+__device__ __forceinline__ unsigned long long stamp_now() { return (unsigned long long)wall_clock64(); }
+__device__ __forceinline__ void stamps_close_iteration(unsigned long long* s) {  // one thread, behind the last stamp
+    const unsigned long long prev7 = s[8];
+    unsigned long long t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = __hip_atomic_load(s + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t[0] != ~0ull && t[2] != ~0ull && t[1] != 0ull) {  // (an iteration whose search took the stamping kernel)
+        if (prev7 != 0ull && t[0] >= prev7) s[16] += t[0] - prev7;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) s[16 + k] += (t[k] >= t[k - 1]) ? t[k] - t[k - 1] : 0ull;
+        s[24] += 1ull;
+    }
+    s[8] = t[7];
+    __hip_atomic_store(s + 0, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(s + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(s + 2, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 constexpr int kLoopHistory = 4096;  // entries of the per-iteration record (a ring: iteration i at i % kLoopHistory)
 constexpr int kStepThreads = 192;  // the least a block that steps may have: three waves with a role each
 
@@ -130,7 +157,8 @@ __device__ __forceinline__ uint32_t loop_state_word(const DevLoop* st_g) {
 // finishes the loop with its error flag set.
 __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys_in, int resume, DevLoop& st_s,
                                                 const StepPre pre = StepPre{false, 0u, 0.0, 0u},
-                                                const MailArgs mail = MailArgs{nullptr, nullptr, 0, 1, 0u, nullptr, nullptr}) {
+                                                const MailArgs mail = MailArgs{nullptr, nullptr, 0, 1, 0u, nullptr, nullptr},
+                                                unsigned long long* stamps = nullptr) {
     constexpr int kWords = (int)(sizeof(DevLoop) / 4);
     constexpr int kSysWord0 = (int)(offsetof(DevLoop, sys) / 4);
     static_assert(sizeof(DevLoop) % 4 == 0 && kWords <= kStepThreads, "DevLoop is copied a word per thread");
@@ -148,6 +176,7 @@ __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys
         if (!ok && tid == 0) st_s.error = 1;
         __syncthreads();
     }
+    if (stamps && tid == 0) stamps[5] = stamp_now();
     __shared__ host::Mat4 s_update;
     __shared__ int s_det_ok, s_update_now;
     DevLoop* st = &st_s;
@@ -191,6 +220,7 @@ __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys
         s_update_now = update_now ? 1 : 0;
     }
     __syncthreads();
+    if (stamps && tid == 0) stamps[6] = stamp_now();  // (the solve; the compose below is a handful of instructions)
     if (wid == 0 && s_update_now) {
         // host::mul4(update, T) and (update, A): lane = 16 * matrix + 4 * column + row; a failed determinant
         // check leaves the identity as the update (solve_system)
@@ -214,6 +244,14 @@ __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys
     }
     __syncthreads();
     if (tid < kWords) reinterpret_cast<uint32_t*>(st_g)[tid] = dst[tid];
+    if (stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            stamps[7] = stamp_now();
+            stamps_close_iteration(stamps);
+        }
+    }
 }
 
 }  // namespace mi

@@ -399,12 +399,17 @@ int mi_icp_comm_init(mi_icp_ctx* c, const char* id128, int nranks, int rank) {
     // container's network does not route) would hold the caller forever -- and a scaling run with it, although the
     // node's mailbox needs no RCCL at all.  So the call runs on a helper thread that owns nothing but its result, and
     // the caller waits MI_ICP_COMM_INIT_MS (default 120 s; <= 0: for ever) for it: past that the communicator is given
-    // up (the thread is left behind, blocked; it touches nothing of this context), the call fails with
-    // MI_ICP_ERR_COMM and the caller may go on with mi_icp_comm_init_local.
+    // up (the thread is left behind, blocked; it touches nothing of this context, and destroys the communicator itself
+    // should it still form), the call fails with MI_ICP_ERR_COMM and the caller may go on with mi_icp_comm_init_local.
+    // The deadline covers the SYMMETRIC failure -- no rank gets a communicator.  Should one rank give up a moment before
+    // its peers' calls return, those peers go on to the agreement all-reduce below without it and wait there: callers
+    // that cannot rule that out run this call beside their main path under their own watchdog, as bench.py does
+    // (rccl_beside), and use mi_icp_comm_init_local for the exchange itself.
     struct InitResult {
         std::mutex m;
         std::condition_variable cv;
         bool done = false;
+        bool abandoned = false;  // the caller has given up: a communicator that still forms is the thread's to destroy
         ncclResult_t r = ncclSuccess;
         ncclComm_t comm = nullptr;
     };
@@ -416,6 +421,10 @@ int mi_icp_comm_init(mi_icp_ctx* c, const char* id128, int nranks, int rank) {
             ncclComm_t comm = nullptr;
             ncclResult_t r = (hipSetDevice(device) == hipSuccess) ? g_rccl.CommInitRank(&comm, nranks, id, rank) : ncclUnhandledCudaError;
             std::lock_guard<std::mutex> g(res->m);
+            if (res->abandoned) {  // (nobody will ever look at the result: do not leak the communicator)
+                if (r == ncclSuccess && comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
+                return;
+            }
             res->r = r;
             res->comm = comm;
             res->done = true;
@@ -425,8 +434,10 @@ int mi_icp_comm_init(mi_icp_ctx* c, const char* id128, int nranks, int rank) {
     {
         std::unique_lock<std::mutex> g(res->m);
         if (init_ms > 0) {
-            if (!res->cv.wait_for(g, std::chrono::milliseconds(init_ms), [&] { return res->done; }))
+            if (!res->cv.wait_for(g, std::chrono::milliseconds(init_ms), [&] { return res->done; })) {
+                res->abandoned = true;
                 return fail(c, MI_ICP_ERR_COMM, "ncclCommInitRank did not return within %ld ms (MI_ICP_COMM_INIT_MS): given up", init_ms);
+            }
         } else {
             res->cv.wait(g, [&] { return res->done; });
         }

@@ -147,6 +147,24 @@ int mi_icp_debug_solve_both(int device, const double* systems, int n, float det_
     return rc;
 }
 
+int mi_icp_debug_set_step_stamps(mi_icp_ctx* c, int enable) {
+    TRY(check_ctx(c));
+    c->stamps_on = enable != 0;  // (takes effect with the next mi_icp_icp_begin / mi_icp_registration_icp)
+    return MI_ICP_OK;
+}
+
+int mi_icp_debug_get_step_stamps(mi_icp_ctx* c, uint64_t* out32, double* ticks_per_us) {
+    TRY(check_ctx(c));
+    if (!out32 || !c->stamps.p) return fail(c, MI_ICP_ERR_STATE, "debug_get_step_stamps: no stamped loop has run on this context");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out32, c->stamps.p, sizeof(uint64_t) * kStampWords, hipMemcpyDeviceToHost));
+    if (ticks_per_us) {
+        int khz = 0;
+        *ticks_per_us = (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0) ? khz / 1000.0 : 100.0;
+    }
+    return MI_ICP_OK;
+}
+
 int mi_icp_debug_drop_seeds(mi_icp_ctx* c) {
     TRY(check_ctx(c));
     c->nn_valid = false;

@@ -65,6 +65,8 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
         if (stats) {
             if (seeded) nn_packet_kernel<true, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
             else nn_packet_kernel<false, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
+        } else if (seeded && loop && c->stamps_on) {  // (mi_icp_debug_set_step_stamps: the same kernel + two stamps per wave)
+            nn_packet_kernel<true, false, true><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
         } else {
             if (seeded) nn_packet_kernel<true, false><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
             else nn_packet_kernel<false, false><<<grid, kNNThreads, 0, c->stream>>>(MI_NN_ARGS);
@@ -218,10 +220,12 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, DevLoop* loop
         const MailArgs no_mail = {nullptr, nullptr, 0, 1, 0u, nullptr, nullptr};
         const bool mail = mail_on(c);
         if (fuse_step && loop && mail) {  // N ranks on one node: exchange + step in the finishing block
-            reduce_pt2pl_kernel<4, 2><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, mail_args(c));
+            if (c->stamps_on) reduce_pt2pl_kernel<4, 2, true><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, mail_args(c));
+            else reduce_pt2pl_kernel<4, 2><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, mail_args(c));
             if (stepped) *stepped = true;
         } else if (fuse_step && loop && !c->comm && !c->mail_dev) {
-            reduce_pt2pl_kernel<4, 1><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
+            if (c->stamps_on) reduce_pt2pl_kernel<4, 1, true><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
+            else reduce_pt2pl_kernel<4, 1><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
             if (stepped) *stepped = true;
         } else {
             reduce_pt2pl_kernel<4, 0><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
@@ -331,7 +335,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
                      &c->dense_idx, &c->flags, &c->pairs_out, &c->seg_start, &c->loop_dev, &c->ticket, &c->mail_state, &c->alt[0],
                      &c->alt[1], &c->alt[2], &c->alt[3], &c->alt[4], &c->alt[5], &c->alt[6], &c->alt[7], &c->alt[8], &c->stage[0],
                      &c->stage[1], &c->stage[2], &c->stage[3], &c->stage[4], &c->stage[5], &c->knn_idx, &c->tscale, &c->vpay[0], &c->vpay[1],
-                     &c->vpay[2], &c->vpay[3], &c->vpay[4], &c->vpay[5]};
+                     &c->vpay[2], &c->vpay[3], &c->vpay[4], &c->vpay[5], &c->stamps};
     for (DevBuf* b : all) release(*b);
     if (c->sys_host) (void)hipHostFree(c->sys_host);
     if (c->cell_total_host) (void)hipHostFree(c->cell_total_host);
@@ -770,6 +774,16 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
     L.n_source_global = c->ns_global > 0 ? c->ns_global : c->ns;
     L.ready = estimator_ready(c, est) ? 1 : 0;
     L.history = 0ull;
+    L.stamps = 0ull;
+    if (c->stamps_on) {  // (mi_icp_debug_set_step_stamps: armed -- minima at all ones -- before the loop's first launch)
+        unsigned long long* st;
+        TRY(ensure(c, c->stamps, kStampWords, &st));
+        unsigned long long init[kStampWords] = {};
+        init[0] = init[2] = ~0ull;
+        HIPCHK(c, hipMemcpyAsync(st, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // (`init` is a local)
+        L.stamps = (uint64_t)(uintptr_t)st;
+    }
     c->iter_reported = 0;
     if (c->iter_fn) {
         float* hist;
@@ -851,6 +865,10 @@ int mi_icp_icp_iterate(mi_icp_ctx* c, int n_iterations, mi_icp_result* out) {
         loop_step_kernel<<<1, kStepThreads, 0, c->stream>>>(d, (double*)c->sys_dev.p, n_iterations, MailArgs{nullptr, nullptr, 0, 1, 0u, nullptr, nullptr});
         KCHK(c);
         TRY(loop_run(c, n_iterations));
+        // (a stepping loop never reaches mi_icp_registration_icp's exit: the halo build's candidate scratch -- 0.9 GB for
+        // a 10M-point target -- is dropped here, once the build is complete; the stream has just been synchronised)
+        (void)halo_poll(c);
+        release_links_scratch(c);
     }
     if (out) {
         std::memset(out, 0, sizeof(*out));

@@ -517,7 +517,7 @@ __device__ __forceinline__ bool nn_packet_body(
 // time: 3 % faster than 4 packets per workgroup), 8 waves per SIMD.
 // (the pass from the root may take 72 registers -- 7 waves per SIMD: with 64 its two rounds spilled 20 bytes per lane,
 // 150 MB of scratch writes per 10M-query launch, and it is bound by its vector instructions, not by its occupancy)
-template <bool SEED, bool STATS>
+template <bool SEED, bool STATS, bool STAMP = false>
 __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SEED ? 8 : 7, 8))) void nn_packet_kernel(
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
         int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
@@ -527,8 +527,12 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SEED
     uint32_t logical;
     if (!xcd_remap(nblocks, logical)) return;
     PacketResult unused;
+    // STAMP (mi_icp_debug_set_step_stamps, loop.h): this wave's start and end into the loop's stamp words
+    unsigned long long* stamps = (STAMP && loop) ? reinterpret_cast<unsigned long long*>(loop->stamps) : nullptr;
+    if (STAMP && stamps && threadIdx.x == 0) atomicMin(stamps + 0, stamp_now());
     (void)nn_packet_body<SEED, STATS>(s_pk[0], logical, sx, sy, sz, ns, records_g, tblk_g, lreg_g, halo_g, leaf_first, Tv, loop,
                                       r2, nn_idx, nn_d2, stats, want, unused);
+    if (STAMP && stamps && threadIdx.x == 0) atomicMax(stamps + 1, stamp_now());
 }
 
 // ---------------------------------------------------------------------------

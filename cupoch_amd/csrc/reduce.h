@@ -92,7 +92,7 @@ typedef double ReduceRows[kReduceThreads / 32][kSysSize];
 __device__ __forceinline__ bool block_finish_rows(ReduceRows& red, double* __restrict__ partial,
                                                   uint32_t* __restrict__ ticket, double* __restrict__ out32,
                                                   StepPre* pre = nullptr, const DevLoop* pre_state = nullptr,
-                                                  const uint32_t* pre_mail_seq = nullptr) {
+                                                  const uint32_t* pre_mail_seq = nullptr, unsigned long long* stamps = nullptr) {
     __shared__ uint32_t s_last;
     __syncthreads();
     if (threadIdx.x < 64) {  // the rows' 32 threads and the ticket's are one wave: no barrier between store and ticket
@@ -111,6 +111,7 @@ __device__ __forceinline__ bool block_finish_rows(ReduceRows& red, double* __res
             const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const bool last = t == gridDim.x - 1u;
             if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // before any wave of this block reads a row
+            if (last && stamps) stamps[3] = stamp_now();
             s_last = last ? 1u : 0u;
         }
     }
@@ -171,7 +172,7 @@ __device__ __forceinline__ bool block_finish_rows(ReduceRows& red, double* __res
 __device__ __forceinline__ bool block_finish(const double* acc, double* __restrict__ partial,
                                              uint32_t* __restrict__ ticket, double* __restrict__ out32,
                                              StepPre* pre = nullptr, const DevLoop* pre_state = nullptr,
-                                             const uint32_t* pre_mail_seq = nullptr) {
+                                             const uint32_t* pre_mail_seq = nullptr, unsigned long long* stamps = nullptr) {
     __shared__ ReduceRows red;
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
 #pragma unroll
@@ -183,7 +184,7 @@ __device__ __forceinline__ bool block_finish(const double* acc, double* __restri
         red[wid][30] = 0.0;
         red[wid][31] = 0.0;
     }
-    return block_finish_rows(red, partial, ticket, out32, pre, pre_state, pre_mail_seq);
+    return block_finish_rows(red, partial, ticket, out32, pre, pre_state, pre_mail_seq, stamps);
 }
 
 // MODE 0: accumulate the linear system; MODE 1: accumulate only the
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_kernel(ReduceArgs a, Xf
 // registers cost it an occupancy step; this kernel runs two blocks per CU and has them to spare.)
 // STEP == 2 (N > 1 on one node): the finishing block first exchanges the sums with the other ranks
 // through the mailbox (mailbox.h), then steps -- still no third launch and no collective.
-template <int kU, int STEP>
+template <int kU, int STEP, bool STAMP = false>
 __global__ __launch_bounds__(kReduceThreads) void reduce_pt2pl_kernel(ReduceArgs a, Xform Tv,
                                                                       DevLoop* __restrict__ loop,
                                                                       double* __restrict__ partial,
@@ -473,10 +474,13 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_pt2pl_kernel(ReduceArgs
     };
     fetch(k0);
     Xform T = Tv;
+    unsigned long long* stamps = nullptr;  // (STAMP only: loop.h "where an iteration's time goes")
     if (loop) {
         if (loop->done) return;
         T = loop->X;
+        if (STAMP) stamps = reinterpret_cast<unsigned long long*>(loop->stamps);
     }
+    if (STAMP && stamps && threadIdx.x == 0) atomicMin(stamps + 2, stamp_now());
     double acc[30];
 #pragma unroll
     for (int k = 0; k < 30; ++k) acc[k] = 0.0;
@@ -514,10 +518,12 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_pt2pl_kernel(ReduceArgs
     // registers: loop.h StepPre)
     StepPre pre{STEP != 0, 0u, 0.0, 0u};
     const bool last = block_finish(acc, partial, ticket, out32, &pre, STEP ? loop : nullptr,
-                                   (STEP == 2) ? mail.seq_dev : nullptr);
+                                   (STEP == 2) ? mail.seq_dev : nullptr, STAMP ? stamps : nullptr);
     if (STEP && last) {
         __shared__ DevLoop st_s;
-        loop_step_block(loop, out32, 0, st_s, pre, (STEP == 2) ? mail : MailArgs{nullptr, nullptr, 0, 1, 0u, nullptr, nullptr});
+        if (STAMP && stamps && threadIdx.x == 0) stamps[4] = stamp_now();
+        loop_step_block(loop, out32, 0, st_s, pre, (STEP == 2) ? mail : MailArgs{nullptr, nullptr, 0, 1, 0u, nullptr, nullptr},
+                        STAMP ? stamps : nullptr);
     }
 }
 

@@ -565,6 +565,17 @@ class Engine:
         self._iter_cb = None if fn is None else ITERATION_FN(lambda _user, i, f, r: fn(int(i), float(f), float(r)))
         self._chk(self._L.mi_icp_set_iteration_callback(self._ctx, C.cast(self._iter_cb, C.c_void_p) if self._iter_cb else None, None))
 
+    def set_step_stamps(self, enable=True):
+        """include/mi_icp_debug.h: the next loop runs the stamping instantiations of its kernels."""
+        self._chk(self._L.mi_icp_debug_set_step_stamps(self._ctx, 1 if enable else 0))
+
+    def get_step_stamps(self):
+        """-> (32 stamp words as uint64, ticks per microsecond)"""
+        out = np.zeros(32, np.uint64)
+        tpu = C.c_double(0.0)
+        self._chk(self._L.mi_icp_debug_get_step_stamps(self._ctx, out.ctypes.data_as(C.c_void_p), C.byref(tpu)))
+        return out, float(tpu.value)
+
     def set_profiling(self, enable=True):
         self._chk(self._L.mi_icp_set_profiling(self._ctx, 1 if enable else 0))
 

@@ -64,7 +64,9 @@ def read_pcd_arrays(path):
                 if name in decoded or not 1 <= sz <= 8:
                     raise ValueError("PCD: field %s has no decodable type/size (%s %d)" % (name, ty, sz))
                 base = {1: "u1", 2: "<u2", 4: "<u4", 8: "<u8"}.get(sz, "V%d" % sz)
-                if mode == "ascii" and base.startswith("V"):
+                if mode == "ascii":
+                    # text: whatever the column holds (a signed or real-valued `intensity I 8`) parses as a double
+                    # and is dropped; an unsigned dtype made np.loadtxt raise where the C++ reader skips
                     base = "<f8"
             dt.append((name, base) if cnt == 1 else (name, base, (cnt,)))
         dt = np.dtype(dt)

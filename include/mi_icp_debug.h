@@ -43,6 +43,15 @@ MI_ICP_API int mi_icp_debug_last_search_kind(const mi_icp_ctx* ctx);
  * which = 0 kd_build_groups, 1 nn_packet_kernel<seeded>, 2 nn_packet_kernel<from the root>, 3 reduce_pt2pl_kernel<4,1>,
  * 4 leaf_halo_build, 5 rs_scatter_pay<8>, 6 voxel_means_wave.  Returns the count, < 0 on error. */
 MI_ICP_API int mi_icp_debug_occupancy(int which);
+/* Where an iteration's time goes (csrc/loop.h): with stamps enabled the NEXT registration loop on the context runs the
+ * same search / point-to-plane reduction kernels instantiated with device-clock stamps (s_memrealtime, one clock for the
+ * whole GPU): the search's first wave start / last wave end, the reduction's first block start, the last block's
+ * ticket, rows totalled, ranks' exchange done, solve done, state written.  get: the 32 stamp words -- [0..7] the
+ * current iteration's stamps (re-armed), [16..23] the SUMS of the eight spans over the iterations counted in [24]:
+ * step-end -> next search start, search, search end -> reduction start, reduction's streaming phase, row total,
+ * exchange, solve, state write -- and the clock's ticks per microsecond. */
+MI_ICP_API int mi_icp_debug_set_step_stamps(mi_icp_ctx* ctx, int enable);
+MI_ICP_API int mi_icp_debug_get_step_stamps(mi_icp_ctx* ctx, uint64_t* out32, double* ticks_per_us);
 /* The loop step's two forms of utility::SolveJacobianSystemAndObtainExtrinsicMatrix side by side, on the
  * device: n systems of 32 doubles each (host memory; the reduction's layout: 21 upper-triangle sums of
  * JtJ, 6 of Jtr, ...) are solved by one thread with the serial routines and by a wave with a matrix row

@@ -18,6 +18,12 @@ sel = np.flatnonzero(np.isfinite(a["points"]).all(1))[::3]
 np.savez_compressed(os.path.join(OUT, "fragment_every3rd.npz"), points=a["points"][sel],
                     normals=a["normals"][sel].astype(np.float16))
 
+# the WHOLE scan, points only (113,662 x 3 float32): the input of the reference's one published benchmark
+# (examples/python/basic/benchmarks.py; its README chart) -- scripts/measure_reference_benchmark.py times the same
+# four calls on it on the GPU box, where /root/reference does not exist
+full = a["points"][np.isfinite(a["points"]).all(1)]
+np.savez_compressed(os.path.join(OUT, "fragment_points.npz"), points=full)
+
 # coloured RGB-D fragment of the reference's colored-ICP example
 # (examples/python/advanced/colored_pointcloud_registration.py): every 2nd vertex
 b = read_ply_arrays(os.path.join(REF, "colored_icp", "frag_115.ply"))

@@ -93,40 +93,39 @@ def test_registration_matches_oracle_on_random_configurations(eng, case):
     o = orc.registration_icp(src, tgt, radius, est=est, tgt_nrm=nrm, det_thresh=-1.0, max_iteration=iters)
     Tg = np.array(res.transformation, np.float32).reshape(4, 4).T
     # These inputs are deliberately nasty (clusters, duplicates, 30-100 % overlap, noise, radii of several
-    # spacings, loops cut off after 1-24 iterations).  Two things can separate the engine from the reference's
-    # form on them, and the transform assertions below say which applies to a case (recorded per case):
-    #  * exact DUPLICATES in the target: equal distances resolve to the lowest slot here, to the first visited
-    #    point in FLANN / the oracle (nn_search.h:19-21) -- the same position, but for point-to-plane a
-    #    different random normal.  Such cases are held to 1e-4 in both forms.
+    # spacings, loops cut off after 1-24 iterations).  What can separate the engine from the reference's form:
     #  * the engine applies the composed T to the pristine source, the reference transforms its copy
     #    incrementally (DESIGN.md deviation 1): positions differ by ~1e-7, and a match that flips between two
     #    near-equidistant targets moves the solution of a few-thousand-point cloud by ~spacing / count.
-    # So every case without duplicates is held (a) to the oracle's restatement of the engine's OWN form
-    # (composed=True: same positions bit for bit, hence the same matches) at 1e-6 -- rounding level, both
-    # estimators -- and (b) to the reference's incremental form at north_star's 1e-5, or at 1e-4 if (a) holds
-    # and the two FORMS of the oracle themselves are further apart than 1e-5 on this input.
+    # So EVERY case is held (a) to the oracle's restatement of the engine's OWN form (composed=True: same
+    # positions bit for bit, hence the same matches) at 1e-6 -- rounding level, both estimators -- and (b) to the
+    # reference's incremental form at north_star's 1e-5, or at 1e-4 if (a) holds and the two FORMS of the oracle
+    # themselves are further apart than 1e-5 on this input.
+    #  * exact DUPLICATES in the target are no exception (round 5; they were held to 1e-4 only): coincident
+    #    points keep their original order in the engine's kd order (the cell sort is stable and the local index
+    #    sits in the low bits of every split key: kd_refine.h), so "lowest slot among equal distances" picks the
+    #    lowest ORIGINAL index among coincident points -- which is exactly the oracle's tie rule
+    #    (icp_oracle.c kd_offer).  Point-to-point could not tell anyway (same position); point-to-plane gets the
+    #    same normal.  (FLANN itself keeps the first point visited: SURVEY quirk, DESIGN section 6 "Ties".)
     scale = max(1.0, ext)
     has_dups = len(np.unique(tgt, axis=0)) < nt
     assert abs(res.fitness - o.fitness) <= 2e-3
     assert abs(res.inlier_rmse - o.inlier_rmse) <= 1e-3 * max(o.inlier_rmse, spacing)
     err_ref = float(np.linalg.norm(Tg - o.transformation))
-    if has_dups:
-        rule = "duplicates: 1e-4 vs the reference form"
-        assert err_ref <= 1e-4 * scale, (case, est, err_ref)
-        err_own = None
+    oc = orc.registration_icp(src, tgt, radius, est=est, tgt_nrm=nrm, det_thresh=-1.0, max_iteration=iters,
+                              composed=True)
+    err_own = float(np.linalg.norm(Tg - oc.transformation))
+    forms = float(np.linalg.norm(oc.transformation - o.transformation))
+    assert err_own <= 1e-6 * scale, (case, est, err_own, has_dups)
+    assert res.iterations == oc.iterations
+    if forms <= 1e-5 * scale:
+        rule = "1e-6 vs the composed form, 1e-5 vs the reference form"
+        assert err_ref <= 1e-5 * scale, (case, est, err_ref, forms)
     else:
-        oc = orc.registration_icp(src, tgt, radius, est=est, tgt_nrm=nrm, det_thresh=-1.0, max_iteration=iters,
-                                  composed=True)
-        err_own = float(np.linalg.norm(Tg - oc.transformation))
-        forms = float(np.linalg.norm(oc.transformation - o.transformation))
-        assert err_own <= 1e-6 * scale, (case, est, err_own)
-        assert res.iterations == oc.iterations
-        if forms <= 1e-5 * scale:
-            rule = "1e-6 vs the composed form, 1e-5 vs the reference form"
-            assert err_ref <= 1e-5 * scale, (case, est, err_ref, forms)
-        else:
-            rule = "1e-6 vs the composed form; the oracle's two forms are %.2g apart here: 1e-4 vs the reference form" % forms
-            assert err_ref <= 1e-4 * scale, (case, est, err_ref, forms)
+        rule = "1e-6 vs the composed form; the oracle's two forms are %.2g apart here: 1e-4 vs the reference form" % forms
+        assert err_ref <= 1e-4 * scale, (case, est, err_ref, forms)
+    if has_dups:
+        rule += " (target with exact duplicates)"
     _RULES.append({"case": case, "estimator": "point-to-point" if est == 1 else "point-to-plane", "target_points": nt,
                    "iterations": iters, "rule": rule, "err_vs_reference_form": err_ref, "err_vs_composed_form": err_own})
     if case == N_REG - 1:

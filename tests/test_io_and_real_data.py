@@ -62,6 +62,11 @@ def test_pcd_reader_skips_auxiliary_fields_of_any_size(tmp_path):
     asc.write_text("VERSION 0.7\nFIELDS x y z timestamp\nSIZE 4 4 4 8\nTYPE F F F U\nCOUNT 1 1 1 1\nWIDTH 2\nHEIGHT 1\nPOINTS 2\n"
                    "DATA ascii\n1 2 3 1234567890123\n4 5 6 1234567890124\n")
     np.testing.assert_array_equal(read_pcd_arrays(str(asc))["points"], [[1, 2, 3], [4, 5, 6]])
+    # ... and a text column that is signed / real-valued whatever its declared type says: skipped all the same
+    neg = tmp_path / "aux_ascii_signed.pcd"
+    neg.write_text("VERSION 0.7\nFIELDS x y z intensity gain\nSIZE 4 4 4 8 2\nTYPE F F F I U\nCOUNT 1 1 1 1 1\nWIDTH 2\nHEIGHT 1\nPOINTS 2\n"
+                   "DATA ascii\n1 2 3 -17 0.5\n4 5 6 -1e3 -2.25\n")
+    np.testing.assert_array_equal(read_pcd_arrays(str(neg))["points"], [[1, 2, 3], [4, 5, 6]])
     bad = tmp_path / "x8.pcd"
     bad.write_bytes(b"VERSION 0.7\nFIELDS x y z\nSIZE 8 4 4\nTYPE I F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA binary\n" + bytes(16))
     with pytest.raises(ValueError):

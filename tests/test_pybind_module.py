@@ -190,12 +190,21 @@ def test_registration_through_a_python_defined_estimator_and_dlpack_round_trips(
     assert np.array_equal(t.cpu().numpy(), d["tgt"])
     t2 = torch.utils.dlpack.from_dlpack(tgt.to_normals_dlpack())
     assert np.array_equal(t2.cpu().numpy(), d["tgt_nrm"])
-    del tgt                                                              # the tensors own their memory
-    assert float(t.sum()) == pytest.approx(float(d["tgt"].astype(np.float64).sum()), rel=1e-5)
+    # ZERO-COPY (round 5; the reference publishes the cloud's own buffer, utility/dl_converter.cu:60-86): what the cloud
+    # does in place shows through the tensor, and a second export is the same memory
+    tgt.translate(np.array([1.0, 2.0, 4.0], np.float32))
+    torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy(), d["tgt"] + np.array([1.0, 2.0, 4.0], np.float32))
+    assert torch.from_dlpack(tgt.to_points_dlpack()).data_ptr() == t.data_ptr()
+    del tgt                                                              # ... and the block outlives the cloud: the tensor holds it too
+    import gc
+    gc.collect()
+    assert float(t.sum()) == pytest.approx(float((d["tgt"].astype(np.float64) + [1.0, 2.0, 4.0]).sum()), rel=1e-5)
+    t = t - torch.tensor([1.0, 2.0, 4.0], device=t.device)
     back = g.PointCloud()
     back.from_points_dlpack(torch.utils.dlpack.to_dlpack(t * 2.0))      # device tensor in
     back.from_normals_dlpack(torch.utils.dlpack.to_dlpack(torch.from_numpy(d["tgt_nrm"])))   # host tensor in
-    assert np.array_equal(np.asarray(back.points.cpu()), d["tgt"] * 2.0)
+    np.testing.assert_allclose(np.asarray(back.points.cpu()), d["tgt"] * 2.0, atol=1e-5)
     assert np.array_equal(np.asarray(back.normals.cpu()), d["tgt_nrm"]) and not back.has_colors()
     with pytest.raises(ValueError):
         back.from_colors_dlpack(torch.utils.dlpack.to_dlpack(torch.zeros(5, 4)))             # not (n, 3)
