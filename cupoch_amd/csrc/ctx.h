@@ -53,6 +53,8 @@ struct mi_icp_ctx {
     bool t_has_nrm = false, t_has_cov = false, t_has_int = false, t_has_grad = false, t_has_rec = false;
     mi::eng::DevBuf tblk, tnrm, trec, tcov, tgrad, nodes, inv_t, tidx, thalo, tlinks_tmp;  // (leaf regions: the leaf lines' fourth rows, lreg_of)
     mi::eng::DevBuf cell_planes, cell_samples, cell_cstart, cell_gstart;
+    mi::eng::DevBuf gplanes;   // every group's own 511 split planes (kd_build.h): with cell_planes / cell_gstart the binary descent of locate_by_planes
+    int cell_levels = -1;      // levels of cell planes of the present target; < 0: no kd cells (Morton-run fallback tree), nothing to descend
     uint32_t* cell_total_host = nullptr;  // pinned
     bool inv_t_valid = false;
     bool links_ready = false, links_allowed = false;  // leaf_halo.h
@@ -81,6 +83,9 @@ struct mi_icp_ctx {
     mi::eng::DevBuf alt[9];  // second set of the source arrays (match-order re-sort ping-pong)
     bool inv_s_valid = false;
     bool nn_valid = false;  // nn_idx holds a search result (usable as seed / correspondences)
+    mi::eng::DevBuf src_bounds;    // min[3], max[3] of the staged source (the loop's step sizes the displacement of its corners: loop.h)
+    bool seeds_located = false;    // nn_idx holds seeds the queries made themselves (locate_by_planes), not matches
+    bool relocate_armed = false;   // this loop's next chunk of iterations carries the gated re-location launches (loop_run)
 
     // ---- explicit correspondence set ----
     mi::eng::DevBuf user_pairs;
@@ -91,7 +96,7 @@ struct mi_icp_ctx {
     mi::eng::DevBuf partial, sys_dev, dense_idx, flags, pairs_out, seg_start;
     mi::eng::DevBuf stage[6];
     mi::eng::DevBuf tscale;   // scratch of kd_build.h tree_scale
-    mi::eng::DevBuf knn_idx;  // candidate indices of the small k-NN lists, [packet][slot][lane] (knn_normals.h)
+    mi::eng::DevBuf knn_idx, knn_flags;  // the k-NN lists' index rows, [XCD][row][slot][lane], and the rows' claim flags (knn_normals.h KnnSlab)
     mi::eng::DevBuf vpay[6];  // VoxelDownSample: two sets of payload arrays (points, normals, colours) the radix passes alternate between
     double* sys_host = nullptr;  // pinned, 32 doubles + spare
     float* f_host = nullptr;     // pinned, 16 floats

@@ -31,6 +31,7 @@ struct GroupBuildArgs {
     float* records;
     float* lreg;              // tblk + kLeafRegOffset: the leaf lines' fourth rows, [ngroups * 512] region records (below)
     int32_t* tidx;            // [ngroups * 4096] original index of every slot (-1: padding)
+    float2* gplanes;          // [ngroups][512] the group's own 511 split planes in heap order (entry 0 unused): nn_search.h locate_by_planes
     float link_delta;         // bound of the halos (leaf_halo.h) as a fraction of the leaf-level node's extent
     float region_margin;      // a leaf's region is kept within this many bounds of its own box
 };
@@ -94,7 +95,7 @@ static __global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_
         s.key[i] = (uint32_t)i;
     }
     __syncthreads();
-    kd_sort_levels<false, true>(s, 9, nullptr, 0u);
+    kd_sort_levels<true, true>(s, 9, a.gplanes + (size_t)g * 512u, 1u);
 
     // ---- leaf lines + sorted attributes: position p of the group = slot g*4096 + p
     const int64_t slot0 = (int64_t)g * kKdGroup;

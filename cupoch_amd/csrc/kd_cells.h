@@ -30,6 +30,7 @@
 // nslots = 4096 * groups entries, padding slots carry original index -1.
 #pragma once
 #include "device_utils.h"
+#include "kd_descend.h"
 #include "kd_refine.h"
 
 namespace mi {
@@ -54,20 +55,6 @@ static __global__ __launch_bounds__(256) void cells_sample_gather(const float* _
     samp[j * 3] = pts[i * 3];
     samp[j * 3 + 1] = pts[i * 3 + 1];
     samp[j * 3 + 2] = pts[i * 3 + 2];
-}
-
-// cell of a point after `levels` planes: right of a plane <=> coordinate >= plane
-// (NaN and anything below go left)
-__device__ __forceinline__ uint32_t descend_cell(const float2* __restrict__ planes, int levels, float x,
-                                                 float y, float z) {
-    uint32_t node = 1u;
-    for (int l = 0; l < levels; ++l) {
-        const float2 pl = planes[node];
-        const int ax = __float_as_int(pl.y);
-        const float v = (ax == 0) ? x : ((ax == 1) ? y : z);
-        node = node * 2u + ((v >= pl.x) ? 1u : 0u);
-    }
-    return node - (1u << levels);
 }
 
 // keys[i] = cell of point i, vals[i] = i  (K: width of the sort keys, primitives.h)

@@ -468,7 +468,7 @@ __device__ __forceinline__ void kd_sort_levels(KdShared& s, int levels, float2* 
         // A wave that holds nothing but padding (a 10M-point target fills its 4096-slot groups to 60 %: six of a
         // group's sixteen waves) has nothing to order -- any arrangement of padding is as good as any other.  It
         // takes part in the siblings' exchange below (with +-inf: no cut) and leaves.
-        const bool idle = !PLANES && lS == 8 && !(mn[0] < INFINITY) && !(mn[1] < INFINITY) && !(mn[2] < INFINITY);
+        const bool idle = lS == 8 && last <= 4 && !(mn[0] < INFINITY) && !(mn[1] < INFINITY) && !(mn[2] < INFINITY);
         if (SAFE && lS >= 6) {
             // the sibling half's extreme along the axis the parent was split along
             const bool left = ((4 * tid) & S) == 0;
@@ -496,6 +496,11 @@ __device__ __forceinline__ void kd_sort_levels(KdShared& s, int levels, float2* 
             if (SAFE && (tid & 15) == 0) {  // its four 64-slot nodes: empty regions
 #pragma unroll
                 for (int e = 0; e < 6; ++e) s.safe[e * 64 + (tid >> 4)] = (e < 3) ? INFINITY : -INFINITY;
+            }
+            if (PLANES && lane < 31) {
+                // the 1 + 2 + 4 + 8 + 16 splits of this wave's 256 positions (rounds lS = 8 .. 4): everything left of +inf
+                const int lvl = 31 - __builtin_clz((uint32_t)lane + 1u), j = lane + 1 - (1 << lvl);
+                planes[(size_t)(heap_root << (4 + lvl)) + (uint32_t)((wid << lvl) + j)] = make_float2(INFINITY, 0.0f);
             }
             break;
         }

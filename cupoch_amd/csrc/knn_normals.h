@@ -45,6 +45,38 @@ __host__ __device__ constexpr int knn_waves(int) { return 1; }
 __host__ __device__ constexpr int knn_capacity(int k) { return k <= kMaxKnn ? kMaxKnn : (k <= kMaxKnnMid ? kMaxKnnMid : kMaxKnnBig); }
 constexpr int kKnnSeedBefore = 4, kKnnSeedAfter = 12;  // leaves around the packet's first leaf
 
+// THE INDEX SLAB IS SIZED BY RESIDENT WAVES, not by packets (round 5; it was [packet][slot][lane]: 1.3 / 2.6 / 4.2 GB
+// per 10M queries at 32 / 64 / 104 slots, streamed through HBM once).  A wave CLAIMS one of `per_xcc` rows of its
+// XCD's pool when it starts -- an atomic compare-and-swap on the row's flag, linear probing from a hashed start -- and
+// gives it back when it ends; the pools hold a quarter more rows than the XCD can have waves resident, so a claim
+// rarely probes twice, and the whole slab (~50 MB at any capacity, any number of queries) stays in the memory-side
+// cache.  Pools are per XCD -- the real one, HW_REG_XCC_ID, not the dispatch order -- because the XCDs' L2s are not
+// coherent with each other: a row only ever sees the stores of one L2, so a former owner's dirty line can never be
+// written back over the present owner's entries.  A former owner's stores are complete (vmcnt(0)) before its flag
+// clears.  Rows carry nothing from one owner to the next: a wave reads only the entries it wrote.
+struct KnnSlab {
+    int32_t* rows;      // [8][per_xcc][KCAP * 64]
+    uint32_t* flags;    // [8][per_xcc], zeroed before the launch
+    uint32_t per_xcc;
+};
+__device__ __forceinline__ uint32_t knn_row_claim(const KnnSlab& sl, uint32_t seed) {
+    uint32_t row = 0u;
+    if (lane_id() == 0) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7u;
+        uint32_t* f = sl.flags + xcc * sl.per_xcc;
+        uint32_t r = (seed * 2654435761u) % sl.per_xcc;
+        while (atomicCAS(f + r, 0u, 1u) != 0u) r = (r + 1u == sl.per_xcc) ? 0u : r + 1u;  // (holders never wait: one frees up)
+        row = xcc * sl.per_xcc + r;
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)row);
+}
+__device__ __forceinline__ void knn_row_release(const KnnSlab& sl, uint32_t row) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores into the row have reached the L2
+    if (lane_id() == 0) __hip_atomic_store(sl.flags + row, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int KCAP>
 struct KnnStateT {
     float worst;  // current bound: +inf (or the search radius) until k candidates are held
@@ -229,7 +261,7 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_normals_kernel(
         const float* __restrict__ records_g, const float* __restrict__ tblk_g, const int32_t* __restrict__ tidx_g,
         uint32_t leaf_first, int64_t n, int nleaf,
         int k, float r2, uint32_t nblocks, float* __restrict__ normals_out,
-        const float4* __restrict__ tnrm, float4* __restrict__ tgrad, int32_t* __restrict__ idx_slab) {
+        const float4* __restrict__ tnrm, float4* __restrict__ tgrad, KnnSlab slab) {
     constexpr int kWaves = knn_waves(KCAP);
     __shared__ float s_d2[kWaves][KCAP * 64];
     uint32_t logical;
@@ -239,9 +271,11 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_normals_kernel(
     float* kd2 = s_d2[wid];
 
     const int pkt = __builtin_amdgcn_readfirstlane((int)logical * kWaves + wid);
-    int32_t* kidx = idx_slab + (size_t)pkt * (KCAP * 64);
     const int leaf0 = pkt * 8;
     if (leaf0 >= nleaf) return;  // whole wave out of range (no block barriers below)
+    const uint32_t row = knn_row_claim(slab, (uint32_t)pkt);
+    int32_t* kidx = slab.rows + (size_t)row * (KCAP * 64);
+    [&]() {  // (lanes leave this body one by one; the row goes back when all of them have)
     const int64_t i = (int64_t)pkt * 64 + lane;
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
     int32_t orig = -1;
@@ -420,6 +454,8 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_normals_kernel(
     normals_out[(int64_t)orig * 3] = nx;
     normals_out[(int64_t)orig * 3 + 1] = ny;
     normals_out[(int64_t)orig * 3 + 2] = nz;
+    }();
+    knn_row_release(slab, row);
 }
 
 // ---- knn::KDTreeFlann::SearchKNN / SearchRadius for arbitrary queries ---------------------
@@ -435,7 +471,7 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
         uint32_t leaf_first, const float* __restrict__ qx_g, const float* __restrict__ qy_g, const float* __restrict__ qz_g,
         const int32_t* __restrict__ qperm, int nq, int nleaf, int k, float r2, uint32_t nblocks,
         int32_t* __restrict__ idx_out, float* __restrict__ d2_out, unsigned long long* __restrict__ found,
-        int32_t* __restrict__ idx_slab) {
+        KnnSlab slab) {
     constexpr int kWaves = knn_waves(KCAP);
     __shared__ float s_d2[kWaves][KCAP * 64];
     uint32_t logical;
@@ -443,9 +479,11 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
     const cfloat_p tblk = (cfloat_p)(uintptr_t)tblk_g;
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
     float* kd2 = s_d2[wid];
-    int32_t* kidx = idx_slab + ((size_t)logical * kWaves + wid) * (KCAP * 64);
     const int64_t i = ((int64_t)logical * kWaves + wid) * 64 + lane;
     if (i - lane >= nq) return;  // whole wave out of range (no block barriers below)
+    const uint32_t row = knn_row_claim(slab, logical * (uint32_t)kWaves + (uint32_t)wid);
+    int32_t* kidx = slab.rows + (size_t)row * (KCAP * 64);
+    [&]() {  // (as in knn_normals_kernel)
     const bool valid = i < nq;
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
     if (valid) {
@@ -662,6 +700,8 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
         }
     }
     if (found) atomicAdd(found, (unsigned long long)st.count);
+    }();
+    knn_row_release(slab, row);
 }
 
 }  // namespace mi

@@ -35,8 +35,16 @@ struct DevLoop {
     int64_t n_source_global;
     uint64_t history;    // device address of float2[kLoopHistory] or 0: (fitness, rmse) an update started from, by iteration
     uint64_t stamps;     // device address of uint64[kStampWords] or 0: where an iteration's time goes (mi_icp_debug_set_step_stamps)
+    // RE-LOCATION (nn_search.h locate_by_planes).  The step sizes what it does to the source: the largest displacement of
+    // the 8 corners of the source's box under the update just solved.  Beyond a quarter of a point spacing the next
+    // search's seeds are stale: `relocate` is set and the gated locate launch in front of that search (when the host
+    // has armed one) replaces every seed by the leaf the moved query falls into.
+    uint64_t near2_ptr;       // device address of the tree's squared "near" radius (~1.25 spacings; kd_build.h tree_scale) or 0: never
+    uint64_t src_bounds_ptr;  // device address of the staged source's min[3], max[3]
     int32_t ready;       // estimator inputs present (normals / covariances)
     int32_t error;       // != 0: the ranks' exchange failed (mailbox.h); the loop is finished, its result void
+    int32_t relocate;    // the step just taken moved the source by more than a quarter spacing
+    int32_t relocations; // steps of this loop that did
     host::Mat4 T;        // reported transformation (column-major)
     host::Mat4 A;        // applied transformation (differs from T only by an ~identity init)
     double sys[32];      // the reduced (and all-reduced) system of the last evaluation
@@ -193,7 +201,18 @@ __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys
         // est 5: no det check (generalized_icp.cu:180)
         const bool ok = !(wave_case && est != 5 && st->det_thresh > 0.0f) || wave_det_passes(st->sys, st->det_thresh);
         if (lane == 0) s_det_ok = ok ? 1 : 0;
-    } else if (wid == 2 && lane == 0) {
+    }
+    // (wave 2, lanes 0..7: the corners of the source's box as the searches saw them -- A is stable until the barrier)
+    float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+    const bool sized = st->near2_ptr != 0ull && st->src_bounds_ptr != 0ull;
+    if (wid == 2 && lane < 8 && sized) {
+        const float* sb = reinterpret_cast<const float*>(st->src_bounds_ptr);
+        const float px = sb[(lane & 1) ? 3 : 0], py = sb[(lane & 2) ? 4 : 1], pz = sb[(lane & 4) ? 5 : 2];
+        cx = host::at(st->A, 0, 0) * px + host::at(st->A, 0, 1) * py + host::at(st->A, 0, 2) * pz + host::at(st->A, 0, 3);
+        cy = host::at(st->A, 1, 0) * px + host::at(st->A, 1, 1) * py + host::at(st->A, 1, 2) * pz + host::at(st->A, 1, 3);
+        cz = host::at(st->A, 2, 0) * px + host::at(st->A, 2, 1) * py + host::at(st->A, 2, 2) * pz + host::at(st->A, 2, 3);
+    }
+    if (wid == 2 && lane == 0) {
         bool update_now = true;
         if (resume > 0) {
             st->max_iterations = st->iterations + resume;
@@ -221,6 +240,25 @@ __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys
     }
     __syncthreads();
     if (stamps && tid == 0) stamps[6] = stamp_now();  // (the solve; the compose below is a handful of instructions)
+    if (wid == 2 && sized) {  // how far does the update move the corners?  (s_update is final; a failed determinant check: identity)
+        float d2 = 0.0f;
+        if (lane < 8 && s_update_now && s_det_ok) {
+            const host::Mat4& U = s_update;
+            const float dx = host::at(U, 0, 0) * cx + host::at(U, 0, 1) * cy + host::at(U, 0, 2) * cz + host::at(U, 0, 3) - cx;
+            const float dy = host::at(U, 1, 0) * cx + host::at(U, 1, 1) * cy + host::at(U, 1, 2) * cz + host::at(U, 1, 3) - cy;
+            const float dz = host::at(U, 2, 0) * cx + host::at(U, 2, 1) * cy + host::at(U, 2, 2) * cz + host::at(U, 2, 3) - cz;
+            d2 = dx * dx + dy * dy + dz * dz;
+        }
+        d2 = fmaxf(d2, __shfl_xor(d2, 1, 64));
+        d2 = fmaxf(d2, __shfl_xor(d2, 2, 64));
+        d2 = fmaxf(d2, __shfl_xor(d2, 4, 64));
+        if (lane == 0) {
+            const float near2 = *reinterpret_cast<const float*>(st->near2_ptr);
+            const int far = (d2 > 0.04f * near2) ? 1 : 0;  // (0.2 * 1.25 spacings)^2; NaN / inf radius: never
+            st->relocate = far;
+            st->relocations += far;
+        }
+    }
     if (wid == 0 && s_update_now) {
         // host::mul4(update, T) and (update, A): lane = 16 * matrix + 4 * column + row; a failed determinant
         // check leaves the identity as the update (solve_system)

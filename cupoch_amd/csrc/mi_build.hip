@@ -409,6 +409,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
         ga.records = nodes;
         ga.lreg = lreg;
         ga.tidx = tidx;
+        TRY(ensure(c, c->gplanes, (size_t)lay.ngroups * 512, &ga.gplanes));
         ga.link_delta = 0.25f;     // the halos' bound: a quarter of the leaf-level node's size (kd_build.h)
         ga.region_margin = 0.5f;   // a leaf's region stays within half that bound of its own box
         kd_build_groups<<<(unsigned)lay.ngroups, kKdThreads, 0, c->stream>>>(ga);
@@ -439,6 +440,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     c->nleaf = nleaf;
     c->leaf_first = leaf_first;
     c->nrecords = nrecords;
+    c->cell_levels = no_cells ? -1 : lay.levels;
     // A context that has run a registration loop will run another.  For a small target (frame-to-frame callers:
     // KinFu, odometry) the halos are started right away, on the private stream, next to the staging of the source:
     // they cost that little, and the loop's first seeded iterations find them ready.  For a large one the build
@@ -484,7 +486,13 @@ int mi_icp_set_source(mi_icp_ctx* c, const float* xyz, const float* normals, con
     // (Measured: the in-group kd split on top of the Morton order, kd_refine.h, costs more here -- 1.2 ms at
     // 10M -- than it saves in that one pass, 0.15 ms.)
     const uint32_t* order;
-    TRY(morton_order(c, d_pts, n, &order, false));
+    float* own_bounds = nullptr;
+    TRY(morton_order(c, d_pts, n, &order, false, nullptr, 0, &own_bounds));
+    {   // (c->bounds is every build's scratch: the source's box is kept for the loop, loop.h "re-location")
+        float* sb;
+        TRY(ensure(c, c->src_bounds, 8, &sb));
+        HIPCHK(c, hipMemcpyAsync(sb, own_bounds, 8 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    }
 
     float *sx, *sy, *sz, *scov = nullptr, *d2;
     int32_t *sperm, *idx;

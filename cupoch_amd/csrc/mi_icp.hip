@@ -25,6 +25,25 @@ static int64_t coarse_first_min() {
     return v;
 }
 
+// The target has kd cells and its groups' planes: a query's own leaf is a binary descent away (nn_search.h
+// locate_by_planes).  MI_ICP_NO_LOCATE_PLANES: A/B switch -- the greedy record descent (locate_leaves) and no
+// sort ahead of the first search, no re-location.
+bool planes_available(const mi_icp_ctx* c) {
+    static const bool off = std::getenv("MI_ICP_NO_LOCATE_PLANES") != nullptr;
+    return !off && c->cell_levels >= 0 && c->gplanes.p != nullptr && c->cell_planes.p != nullptr && c->cell_gstart.p != nullptr &&
+           c->leaf_first > 1u && c->nleaf > 0;
+}
+
+// seeds for every source point under T (or the loop's transform) into nn_idx; gated: only if the loop's last step asks
+int launch_locate_by_planes(mi_icp_ctx* c, const Xform& X, const DevLoop* loop, int gated) {
+    const int grid = (int)std::min<int64_t>(blocks_for(c->ns), 8192);
+    locate_by_planes<<<grid, 256, 0, c->stream>>>((const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns,
+                                                 (const float2*)c->cell_planes.p, c->cell_levels, (const uint32_t*)c->cell_gstart.p,
+                                                 (const float2*)c->gplanes.p, (uint32_t)c->nleaf, X, loop, gated, (int32_t*)c->nn_idx.p);
+    KCHK(c);
+    return MI_ICP_OK;
+}
+
 int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long long* stats, const DevLoop* loop) {
     if (c->ns <= 0) return MI_ICP_OK;
     int32_t* idx = (int32_t*)c->nn_idx.p;
@@ -78,14 +97,20 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
     // whose seed leaf's region does not finish it walks up from there -- under the displacement a registration
     // starts with that is most packets, and costs more than the walk from the root: 10M points 3.9 against 1.2 ms.)
     if (!use_seed && !stats && !no_coarse && c->leaf_first > 1u && c->ns >= coarse_first_min() && have_halo) {
-        locate_leaves<<<blocks_for(c->ns), 256, 0, c->stream>>>((const float*)c->sx.p, (const float*)c->sy.p,
-                                                                (const float*)c->sz.p, (int)c->ns,
-                                                                (const float*)c->nodes.p, c->leaf_first,
-                                                                (uint32_t)c->nleaf, X, loop, idx);
-        KCHK(c);
+        if (planes_available(c)) {
+            TRY(launch_locate_by_planes(c, X, loop, 0));
+        } else {
+            locate_leaves<<<blocks_for(c->ns), 256, 0, c->stream>>>((const float*)c->sx.p, (const float*)c->sy.p,
+                                                                    (const float*)c->sz.p, (int)c->ns,
+                                                                    (const float*)c->nodes.p, c->leaf_first,
+                                                                    (uint32_t)c->nleaf, X, loop, idx);
+            KCHK(c);
+        }
         self_seeded = true;
     }
-    c->last_search_kind = use_seed ? 1 : (self_seeded ? 2 : 0);
+    // (seeds_located: the caller has located -- and sorted by -- the queries' own leaves already: loop_begin)
+    c->last_search_kind = (use_seed && !c->seeds_located) ? 1 : ((self_seeded || c->seeds_located) ? 2 : 0);
+    c->seeds_located = false;
     launch(use_seed || self_seeded, (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, c->ns, idx,
            loop ? nullptr : d2);
     KCHK(c);
@@ -335,7 +360,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
                      &c->dense_idx, &c->flags, &c->pairs_out, &c->seg_start, &c->loop_dev, &c->ticket, &c->mail_state, &c->alt[0],
                      &c->alt[1], &c->alt[2], &c->alt[3], &c->alt[4], &c->alt[5], &c->alt[6], &c->alt[7], &c->alt[8], &c->stage[0],
                      &c->stage[1], &c->stage[2], &c->stage[3], &c->stage[4], &c->stage[5], &c->knn_idx, &c->tscale, &c->vpay[0], &c->vpay[1],
-                     &c->vpay[2], &c->vpay[3], &c->vpay[4], &c->vpay[5], &c->stamps};
+                     &c->vpay[2], &c->vpay[3], &c->vpay[4], &c->vpay[5], &c->stamps, &c->knn_flags, &c->gplanes, &c->src_bounds};
     for (DevBuf* b : all) release(*b);
     if (c->sys_host) (void)hipHostFree(c->sys_host);
     if (c->cell_total_host) (void)hipHostFree(c->cell_total_host);
@@ -681,6 +706,14 @@ static int launch_fused_iteration(mi_icp_ctx* c, DevLoop* d) {
 // one evaluation: search under the loop's transform, reduction, all-reduce, step kernel
 static int loop_enqueue_evaluation(mi_icp_ctx* c, bool seed) {
     DevLoop* d = (DevLoop*)c->loop_dev.p;
+    // RE-LOCATION (loop.h): while this loop's steps are still large the seeded search is preceded by a launch that
+    // does nothing unless the step just taken moved the source by more than a quarter spacing -- then every seed is
+    // replaced by the leaf the moved query falls into.  Armed per chunk by loop_run; needs the halos (a located seed
+    // without them walks like a stale one).
+    if (seed && c->relocate_armed && c->halo_use && c->nn_valid && c->n_user_pairs < 0 && c->ns > 0 && c->nt > 0) {
+        const Xform none = {};
+        TRY(launch_locate_by_planes(c, none, d, 1));
+    }
     if (fused_iteration_applies(c, seed)) return launch_fused_iteration(c, d);
     const Mat4 I = host::identity4();
     TRY(launch_nn(c, I, c->loop_r2, seed, nullptr, d));
@@ -724,11 +757,15 @@ static int loop_run(mi_icp_ctx* c, int budget) {
         if (undecided && c->ns >= kLarge && !several_ranks) n = 1;
         const int passes_before = c->loop_host->passes;
         c->halo_use = halo_poll(c);
+        const bool carried = c->relocate_armed && c->halo_use;  // this chunk's iterations carry the gated re-location launches
+        const int relocations_before = c->loop_host->relocations;
         for (int i = 0; i < n; ++i) TRY(loop_enqueue_evaluation(c, true));
         if (no_halo) HIPCHK(c, hipMemcpyAsync(c->u_host + 8, c->halo_want.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         TRY(loop_pull(c));
         const int executed = c->loop_host->passes - passes_before;
         collect_pooled(c, executed);
+        // (a chunk that carried the launches and never needed one: the steps have become small, and they only shrink)
+        if (carried && c->loop_host->relocations == relocations_before) c->relocate_armed = false;
         budget -= n;
         c->halo_iters += executed;
         if (no_halo) {
@@ -775,6 +812,11 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
     L.ready = estimator_ready(c, est) ? 1 : 0;
     L.history = 0ull;
     L.stamps = 0ull;
+    // re-location (loop.h): sized only where the descent exists and the source is large enough to make its own seeds
+    const bool can_locate = planes_available(c) && c->ns >= coarse_first_min() && c->src_bounds.p != nullptr && c->nt > 0;
+    L.near2_ptr = can_locate ? (uint64_t)(uintptr_t)((const float*)c->nodes.p + kRecordNear2) : 0ull;
+    L.src_bounds_ptr = can_locate ? (uint64_t)(uintptr_t)c->src_bounds.p : 0ull;
+    c->relocate_armed = can_locate;
     if (c->stamps_on) {  // (mi_icp_debug_set_step_stamps: armed -- minima at all ones -- before the loop's first launch)
         unsigned long long* st;
         TRY(ensure(c, c->stamps, kStampWords, &st));
@@ -832,11 +874,23 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
             c->halo_use = halo_poll(c);
         }
     }
+    static const bool no_resort = std::getenv("MI_ICP_NO_RESORT") != nullptr;  // A/B switch for tuning
+    const bool resort = !no_resort && c->ns >= 32768 && (max_iterations >= 4 || max_iterations == 0);
+    static const bool no_coarse = std::getenv("MI_ICP_NO_COARSE_FIRST") != nullptr;
+    if (resort && can_locate && c->halo_use && !no_coarse && c->n_user_pairs < 0) {
+        // LOCATE, SORT, THEN SEARCH (nn_search.h locate_by_planes): the match-order sort is paid either way; taken ahead
+        // of the first search -- on the leaves the queries fall into -- it makes that search's packets share their
+        // leaf and halo lines
+        TRY(launch_locate_by_planes(c, L.X, nullptr, 0));
+        c->nn_valid = true;
+        TRY(resort_source_by_match(c));
+        c->seeds_located = true;
+        TRY(loop_enqueue_evaluation(c, true));
+        return MI_ICP_OK;
+    }
     TRY(loop_enqueue_evaluation(c, false));
     // from here on the packets follow the target's order (pays for itself in ~4 iterations)
-    static const bool no_resort = std::getenv("MI_ICP_NO_RESORT") != nullptr;  // A/B switch for tuning
-    if (!no_resort && c->ns >= 32768 && (max_iterations >= 4 || max_iterations == 0))
-        TRY(resort_source_by_match(c));
+    if (resort) TRY(resort_source_by_match(c));
     return MI_ICP_OK;
 }
 

@@ -8,6 +8,28 @@ using namespace mi;
 using namespace mi::eng;
 using host::Mat4;
 
+namespace {
+
+// The index rows of one k-NN launch (knn_normals.h KnnSlab): a quarter more rows per XCD than the XCD can hold waves of
+// this kernel, flags cleared on the stream ahead of the launch.  `kernel`: the instantiation about to be launched.
+template <class K>
+int knn_slab(mi_icp_ctx* c, K kernel, int cap, KnnSlab* out) {
+    static const int ncu = [] { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); return (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }();
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, knn_waves(cap) * 64, 0) != hipSuccess || occ <= 0) {
+        (void)hipGetLastError();
+        occ = std::min(32, (160 * 1024) / (cap * 64 * 4));  // one wave per workgroup; the lists' distances fill the LDS
+    }
+    const uint32_t per_xcc = (uint32_t)(((int64_t)occ * knn_waves(cap) * ((ncu + 7) / 8) * 5 + 3) / 4 + 8);
+    TRY(ensure(c, c->knn_idx, (size_t)8 * per_xcc * cap * 64, &out->rows));
+    TRY(ensure(c, c->knn_flags, (size_t)8 * per_xcc, &out->flags));
+    HIPCHK(c, hipMemsetAsync(out->flags, 0, (size_t)8 * per_xcc * sizeof(uint32_t), c->stream));
+    out->per_xcc = per_xcc;
+    return MI_ICP_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 static int estimate_normals_impl(mi_icp_ctx* c, const float* xyz, int64_t n, int knn, float r2,
@@ -32,8 +54,10 @@ static int estimate_normals_impl(mi_icp_ctx* c, const float* xyz, int64_t n, int
         const int cap = knn_capacity(knn), waves = knn_waves(cap);
         const uint32_t nblocks = (uint32_t)((a->nleaf + waves * 8 - 1) / (waves * 8));
         const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
-        int32_t* slab;
-        TRY(ensure(a, a->knn_idx, (size_t)nblocks * waves * cap * 64, &slab));
+        KnnSlab slab;
+        if (cap == kMaxKnn) TRY(knn_slab(a, knn_normals_kernel<0, kMaxKnn>, cap, &slab));
+        else if (cap == kMaxKnnMid) TRY(knn_slab(a, knn_normals_kernel<0, kMaxKnnMid>, cap, &slab));
+        else TRY(knn_slab(a, knn_normals_kernel<0, kMaxKnnBig>, cap, &slab));
 #define MI_NRM_ARGS (const float*)a->nodes.p, (const float*)a->tblk.p, (const int32_t*)a->tidx.p, a->leaf_first, a->nts, a->nleaf, knn, r2, nblocks, \
                     dn, nullptr, nullptr, slab
         if (cap == kMaxKnn) knn_normals_kernel<0, kMaxKnn><<<grid, waves * 64, 0, a->stream>>>(MI_NRM_ARGS);
@@ -86,8 +110,10 @@ int mi_icp_search_knn(mi_icp_ctx* c, const float* queries, int64_t nq, int knn, 
     const int cap = knn_capacity(knn), waves = knn_waves(cap);
     const uint32_t nblocks = (npackets + waves - 1) / waves;
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
-    int32_t* slab;
-    TRY(ensure(c, c->knn_idx, (size_t)nblocks * waves * cap * 64, &slab));
+    KnnSlab slab;
+    if (cap == kMaxKnn) TRY(knn_slab(c, knn_search_kernel<kMaxKnn>, cap, &slab));
+    else if (cap == kMaxKnnMid) TRY(knn_slab(c, knn_search_kernel<kMaxKnnMid>, cap, &slab));
+    else TRY(knn_slab(c, knn_search_kernel<kMaxKnnBig>, cap, &slab));
 #define MI_KNN_ARGS (const float*)c->nodes.p, (const float*)c->tblk.p, (const int32_t*)c->tidx.p, c->leaf_first, (const float*)c->sx.p, \
                     (const float*)c->sy.p, (const float*)c->sz.p, (const int32_t*)c->sperm.p, (int)nq, c->nleaf, knn, \
                     radius > 0.0f ? radius * radius : INFINITY, nblocks, d_idx, d_d2, cnt, slab
@@ -122,8 +148,10 @@ int mi_icp_compute_color_gradients(mi_icp_ctx* c, float radius, int max_nn, floa
     const int cap = knn_capacity(max_nn), waves = knn_waves(cap);
     const uint32_t nblocks = (uint32_t)((c->nleaf + waves * 8 - 1) / (waves * 8));
     const uint32_t grid = ((nblocks + 7u) / 8u) * 8u;
-    int32_t* slab;
-    TRY(ensure(c, c->knn_idx, (size_t)nblocks * waves * cap * 64, &slab));
+    KnnSlab slab;
+    if (cap == kMaxKnn) TRY(knn_slab(c, knn_normals_kernel<1, kMaxKnn>, cap, &slab));
+    else if (cap == kMaxKnnMid) TRY(knn_slab(c, knn_normals_kernel<1, kMaxKnnMid>, cap, &slab));
+    else TRY(knn_slab(c, knn_normals_kernel<1, kMaxKnnBig>, cap, &slab));
 #define MI_GRAD_ARGS (const float*)c->nodes.p, (const float*)c->tblk.p, (const int32_t*)c->tidx.p, c->leaf_first, c->nts, c->nleaf, max_nn, \
                      radius * radius, nblocks, dg, (const float4*)c->tnrm.p, tgrad, slab
     if (cap == kMaxKnn) knn_normals_kernel<1, kMaxKnn><<<grid, waves * 64, 0, c->stream>>>(MI_GRAD_ARGS);

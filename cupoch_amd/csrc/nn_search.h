@@ -22,6 +22,7 @@
 #pragma once
 #include "device_utils.h"
 #include "halo_format.h"
+#include "kd_descend.h"
 #include "loop.h"
 #include "traverse.h"
 
@@ -529,10 +530,12 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SEED
     PacketResult unused;
     // STAMP (mi_icp_debug_set_step_stamps, loop.h): this wave's start and end into the loop's stamp words
     unsigned long long* stamps = (STAMP && loop) ? reinterpret_cast<unsigned long long*>(loop->stamps) : nullptr;
-    if (STAMP && stamps && threadIdx.x == 0) atomicMin(stamps + 0, stamp_now());
+    // (only the first 64 and the last 256 workgroups of the dispatch order touch the two words: every wave doing so --
+    // 156k atomics on one address -- made a 10M-query launch 3.5 ms instead of 0.08)
+    if (STAMP && stamps && threadIdx.x == 0 && blockIdx.x < 64u) atomicMin(stamps + 0, stamp_now());
     (void)nn_packet_body<SEED, STATS>(s_pk[0], logical, sx, sy, sz, ns, records_g, tblk_g, lreg_g, halo_g, leaf_first, Tv, loop,
                                       r2, nn_idx, nn_d2, stats, want, unused);
-    if (STAMP && stamps && threadIdx.x == 0) atomicMax(stamps + 1, stamp_now());
+    if (STAMP && stamps && threadIdx.x == 0 && blockIdx.x + 256u >= gridDim.x) atomicMax(stamps + 1, stamp_now());
 }
 
 // ---------------------------------------------------------------------------
@@ -615,6 +618,39 @@ static __global__ __launch_bounds__(256) void locate_leaves(const float* __restr
     }
     const uint32_t leaf = min(8u * (id - leaf_first) + c, nleaf - 1u);
     if (i < ns) nn_idx[i] = (int32_t)(leaf * (uint32_t)kLeaf);
+}
+
+// THE SAME BY BINARY PLANES (round 5): the leaf a query FALLS INTO -- cell planes (kd_cells.h), the cell's first group,
+// the group's own 511 planes (kd_build.h) -- 21 dependent 8-byte loads per query at 10M points instead of seven
+// 192-byte records with 48 compares each; consecutive queries are neighbours, so the upper levels are broadcasts and the
+// lower ones hit a 4-KB table per group.  Two users:
+//  * a loop's first pass when the target's halos exist: locate, SORT the source by located leaf (the match-order sort
+//    the loop pays anyway, taken before the first search instead of after it), then the seeded search on packets whose
+//    64 lanes share a handful of leaves -- their leaf / halo lines come out of the L1 instead of six vector loads per
+//    (lane, line) going to the L2 each;
+//  * RE-LOCATION inside a loop (gated != 0: nothing happens unless the step just taken set loop->relocate, loop.h): a
+//    step that moved the points by more than a quarter spacing leaves every seed a leaf or two off; trusting it costs
+//    a halo phase AND a 19-record climb for the lanes beyond their stale leaf's reach (r04_transient_census.txt).
+// An overflowing cell (several groups) sends its queries to its first group: a seed like any other.
+static __global__ __launch_bounds__(256) void locate_by_planes(
+        const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int ns,
+        const float2* __restrict__ cell_planes, int cell_levels, const uint32_t* __restrict__ gstart,
+        const float2* __restrict__ gplanes, uint32_t nleaf, Xform Tv, const DevLoop* __restrict__ loop, int gated,
+        int32_t* __restrict__ nn_idx) {
+    Xform T = Tv;
+    if (loop) {
+        if (loop->done) return;
+        if (gated && loop->relocate == 0) return;
+        T = loop->X;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ns; i += (int64_t)gridDim.x * 256) {
+        float qx, qy, qz;
+        xform_point(T, sx[i], sy[i], sz[i], qx, qy, qz);
+        const uint32_t cell = descend_cell(cell_planes, cell_levels, qx, qy, qz);
+        const uint32_t g = gstart[cell];
+        const uint32_t leaf = min(g * 512u + descend_group(gplanes + (size_t)g * 512u, qx, qy, qz), nleaf - 1u);
+        nn_idx[i] = (int32_t)(leaf * (uint32_t)kLeaf);
+    }
 }
 
 static __global__ __launch_bounds__(256) void export_dense(const int32_t* __restrict__ nn_idx,

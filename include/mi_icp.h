@@ -328,8 +328,9 @@ MI_ICP_API int mi_icp_covariances_from_normals(mi_icp_ctx* ctx, const float* nor
  * (geometry/estimate_normals.cu:82-127), knn <= 100 (knn::NUM_MAX_NN,
  * knn/kdtree_search_param.h:26; lists of up to 32 neighbours take the faster kernel).
  * Workspace: the k-NN kernels (this call, mi_icp_search_knn, the colour gradients) keep
- * their candidates' INDICES in a device slab of 128 B per point / query for k <= 32
- * (256 B up to 64, 416 B up to 100: 1.3 / 2.6 / 4.2 GB per 10M), allocated by the first
+ * their candidates' INDICES in a device slab sized by the waves the GPU can hold at once,
+ * not by the queries: ~50 MB at any list length and any number of points (a wave claims a
+ * row of its XCD's pool when it starts and returns it when it ends), allocated by the first
  * such call of a context and reused by the later ones; EstimateNormals builds the cloud's
  * tree in a private scratch context of its own (the caller's target / source / loop
  * state survive the call). */

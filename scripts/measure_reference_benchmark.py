@@ -101,9 +101,28 @@ def main():
     gn = np.asarray(pc.normals.cpu())
     on = orc.estimate_normals_knn(pts, KNN)
     dots = np.abs(np.sum(gn * on, 1))                    # (the sign of an eigenvector is free)
-    agree = float((dots > 1.0 - 1e-4).mean())
-    rows["estimate_normals"] = dict(first_ms=f, ms=m, ok=agree > 0.995,
-                                    parity="|<n, n_oracle>| > 1 - 1e-4 for %.4f %% of the points (near-degenerate neighbourhoods excepted)" % (100 * agree))
+    # The reference forms the covariance from fp32 RAW moments (estimate_normals.cu:38-64): on a metre-scale scan the
+    # cancellation leaves both the engine's and the port's normals a rounding-order apart wherever the smallest eigenvalue
+    # is not well separated.  Parity as tests/test_gpu_parity.py::test_estimate_normals_disagreements_are_explained states
+    # it: the neighbour SETS are identical (bit-exact distances), and no disagreement sits on a well-separated covariance.
+    from cupoch_amd.engine import Engine
+    e2 = Engine(0)
+    e2.set_target(pts)
+    _, idx, d2 = e2.search_knn(pts, KNN)
+    e2.close()
+    _, oi, od = orc.search_knn(pts, pts, KNN)
+    sets_equal = (np.sort(idx, 1) == np.sort(oi, 1)).all(1)
+    P = pts[idx].astype(np.float64)
+    Cm = np.einsum("nki,nkj->nij", P, P) / KNN - np.einsum("ni,nj->nij", P.mean(1), P.mean(1))
+    w = np.linalg.eigvalsh(Cm)
+    well = (w[:, 1] - w[:, 0]) / np.maximum(w[:, 2], 1e-300) > 0.02
+    bad = dots < 1.0 - 1e-4
+    unexplained = int((bad & well & sets_equal).sum())
+    rows["estimate_normals"] = dict(first_ms=f, ms=m, ok=bool(np.array_equal(d2, od)) and unexplained == 0,
+                                    parity="k-NN distances bit-exact: %s; neighbour sets equal for %.3f %%; |<n, n_oracle>| > 1 - 1e-4 for %.2f %% of the "
+                                           "points (> 1 - 1e-2: %.2f %%); disagreements on a well-separated covariance with equal sets: %d"
+                                           % (bool(np.array_equal(d2, od)), 100 * sets_equal.mean(), 100 * (dots > 1 - 1e-4).mean(),
+                                              100 * (dots > 1 - 1e-2).mean(), unexplained))
     # -- voxel_down_sample(0.005) (benchmarks.py:38-40)
     down, f, m = first_and_median(lambda: pc.voxel_down_sample(VOXEL))
     gp = np.asarray(down.points.cpu())
@@ -125,6 +144,7 @@ def main():
                                            % (err, len(res.correspondence_set), len(ref.correspondence_set), res.fitness, ref.fitness))
     one = cpu_times(1)
     allt = cpu_times(0)
+    some = cpu_times(16)
     for name in ("transform", "estimate_normals", "voxel_down_sample", "registration_icp"):
         r = rows[name]
         print(json.dumps({
@@ -132,8 +152,9 @@ def main():
             "as_called_by": "/root/reference/examples/python/basic/benchmarks.py",
             "gpu_first_call_ms": round(r["first_ms"], 3), "gpu_ms": round(r["ms"], 3),
             "gpu_ms_is": "median of 5 further calls, host-visible wall time, cloud resident on the device, pybind11 module",
-            "cpu_port_1_thread_ms": round(one[name] * 1e3, 2), "cpu_port_all_threads_ms": round(allt[name] * 1e3, 2),
-            "cpu_threads": allt["threads"],
+            "cpu_port_1_thread_ms": round(one[name] * 1e3, 2), "cpu_port_16_threads_ms": round(some[name] * 1e3, 2),
+            "cpu_port_all_threads_ms": round(allt[name] * 1e3, 2), "cpu_threads": allt["threads"],
+            "speedup_vs_best_cpu": round(min(one[name], some[name], allt[name]) * 1e3 / r["ms"], 1),
             "speedup_vs_1_thread": round(one[name] * 1e3 / r["ms"], 1), "speedup_vs_1_thread_first_call": round(one[name] * 1e3 / r["first_ms"], 1),
             "speedup_vs_all_threads": round(allt[name] * 1e3 / r["ms"], 1),
             "reference_published_speedup_gtx1070_vs_open3d_1_thread": PUBLISHED[name],
