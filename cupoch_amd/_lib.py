@@ -43,23 +43,27 @@ def needs_build():
     return any(os.path.getmtime(s) > t for s in _sources())
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, variant=None, defines=()):
     """hipcc --offload-arch=gfx950 -c csrc/<unit>.hip for every unit (in parallel; a unit whose object is newer than
-    every source is kept), then hipcc -shared ... -o cupoch_amd/lib/libmi_icp.so"""
-    if not force and not needs_build():
+    every source is kept), then hipcc -shared ... -o cupoch_amd/lib/libmi_icp.so
+    variant / defines: a second build for same-box A/B runs (MI_ICP_LIB_PATH), e.g. variant="h4",
+    defines=("-DMI_HALO_STORED=4",) -> cupoch_amd/lib/libmi_icp_h4.so"""
+    lib_path = LIB_PATH if not variant else os.path.join(LIB_DIR, "libmi_icp_%s.so" % variant)
+    obj_dir = OBJ_DIR if not variant else OBJ_DIR + "_" + variant
+    if not force and not variant and not needs_build():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise MiIcpError("hipcc not found; cannot build libmi_icp.so")
-    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(obj_dir, exist_ok=True)
     headers = [s for s in _sources() if s.endswith(".h")]
     newest_header = max(os.path.getmtime(h) for h in headers)
 
     def compile_unit(u):
-        src, obj = os.path.join(CSRC, u + ".hip"), os.path.join(OBJ_DIR, u + ".o")
+        src, obj = os.path.join(CSRC, u + ".hip"), os.path.join(obj_dir, u + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(newest_header, os.path.getmtime(src)):
             return obj
-        cmd = [hipcc] + HIPCC_FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + HIPCC_FLAGS + list(defines) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -68,12 +72,12 @@ def build(force=False, verbose=False):
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=len(UNITS)) as pool:
         objs = list(pool.map(compile_unit, UNITS))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH + ".tmp"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_path + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(lib_path + ".tmp", lib_path)
+    return lib_path
 
 
 ITERATION_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_float, C.c_float)   # mi_icp_iteration_fn

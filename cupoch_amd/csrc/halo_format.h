@@ -8,6 +8,14 @@ namespace mi {
 constexpr int kHaloLines = 8;            // halo lines per leaf (leaf_halo.h): the 64 nearest points of other leaves, 8 per line, in rings
 constexpr int kHaloLineFloats = 32;      // x[8] y[8] z[8] slot[8]: a leaf line with the points' slots in its fourth row
 constexpr float kHaloUnit = 1.0f / 64.0f;
+// How many of the eight lines are STORED (a build-time knob for one measurement, VERDICT r4 next-6: -DMI_HALO_STORED=4
+// keeps the nearest 32 points, 512 B per leaf; the reaches of the lines that are not stored equal the last stored
+// one's, so a cube that needs more walks).  8 in the shipped library.
+#ifndef MI_HALO_STORED
+#define MI_HALO_STORED 8
+#endif
+constexpr int kHaloStored = MI_HALO_STORED;
+static_assert(kHaloStored >= 1 && kHaloStored <= kHaloLines, "MI_HALO_STORED: 1 .. 8");
 
 // The reaches of a leaf's eight halo lines travel in the two spare words of its region record, as 6-bit
 // fractions q_k of the bound (the reach a line has when no point lies behind it): word A = q0 .. q4 from bit 0,

@@ -225,7 +225,7 @@ static __global__ __launch_bounds__(64) void leaf_halo_build(float* __restrict__
         const uint32_t L = base + (uint32_t)li;  // wave-uniform
         if (L >= (uint32_t)nleaf) break;
         const int count = __shfl(cnt_mine, li, 64);
-        float* lines = halo + (size_t)L * (kHaloLines * kHaloLineFloats);
+        float* lines = halo + (size_t)L * (kHaloStored * kHaloLineFloats);
         const float4* rg = reinterpret_cast<const float4*>(lreg + (size_t)L * kLeafRegStride);
         const float4 g0 = rg[0], g1 = rg[1];
         float bound = g0.w;  // (collect's final bound; 0: not usable)
@@ -316,7 +316,7 @@ static __global__ __launch_bounds__(64) void leaf_halo_build(float* __restrict__
         }
         // ---- the rings: sorted elements 8k .. 8k+7 are line k, i.e. lane = (line, entry) holds its point already
         uint32_t slot = 0xffffffffu;
-        if (lane < 8 * kHaloLines && sk[0] != 0xffffffffu) {
+        if (lane < 8 * kHaloStored && sk[0] != 0xffffffffu) {
             const uint32_t idx = sk[0] & 511u;  // candidate * 8 + slot
             slot = (s_ids[li * 65 + (int)(idx >> 3)] & kLinkIdMask) * (uint32_t)kLeaf + (idx & 7u);
         }
@@ -331,7 +331,7 @@ static __global__ __launch_bounds__(64) void leaf_halo_build(float* __restrict__
             o = lane_xor<2>(slot); slot = ((lane & 2) == 0) ? min(slot, o) : max(slot, o);
             o = lane_xor<1>(slot); slot = ((lane & 1) == 0) ? min(slot, o) : max(slot, o);
         }
-        if (lane < 8 * kHaloLines) {
+        if (lane < 8 * kHaloStored) {
             float x = INFINITY, y = INFINITY, z = INFINITY;
             if (slot != 0xffffffffu) {
                 const float* ln = tblk + (size_t)(slot >> 3) * kLeafFloats + (slot & 7u);
@@ -357,6 +357,7 @@ static __global__ __launch_bounds__(64) void leaf_halo_build(float* __restrict__
                                       __uint_as_float(bbits));
             uint32_t q = (uint32_t)fminf(reach * __builtin_amdgcn_rcpf(unit) + 1.0f, 63.0f);
             while (q > 0u && !(unit * (float)q <= reach)) --q;  // (the search's own arithmetic)
+            if (kHaloStored < kHaloLines) q = (uint32_t)__shfl((int)q, min(lane, kHaloStored - 1), 64);  // (lines not stored: nothing beyond the last stored one's reach)
             if (lane < 5) pa = q << (6 * lane);
             else if (lane < 7) pb = q << (6 * (lane - 5));
             else {

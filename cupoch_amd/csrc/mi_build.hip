@@ -174,7 +174,7 @@ int build_links(mi_icp_ctx* c, hipStream_t st) {
     if (!c->links_allowed || no_links) return MI_ICP_OK;  // (every leaf's largest reach is 0 as built: no query asks for a line)
     float* halo;
     const size_t ntiles = ((size_t)c->nleaf + 63) / 64;
-    TRY(ensure(c, c->thalo, ntiles * 64 * kHaloLines * kHaloLineFloats, &halo));
+    TRY(ensure(c, c->thalo, ntiles * 64 * kHaloStored * kHaloLineFloats, &halo));
     uint2* cand;  // scratch: up to 64 candidate leaves per leaf
     TRY(ensure(c, c->tlinks_tmp, ntiles * 64 * kLinkCand, &cand));
     const uint32_t lblocks = (uint32_t)ntiles;

@@ -102,7 +102,7 @@ int mi_icp_debug_get_leaf_halos(mi_icp_ctx* c, float* halos_out) {
     TRY(check_ctx(c));
     if (!halos_out || c->nt <= 0) return fail(c, MI_ICP_ERR_INVALID, "debug_get_leaf_halos: no target / bad arguments");
     TRY(ensure_links(c));
-    const size_t count = (size_t)c->nleaf * kHaloLines * kHaloLineFloats;
+    const size_t count = (size_t)c->nleaf * kHaloStored * kHaloLineFloats;
     if (!c->thalo.p) {  // no halos on this tree (MI_ICP_NO_CELLS / MI_ICP_NO_LINKS)
         std::memset(halos_out, 0, count * sizeof(float));
         return MI_ICP_OK;

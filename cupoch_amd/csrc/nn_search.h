@@ -142,7 +142,7 @@ __device__ __forceinline__ void drain_halo(PacketShared& sh, const float* halo_g
     const float oy = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(qy)));
     const float oz = __int_as_float(__builtin_amdgcn_ds_bpermute(ql << 2, __float_as_int(qz)));
     if (have) {
-        const float* lf = halo_g + ((size_t)L * kHaloLines + f) * kHaloLineFloats;
+        const float* lf = halo_g + ((size_t)L * kHaloStored + f) * kHaloLineFloats;
         const float4* line = reinterpret_cast<const float4*>(lf);
         const float4 x0 = line[0], x1 = line[1], y0 = line[2], y1 = line[3], z0 = line[4], z1 = line[5];
         const uint32_t held_bits = (uint32_t)(sh.best[ql] >> 32);  // what the owner holds (or a batch-mate has found)
@@ -263,7 +263,7 @@ __device__ __forceinline__ bool nn_packet_body(
                 const float lx = g0.x - cube.lox, ly = g0.y - cube.loy, lz = g0.z - cube.loz;
                 const float over = fmaxf(fmaxf(fmaxf(ux, lx), fmaxf(uy, ly)), fmaxf(uz, lz)) * 1.000001f;
                 nlines = halo_lines_needed(g0.w, g1.w, over);
-                linked = halo_g != nullptr && nlines <= (uint32_t)kHaloLines;  // (no halos (yet), or beyond their reach: walk)
+                linked = halo_g != nullptr && nlines <= (uint32_t)kHaloStored;  // (no halos (yet), or beyond their reach: walk)
                 if (STATS) why = !(g0.x <= g1.x) ? 1u : (__float_as_uint(g1.w) == 0u ? 2u : (!linked ? 3u : 0u));
             }
         }
@@ -288,7 +288,7 @@ __device__ __forceinline__ bool nn_packet_body(
             // every lane that needs anything needs its leaf's first line only: each evaluates its own (no queue,
             // no exchange; the common case of small noise)
             if (STATS) ++batches, halo_items += (uint32_t)__popcll(__ballot(linked));
-            const float* lf = halo_g + (size_t)seed_leaf * (kHaloLines * kHaloLineFloats);
+            const float* lf = halo_g + (size_t)seed_leaf * (kHaloStored * kHaloLineFloats);
             const float4* line = reinterpret_cast<const float4*>(lf);
             const float4 x0 = line[0], x1 = line[1], y0 = line[2], y1 = line[3], z0 = line[4], z1 = line[5];
             if (linked) {
