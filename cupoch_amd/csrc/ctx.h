@@ -52,7 +52,7 @@ struct mi_icp_ctx {
     uint32_t leaf_first = 1, nrecords = 0;  // 8-ary tree: first last-level node id, record count
     bool t_has_nrm = false, t_has_cov = false, t_has_int = false, t_has_grad = false, t_has_rec = false;
     mi::eng::DevBuf tblk, tnrm, trec, tcov, tgrad, nodes, inv_t, tidx, thalo, tlinks_tmp;  // (leaf regions: the leaf lines' fourth rows, lreg_of)
-    mi::eng::DevBuf cell_planes, cell_samples, cell_cstart, cell_gstart;
+    mi::eng::DevBuf cell_planes, cell_samples, cell_cstart, cell_gstart, cell_boxes, cell_hist;  // (kd_planes.h: the sample's boxes and histograms)
     mi::eng::DevBuf gplanes;   // every group's own 511 split planes (kd_build.h): with cell_planes / cell_gstart the binary descent of locate_by_planes
     int cell_levels = -1;      // levels of cell planes of the present target; < 0: no kd cells (Morton-run fallback tree), nothing to descend
     uint32_t* cell_total_host = nullptr;  // pinned

@@ -20,7 +20,7 @@ struct GroupBuildArgs {
     const uint32_t* cstart;   // [ncells + 1] first sorted position of every cell
     const uint32_t* gstart;   // [ncells] first group of every cell
     const float2* planes;     // the cells' split planes in heap order (kd_cells.h)
-    int cell_levels;          // ncells = 2^cell_levels
+    int cell_levels;          // depth of the cells' plane tree + its layout flag (kd_descend.h)
     int ncells;
     uint32_t ngroups;
     uint32_t leaf_first;      // id of the first leaf-level node (8^k >= 64 * ngroups)
@@ -71,7 +71,7 @@ static __global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_
         s_src[2] = ((lo + 1 < a.ncells) ? a.gstart[lo + 1] : a.ngroups) - a.gstart[lo];
         // the cell's region: every point of another cell lies on or beyond one of its faces
         float reg[6];
-        cell_region(a.planes, a.cell_levels, a.cell_levels, (uint32_t)lo, reg);
+        cell_region(a.planes, a.cell_levels, cell_depth(a.cell_levels), heap_leaf_of_cell(a.cell_levels, (uint32_t)lo), reg);
 #pragma unroll
         for (int e = 0; e < 6; ++e) {
             s.safe[e * 64] = reg[e];

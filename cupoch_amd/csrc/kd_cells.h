@@ -10,12 +10,11 @@
 // cell; this file does the same for the levels above, without a global kd build
 // (a segmented sort per level, what the reference's FLANN builder does):
 //
-//   1. d = ceil(log2(N / 2731)) binary levels, C = 2^d cells (mean fill <= 2/3 of a
-//      group, so sampling noise does not overflow 4096);
-//   2. split planes from a stride sample of 128*C points, resolved <= 5 levels per stage:
-//      every cell of the current depth gets one workgroup that median-splits 4096 of
-//      its samples in LDS (kd_sort_levels) and writes the planes in heap order; the
-//      samples are then re-assigned and re-sorted by cell for the next stage;
+//   1. the layout with the fewest cells whose mean fill stays within 3300 points, 80 % of a group: 2^d cells or
+//      3 * 2^k (kd_descend.h TRI; cell_layout_for below);
+//   2. split planes, level by level, from histograms over a stride sample of 512 points per cell (kd_planes.h: every
+//      split sees all the samples of its node, so a cell's count comes out within ~4.5 % -- the sampled medians of
+//      rounds 2-4, 4096 samples per workgroup and five levels per stage, gave +-12 % and held the fill to two thirds);
 //   3. every point descends the d planes -> cell id; one short radix sort by cell id
 //      (ceil(d/8) passes instead of the 5 of a 39-bit Morton key);
 //   4. cell c owns max(1, ceil(count_c/4096)) groups of 4096 SLOTS, points left-packed,
@@ -35,15 +34,18 @@
 
 namespace mi {
 
-constexpr int kCellTargetFill = 2731;     // mean points per cell <= 2/3 of a group
-constexpr int kCellSamples = 128;         // samples per final cell: count noise ~9 % (sigma)
-constexpr int kCellStageLevels = 5;       // 4096 samples / 2^5 = 128 per cell
+constexpr int kCellTargetFill = 3300;     // mean points per cell <= 80 % of a group: the planes (kd_planes.h) put a cell's count within ~4.5 % (sigma)
 constexpr int kCellMaxLevels = 19;
 
-static inline int cell_levels_for(int64_t n) {
+// The layout with the fewest cells whose mean fill stays within kCellTargetFill: 2^d cells, or 3 * 2^k (kd_descend.h
+// TRI).  Returns the plane tree's depth, + kCellTriFlag for a TRI layout.
+static inline int cell_layout_for(int64_t n) {
     int d = 0;
     while (d < kCellMaxLevels && ((int64_t)kCellTargetFill << d) < n) ++d;
-    return d;
+    int k = 0;
+    while (k + 2 < kCellMaxLevels && ((int64_t)kCellTargetFill * 3 << k) < n) ++k;
+    const bool tri = ((int64_t)3 << k) < ((int64_t)1 << d) && ((int64_t)kCellTargetFill * 3 << k) >= n;
+    return tri ? (k + 2) | kCellTriFlag : d;
 }
 
 // sample j = point floor(j * n / S)
@@ -120,56 +122,6 @@ static __global__ __launch_bounds__(1024) void cells_layout(const uint32_t* __re
         __syncthreads();
     }
     if (tid == 0) total[0] = s_carry;
-}
-
-// One workgroup per cell b of depth `base_level`: takes 4096 of the cell's samples (a
-// stride subsample when it has more, wrapped around when fewer) and resolves `levels`
-// more levels.  keys/vals: the samples sorted by their depth-base_level cell (vals =
-// sample index); base_level == 0: all S samples in order.
-static __global__ __launch_bounds__(kKdThreads) void cells_planes(const float* __restrict__ samp, int64_t S,
-                                                           const uint64_t* __restrict__ keys,
-                                                           const uint32_t* __restrict__ vals, int base_level,
-                                                           int levels, float2* __restrict__ planes) {
-    __shared__ KdShared s;
-    __shared__ int64_t s_range[2];
-    const int tid = (int)threadIdx.x;
-    const uint32_t b = blockIdx.x;
-    if (tid < 2) {
-        int64_t r;
-        if (base_level == 0) {
-            r = tid ? S : 0;
-        } else {  // lower_bound(keys, b + tid)
-            const uint64_t want = (uint64_t)b + (uint64_t)tid;
-            int64_t lo = 0, hi = S;
-            while (lo < hi) {
-                const int64_t mid = (lo + hi) >> 1;
-                if (keys[mid] < want) lo = mid + 1;
-                else hi = mid;
-            }
-            r = lo;
-        }
-        s_range[tid] = r;
-    }
-    __syncthreads();
-    const int64_t s0 = s_range[0], m = s_range[1] - s_range[0];
-    for (int i = tid; i < kKdGroup; i += kKdThreads) {
-        float x = INFINITY, y = INFINITY, z = INFINITY;  // empty cell: every plane becomes +inf
-        if (m > 0) {
-            const int64_t k = s0 + ((m >= kKdGroup) ? (((int64_t)i * m) >> 12) : ((int64_t)i % m));
-            const int64_t j = (base_level == 0) ? k : (int64_t)vals[k];
-            x = samp[j * 3];
-            y = samp[j * 3 + 1];
-            z = samp[j * 3 + 2];
-            // non-finite coordinates would poison the segment extents; park them as padding
-            if (!(fabsf(x) < INFINITY) || !(fabsf(y) < INFINITY) || !(fabsf(z) < INFINITY)) x = y = z = INFINITY;
-        }
-        s.cx[i] = x;
-        s.cy[i] = y;
-        s.cz[i] = z;
-        s.key[i] = (uint32_t)i;
-    }
-    __syncthreads();
-    kd_sort_levels<true>(s, levels, planes, (1u << base_level) + b);
 }
 
 // sorted position p (cell-major, stable) -> slot gstart[cell] * 4096 + rank within the cell

@@ -1,0 +1,216 @@
+// kd_planes.h -- the split planes of the target's cells (kd_cells.h), by HISTOGRAMS over a sample (round 5).
+//
+// The planes used to be medians of 4096-sample subsets sorted in LDS, five levels per stage: whatever the sample's
+// size, a stage's last split saw 256 samples, and a 10M-point target's cell counts came out +-12 % (sigma).  With
+// cells that must not exceed 4096 points the mean fill therefore had to stay below two thirds -- and the groups
+// kd_build_groups sorts were 40 % padding.  Here every split sees ALL the samples of its node (512 per final cell:
+// sigma ~4.5 %), so cells can be filled to 80 % (kCellTargetFill, kd_cells.h), and a split may sit at any quantile --
+// which is what the TRI layout's root needs (kd_descend.h).
+//
+// Per level l (the nodes of depth l are split):
+//   hp_assign_bbox  (levels 1 .. 5) every sample steps through its parent's plane; the samples' EXACT bounding box
+//                   per node, min / max as order-preserving integers: atomics in LDS, one global atomic per node and
+//                   block (<= 32 nodes);
+//   hp_hist         every sample's bin along its node's longest axis (256 bins, more while the level has few nodes:
+//                   bins x nodes >= 16384 keeps the global atomics spread); from level 6 on the step through the
+//                   parent's plane happens here and the node's box is its parent's cut at the plane (written by
+//                   hp_select) -- by then the boxes hug the data, and no level needs box atomics on 64+ nodes;
+//   hp_select       a wave per node: the bin boundary that leaves the wanted share of the samples (1/2; 1/3 at a TRI
+//                   root) on the left is the plane -- a plane may be any coordinate, it need not be a sample's.
+// An empty or point-like node gets a +inf plane (everything left), as before.
+#pragma once
+#include "device_utils.h"
+#include "kd_descend.h"
+
+namespace mi {
+
+constexpr int kPlaneExactBoxLevels = 6;  // nodes of depth < 6 take their samples' exact box
+constexpr int kPlaneMinBins = 256;
+constexpr int kPlaneBinBudget = 16384;   // bins x nodes of a level
+constexpr int kPlaneSamples = 512;       // samples per final cell
+
+__host__ __device__ __forceinline__ int plane_bins(int level) {
+    return (level >= 6) ? kPlaneMinBins : kPlaneBinBudget >> level;  // 16384, 8192, ... 512, then 256
+}
+
+// floats as integers that order the same way (for atomicMin / atomicMax); 0xffffffff decodes to a NaN: "no value"
+__device__ __forceinline__ uint32_t fenc(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fdec(uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e); }
+
+// a node's splitting axis (the longest of its box), the box's lower face along it and bins per unit length
+// (scale 0: empty or point-like node -- every sample lands in bin 0)
+__device__ __forceinline__ void plane_axis(const uint32_t* __restrict__ boxmin, const uint32_t* __restrict__ boxmax,
+                                           uint32_t node, int bins, int& ax, float& lo, float& ext, float& scale) {
+    const uint4 mn = reinterpret_cast<const uint4*>(boxmin)[node], mx = reinterpret_cast<const uint4*>(boxmax)[node];
+    ax = 0;
+    lo = 0.0f;
+    ext = 0.0f;
+    scale = 0.0f;
+    if (mn.x == 0xffffffffu) return;  // no sample
+    const float l0 = fdec(mn.x), l1 = fdec(mn.y), l2 = fdec(mn.z);
+    const float e0 = fdec(mx.x) - l0, e1 = fdec(mx.y) - l1, e2 = fdec(mx.z) - l2;
+    float e = e0;
+    lo = l0;
+    if (e1 > e) {
+        e = e1;
+        ax = 1;
+        lo = l1;
+    }
+    if (e2 > e) {
+        e = e2;
+        ax = 2;
+        lo = l2;
+    }
+    if (e > 0.0f && e < INFINITY) {
+        ext = e;
+        scale = (float)bins / e;
+    }
+}
+
+__device__ __forceinline__ uint32_t plane_step(const float2* __restrict__ planes, uint32_t node, float x, float y, float z) {
+    const float2 pl = planes[node];
+    const int ax = __float_as_int(pl.y);
+    const float v = (ax == 0) ? x : ((ax == 1) ? y : z);
+    return node * 2u + ((v >= pl.x) ? 1u : 0u);
+}
+
+// levels 0 .. 5: step (level > 0) and the exact boxes of the nodes of depth `level`
+static __global__ __launch_bounds__(256) void hp_assign_bbox(const float* __restrict__ samp, int64_t S,
+                                                             const float2* __restrict__ planes, uint32_t* __restrict__ snode,
+                                                             int level, uint32_t* __restrict__ boxmin, uint32_t* __restrict__ boxmax) {
+    __shared__ uint32_t smin[32 * 3], smax[32 * 3];
+    const uint32_t first = 1u << level, count = 1u << level;
+    for (uint32_t e = threadIdx.x; e < count * 3u; e += 256u) {
+        smin[e] = 0xffffffffu;
+        smax[e] = 0u;
+    }
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < S; i += (int64_t)gridDim.x * 256) {
+        const float x = samp[i * 3], y = samp[i * 3 + 1], z = samp[i * 3 + 2];
+        uint32_t node = 1u;
+        if (level > 0) {
+            node = plane_step(planes, (level == 1) ? 1u : snode[i], x, y, z);
+            snode[i] = node;
+        }
+        if (fabsf(x) < INFINITY && fabsf(y) < INFINITY && fabsf(z) < INFINITY) {  // (non-finite samples shape no box)
+            const uint32_t k = (node - first) * 3u;
+            atomicMin(&smin[k], fenc(x));
+            atomicMin(&smin[k + 1u], fenc(y));
+            atomicMin(&smin[k + 2u], fenc(z));
+            atomicMax(&smax[k], fenc(x));
+            atomicMax(&smax[k + 1u], fenc(y));
+            atomicMax(&smax[k + 2u], fenc(z));
+        }
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < count * 3u; e += 256u) {
+        if (smin[e] != 0xffffffffu) {
+            const uint32_t at = (first + e / 3u) * 4u + e % 3u;
+            atomicMin(&boxmin[at], smin[e]);
+            atomicMax(&boxmax[at], smax[e]);
+        }
+    }
+}
+
+// every level: the histogram of the nodes of depth `level` (step != 0: the samples still stand at depth level - 1)
+static __global__ __launch_bounds__(256) void hp_hist(const float* __restrict__ samp, int64_t S, const float2* __restrict__ planes,
+                                                      uint32_t* __restrict__ snode, int level, int step,
+                                                      const uint32_t* __restrict__ boxmin, const uint32_t* __restrict__ boxmax,
+                                                      uint32_t* __restrict__ hist, int bins) {
+    const uint32_t first = 1u << level;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < S; i += (int64_t)gridDim.x * 256) {
+        const float x = samp[i * 3], y = samp[i * 3 + 1], z = samp[i * 3 + 2];
+        uint32_t node = (level == 0) ? 1u : snode[i];
+        if (step) {
+            node = plane_step(planes, node, x, y, z);
+            snode[i] = node;
+        }
+        if (!(fabsf(x) < INFINITY && fabsf(y) < INFINITY && fabsf(z) < INFINITY)) continue;
+        int ax;
+        float lo, ext, scale;
+        plane_axis(boxmin, boxmax, node, bins, ax, lo, ext, scale);
+        const float v = (ax == 0) ? x : ((ax == 1) ? y : z);
+        const int b = (int)fminf(fmaxf((v - lo) * scale, 0.0f), (float)(bins - 1));
+        atomicAdd(&hist[(size_t)(node - first) * (size_t)bins + (size_t)b], 1u);
+    }
+}
+
+// a wave per node of depth `level`: the plane, and -- child_boxes -- the children's boxes (the node's, cut at the plane)
+static __global__ __launch_bounds__(64) void hp_select(float2* __restrict__ planes, int level, int tri, uint32_t* __restrict__ boxmin,
+                                                       uint32_t* __restrict__ boxmax, uint32_t* __restrict__ hist, int bins,
+                                                       int child_boxes) {
+    const uint32_t first = 1u << level, node = first + blockIdx.x;
+    const int lane = (int)threadIdx.x;
+    int ax;
+    float lo, ext, scale;
+    plane_axis(boxmin, boxmax, node, bins, ax, lo, ext, scale);
+    const int seg = bins >> 6;  // bins per lane (4 .. 256)
+    uint32_t* h = hist + (size_t)blockIdx.x * (size_t)bins + (size_t)lane * (size_t)seg;
+    uint32_t mine = 0u;
+    for (int j = 0; j < seg; ++j) mine += h[j];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += y;
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    // the share that goes LEFT: a third at a TRI root, everything at its node 2 (whose children are node 4 and nobody)
+    const bool all_left = tri && node == 2u;
+    const float share = (tri && node == 1u) ? (1.0f / 3.0f) : 0.5f;
+    uint32_t target = (uint32_t)(share * (float)total + 0.5f);
+    target = max(target, 1u);
+    float plane = INFINITY;
+    int pax = 0;
+    if (total > 0u && scale > 0.0f && !all_left) {
+        // boundary behind bin b: cum(b) samples on the left; the b whose cum(b) is nearest to the target
+        const uint64_t reached = __ballot(incl >= target);
+        const int owner = (int)__builtin_ctzll(reached);  // (total >= target: some lane reaches it)
+        int b = 0;
+        if (lane == owner) {
+            uint32_t run = incl - mine;
+            for (int j = 0; j < seg; ++j) {
+                const uint32_t before = run;
+                run += h[j];
+                if (run >= target) {
+                    b = lane * seg + j;
+                    // (the boundary in front of this bin, if that is nearer and leaves something on the left)
+                    if (before > 0u && target - before < run - target) b -= 1;
+                    break;
+                }
+            }
+        }
+        b = __builtin_amdgcn_readlane(b, owner);
+        plane = lo + (float)(b + 1) * (ext / (float)bins);
+        pax = ax;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < seg; ++j) h[j] = 0u;  // (the table is all zeroes again for the next level)
+    if (lane == 0) planes[node] = make_float2(plane, __int_as_float(pax));
+    if (child_boxes && lane < 2) {
+        // lane 0: the left child, lane 1: the right one
+        uint4 mn = reinterpret_cast<const uint4*>(boxmin)[node], mx = reinterpret_cast<const uint4*>(boxmax)[node];
+        const uint32_t pe = fenc(plane);
+        if (!(plane < INFINITY)) {
+            if (lane == 1) {  // nobody goes right
+                mn = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+                mx = make_uint4(0u, 0u, 0u, 0u);
+            }
+        } else if (lane == 0) {
+            if (pax == 0) mx.x = min(mx.x, pe);
+            else if (pax == 1) mx.y = min(mx.y, pe);
+            else mx.z = min(mx.z, pe);
+        } else {
+            if (pax == 0) mn.x = max(mn.x, pe);
+            else if (pax == 1) mn.y = max(mn.y, pe);
+            else mn.z = max(mn.z, pe);
+        }
+        reinterpret_cast<uint4*>(boxmin)[2u * node + (uint32_t)lane] = mn;
+        reinterpret_cast<uint4*>(boxmax)[2u * node + (uint32_t)lane] = mx;
+    }
+}
+
+}  // namespace mi

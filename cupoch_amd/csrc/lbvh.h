@@ -15,6 +15,7 @@
 // target (MI_ICP_NO_CELLS).
 #pragma once
 #include "device_utils.h"
+#include "kd_descend.h"
 #include "traverse.h"
 
 namespace mi {
@@ -269,8 +270,11 @@ static __global__ __launch_bounds__(256) void build_level(float* __restrict__ re
                 mx[d] = fmaxf(mx[d], fmaxf(rec[p * kPairStride + 6 + 2 * d], rec[p * kPairStride + 6 + 2 * d + 1]));
             }
         if (own_flag) {
+            // node t of this level = the cells [t << s, (t + 1) << s), s = depth - region_depth: one heap node while they
+            // lie inside one of a TRI layout's three parts (the caller clears own_flag for the levels above that)
             float reg[6];
-            cell_region(planes, cell_levels, region_depth, t, reg);
+            const int s = cell_depth(cell_levels) - region_depth;
+            cell_region(planes, cell_levels, region_depth, heap_leaf_of_cell(cell_levels, t << s) >> s, reg);
             store_own(records, id, reg, reg + 3, 1u);
         } else {
             store_own(records, id, mn, mx, 0u);

@@ -4,6 +4,7 @@
 #include "ctx.h"
 #include "kd_build.h"
 #include "kd_cells.h"
+#include "kd_planes.h"
 #include "kd_refine.h"
 #include "lbvh.h"
 #include "leaf_halo.h"
@@ -106,42 +107,53 @@ struct CellLayout {
     int ncells;
     int64_t ngroups;
     const float2* planes;  // split planes, heap order
-    int levels;            // ncells = 2^levels
+    int levels;            // depth of the plane tree + layout flag (kd_descend.h)
 };
 
 int kd_cell_layout(mi_icp_ctx* c, const float* pts, int64_t n, CellLayout* out) {
-    const int d = cell_levels_for(n);
-    const int ncells = 1 << d;
+    const int lv = cell_layout_for(n);       // depth of the plane tree + layout flag (kd_descend.h)
+    const int d = cell_depth(lv);
+    const int ncells = (int)cell_count(lv);
     SortBuffers sb;
     TRY(sort_buffers(c, n, &sb));
     float2* planes;
-    TRY(ensure(c, c->cell_planes, (size_t)ncells * 2, &planes));
+    TRY(ensure(c, c->cell_planes, (size_t)2 << d, &planes));
     if (d > 0) {
-        const int64_t S = std::min<int64_t>(n, (int64_t)kCellSamples * ncells);
+        // the planes, level by level, from histograms over a sample (kd_planes.h)
+        const int64_t S = std::min<int64_t>(n, (int64_t)kPlaneSamples * ncells);
         float* samp;
         TRY(ensure(c, c->cell_samples, (size_t)S * 3, &samp));
         cells_sample_gather<<<blocks_for(S), 256, 0, c->stream>>>(pts, n, S, samp);
         KCHK(c);
-        const int stages = (d + kCellStageLevels - 1) / kCellStageLevels;
-        int base = 0;
-        int cur = 0;
-        for (int st = 0; st < stages; ++st) {
-            const int levels = (st == 0) ? d - kCellStageLevels * (stages - 1) : kCellStageLevels;
-            if (base > 0) {  // samples grouped by their depth-`base` cell
-                cells_assign<uint64_t><<<blocks_for(S), 256, 0, c->stream>>>(samp, S, planes, base, sb.keys[0], sb.vals[0]);
-                KCHK(c);
-                cur = radix_sort_pairs(c->stream, sb, S, base);
+        uint32_t *boxmin, *boxmax, *hist;
+        const size_t nbox = (size_t)4 << d;  // [node < 2^d][4]
+        const size_t nhist = std::max<size_t>((size_t)kPlaneBinBudget, ((size_t)1 << (d - 1)) * kPlaneMinBins);
+        TRY(ensure(c, c->cell_boxes, nbox * 2, &boxmin));
+        boxmax = boxmin + nbox;
+        TRY(ensure(c, c->cell_hist, nhist, &hist));
+        HIPCHK(c, hipMemsetAsync(boxmin, 0xff, nbox * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(boxmax, 0, nbox * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(hist, 0, nhist * sizeof(uint32_t), c->stream));
+        uint32_t* snode = reinterpret_cast<uint32_t*>(sb.keys[1]);  // (free until the points' cell ids are sorted, below)
+        const int sgrid = (int)std::min<int64_t>(blocks_for(S), 2048);
+        const int tri = cell_tri(lv) ? 1 : 0;
+        for (int l = 0; l < d; ++l) {
+            const int bins = plane_bins(l);
+            if (l < kPlaneExactBoxLevels) {
+                hp_assign_bbox<<<sgrid, 256, 0, c->stream>>>(samp, S, planes, snode, l, boxmin, boxmax);
                 KCHK(c);
             }
-            cells_planes<<<1 << base, kKdThreads, 0, c->stream>>>(samp, S, sb.keys[cur], sb.vals[cur], base, levels, planes);
+            hp_hist<<<sgrid, 256, 0, c->stream>>>(samp, S, planes, snode, l, l >= kPlaneExactBoxLevels ? 1 : 0, boxmin, boxmax, hist, bins);
             KCHK(c);
-            base += levels;
+            hp_select<<<1 << l, 64, 0, c->stream>>>(planes, l, tri, boxmin, boxmax, hist, bins,
+                                                    (l + 1 >= kPlaneExactBoxLevels && l + 1 < d) ? 1 : 0);
+            KCHK(c);
         }
     }
     uint32_t *cstart, *gstart;
     TRY(ensure(c, c->cell_cstart, (size_t)ncells + 2, &cstart));
     TRY(ensure(c, c->cell_gstart, (size_t)ncells, &gstart));
-    cells_assign<uint32_t><<<blocks_for(n), 256, 0, c->stream>>>(pts, n, planes, d, (uint32_t*)sb.keys[0], sb.vals[0]);
+    cells_assign<uint32_t><<<blocks_for(n), 256, 0, c->stream>>>(pts, n, planes, lv, (uint32_t*)sb.keys[0], sb.vals[0]);
     KCHK(c);
     const int cur = radix_sort_pairs32(c->stream, sb, n, d);  // (cell ids: narrow keys)
     KCHK(c);
@@ -161,7 +173,7 @@ int kd_cell_layout(mi_icp_ctx* c, const float* pts, int64_t n, CellLayout* out) 
     out->ncells = ncells;
     out->ngroups = ngroups;
     out->planes = planes;
-    out->levels = d;
+    out->levels = lv;
     return MI_ICP_OK;
 }
 
@@ -420,8 +432,12 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     int above_groups = 1;  // 8-ary levels between `first` and the groups' level
     for (; first > 1u; first /= 8u, ++above_groups) {
         const uint32_t count = ((used + 7u) / 8u) * 8u;
-        build_level<<<blocks_for(count), 256, 0, c->stream>>>(nodes, first, used, count, upper_flag, lay.planes,
-                                                              lay.levels, lay.levels - 3 * above_groups);
+        // (a TRI layout's nodes are kd subtrees only while they lie inside one of its three parts: 8^above_groups
+        // cells <= 2^(depth - 2); the one or two levels above that keep their points' boxes, no early stop there)
+        const int region_depth = cell_depth(lay.levels) - 3 * above_groups;
+        const uint32_t flag = (upper_flag && (!cell_tri(lay.levels) || region_depth >= 2)) ? 1u : 0u;
+        build_level<<<blocks_for(count), 256, 0, c->stream>>>(nodes, first, used, count, flag, lay.planes,
+                                                              lay.levels, region_depth);
         KCHK(c);
         used = (used + 7u) / 8u;
     }

@@ -128,9 +128,11 @@ def test_iteration_limits_and_immediate_convergence(eng):
 
 
 # ---- the kd-cell layout of the target (kd_cells.h): group boundaries, overflowing cells
-@pytest.mark.parametrize("n", [2730, 2731, 2732, 4095, 4096, 4097, 5462, 5463, 8191, 8193, 21848, 21849, 43700])
+@pytest.mark.parametrize("n", [3299, 3300, 3301, 4095, 4096, 4097, 6600, 6601, 8191, 8193, 9900, 9901, 13200, 13201, 19801, 26401,
+                               39600, 39601, 52801, 79201, 105601])
 def test_search_around_cell_and_group_boundaries(eng, n):
-    # 2731 is the mean cell fill at which another level of planes is added; 4096 the group size
+    # 3300 is the mean cell fill beyond which the layout takes more cells -- 2^d or 3 * 2^k of them, whichever is fewer
+    # (kd_cells.h cell_layout_for: 1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48 cells change over at these sizes); 4096 the group size
     rng = np.random.default_rng(n)
     tgt = rng.random((n, 3), dtype=np.float32)
     src = (tgt[rng.permutation(n)[: max(1, n // 2)]] + rng.normal(0, 0.01, (max(1, n // 2), 3))).astype(np.float32)
