@@ -119,34 +119,54 @@ int kd_cell_layout(mi_icp_ctx* c, const float* pts, int64_t n, CellLayout* out) 
     float2* planes;
     TRY(ensure(c, c->cell_planes, (size_t)2 << d, &planes));
     if (d > 0) {
-        // the planes, level by level, from histograms over a sample (kd_planes.h)
+        // the planes (kd_planes.h): histogram levels over a quarter of the sample, then the last three levels from all
+        // of a node's samples in LDS
         const int64_t S = std::min<int64_t>(n, (int64_t)kPlaneSamples * ncells);
         float* samp;
         TRY(ensure(c, c->cell_samples, (size_t)S * 3, &samp));
         cells_sample_gather<<<blocks_for(S), 256, 0, c->stream>>>(pts, n, S, samp);
         KCHK(c);
-        uint32_t *boxmin, *boxmax, *hist;
-        const size_t nbox = (size_t)4 << d;  // [node < 2^d][4]
-        const size_t nhist = std::max<size_t>((size_t)kPlaneBinBudget, ((size_t)1 << (d - 1)) * kPlaneMinBins);
-        TRY(ensure(c, c->cell_boxes, nbox * 2, &boxmin));
-        boxmax = boxmin + nbox;
-        TRY(ensure(c, c->cell_hist, nhist, &hist));
-        HIPCHK(c, hipMemsetAsync(boxmin, 0xff, nbox * sizeof(uint32_t), c->stream));
-        HIPCHK(c, hipMemsetAsync(boxmax, 0, nbox * sizeof(uint32_t), c->stream));
-        HIPCHK(c, hipMemsetAsync(hist, 0, nhist * sizeof(uint32_t), c->stream));
-        uint32_t* snode = reinterpret_cast<uint32_t*>(sb.keys[1]);  // (free until the points' cell ids are sorted, below)
-        const int sgrid = (int)std::min<int64_t>(blocks_for(S), 2048);
-        const int tri = cell_tri(lv) ? 1 : 0;
-        for (int l = 0; l < d; ++l) {
-            const int bins = plane_bins(l);
-            if (l < kPlaneExactBoxLevels) {
-                hp_assign_bbox<<<sgrid, 256, 0, c->stream>>>(samp, S, planes, snode, l, boxmin, boxmax);
+        // histogram levels (a TRI layout's first two -- the 1/3 cut, the dummy -- are no medians: always histogram levels)
+        const int dh = std::max(cell_tri(lv) ? 2 : 0, d - kPlaneLdsLevels);
+        if (dh > 0) {
+            uint32_t *boxmin, *boxmax, *hist;
+            const size_t nbox = (size_t)4 << dh;  // [node < 2^dh][4]
+            const size_t nhist = std::max<size_t>((size_t)kPlaneBinBudget, ((size_t)1 << (dh - 1)) * kPlaneMinBins);
+            TRY(ensure(c, c->cell_boxes, nbox * 2, &boxmin));
+            boxmax = boxmin + nbox;
+            TRY(ensure(c, c->cell_hist, nhist, &hist));
+            HIPCHK(c, hipMemsetAsync(boxmin, 0xff, nbox * sizeof(uint32_t), c->stream));
+            HIPCHK(c, hipMemsetAsync(boxmax, 0, nbox * sizeof(uint32_t), c->stream));
+            HIPCHK(c, hipMemsetAsync(hist, 0, nhist * sizeof(uint32_t), c->stream));
+            uint32_t* snode = reinterpret_cast<uint32_t*>(sb.keys[1]);  // (free until the samples / the points' cell ids are sorted, below)
+            const int stride = (S >= (int64_t)kPlaneStride * 65536) ? kPlaneStride : 1;  // (small clouds: every sample)
+            const int64_t Sh = (S + stride - 1) / stride;
+            const int sgrid = (int)std::min<int64_t>(blocks_for(Sh), 2048);
+            const int tri = cell_tri(lv) ? 1 : 0;
+            for (int l = 0; l < dh; ++l) {
+                const int bins = plane_bins(l);
+                if (l < kPlaneExactBoxLevels) {
+                    hp_assign_bbox<<<std::min(sgrid, 256), 256, 0, c->stream>>>(samp, Sh, stride, planes, snode, l, boxmin, boxmax);
+                    KCHK(c);
+                }
+                hp_hist<<<sgrid, 256, 0, c->stream>>>(samp, Sh, stride, planes, snode, l, l >= kPlaneExactBoxLevels ? 1 : 0, boxmin, boxmax,
+                                                      hist, bins);
+                KCHK(c);
+                hp_select<<<1 << l, 64, 0, c->stream>>>(planes, l, tri, boxmin, boxmax, hist, bins,
+                                                        (l + 1 >= kPlaneExactBoxLevels && l + 1 < dh) ? 1 : 0);
                 KCHK(c);
             }
-            hp_hist<<<sgrid, 256, 0, c->stream>>>(samp, S, planes, snode, l, l >= kPlaneExactBoxLevels ? 1 : 0, boxmin, boxmax, hist, bins);
+        }
+        // the levels dh .. d - 1: every node of depth dh sorts its samples in LDS
+        int cur = 0;
+        if (dh > 0) {  // samples grouped by their depth-dh node (plain heap numbering: no layout flag; narrow keys)
+            cells_assign<uint32_t><<<blocks_for(S), 256, 0, c->stream>>>(samp, S, planes, dh, (uint32_t*)sb.keys[0], sb.vals[0]);
             KCHK(c);
-            hp_select<<<1 << l, 64, 0, c->stream>>>(planes, l, tri, boxmin, boxmax, hist, bins,
-                                                    (l + 1 >= kPlaneExactBoxLevels && l + 1 < d) ? 1 : 0);
+            cur = radix_sort_pairs32(c->stream, sb, S, dh);
+            KCHK(c);
+        }
+        if (d > dh) {
+            hp_last_levels<uint32_t><<<1 << dh, 256, 0, c->stream>>>(samp, S, (const uint32_t*)sb.keys[cur], sb.vals[cur], dh, d - dh, planes);
             KCHK(c);
         }
     }

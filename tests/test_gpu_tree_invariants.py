@@ -92,7 +92,8 @@ def check_tree(eng, pts, expect_all_flagged):
             assert not strictly_inside.any(), (first, t, int(strictly_inside.sum()))
             own = xyz[finite & mine]
             inside = ((own >= lo) & (own <= hi)).all(1)
-            assert inside.mean() > 0.99                                                       # (near-ties at a median may sit outside)
+            # (near-ties at a median may sit outside: at most 1 % of the node's points -- and one point of a 64-slot node)
+            assert len(own) - int(inside.sum()) <= max(1, len(own) // 100), (first, t, len(own), int(inside.sum()))
         if first == 1:
             break
         first //= 8
