@@ -165,6 +165,18 @@ int mi_icp_debug_get_step_stamps(mi_icp_ctx* c, uint64_t* out32, double* ticks_p
     return MI_ICP_OK;
 }
 
+int mi_icp_debug_loop_counters(mi_icp_ctx* c, int32_t* out4) {
+    TRY(check_ctx(c));
+    if (!out4 || !c->loop_host) return fail(c, MI_ICP_ERR_INVALID, "debug_loop_counters: bad arguments");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // (the pinned mirror of the loop's device state as of the last look: every loop entry point ends with one)
+    out4[0] = c->loop_host->iterations;
+    out4[1] = c->loop_host->passes;
+    out4[2] = c->loop_host->relocations;
+    out4[3] = c->relocate_armed ? 1 : 0;
+    return MI_ICP_OK;
+}
+
 int mi_icp_debug_drop_seeds(mi_icp_ctx* c) {
     TRY(check_ctx(c));
     c->nn_valid = false;

@@ -50,6 +50,11 @@ MI_ICP_API int mi_icp_debug_occupancy(int which);
  * current iteration's stamps (re-armed), [16..23] the SUMS of the eight spans over the iterations counted in [24]:
  * step-end -> next search start, search, search end -> reduction start, reduction's streaming phase, row total,
  * exchange, solve, state write -- and the clock's ticks per microsecond. */
+/* Counters of the present registration loop as of its last host-side look: out4 = {iterations (updates applied),
+ * passes (evaluations), re-locations (steps that moved the source by more than a quarter point spacing and had the next
+ * search's seeds replaced by the leaves the moved queries fall into: csrc/loop.h, nn_search.h locate_by_planes),
+ * 1 if the next chunk of iterations would still carry the gated re-location launches}. */
+MI_ICP_API int mi_icp_debug_loop_counters(mi_icp_ctx* ctx, int32_t* out4);
 MI_ICP_API int mi_icp_debug_set_step_stamps(mi_icp_ctx* ctx, int enable);
 MI_ICP_API int mi_icp_debug_get_step_stamps(mi_icp_ctx* ctx, uint64_t* out32, double* ticks_per_us);
 /* The loop step's two forms of utility::SolveJacobianSystemAndObtainExtrinsicMatrix side by side, on the

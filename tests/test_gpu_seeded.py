@@ -238,3 +238,78 @@ def test_one_launch_iteration_equals_the_two_kernel_form(tmp_path):
     assert np.linalg.norm(a["T"] - b["T"]) <= 1e-6
     assert a["stat"][0] == pytest.approx(b["stat"][0], abs=1e-7) and a["stat"][1] == pytest.approx(b["stat"][1], rel=1e-5)
     assert np.array_equal(a["corr"], b["corr"])
+
+
+def _loop_counters(e):
+    import ctypes as C
+    out = (C.c_int32 * 4)()
+    e._chk(e._L.mi_icp_debug_loop_counters(e._ctx, out))
+    return [int(v) for v in out]
+
+
+def test_relocation_after_large_steps_changes_nothing_but_the_seeds():
+    """Round 5: a step that moves the source by more than a quarter point spacing (sized on the device from the update
+    and the source's box, loop.h) makes the gated launch in front of the next search replace every seed by the leaf the
+    moved query falls into (nn_search.h locate_by_planes).  On a surface started 6 spacings above it the first steps are that
+    large: re-locations happen, stop once the steps are small (the launches are disarmed), and the loop's every number
+    equals the oracle's restatement of the engine's form -- seeds never change an answer."""
+    from cupoch_amd.engine import Engine
+    rng = np.random.default_rng(91)
+    n = 200_000
+    tgt = cloud("surface", n, rng)
+    nrm = rng.standard_normal((n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    spacing = n ** (-0.5)
+    src = (tgt[rng.permutation(n)[: int(0.7 * n)]] + rng.standard_normal((int(0.7 * n), 3)).astype(np.float32) * np.float32(0.05 * spacing)).astype(np.float32)
+    init = rigid(0.004, [0, 0, 1], [0.5 * spacing, -0.5 * spacing, 6 * spacing])   # (off the sheet: the first step is ~6 spacings long)
+    radius = 12.0 * spacing
+    e = Engine(0)
+    e.set_target(cuda(tgt), cuda(nrm))
+    e.set_source(cuda(src))
+    build_halos(e)
+    res = e.registration_icp(P2P, radius, init, 0.0, 0.0, 25, -1.0)
+    it, passes, reloc, armed = _loop_counters(e)
+    have_planes = os.environ.get("MI_ICP_NO_CELLS") is None and os.environ.get("MI_ICP_NO_LOCATE_PLANES") is None
+    if have_planes:
+        assert e.last_search_kind() in (1, 2)
+        assert 1 <= reloc < it, (reloc, it)            # the early steps re-located, the late ones did not
+        assert armed == 0                              # ... and the launches were taken off again
+    else:
+        assert reloc == 0
+    o = orc.registration_icp(src, tgt, radius, init=init, est=orc.EST_P2P, det_thresh=-1.0, max_iteration=25,
+                             relative_fitness=0.0, relative_rmse=0.0, composed=True)
+    T = np.array(res.transformation, np.float32).reshape(4, 4).T
+    assert res.iterations == o.iterations == 25
+    assert np.linalg.norm(T - o.transformation) <= 1e-6
+    assert abs(res.fitness - o.fitness) <= 1e-6
+    e.close()
+
+
+def test_step_stamps_account_for_the_iteration():
+    """mi_icp_debug_set_step_stamps (csrc/loop.h): the stamping instantiations of the seeded search and the point-to-plane
+    reduction leave the eight spans of every iteration in the loop's stamp words; they are positive where something runs
+    and add up to no more than the wall clock of the same iterations."""
+    import time
+    from cupoch_amd.engine import Engine
+    from conftest import make_pair
+    d = make_pair(400_000, seed=5)
+    e = Engine(0)
+    e.set_target(cuda(d["tgt"]), cuda(d["tgt_nrm"]))
+    e.set_source(cuda(d["src"]))
+    e.set_step_stamps(True)
+    e.icp_begin(PT2PL, d["max_dist"], None, -1.0)
+    e.icp_iterate(16)
+    a, tpu = e.get_step_stamps()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e.icp_iterate(40)
+    torch.cuda.synchronize()
+    wall_us = (time.perf_counter() - t0) * 1e6
+    b, _ = e.get_step_stamps()
+    cnt = int(b[24] - a[24])
+    spans = (b[16:24].astype(np.float64) - a[16:24].astype(np.float64)) / tpu
+    assert cnt == 40 and tpu > 0
+    assert spans[1] > 0 and spans[3] > 0 and spans[6] > 0          # search, reduction's streaming phase, solve
+    assert spans.sum() <= 1.05 * wall_us + 50.0
+    e.set_step_stamps(False)
+    e.close()
