@@ -125,7 +125,7 @@ def secondary(eng, src, tgt, nrm, d_tgt, d_nrm, d_src, max_dist, n, torch, _lib)
     out["build_ms_source"] = round(med(ts) * 1e3, 3)
     # -- a pass without previous matches (what every new pair of clouds pays once): from the root here -- the
     # exact clouds' loop never asked for halos --, from the queries' own seeds further down, once they exist
-    kinds = {0: "from the root", 1: "seeded", 2: "own seeds (greedy descent) + seeded search"}
+    kinds = {0: "from the root", 1: "seeded", 2: "own seeds (binary descent through the split planes) + seeded search"}
 
     def first_pass():
         fp = []
@@ -415,11 +415,9 @@ def main():
         # RCCL communicator + mailbox, and -- should neither come up on every rank -- a host-driven loop over
         # torch.distributed.  The in-library ncclAllReduce is self-tested and timed BESIDE the first one, on a scratch
         # context and under a watchdog (rccl_beside, below): its figure is reported, and a communicator that never
-        # forms cannot hold the run.  MI_ICP_BENCH_RCCL_FIRST=1: the communicator on the engine itself, first.
+        # forms cannot hold the run.
         tried = []
         order = ("mailbox",) if one_device else ("mailbox", "rccl+mailbox")
-        if os.environ.get("MI_ICP_BENCH_RCCL_FIRST") == "1" and not one_device:
-            order = ("rccl+mailbox", "mailbox")
         for attempt in order:
             ok, why, tune = 1, "", None
             try:

@@ -18,7 +18,7 @@
 // boxes (1.64 / 2.2 at the 64 / 512 levels, for Morton groups).
 // Users: kd_build_groups (kd_build.h: the target's groups, written out as finished tree
 // pieces), cells_planes (kd_cells.h: split planes from samples), kd_refine_groups (below:
-// order only -- the Morton-run fallback tree, and the source when MI_ICP_SOURCE_KD is set).
+// order only -- the Morton-run fallback tree).
 // Cost: 4 partition rounds + 110 compare-exchange stages per group, 1.19 ms for the 2442 groups of a
 // 10M-point target with normals (of which 0.57 ms are the gathers of the points / normals and the
 // stores; the all-sort first version: 354 stages, 1.29 ms).

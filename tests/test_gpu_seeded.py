@@ -299,9 +299,9 @@ def test_step_stamps_account_for_the_iteration():
     e.set_step_stamps(True)
     e.icp_begin(PT2PL, d["max_dist"], None, -1.0)
     e.icp_iterate(16)
-    a, tpu = e.get_step_stamps()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    t0 = time.perf_counter()       # (ahead of the first look: the first counted iteration's "since the last step" span
+    a, tpu = e.get_step_stamps()   # reaches back to the end of the 16th iteration, across this host-side pause)
     e.icp_iterate(40)
     torch.cuda.synchronize()
     wall_us = (time.perf_counter() - t0) * 1e6
