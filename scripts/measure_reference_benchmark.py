@@ -112,17 +112,22 @@ def main():
     e2.close()
     _, oi, od = orc.search_knn(pts, pts, KNN)
     sets_equal = (np.sort(idx, 1) == np.sort(oi, 1)).all(1)
+    # (both are normals of fp32 RAW-MOMENT covariances: on a scan in metres -- E[xx] ~ 10, a surface patch's smallest
+    # eigenvalue ~ 1e-6 -- the cancellation costs both of them digits, and a different summation order moves a normal
+    # by minutes of arc.  So each is also held against the fp64 normal of the very same neighbours.)
     P = pts[idx].astype(np.float64)
     Cm = np.einsum("nki,nkj->nij", P, P) / KNN - np.einsum("ni,nj->nij", P.mean(1), P.mean(1))
-    w = np.linalg.eigvalsh(Cm)
-    well = (w[:, 1] - w[:, 0]) / np.maximum(w[:, 2], 1e-300) > 0.02
-    bad = dots < 1.0 - 1e-4
-    unexplained = int((bad & well & sets_equal).sum())
-    rows["estimate_normals"] = dict(first_ms=f, ms=m, ok=bool(np.array_equal(d2, od)) and unexplained == 0,
-                                    parity="k-NN distances bit-exact: %s; neighbour sets equal for %.3f %%; |<n, n_oracle>| > 1 - 1e-4 for %.2f %% of the "
-                                           "points (> 1 - 1e-2: %.2f %%); disagreements on a well-separated covariance with equal sets: %d"
-                                           % (bool(np.array_equal(d2, od)), 100 * sets_equal.mean(), 100 * (dots > 1 - 1e-4).mean(),
-                                              100 * (dots > 1 - 1e-2).mean(), unexplained))
+    w, v = np.linalg.eigh(Cm)
+    n64 = v[:, :, 0]
+    eg, eo = 1.0 - np.abs((gn * n64).sum(1)), 1.0 - np.abs((on * n64).sum(1))
+    q = lambda e: "median %.1e, 99 %%: %.1e" % (np.median(e), np.quantile(e, 0.99))
+    ok_n = bool(np.array_equal(d2, od)) and np.quantile(eg, 0.99) <= 2.0 * np.quantile(eo, 0.99) + 1e-6 and np.median(eg) <= 2.0 * np.median(eo) + 1e-7
+    rows["estimate_normals"] = dict(first_ms=f, ms=m, ok=ok_n,
+                                    parity="k-NN distances bit-exact: %s; neighbour sets equal for %.3f %%; 1 - |<n, n_fp64 of the same neighbours>|: "
+                                           "engine %s, CPU port %s (both fp32 raw-moment covariances, estimate_normals.cu:38-64); engine against "
+                                           "port: within 1e-4 for %.2f %% of the points, within 1e-2 for %.2f %%"
+                                           % (bool(np.array_equal(d2, od)), 100 * sets_equal.mean(), q(eg), q(eo),
+                                              100 * (dots > 1 - 1e-4).mean(), 100 * (dots > 1 - 1e-2).mean()))
     # -- voxel_down_sample(0.005) (benchmarks.py:38-40)
     down, f, m = first_and_median(lambda: pc.voxel_down_sample(VOXEL))
     gp = np.asarray(down.points.cpu())
