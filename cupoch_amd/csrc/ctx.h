@@ -84,7 +84,6 @@ struct mi_icp_ctx {
     bool inv_s_valid = false;
     bool nn_valid = false;  // nn_idx holds a search result (usable as seed / correspondences)
     mi::eng::DevBuf src_bounds;    // min[3], max[3] of the staged source (the loop's step sizes the displacement of its corners: loop.h)
-    bool seeds_located = false;    // nn_idx holds seeds the queries made themselves (locate_by_planes), not matches
     bool relocate_armed = false;   // this loop's next chunk of iterations carries the gated re-location launches (loop_run)
 
     // ---- explicit correspondence set ----

@@ -39,6 +39,11 @@ constexpr int kCellMaxLevels = 19;
 
 // The layout with the fewest cells whose mean fill stays within kCellTargetFill: 2^d cells, or 3 * 2^k (kd_descend.h
 // TRI).  Returns the plane tree's depth, + kCellTriFlag for a TRI layout.
+static inline int cell_layout_pow2(int64_t n, int fill) {  // 2^d cells only (A/B: MI_ICP_CELL_LAYOUT)
+    int d = 0;
+    while (d < kCellMaxLevels && ((int64_t)fill << d) < n) ++d;
+    return d;
+}
 static inline int cell_layout_for(int64_t n) {
     int d = 0;
     while (d < kCellMaxLevels && ((int64_t)kCellTargetFill << d) < n) ++d;

@@ -111,7 +111,10 @@ struct CellLayout {
 };
 
 int kd_cell_layout(mi_icp_ctx* c, const float* pts, int64_t n, CellLayout* out) {
-    const int lv = cell_layout_for(n);       // depth of the plane tree + layout flag (kd_descend.h)
+    // (MI_ICP_CELL_LAYOUT, A/B switch: "pow2" -- 2^d cells only, still filled to 80 %; "r4" -- 2^d cells at <= 2/3 fill,
+    // rounds 2-4's layout, on this round's planes)
+    static const int forced = [] { const char* e = std::getenv("MI_ICP_CELL_LAYOUT"); return !e ? 0 : (std::strcmp(e, "pow2") == 0 ? 1 : (std::strcmp(e, "r4") == 0 ? 2 : 0)); }();
+    const int lv = forced == 0 ? cell_layout_for(n) : cell_layout_pow2(n, forced == 2 ? 2731 : kCellTargetFill);
     const int d = cell_depth(lv);
     const int ncells = (int)cell_count(lv);
     SortBuffers sb;

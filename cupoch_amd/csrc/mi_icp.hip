@@ -108,9 +108,7 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
         }
         self_seeded = true;
     }
-    // (seeds_located: the caller has located -- and sorted by -- the queries' own leaves already: loop_begin)
-    c->last_search_kind = (use_seed && !c->seeds_located) ? 1 : ((self_seeded || c->seeds_located) ? 2 : 0);
-    c->seeds_located = false;
+    c->last_search_kind = use_seed ? 1 : (self_seeded ? 2 : 0);
     launch(use_seed || self_seeded, (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, c->ns, idx,
            loop ? nullptr : d2);
     KCHK(c);
@@ -876,18 +874,10 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
     }
     static const bool no_resort = std::getenv("MI_ICP_NO_RESORT") != nullptr;  // A/B switch for tuning
     const bool resort = !no_resort && c->ns >= 32768 && (max_iterations >= 4 || max_iterations == 0);
-    static const bool no_coarse = std::getenv("MI_ICP_NO_COARSE_FIRST") != nullptr;
-    if (resort && can_locate && c->halo_use && !no_coarse && c->n_user_pairs < 0) {
-        // LOCATE, SORT, THEN SEARCH (nn_search.h locate_by_planes): the match-order sort is paid either way; taken ahead
-        // of the first search -- on the leaves the queries fall into -- it makes that search's packets share their
-        // leaf and halo lines
-        TRY(launch_locate_by_planes(c, L.X, nullptr, 0));
-        c->nn_valid = true;
-        TRY(resort_source_by_match(c));
-        c->seeds_located = true;
-        TRY(loop_enqueue_evaluation(c, true));
-        return MI_ICP_OK;
-    }
+    // (Round 5 tried the match-order sort AHEAD of the first search, on the leaves the queries fall into
+    // (locate_by_planes): the first search gains nothing from packets that share their lines -- 0.85 ms against 0.79 --
+    // and every later iteration of a clean registration loses ~20 %, because the order then follows where the queries
+    // STARTED, not what they match: an 8-way shard's step 0.0393 ms instead of 0.0374.  Taken out; EXPERIMENTS.md.)
     TRY(loop_enqueue_evaluation(c, false));
     // from here on the packets follow the target's order (pays for itself in ~4 iterations)
     if (resort) TRY(resort_source_by_match(c));

@@ -624,10 +624,7 @@ static __global__ __launch_bounds__(256) void locate_leaves(const float* __restr
 // the group's own 511 planes (kd_build.h) -- 21 dependent 8-byte loads per query at 10M points instead of seven
 // 192-byte records with 48 compares each; consecutive queries are neighbours, so the upper levels are broadcasts and the
 // lower ones hit a 4-KB table per group.  Two users:
-//  * a loop's first pass when the target's halos exist: locate, SORT the source by located leaf (the match-order sort
-//    the loop pays anyway, taken before the first search instead of after it), then the seeded search on packets whose
-//    64 lanes share a handful of leaves -- their leaf / halo lines come out of the L1 instead of six vector loads per
-//    (lane, line) going to the L2 each;
+//  * a first pass when the target's halos exist: locate, then the seeded search (launch_nn);
 //  * RE-LOCATION inside a loop (gated != 0: nothing happens unless the step just taken set loop->relocate, loop.h): a
 //    step that moved the points by more than a quarter spacing leaves every seed a leaf or two off; trusting it costs
 //    a halo phase AND a 19-record climb for the lanes beyond their stale leaf's reach (r04_transient_census.txt).
