@@ -84,7 +84,11 @@ static __global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_
     for (int i = tid; i < kKdGroup; i += kKdThreads) {
         float x = INFINITY, y = INFINITY, z = INFINITY;  // padding sorts to the end on every axis
         if (i < count) {
+#ifdef MI_AB_COHERENT
+            const int64_t o = src0 + i;
+#else
             const int64_t o = a.vals[src0 + i];
+#endif
             x = a.pts[o * 3];
             y = a.pts[o * 3 + 1];
             z = a.pts[o * 3 + 2];
@@ -95,14 +99,23 @@ static __global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_
         s.key[i] = (uint32_t)i;
     }
     __syncthreads();
+#ifndef MI_AB_NO_SORT
     kd_sort_levels<true, true>(s, 9, a.gplanes + (size_t)g * 512u, 1u);
+#endif
 
     // ---- leaf lines + sorted attributes: position p of the group = slot g*4096 + p
     const int64_t slot0 = (int64_t)g * kKdGroup;
     for (int p = tid; p < kKdGroup; p += kKdThreads) {
         const int li = (int)(s.key[p] & 4095u);
         const bool real = li < count;
+#ifdef MI_AB_COHERENT
+        const int64_t o = real ? (int64_t)(src0 + li) : -1;
+#else
         const int64_t o = real ? (int64_t)a.vals[src0 + li] : -1;
+#endif
+#ifdef MI_AB_NO_WRITE
+        if (a.link_delta != 12345.0f) continue;
+#endif
         float* line = a.tblk + (slot0 + p) / kLeaf * kLeafFloats + (p & 7);
         line[0] = s.cx[li];
         line[8] = s.cy[li];

@@ -191,6 +191,11 @@ __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys
     const int est = st->est;
     const bool wave_case = (est == 2 || est == 4 || est == 5) && st->ready != 0 && st->sys[29] > 0.0;
     if (wid == 0) {
+#ifdef MI_AB_NO_SOLVE
+        if (wave_case) {
+            if (lane < 16) s_update.m[lane] = (lane % 5 == 0) ? 1.0f : 0.0f;
+        } else
+#endif
         if (wave_case) {
             const host::Mat4 U = wave_solve_update(st->sys);
             if (lane < 16) s_update.m[lane] = select16(U.m, lane);
@@ -204,7 +209,11 @@ __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys
     }
     // (wave 2, lanes 0..7: the corners of the source's box as the searches saw them -- A is stable until the barrier)
     float cx = 0.0f, cy = 0.0f, cz = 0.0f, far2 = INFINITY;  // far2: (a quarter spacing)^2 = (0.2 * 1.25 spacings)^2
+#ifdef MI_AB_NO_SIZING
+    const bool sized = false;
+#else
     const bool sized = st->near2_ptr != 0ull && st->src_bounds_ptr != 0ull;
+#endif
     // (everything this needs from memory is asked for BEFORE the barrier, beside the solve: a load behind it was 2 us on
     // every step's critical path -- 6 % of an 8-way shard's)
     if (wid == 2 && lane == 0 && sized) far2 = 0.04f * *reinterpret_cast<const float*>(st->near2_ptr);

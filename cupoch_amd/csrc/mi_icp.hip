@@ -26,8 +26,7 @@ static int64_t coarse_first_min() {
 }
 
 // The target has kd cells and its groups' planes: a query's own leaf is a binary descent away (nn_search.h
-// locate_by_planes).  MI_ICP_NO_LOCATE_PLANES: A/B switch -- the greedy record descent (locate_leaves) and no
-// sort ahead of the first search, no re-location.
+// locate_by_planes).  MI_ICP_NO_LOCATE_PLANES: A/B switch -- the greedy record descent (locate_leaves), no re-location.
 bool planes_available(const mi_icp_ctx* c) {
     static const bool off = std::getenv("MI_ICP_NO_LOCATE_PLANES") != nullptr;
     return !off && c->cell_levels >= 0 && c->gplanes.p != nullptr && c->cell_planes.p != nullptr && c->cell_gstart.p != nullptr &&
