@@ -18,7 +18,7 @@ init[:3, :3] = np.array([[np.cos(ang), -np.sin(ang), 0.0], [np.sin(ang), np.cos(
 rng = np.random.default_rng(6)
 noisy_all = (src + rng.normal(0.0, 0.15 * s, src.shape)).astype(np.float32)
 d_noisy = torch.from_numpy(np.ascontiguousarray(noisy_all)).cuda()
-mode = "former form (MI_ICP_NO_LOCATE_PLANES)" if os.environ.get("MI_ICP_NO_LOCATE_PLANES") else "locate by planes + sort + re-location"
+mode = "former form (MI_ICP_NO_LOCATE_PLANES)" if os.environ.get("MI_ICP_NO_LOCATE_PLANES") else "locate by planes + re-location"
 for rep in range(2):      # (the first repetition builds the halos inside the loop; the second -- a context that has asked before -- ahead of it)
     eng.set_target(d_tgt, d_nrm)
     eng.set_source(d_noisy)
