@@ -165,6 +165,7 @@ SIGNATURES = {
     "mi_icp_debug_last_search_kind": (_I, [_P]),
     "mi_icp_debug_occupancy": (_I, [_I]),
     "mi_icp_debug_loop_counters": (_I, [_P, _P]),
+    "mi_icp_debug_locate": (_I, [_P, _P, _P]),
     "mi_icp_debug_set_step_stamps": (_I, [_P, _I]),
     "mi_icp_debug_get_step_stamps": (_I, [_P, _P, C.POINTER(C.c_double)]),
     "mi_icp_debug_solve_both": (_I, [_I, _P, _I, C.c_float, _P, _P, _P, _P]),

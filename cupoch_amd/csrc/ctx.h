@@ -73,7 +73,7 @@ struct mi_icp_ctx {
     int64_t halo_want_seen = 0;  // the counter's value at the last look (it is zeroed when a loop begins)
     int halo_looks = 0;          // looks of this loop while undecided
     bool halo_use = false;       // the loop's launches take the halos (looked up once per chunk: an event query costs microseconds)
-    mi::eng::DevBuf halo_want;            // the counter (one word)
+    mi::eng::DevBuf halo_want;            // the counter (nn_search.h kWantSlots words, summed by the host)
 
     // ---- source (Morton order) ----
     int64_t ns = 0, ns_global = 0;
@@ -99,7 +99,7 @@ struct mi_icp_ctx {
     mi::eng::DevBuf vpay[6];  // VoxelDownSample: two sets of payload arrays (points, normals, colours) the radix passes alternate between
     double* sys_host = nullptr;  // pinned, 32 doubles + spare
     float* f_host = nullptr;     // pinned, 16 floats
-    uint32_t* u_host = nullptr;  // pinned, 16 words ([0]: counts read back by the one-shot entry points, [8]: the halo_want counter)
+    uint32_t* u_host = nullptr;  // pinned, 16 + kWantSlots words ([0]: counts read back by the one-shot entry points, [16..]: the halo_want counter's words)
     void* od_host = nullptr;     // pinned OdState mirror (odometry), allocated on first use
 
     // ---- registration loop (device-resident, loop.h) ----
@@ -324,6 +324,8 @@ int occupancy_build(int which);           // mi_icp_debug_occupancy: the kernels
 int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long long* stats = nullptr,
               const DevLoop* loop = nullptr);
 int occupancy_loop(int which);
+bool planes_available(const mi_icp_ctx* c);
+int launch_locate_by_planes(mi_icp_ctx* c, const Xform& X, const DevLoop* loop, int gated);
 // ---- mi_geometry.hip
 int occupancy_geometry(int which);
 // ---- mi_comm.hip

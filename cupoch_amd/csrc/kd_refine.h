@@ -284,6 +284,17 @@ __device__ __forceinline__ uint32_t kd_make_key(float x, float lo, float sc, uin
     return ((x < INFINITY) ? ((uint32_t)q << 12) : 0xfffff000u) | li;
 }
 
+// A split's plane for the binary descent (kd_descend.h: right of it <=> coordinate >= plane): HALFWAY between the
+// largest coordinate of the lower half and the smallest of the upper half.  (Until late in round 5 it was the median
+// element's own coordinate: one point in eight then lay exactly ON a plane of its group, and a query a hair away from
+// such a point -- a converged registration's -- fell on either side: 8 % of the queries of a clean 10M-point call were
+// located next door to their partner's leaf.)  No upper half (padding only): +inf, nothing goes right.  Halves that
+// overlap by a sliver (the quantised split, below) or are a rounding apart: the upper half's minimum, as before.
+__device__ __forceinline__ float kd_plane_between(float lower_max, float upper_min) {
+    const float mid = 0.5f * (lower_max + upper_min);  // (-inf + inf: NaN -> the upper minimum, +inf)
+    return (mid > lower_max) ? mid : upper_min;
+}
+
 // `levels` rounds of {per-segment bbox -> longest axis -> split of the segment at its median
 // along it} over the group in s (cx/cy/cz loaded, key[i] = i; +inf = padding, sorts to
 // the end on every axis).  Segment sizes 4096, 2048, ...: after round r the group is
@@ -301,8 +312,8 @@ __device__ __forceinline__ uint32_t kd_make_key(float x, float lo, float sc, uin
 // keys stay in registers from round to round.  No block barrier, no LDS traffic but the
 // coordinate reads: the waves run these rounds independently of each other.
 //
-// PLANES: also record every split as {coordinate of the segment's median element, axis}
-// at heap position (heap_root << round) + segment (kd_cells.h).
+// PLANES: also record every split as {kd_plane_between the halves, axis} at heap position (heap_root << round) +
+// segment (kd_cells.h); needs SAFE and all 9 levels (a block round's planes are written by the round after it).
 //
 // The split orders by the QUANTISED coordinate, so two points that share the median's bucket
 // can end up on the wrong sides of it; the halves' boxes then overlap by a sliver along the
@@ -372,6 +383,8 @@ __device__ __forceinline__ void kd_sort_levels(KdShared& s, int levels, float2* 
                 const int cl = tid * chunks_per_seg, cr = cl + chunks_per_seg;
                 lmax = s.bb[(3 + ax) * kKdChunks + cl];
                 rmin = s.bb[ax * kKdChunks + cr];
+                // (PLANES: the previous round's split, now that both halves' exact extremes are known)
+                if (PLANES) planes[(size_t)(heap_root << (11 - lS)) + (uint32_t)(tid >> 1)] = make_float2(kd_plane_between(lmax, rmin), __int_as_float(ax));
                 if (SAFE) {
 #pragma unroll
                     for (int e = 0; e < 6; ++e) P[e] = s.safe[e * 64 + (tid >> 1)];
@@ -421,15 +434,7 @@ __device__ __forceinline__ void kd_sort_levels(KdShared& s, int levels, float2* 
         }
         // ---- (c) lower half = below the median
         kd_median_partition(s, v, tid, lS);
-        if (PLANES) {
-            if (tid < nseg) {
-                const uint32_t li = kd_sel_state(s)[tid] & 4095u;
-                const int ax = s.seg_axis[tid];
-                const float x = (ax == 0) ? s.cx[li] : ((ax == 1) ? s.cy[li] : s.cz[li]);
-                planes[(size_t)(heap_root << (12 - lS)) + (uint32_t)tid] = make_float2(x, __int_as_float(ax));
-            }
-            // (the next round overwrites neither the medians nor seg_axis before its first barrier)
-        }
+        // (PLANES: this round's planes are written by the NEXT round, from the halves' boxes: kd_plane_between)
     }
     if (lS < last) return;  // (past a barrier)
 
@@ -479,6 +484,9 @@ __device__ __forceinline__ void kd_sort_levels(KdShared& s, int levels, float2* 
                 if (lane == 0) s.bb[wid] = mine;
                 __syncthreads();
                 sib = s.bb[wid ^ 1];
+                // (PLANES: the last block round's split of this wave's 512-segment, from the two waves' extremes)
+                if (PLANES && left && lane == 0)
+                    planes[(size_t)(heap_root << 3) + (uint32_t)(wid >> 1)] = make_float2(kd_plane_between(mine, sib), __int_as_float(pax));
             } else {
                 sib = __shfl_xor(mine, S >> 2, 64);
             }
@@ -517,10 +525,11 @@ __device__ __forceinline__ void kd_sort_levels(KdShared& s, int levels, float2* 
         kd_bitonic_sort(s, v, tid, lS);  // (lS <= 8: register stages only)
         if (PLANES) {
             reinterpret_cast<uint4*>(s.key)[tid] = make_uint4(v[0], v[1], v[2], v[3]);
-            if (((4 * tid) & (S - 1)) == 0) {  // (the median sits in this wave's own part of s.key)
-                const uint32_t li = s.key[4 * tid + (S >> 1)] & 4095u;
+            if (((4 * tid) & (S - 1)) == 0) {  // (the median and the element below it sit in this wave's own part of s.key)
+                const uint32_t li = s.key[4 * tid + (S >> 1)] & 4095u, lj = s.key[4 * tid + (S >> 1) - 1] & 4095u;
                 const float x = (ax == 0) ? s.cx[li] : ((ax == 1) ? s.cy[li] : s.cz[li]);
-                planes[(size_t)(heap_root << (12 - lS)) + (uint32_t)((4 * tid) >> lS)] = make_float2(x, __int_as_float(ax));
+                const float xl = (ax == 0) ? s.cx[lj] : ((ax == 1) ? s.cy[lj] : s.cz[lj]);
+                planes[(size_t)(heap_root << (12 - lS)) + (uint32_t)((4 * tid) >> lS)] = make_float2(kd_plane_between(xl, x), __int_as_float(ax));
             }
         }
     }

@@ -2,6 +2,7 @@
 // export, occupancy, the step's two solvers side by side)
 // (one translation unit of libmi_icp.so; csrc/ctx.h lists them)
 #include "ctx.h"
+#include <vector>
 #include "halo_format.h"
 #include "traverse.h"
 #include "wave_solver.h"
@@ -180,6 +181,21 @@ int mi_icp_debug_loop_counters(mi_icp_ctx* c, int32_t* out4) {
 int mi_icp_debug_drop_seeds(mi_icp_ctx* c) {
     TRY(check_ctx(c));
     c->nn_valid = false;
+    return MI_ICP_OK;
+}
+
+int mi_icp_debug_locate(mi_icp_ctx* c, const float* T, int32_t* leaf_out) {
+    TRY(check_ctx(c));
+    if (!leaf_out || c->ns <= 0 || c->nt <= 0) return fail(c, MI_ICP_ERR_INVALID, "debug_locate: bad state/arguments");
+    if (!planes_available(c)) return fail(c, MI_ICP_ERR_INVALID, "debug_locate: this tree has no split planes");
+    TRY(launch_locate_by_planes(c, make_xform(load_T(T)), nullptr, 0));
+    c->nn_valid = true;  // (the seeds of the next seeded pass)
+    c->n_user_pairs = -1;
+    std::vector<int32_t> seeds((size_t)c->ns), perm((size_t)c->ns);
+    HIPCHK(c, hipMemcpyAsync(seeds.data(), c->nn_idx.p, sizeof(int32_t) * (size_t)c->ns, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(perm.data(), c->sperm.p, sizeof(int32_t) * (size_t)c->ns, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < c->ns; ++i) leaf_out[perm[(size_t)i]] = seeds[(size_t)i] >> 3;
     return MI_ICP_OK;
 }
 

@@ -317,7 +317,7 @@ int mi_icp_create(int device, mi_icp_ctx** out) {
     c->device = device;
     bool ok = hipHostMalloc((void**)&c->sys_host, 64 * sizeof(double), hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void**)&c->f_host, 64 * sizeof(float), hipHostMallocDefault) == hipSuccess &&
-              hipHostMalloc((void**)&c->u_host, 16 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+              hipHostMalloc((void**)&c->u_host, (16 + kWantSlots) * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&c->loop_host, sizeof(DevLoop), hipHostMallocDefault) == hipSuccess;
     for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     // (lowest priority: the halo build fills what the context's own stream leaves idle)
@@ -706,7 +706,9 @@ static int loop_enqueue_evaluation(mi_icp_ctx* c, bool seed) {
     // RE-LOCATION (loop.h): while this loop's steps are still large the seeded search is preceded by a launch that
     // does nothing unless the step just taken moved the source by more than a quarter spacing -- then every seed is
     // replaced by the leaf the moved query falls into.  Armed per chunk by loop_run; needs the halos (a located seed
-    // without them walks like a stale one).
+    // without them walks like a stale one: measured on the bench's cold call, whose second search -- the queries a few
+    // thousandths of a spacing from their partners after the first step -- leaves 0.85 lanes per packet unfinished from
+    // located seeds against 1.18 from the first pass's matches, 0.21 against 0.196 ms, and the descent costs 0.12).
     if (seed && c->relocate_armed && c->halo_use && c->nn_valid && c->n_user_pairs < 0 && c->ns > 0 && c->nt > 0) {
         const Xform none = {};
         TRY(launch_locate_by_planes(c, none, d, 1));
@@ -757,7 +759,7 @@ static int loop_run(mi_icp_ctx* c, int budget) {
         const bool carried = c->relocate_armed && c->halo_use;  // this chunk's iterations carry the gated re-location launches
         const int relocations_before = c->loop_host->relocations;
         for (int i = 0; i < n; ++i) TRY(loop_enqueue_evaluation(c, true));
-        if (no_halo) HIPCHK(c, hipMemcpyAsync(c->u_host + 8, c->halo_want.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        if (no_halo) HIPCHK(c, hipMemcpyAsync(c->u_host + 16, c->halo_want.p, kWantSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         TRY(loop_pull(c));
         const int executed = c->loop_host->passes - passes_before;
         collect_pooled(c, executed);
@@ -768,8 +770,10 @@ static int loop_run(mi_icp_ctx* c, int budget) {
         if (no_halo) {
             // (a 32-bit device counter that keeps counting through a long stepping loop: the difference is taken
             // modulo 2^32, so a wrap between two looks costs nothing)
-            const int64_t asked = (int64_t)(uint32_t)(c->u_host[8] - (uint32_t)c->halo_want_seen);  // by this chunk's iterations
-            c->halo_want_seen = (int64_t)c->u_host[8];
+            uint32_t counted = 0u;  // (nn_search.h kWantSlots: the counter's words, summed modulo 2^32)
+            for (uint32_t k = 0; k < kWantSlots; ++k) counted += c->u_host[16 + k];
+            const int64_t asked = (int64_t)(uint32_t)(counted - (uint32_t)c->halo_want_seen);  // by this chunk's iterations
+            c->halo_want_seen = (int64_t)counted;
             c->halo_asked += asked;
             if (undecided) {
                 ++c->halo_looks;
@@ -854,8 +858,8 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
     c->ran_loop = true;
     {
         uint32_t* want;
-        TRY(ensure(c, c->halo_want, 64, &want));
-        HIPCHK(c, hipMemsetAsync(want, 0, sizeof(uint32_t), c->stream));
+        TRY(ensure(c, c->halo_want, kWantSlots, &want));
+        HIPCHK(c, hipMemsetAsync(want, 0, kWantSlots * sizeof(uint32_t), c->stream));
     }
     c->halo_use = halo_poll(c);
     // A context whose loops have asked for halos before builds them NOW, on the loop's own stream, ahead of the first

@@ -28,6 +28,7 @@
 
 namespace mi {
 
+constexpr uint32_t kWantSlots = 1024u;  // words of the halo_want counter (below; a power of two)
 constexpr int kNNThreads = 64;   // one packet per workgroup: the dispatcher refills wave slots one at a time (3 % faster than 4)
 constexpr int kNNPacketsPerBlock = kNNThreads / 64;
 
@@ -269,10 +270,13 @@ __device__ __forceinline__ bool nn_packet_body(
         }
     }
     // No halos (yet): the lanes one would serve are counted, so that the host can tell whether to build them
-    // (clean data never needs them: every lane ends in its seed leaf's region).
+    // (clean data never needs them: every lane ends in its seed leaf's region).  The count is kept in kWantSlots
+    // words, a packet adds to word (packet mod kWantSlots) and the host sums them: atomics on ONE word are carried out
+    // one after the other at the memory side, ~11 ns each, and a registration's first seeded search -- where most
+    // packets have a lane that asks -- took 1.09 ms instead of ~0.1 at 10M points for its 94k additions alone.
     if (SEED && __builtin_expect(want != nullptr, 0)) {
         const uint64_t m = __ballot(valid && !retired && seed_j >= 0);
-        if (m != 0ull && lane == 0) atomicAdd(want, (uint32_t)__popcll(m));
+        if (m != 0ull && lane == 0) atomicAdd(want + (packet & (kWantSlots - 1u)), (uint32_t)__popcll(m));
     }
     // the lane's running result lives in LDS, where any lane may improve it
     sh.best[lane] = ((unsigned long long)__float_as_uint(fmaxf(best, 0.0f)) << 32) | (unsigned long long)(uint32_t)bidx;

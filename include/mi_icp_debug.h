@@ -55,6 +55,11 @@ MI_ICP_API int mi_icp_debug_occupancy(int which);
  * search's seeds replaced by the leaves the moved queries fall into: csrc/loop.h, nn_search.h locate_by_planes),
  * 1 if the next chunk of iterations would still carry the gated re-location launches}. */
 MI_ICP_API int mi_icp_debug_loop_counters(mi_icp_ctx* ctx, int32_t* out4);
+/* The leaf every staged source point FALLS INTO under T (column-major 4x4 or NULL) by the binary descent through the
+ * cell planes and its group's planes (nn_search.h locate_by_planes): leaf_out[original source index] = leaf (host memory,
+ * one per source point).  The located leaves are left behind as the seeds of the next seeded pass.  Fails on a tree
+ * without planes (MI_ICP_NO_CELLS, a target below one group). */
+MI_ICP_API int mi_icp_debug_locate(mi_icp_ctx* ctx, const float* T, int32_t* leaf_out);
 MI_ICP_API int mi_icp_debug_set_step_stamps(mi_icp_ctx* ctx, int enable);
 MI_ICP_API int mi_icp_debug_get_step_stamps(mi_icp_ctx* ctx, uint64_t* out32, double* ticks_per_us);
 /* The loop step's two forms of utility::SolveJacobianSystemAndObtainExtrinsicMatrix side by side, on the

@@ -250,3 +250,40 @@ def test_overflowing_cell_has_no_regions_but_the_rest_does(eng):
         assert 0 < flagged < total
     else:
         assert flagged == 0                      # Morton runs are not kd cells: no regions at all
+
+
+@pytest.mark.parametrize("n", [70000, 307200, 1000000, 3000000])
+def test_locate_by_planes_finds_the_leaf_a_target_point_lives_in(eng, n):
+    """The binary descent through the cell planes and the group's own planes (nn_search.h locate_by_planes; seeds of a
+    first pass with halos and of every re-location) must land in the leaf that HOLDS a point when the query is that
+    point: any leaf is a valid seed, so the search tests cannot see a descent that lands next door -- only its cost
+    does.  The target's own points as the source, under the identity: all but a handful (a coordinate equal to a plane
+    through a quantised median, kd_refine.h) are found where they are stored."""
+    if os.environ.get("MI_ICP_NO_CELLS") is not None or os.environ.get("MI_ICP_NO_LOCATE_PLANES") is not None:
+        pytest.skip("no split planes on this tree")
+    rng = np.random.default_rng(n + 7)
+    pts = rng.random((n, 3), dtype=np.float32)
+    eng.set_target(pts)
+    eng.set_source(pts)
+    nts, nleaf, leaf_first, rec, lines, nt = get_tree(eng)
+    orig = lines[:, 24:32].copy().view(np.int32).reshape(-1)
+    lives = np.empty(n, np.int64)
+    real = orig >= 0
+    lives[orig[real]] = np.nonzero(real)[0] >> 3
+    got = np.empty(n, np.int32)
+    eng._chk(eng._L.mi_icp_debug_locate(eng._ctx, None, got.ctypes.data_as(C.c_void_p)))
+    wrong = np.nonzero(got != lives)[0]
+    assert len(wrong) <= max(4, n // 20000), (n, len(wrong), got[wrong[:8]], lives[wrong[:8]])
+    # ... and the search that starts from those seeds finds every point at distance 0
+    idx, d2, _ = eng.search_radius_1nn(0.01, None)
+    assert (d2 == 0.0).all() and (pts[idx] == pts).all()
+    # A query a hair away from a target point (a converged registration's: 0.005 point spacings per coordinate) is
+    # still found in that point's leaf unless the point lies that close to one of the leaf's faces (~1.5 %).  While a
+    # split's plane was the median element's own coordinate one point in eight lay exactly ON a plane and its
+    # neighbourhood fell on either side: 92 % instead of 98.5 (kd_refine.h kd_plane_between).
+    s = float(n) ** (-1.0 / 3.0)
+    near = (pts + rng.normal(0.0, 0.005 * s, pts.shape)).astype(np.float32)
+    eng.set_source(near)
+    eng._chk(eng._L.mi_icp_debug_locate(eng._ctx, None, got.ctypes.data_as(C.c_void_p)))
+    right = float((got == lives).mean())
+    assert right >= 0.97, (n, right)
