@@ -482,8 +482,9 @@ static int rgbd_odometry_impl(mi_icp_ctx* c, const float* source_color, const fl
     total += (size_t)n0 + 64;
     float* arena;
     TRY(ensure(c, c->stage[4], total, &arena));
-    double* sums;
+    double *sums, *rows;  // the 32 totals; the rows of od_accumulate's larger grids (the ICP reduction's row buffer: transient there too)
     TRY(ensure(c, c->sys_dev, kSysSize, &sums));
+    TRY(ensure(c, c->partial, (size_t)kSysSize * kOdMaxBlocks, &rows));
     float *col[2][MI_ICP_ODOMETRY_MAX_LEVELS], *dep[2][MI_ICP_ODOMETRY_MAX_LEVELS], *grad[4][MI_ICP_ODOMETRY_MAX_LEVELS];
     {
         float* p = arena;
@@ -552,6 +553,7 @@ static int rgbd_odometry_impl(mi_icp_ctx* c, const float* source_color, const fl
     HIPCHK(c, hipMemsetAsync(sums, 0, 32 * sizeof(double), c->stream));
     OdArgs a{};
     a.out = sums;
+    a.rows = rows;
     a.state = state;
     a.max_depth_diff = option->max_depth_diff;
     auto level_args = [&](int l) {
@@ -568,13 +570,16 @@ static int rgbd_odometry_impl(mi_icp_ctx* c, const float* source_color, const fl
     };
     auto grid_for = [&](int l) {
         const int64_t n = (int64_t)lw[l] * lh[l];
-        return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + kOdThreads - 1) / kOdThreads));
+        return (int)std::min<int64_t>(kOdMaxBlocks, std::max<int64_t>(1, (n + kOdThreads - 1) / kOdThreads));
     };
+    // rows left by an evaluation of level l for whoever consumes its sums (0: it added to the totals itself)
+    auto rows_of = [&](int l) { const int g = grid_for(l); return g > kOdAtomicBlocks ? g : 0; };
     {   // NormalizeIntensity (:416-436) over the correspondences under odo_init
         TRY(set_T(init));
-        od_step<<<1, 64, 0, c->stream>>>(state, sums, cam[0], 0);
+        od_step<<<1, kOdStepThreads, 0, c->stream>>>(state, sums, cam[0], 0, rows, 0);
         level_args(0);
         od_accumulate<kOdMeans><<<grid_for(0), kOdThreads, 0, c->stream>>>(a);
+        if (rows_of(0)) od_total<<<1, kOdStepThreads, 0, c->stream>>>(rows, rows_of(0), sums);
         od_scale_by_mean<<<blocks(n0), kOdThreads, 0, c->stream>>>(col[0][0], n0, sums, 0);
         od_scale_by_mean<<<blocks(n0), kOdThreads, 0, c->stream>>>(col[1][0], n0, sums, 1);
         KCHK(c);
@@ -603,7 +608,7 @@ static int rgbd_odometry_impl(mi_icp_ctx* c, const float* source_color, const fl
         bool zero = true;
         for (int i = 0; i < 16; ++i) zero = zero && (init.data()[i] == 0.0f);
         TRY(set_T(zero ? I4 : init));
-        od_step<<<1, 64, 0, c->stream>>>(state, sums, cam[L - 1], 0);  // terms for the coarsest level; zeroes the sums
+        od_step<<<1, kOdStepThreads, 0, c->stream>>>(state, sums, cam[L - 1], 0, rows, 0);  // terms for the coarsest level; zeroes the sums
     }
     for (int level = L - 1; level >= 0; --level) {
         level_args(level);
@@ -613,21 +618,22 @@ static int rgbd_odometry_impl(mi_icp_ctx* c, const float* source_color, const fl
             const int next = (iter + 1 < iters) ? level : std::max(level - 1, 0);
             if (weighted) {  // two passes: the weights' normalisation, then the weighted system
                 od_accumulate<kOdWeightSum><<<grid_for(level), kOdThreads, 0, c->stream>>>(a);
-                od_step<<<1, 64, 0, c->stream>>>(state, sums, cam[level], 3);
+                od_step<<<1, kOdStepThreads, 0, c->stream>>>(state, sums, cam[level], 3, rows, rows_of(level));
                 od_accumulate<kOdWeighted><<<grid_for(level), kOdThreads, 0, c->stream>>>(a);
-                od_step<<<1, 64, 0, c->stream>>>(state, sums, cam[next], 2);
+                od_step<<<1, kOdStepThreads, 0, c->stream>>>(state, sums, cam[next], 2, rows, rows_of(level));
                 continue;
             }
             if (jacobian == MI_ICP_ODOMETRY_COLOR_TERM) od_accumulate<kOdColor><<<grid_for(level), kOdThreads, 0, c->stream>>>(a);
             else od_accumulate<kOdHybrid><<<grid_for(level), kOdThreads, 0, c->stream>>>(a);
-            od_step<<<1, 64, 0, c->stream>>>(state, sums, cam[next], 1);
+            od_step<<<1, kOdStepThreads, 0, c->stream>>>(state, sums, cam[next], 1, rows, rows_of(level));
         }
-        if (iters <= 0 && level > 0) od_step<<<1, 64, 0, c->stream>>>(state, sums, cam[level - 1], 0);
+        if (iters <= 0 && level > 0) od_step<<<1, kOdStepThreads, 0, c->stream>>>(state, sums, cam[level - 1], 0, rows, 0);
     }
     KCHK(c);
     // CreateInformationMatrix (:349-394): I + sum G^T G over the final correspondences
     level_args(0);
     od_accumulate<kOdInformation><<<grid_for(0), kOdThreads, 0, c->stream>>>(a);
+    if (rows_of(0)) od_total<<<1, kOdStepThreads, 0, c->stream>>>(rows, rows_of(0), sums);
     KCHK(c);
     HIPCHK(c, hipMemcpyAsync(c->sys_host, sums, 32 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&hst->T, &state->T, sizeof(Mat4), hipMemcpyDeviceToHost, c->stream));

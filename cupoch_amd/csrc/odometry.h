@@ -11,7 +11,11 @@
 //     PreprocessDepth's NaN rule applied on load where asked;
 //   * od_accumulate: ONE kernel per iteration -- every source pixel applies the
 //     correspondence rule, evaluates its Jacobian rows and adds them to fp64 register
-//     accumulators; wave sums on the DPP network, 29 fp64 atomics per block.  No
+//     accumulators; wave sums on the DPP network, then the block's ROW of sums into memory, totalled in
+//     a fixed order by whatever consumes them (od_step, od_total) -- grids of up to kOdAtomicBlocks
+//     workgroups add theirs to the totals with 29 fp64 atomics instead.  (Until late in round 5 every
+//     grid did: additions to one word are carried out one after the other at the memory side, ~11 ns
+//     each, and the 1024 workgroups of a 640x480 level spent 15 of their kernel's 22 us queueing.)  No
 //     correspondence list exists; the same kernel (other MODEs) forms NormalizeIntensity's
 //     means and the information matrix.
 // Per-pixel arithmetic is fp32 in the reference's order (the library is built with
@@ -23,6 +27,9 @@
 namespace mi {
 
 constexpr int kOdThreads = 256;
+constexpr int kOdMaxBlocks = 512;     // of an od_accumulate grid
+constexpr int kOdAtomicBlocks = 96;   // grids up to this size add to the totals atomically (a queue of ~1 us), larger ones write rows
+constexpr int kOdStepThreads = 256;
 
 // Image::Filter(type) (geometry/image.cu:30-75,176-205,557-570): clamp-to-edge, horizontal
 // pass with kx, then vertical pass with ky.  TYPE 0 Gaussian3, 1 Sobel3Dx, 2 Sobel3Dy.
@@ -100,6 +107,7 @@ struct OdArgs {
     float max_depth_diff;
     const OdState* state;
     double* out;    // 32 doubles, zero on entry (od_step leaves them so): the layout of the ICP system (reduce.h)
+    double* rows;   // [gridDim.x][32]: the blocks' sums when the grid is larger than kOdAtomicBlocks (od_total_rows)
 };
 
 constexpr int kOdColor = 0, kOdHybrid = 1, kOdMeans = 2, kOdInformation = 3, kOdWeightSum = 4, kOdWeighted = 5;
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(kOdThreads) void od_accumulate(OdArgs a) {
             }
         }
     }
-    // block totals: DPP wave sums -> LDS -> one fp64 atomic per value
+    // block totals: DPP wave sums -> LDS -> the block's row (or one fp64 atomic per value: small grids)
     __shared__ double red[kOdThreads / 64][30];
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
 #pragma unroll
@@ -247,12 +255,57 @@ __global__ __launch_bounds__(kOdThreads) void od_accumulate(OdArgs a) {
     }
     __syncthreads();
     const int k = (int)threadIdx.x;
-    if (k < kAcc || k == 29) {
-        double t = 0.0;
+    const bool mine = k < kAcc || k == 29;
+    double t = 0.0;
+    if (mine) {
 #pragma unroll
         for (int p = 0; p < kOdThreads / 64; ++p) t += red[p][k];
-        if (t != 0.0) atomicAdd(a.out + k, t);
     }
+    if ((int)gridDim.x > kOdAtomicBlocks) {
+        if (k < 32) a.rows[(int64_t)blockIdx.x * 32 + k] = t;  // (the next kernel on the stream totals them)
+    } else if (mine && t != 0.0) {
+        atomicAdd(a.out + k, t);
+    }
+}
+
+// The rows of a grid of `nrows` blocks totalled in a fixed order (reduce.h block_finish_rows' scheme: eight parts of
+// 32 columns, eight loads in flight per thread) into sys[32]; all kOdStepThreads threads of the block, which leave
+// past a barrier.
+__device__ __forceinline__ void od_total_rows(const double* __restrict__ rows, int nrows, double* sys) {
+    __shared__ double part[kOdStepThreads / 32][32];
+    const int k = (int)(threadIdx.x & 31u), p = (int)(threadIdx.x >> 5);
+    constexpr int kParts = kOdStepThreads / 32, kU = 8;
+    double acc[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) acc[u] = 0.0;
+    for (int b = p; b < nrows; b += kU * kParts) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int bb = b + u * kParts;
+            const double v = rows[(int64_t)(bb < nrows ? bb : 0) * 32 + k];
+            acc[u] += (bb < nrows) ? v : 0.0;
+        }
+    }
+#pragma unroll
+    for (int w = kU / 2; w > 0; w >>= 1)
+#pragma unroll
+        for (int u = 0; u < w; ++u) acc[u] += acc[u + w];
+    part[p][k] = acc[0];
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < kParts; ++q) t += part[q][k];
+        sys[k] = t;
+    }
+    __syncthreads();
+}
+
+// ... for the consumers that are not od_step (od_scale_by_mean, the information matrix's copy): sums <- the total
+static __global__ __launch_bounds__(kOdStepThreads) void od_total(const double* __restrict__ rows, int nrows, double* __restrict__ sums) {
+    __shared__ double sys[32];
+    od_total_rows(rows, nrows, sys);
+    if (threadIdx.x < 32) sums[threadIdx.x] = sys[threadIdx.x];
 }
 
 // Eigen's 3x3 inverse by cofactors and 3x3 product, fp32, row-major (K.inverse(), K * R * K_inv)
@@ -323,24 +376,32 @@ __host__ __device__ inline void od_matrix4_to_vector6(const host::Mat4& T, float
 // update: 0 derive the terms only, 1 plain iteration, 2 weighted iteration (the system gets the
 // motion prior first, the velocity and sigma2 are advanced; DoSingleIterationWeighted :690-705,
 // ComputeMultiscaleWeighted :806-818), 3 the weighted variant's half step: w_sum <- sums[0].
-static __global__ __launch_bounds__(64) void od_step(OdState* st, double* sums, OdCamera cam, int update) {
+// nrows > 0: the evaluation just made left its sums as `nrows` rows (od_accumulate on a large grid) -- totalled here.
+static __global__ __launch_bounds__(kOdStepThreads) void od_step(OdState* st, double* sums, OdCamera cam, int update,
+                                                                const double* __restrict__ rows, int nrows) {
     __shared__ double sys[32];
-    if (threadIdx.x < 32) sys[threadIdx.x] = sums[threadIdx.x];
-    __syncthreads();
+    if (nrows > 0) {
+        od_total_rows(rows, nrows, sys);
+    } else {
+        if (threadIdx.x < 32) sys[threadIdx.x] = sums[threadIdx.x];
+        __syncthreads();
+    }
     if (threadIdx.x == 0 && update == 3) st->w_sum = (float)sys[0];
+    if (threadIdx.x == 0 && update == 2) {
+        float cv[6];
+        od_matrix4_to_vector6(st->vel, cv);
+        const int diag[6] = {0, 6, 11, 15, 18, 20};  // JTJ(i,i) in the packed upper triangle
+        for (int a = 0; a < 6; ++a) {
+            sys[diag[a]] = (double)((float)sys[diag[a]] + st->inv_sigma[a]);
+            sys[21 + a] = (double)((float)sys[21 + a] - st->inv_sigma[a] * (st->prev_twist[a] - cv[a]));
+        }
+        st->sigma2 = st->w_sum;
+    }
     if (threadIdx.x == 0 && update != 3) {
         host::Mat4 T = st->T;
-        if (update == 2) {
-            float cv[6];
-            od_matrix4_to_vector6(st->vel, cv);
-            const int diag[6] = {0, 6, 11, 15, 18, 20};  // JTJ(i,i) in the packed upper triangle
-            for (int a = 0; a < 6; ++a) {
-                sys[diag[a]] = (double)((float)sys[diag[a]] + st->inv_sigma[a]);
-                sys[21 + a] = (double)((float)sys[21 + a] - st->inv_sigma[a] * (st->prev_twist[a] - cv[a]));
-            }
-            st->sigma2 = st->w_sum;
-        }
         if (update) {
+            // (the registration loop's solve with a matrix row per lane, wave_solver.h, measured no faster here -- same
+            // box, 0.56-0.59 ms per 320x240 call either way: the call is bound by its 70-odd launches, not by this thread)
             host::Mat4 upd;
             host::solve_system(sys, -1.0f, upd);
             T = host::mul4(upd, T);
