@@ -291,6 +291,9 @@ __device__ __forceinline__ uint32_t kd_make_key(float x, float lo, float sc, uin
 // located next door to their partner's leaf.)  No upper half (padding only): +inf, nothing goes right.  Halves that
 // overlap by a sliver (the quantised split, below) or are a rounding apart: the upper half's minimum, as before.
 __device__ __forceinline__ float kd_plane_between(float lower_max, float upper_min) {
+#ifdef MI_AB_PLANES_THROUGH
+    return upper_min;
+#endif
     const float mid = 0.5f * (lower_max + upper_min);  // (-inf + inf: NaN -> the upper minimum, +inf)
     return (mid > lower_max) ? mid : upper_min;
 }

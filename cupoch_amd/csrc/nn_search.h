@@ -28,7 +28,11 @@
 
 namespace mi {
 
+#ifdef MI_AB_WANT_ONE
+constexpr uint32_t kWantSlots = 1u;
+#else
 constexpr uint32_t kWantSlots = 1024u;  // words of the halo_want counter (below; a power of two)
+#endif
 constexpr int kNNThreads = 64;   // one packet per workgroup: the dispatcher refills wave slots one at a time (3 % faster than 4)
 constexpr int kNNPacketsPerBlock = kNNThreads / 64;
 
