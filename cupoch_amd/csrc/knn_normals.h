@@ -596,6 +596,13 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
     }
     if (solo) st.worst = -1.0f;
     // ---- B: the exact walk
+#ifdef MI_KNN_CENSUS
+    unsigned long long cs_leaves = 0ull, cs_waveacc = 0ull, cs_laneacc = 0ull, cs_shrinks = 0ull;
+    const float cs_bound0 = st.worst;
+#endif
+#ifdef MI_KNN_CENSUS
+    const uint32_t cs_records =
+#endif
     traverse_wide(records_g, leaf_first, cube, [&](uint32_t Lu) {
         const bool seeded = Lu >= seed_lo && Lu < seed_hi;  // this lane has these points already
         const int L = __builtin_amdgcn_readfirstlane((int)Lu);
@@ -604,10 +611,43 @@ __global__ __launch_bounds__(knn_waves(KCAP) * 64) void knn_search_kernel(
 #pragma unroll
         for (int t = 0; t < kLeaf; ++t) {
             const float d2 = seeded ? INFINITY : sq3(qx - p.x[t], qy - p.y[t], qz - p.z[t]);
+#ifdef MI_KNN_CENSUS
+            const uint64_t cs_m = __ballot(d2 < st.worst);
+            cs_waveacc += cs_m != 0ull ? 1ull : 0ull;
+            cs_laneacc += (unsigned long long)__popcll(cs_m);
+#endif
             shrunk |= knn_offer(kd2, kidx, lane, k, st, d2, L * kLeaf + t);  // padding points: d2 = +inf
         }
+#ifdef MI_KNN_CENSUS
+        cs_leaves += 1ull;
+        cs_shrinks += __ballot(shrunk) != 0ull ? 1ull : 0ull;
+#endif
         if (shrunk) set_cube(cube, qx, qy, qz, st.worst);
     });
+#ifdef MI_KNN_CENSUS
+    if (found) {
+        // sums over the packets: leaves offered, candidates some lane accepted, lane-accepts, leaves after which a cube
+        // shrank, records visited, packets; and the lanes' bounds (radii) before / after the walk, summed over finite ones
+        const float r0 = __builtin_amdgcn_sqrtf(fmaxf(cs_bound0, 0.0f)), r1 = __builtin_amdgcn_sqrtf(fmaxf(st.worst, 0.0f));
+        const bool fin = valid && k > 0 && r0 < INFINITY && !solo;
+        const float s0 = wave_all_sum(fin ? r0 : 0.0f), s1 = wave_all_sum(fin ? r1 : 0.0f), sn = wave_all_sum(fin ? 1.0f : 0.0f);
+        const float mx0 = wave_all_max(fin ? r0 : 0.0f), mn0 = wave_all_min(fin ? r0 : INFINITY);
+        if (lane == 0) {
+            atomicAdd(found + 1, cs_leaves);
+            atomicAdd(found + 2, cs_waveacc);
+            atomicAdd(found + 3, cs_laneacc);
+            atomicAdd(found + 4, cs_shrinks);
+            atomicAdd(found + 5, (unsigned long long)cs_records);
+            atomicAdd(found + 6, 1ull);
+            atomicAdd(reinterpret_cast<double*>(found + 7), (double)s0);
+            atomicAdd(reinterpret_cast<double*>(found + 8), (double)s1);
+            atomicAdd(reinterpret_cast<double*>(found + 9), (double)sn);
+            atomicAdd(reinterpret_cast<double*>(found + 10), (double)mx0);
+            atomicAdd(reinterpret_cast<double*>(found + 11), (double)mn0);
+            atomicAdd(found + 12, (unsigned long long)__popcll(__ballot(solo)));
+        }
+    }
+#endif
     if (__ballot(solo) != 0ull) {
         if (solo) st.worst = solo_bound;
         solo_walk(records_g, leaf_first, solo, qx, qy, qz, [&]() { return st.worst; }, [&](uint32_t L) {

@@ -104,8 +104,8 @@ int mi_icp_search_knn(mi_icp_ctx* c, const float* queries, int64_t nq, int knn, 
         TRY(ensure(c, c->stage[5], (size_t)nq * knn, &d_d2));
     }
     unsigned long long* cnt;
-    TRY(ensure(c, c->flags, 8, (unsigned long long**)&cnt));
-    HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(unsigned long long), c->stream));
+    TRY(ensure(c, c->flags, 16, (unsigned long long**)&cnt));
+    HIPCHK(c, hipMemsetAsync(cnt, 0, 16 * sizeof(unsigned long long), c->stream));
     const uint32_t npackets = (uint32_t)((nq + 63) / 64);
     const int cap = knn_capacity(knn), waves = knn_waves(cap);
     const uint32_t nblocks = (npackets + waves - 1) / waves;
@@ -126,9 +126,19 @@ int mi_icp_search_knn(mi_icp_ctx* c, const float* queries, int64_t nq, int knn, 
         TRY(from_device(c, (const int32_t*)d_idx, idx_out, (size_t)nq * knn, mem_kind));
         TRY(from_device(c, (const float*)d_d2, d2_out, (size_t)nq * knn, mem_kind));
     }
-    HIPCHK(c, hipMemcpyAsync(c->sys_host, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sys_host, cnt, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (found) *found = (int64_t) * reinterpret_cast<unsigned long long*>(c->sys_host);
+#ifdef MI_KNN_CENSUS
+    {   // (a census build: scripts/dev/knn_census.sh)
+        const unsigned long long* u = reinterpret_cast<const unsigned long long*>(c->sys_host);
+        const double* d = reinterpret_cast<const double*>(c->sys_host);
+        const double p = (double)std::max<unsigned long long>(u[6], 1ull), ln = std::max(d[9], 1.0);
+        std::fprintf(stderr, "knn census k=%d: per packet: leaves offered %.1f, candidates some lane accepted %.1f (%.1f %% of the offered), lane-accepts %.1f, "
+                     "leaves after which a cube shrank %.1f, records %.1f; mean bound before the walk %.3g (packet max %.3g, min %.3g), after %.3g; lanes that walked alone %.2f\n",
+                     knn, u[1] / p, u[2] / p, 100.0 * u[2] / std::max<double>(8.0 * u[1], 1.0), u[3] / p, u[4] / p, u[5] / p, d[7] / ln, d[10] / p, d[11] / p, d[8] / ln, u[12] / p);
+    }
+#endif
     return MI_ICP_OK;
 }
 
