@@ -21,6 +21,7 @@ namespace mi {
 constexpr int kSysSize = 32;  // the reduced system: 21 + 6 sums, r^2, d^2, count, two spare (reduce.h)
 constexpr int kEstP2P = 1, kEstPt2Pl = 2, kEstSym = 3, kEstColored = 4, kEstGICP = 5;  // MI_ICP_EST_* (include/mi_icp.h)
 
+constexpr float kRelocateNears = 1.5f;  // a step beyond this many near radii (kd_build.h tree_scale) re-locates the next search's seeds
 struct DevLoop {
     Xform X;             // what the source points see (row-major 3x4), read by the kernels
     int32_t done;        // != 0: loop finished (converged or iteration budget spent)
@@ -36,14 +37,18 @@ struct DevLoop {
     uint64_t history;    // device address of float2[kLoopHistory] or 0: (fitness, rmse) an update started from, by iteration
     uint64_t stamps;     // device address of uint64[kStampWords] or 0: where an iteration's time goes (mi_icp_debug_set_step_stamps)
     // RE-LOCATION (nn_search.h locate_by_planes).  The step sizes what it does to the source: the largest displacement of
-    // the 8 corners of the source's box under the update just solved.  Beyond a quarter of a point spacing the next
-    // search's seeds are stale: `relocate` is set and the gated locate launch in front of that search (when the host
-    // has armed one) replaces every seed by the leaf the moved query falls into.
+    // the 8 corners of the source's box under the update just solved.  Beyond about a LEAF'S WIDTH (kRelocateNears x the
+    // tree's near radius: ~1.9 point spacings) the next search's seeds are stale: `relocate` is set and the gated locate
+    // launch in front of that search (when the host has armed one) replaces every seed by the leaf the moved query
+    // falls into.  (The bound was a quarter spacing until late in round 5.  A step that short leaves a query in its
+    // seed's leaf or the one beside it, where a located seed is no better than the stale one -- and a registration
+    // that keeps sliding re-located at EVERY iteration: the reference's own benchmark call, 113k points turned by 30
+    // degrees against themselves, spent 0.2 of its 2.04 ms on 26 descents that changed nothing.)
     uint64_t near2_ptr;       // device address of the tree's squared "near" radius (~1.25 spacings; kd_build.h tree_scale) or 0: never
     uint64_t src_bounds_ptr;  // device address of the staged source's min[3], max[3]
     int32_t ready;       // estimator inputs present (normals / covariances)
     int32_t error;       // != 0: the ranks' exchange failed (mailbox.h); the loop is finished, its result void
-    int32_t relocate;    // the step just taken moved the source by more than a quarter spacing
+    int32_t relocate;    // the step just taken moved the source by more than about a leaf's width
     int32_t relocations; // steps of this loop that did
     host::Mat4 T;        // reported transformation (column-major)
     host::Mat4 A;        // applied transformation (differs from T only by an ~identity init)
@@ -208,7 +213,7 @@ __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys
         if (lane == 0) s_det_ok = ok ? 1 : 0;
     }
     // (wave 2, lanes 0..7: the corners of the source's box as the searches saw them -- A is stable until the barrier)
-    float cx = 0.0f, cy = 0.0f, cz = 0.0f, far2 = INFINITY;  // far2: (a quarter spacing)^2 = (0.2 * 1.25 spacings)^2
+    float cx = 0.0f, cy = 0.0f, cz = 0.0f, far2 = INFINITY;  // far2: (a leaf's width)^2 = (kRelocateNears * ~1.25 spacings)^2
 #ifdef MI_AB_NO_SIZING
     const bool sized = false;
 #else
@@ -216,7 +221,7 @@ __device__ __forceinline__ void loop_step_block(DevLoop* st_g, const double* sys
 #endif
     // (everything this needs from memory is asked for BEFORE the barrier, beside the solve: a load behind it was 2 us on
     // every step's critical path -- 6 % of an 8-way shard's)
-    if (wid == 2 && lane == 0 && sized) far2 = 0.04f * *reinterpret_cast<const float*>(st->near2_ptr);
+    if (wid == 2 && lane == 0 && sized) far2 = (kRelocateNears * kRelocateNears) * *reinterpret_cast<const float*>(st->near2_ptr);
     if (wid == 2 && lane < 8 && sized) {
         const float* sb = reinterpret_cast<const float*>(st->src_bounds_ptr);
         const float px = sb[(lane & 1) ? 3 : 0], py = sb[(lane & 2) ? 4 : 1], pz = sb[(lane & 4) ? 5 : 2];

@@ -704,7 +704,7 @@ static int launch_fused_iteration(mi_icp_ctx* c, DevLoop* d) {
 static int loop_enqueue_evaluation(mi_icp_ctx* c, bool seed) {
     DevLoop* d = (DevLoop*)c->loop_dev.p;
     // RE-LOCATION (loop.h): while this loop's steps are still large the seeded search is preceded by a launch that
-    // does nothing unless the step just taken moved the source by more than a quarter spacing -- then every seed is
+    // does nothing unless the step just taken moved the source by more than about a leaf's width -- then every seed is
     // replaced by the leaf the moved query falls into.  Armed per chunk by loop_run; needs the halos (a located seed
     // without them walks like a stale one: measured on the bench's cold call, whose second search -- the queries a few
     // thousandths of a spacing from their partners after the first step -- leaves 0.85 lanes per packet unfinished from

@@ -634,8 +634,8 @@ static __global__ __launch_bounds__(256) void locate_leaves(const float* __restr
 // lower ones hit a 4-KB table per group.  Two users:
 //  * a first pass when the target's halos exist: locate, then the seeded search (launch_nn);
 //  * RE-LOCATION inside a loop (gated != 0: nothing happens unless the step just taken set loop->relocate, loop.h): a
-//    step that moved the points by more than a quarter spacing leaves every seed a leaf or two off; trusting it costs
-//    a halo phase AND a 19-record climb for the lanes beyond their stale leaf's reach (r04_transient_census.txt).
+//    step that moved the points by more than a leaf's width leaves every seed a leaf or more off, and the seeded walk
+//    climbs from there.
 // An overflowing cell (several groups) sends its queries to its first group: a seed like any other.
 static __global__ __launch_bounds__(256) void locate_by_planes(
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int ns,

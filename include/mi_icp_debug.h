@@ -51,7 +51,7 @@ MI_ICP_API int mi_icp_debug_occupancy(int which);
  * step-end -> next search start, search, search end -> reduction start, reduction's streaming phase, row total,
  * exchange, solve, state write -- and the clock's ticks per microsecond. */
 /* Counters of the present registration loop as of its last host-side look: out4 = {iterations (updates applied),
- * passes (evaluations), re-locations (steps that moved the source by more than a quarter point spacing and had the next
+ * passes (evaluations), re-locations (steps that moved the source by more than about a leaf's width, ~1.9 point spacings, and had the next
  * search's seeds replaced by the leaves the moved queries fall into: csrc/loop.h, nn_search.h locate_by_planes),
  * 1 if the next chunk of iterations would still carry the gated re-location launches}. */
 MI_ICP_API int mi_icp_debug_loop_counters(mi_icp_ctx* ctx, int32_t* out4);

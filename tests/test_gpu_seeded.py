@@ -248,7 +248,7 @@ def _loop_counters(e):
 
 
 def test_relocation_after_large_steps_changes_nothing_but_the_seeds():
-    """Round 5: a step that moves the source by more than a quarter point spacing (sized on the device from the update
+    """Round 5: a step that moves the source by more than about a leaf's width (~1.9 point spacings; sized on the device from the update
     and the source's box, loop.h) makes the gated launch in front of the next search replace every seed by the leaf the
     moved query falls into (nn_search.h locate_by_planes).  On a surface started 6 spacings above it the first steps are that
     large: re-locations happen, stop once the steps are small (the launches are disarmed), and the loop's every number
@@ -299,9 +299,9 @@ def test_step_stamps_account_for_the_iteration():
     e.set_step_stamps(True)
     e.icp_begin(PT2PL, d["max_dist"], None, -1.0)
     e.icp_iterate(16)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()       # (ahead of the first look: the first counted iteration's "since the last step" span
-    a, tpu = e.get_step_stamps()   # reaches back to the end of the 16th iteration, across this host-side pause)
+    t0 = time.perf_counter()       # (right behind the call whose last act was to wait for the 16th iteration, and ahead of
+    torch.cuda.synchronize()       # everything else: the first counted iteration's "since the last step" span reaches back
+    a, tpu = e.get_step_stamps()   # to the end of that iteration, across this whole host-side pause)
     e.icp_iterate(40)
     torch.cuda.synchronize()
     wall_us = (time.perf_counter() - t0) * 1e6
