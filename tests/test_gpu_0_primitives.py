@@ -39,7 +39,7 @@ def test_radix_sort_is_a_stable_sort(eng, n, bits):
     np.testing.assert_array_equal(v, vals[order])
 
 
-@pytest.mark.parametrize("n", [1, 7, 255, 256, 2047, 2048, 2049, 5000, 4194304 + 17])
+@pytest.mark.parametrize("n", [1, 7, 255, 256, 2047, 2048, 2049, 5000, 8191, 8192, 8193, 40000, 65535, 65536, 65537, 70000, 4194304 + 17])
 def test_exclusive_scan(eng, n):
     rng = np.random.default_rng(n)
     a = rng.integers(0, 5, n, dtype=np.uint32)
