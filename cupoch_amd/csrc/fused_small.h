@@ -1,4 +1,4 @@
-// fused_small.h -- ONE launch per ICP iteration for small clouds (point-to-plane, single GPU).
+// fused_small.h -- ONE launch per ICP iteration for small clouds (point-to-plane and point-to-point, single GPU).
 //
 // On a 10M-point cloud an iteration is two bandwidth-sized kernels; on a depth frame's 20k-300k points
 // (KinFu's PoseEstimation) it is two kernels of a few dependent memory round trips
@@ -12,6 +12,10 @@
 // is why this is a kernel of its own and not a mode of nn_packet_kernel.
 // Same per-element arithmetic as reduce_pt2pl_kernel (the transformed point is the search's own, bit for
 // bit); the summation order differs, so the sums agree to ~1e-15 relative, not bitwise.
+// EST = point-to-point (late in round 5): the wave's rows are {transformed point, matched point, d^2} and its lanes
+// total the Kabsch sums of reduce_kernel<point-to-point, 0> (sums of both, the nine products, d^2 twice, the count).
+// Those loops ran three launches per iteration -- search, reduction, step: the reference's own benchmark call, 113k
+// points, spent 0.3 of its 1.9 ms in the launches' fixed parts.
 #pragma once
 #include "nn_search.h"
 #include "reduce.h"
@@ -20,7 +24,8 @@ namespace mi {
 
 constexpr int kFusedPackets = kReduceThreads / 64;  // packets per workgroup
 
-static __global__ __launch_bounds__(kReduceThreads) void icp_small_iteration_kernel(
+template <int EST>
+__global__ __launch_bounds__(kReduceThreads) void icp_small_iteration_kernel(
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int ns,
         const float* __restrict__ records_g, const float* __restrict__ tblk_g, const float* __restrict__ lreg_g,
         const float* __restrict__ halo_g, uint32_t leaf_first, float r2, uint32_t npackets, uint32_t nblocks,
@@ -50,19 +55,34 @@ static __global__ __launch_bounds__(kReduceThreads) void icp_small_iteration_ker
     __shared__ ReduceRows red;
     const int lane = lane_id();
     const bool have = r.valid && r.bidx >= 0;
-    const F3* rec = reinterpret_cast<const F3*>(trec + (int64_t)(have ? r.bidx : 0) * 6);
-    const F3 tp = rec[0], tn = rec[1];
     float row[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (have) {
-        const float vs[3] = {r.qx, r.qy, r.qz};
-        const float nt[3] = {tn.x, tn.y, tn.z};
-        const float d[3] = {vs[0] - tp.x, vs[1] - tp.y, vs[2] - tp.z};
-        cross3(vs, nt, row);
-        row[3] = nt[0];
-        row[4] = nt[1];
-        row[5] = nt[2];
-        row[6] = dot3(d, nt);
-        row[7] = sq3(d[0], d[1], d[2]);
+    if (EST == kEstPt2Pl) {
+        const F3* rec = reinterpret_cast<const F3*>(trec + (int64_t)(have ? r.bidx : 0) * 6);
+        const F3 tp = rec[0], tn = rec[1];
+        if (have) {
+            const float vs[3] = {r.qx, r.qy, r.qz};
+            const float nt[3] = {tn.x, tn.y, tn.z};
+            const float d[3] = {vs[0] - tp.x, vs[1] - tp.y, vs[2] - tp.z};
+            cross3(vs, nt, row);
+            row[3] = nt[0];
+            row[4] = nt[1];
+            row[5] = nt[2];
+            row[6] = dot3(d, nt);
+            row[7] = sq3(d[0], d[1], d[2]);
+        }
+    } else {  // point-to-point: the matched point from its leaf line (reduce_kernel's gather)
+        const int32_t j = have ? r.bidx : 0;
+        const float* line = tblk_g + (int64_t)(j >> 3) * kLeafFloats + (j & 7);
+        const float tx = line[0], ty = line[8], tz = line[16];
+        if (have) {
+            row[0] = r.qx;
+            row[1] = r.qy;
+            row[2] = r.qz;
+            row[3] = tx;
+            row[4] = ty;
+            row[5] = tz;
+            row[7] = sq3(r.qx - tx, r.qy - ty, r.qz - tz);
+        }
     }
     float* mine = s_rows[wid];
 #pragma unroll
@@ -73,7 +93,27 @@ static __global__ __launch_bounds__(kReduceThreads) void icp_small_iteration_ker
     // upper-triangle entries of JtJ, the 6 of Jtr, r^2, d^2, the count -- accum_row's numbering.  One pass of
     // 64 rows for 30 lanes instead of 30 wave-wide reductions (which made a 300k-point iteration 40 % slower
     // than the two-kernel form).
-    if (lane < kSysSize) {
+    if (EST != kEstPt2Pl) {
+        // the Kabsch sums, reduce_kernel<point-to-point, 0>'s numbering: [0..2] the transformed points, [3..5] the matched
+        // ones, [6 + 3p + q] the products (exact in fp64), [27] and [28] d^2, [29] the count
+        if (lane < kSysSize) {
+            double sum = 0.0;
+            if (lane < 6) {
+                const float* A = mine + lane * 65;
+                for (int t = 0; t < 64; ++t) sum += (double)A[t];
+            } else if (lane < 15) {
+                const float* A = mine + ((lane - 6) / 3) * 65;
+                const float* B = mine + (3 + (lane - 6) % 3) * 65;
+                for (int t = 0; t < 64; ++t) sum = __builtin_fma((double)A[t], (double)B[t], sum);
+            } else if (lane == 27 || lane == 28) {
+                const float* A = mine + 7 * 65;
+                for (int t = 0; t < 64; ++t) sum += (double)A[t];
+            } else if (lane == 29) {
+                sum = (double)__popcll(hm);
+            }
+            red[wid][lane] = sum;
+        }
+    } else if (lane < kSysSize) {
         int ca = 6, cb = 6;  // k = 27: r * r
         if (lane < 21) {
             int k = lane;

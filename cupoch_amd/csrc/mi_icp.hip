@@ -665,9 +665,9 @@ constexpr int64_t kFusedMax = 170000;
 static bool fused_iteration_applies(const mi_icp_ctx* c, bool seed) {
     static const bool off = std::getenv("MI_ICP_NO_FUSED_ITERATION") != nullptr;  // A/B switch
     static const int64_t limit = [] { const char* e = std::getenv("MI_ICP_FUSED_MAX"); return e ? std::atoll(e) : kFusedMax; }();
-    return !off && seed && c->nn_valid && c->loop_est == kEstPt2Pl && estimator_ready(c, kEstPt2Pl) && c->t_has_rec &&
-           c->trec.p != nullptr && !c->comm && !c->mail_dev && c->n_user_pairs < 0 && c->ns > 0 && c->ns <= limit &&
-           c->nt > 0;
+    const bool pt2pl = c->loop_est == kEstPt2Pl && estimator_ready(c, kEstPt2Pl) && c->t_has_rec && c->trec.p != nullptr;
+    return !off && seed && c->nn_valid && (pt2pl || c->loop_est == kEstP2P) && !c->comm && !c->mail_dev &&
+           c->n_user_pairs < 0 && c->ns > 0 && c->ns <= limit && c->nt > 0;
 }
 
 static int launch_fused_iteration(mi_icp_ctx* c, DevLoop* d) {
@@ -691,10 +691,12 @@ static int launch_fused_iteration(mi_icp_ctx* c, DevLoop* d) {
         HIPCHK(c, hipMemsetAsync(ticket, 0, 256, c->stream));
     }
     EvTimer t(c, 0, true);
-    icp_small_iteration_kernel<<<grid, kReduceThreads, 0, c->stream>>>(
-            (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns, (const float*)c->nodes.p,
-            (const float*)c->tblk.p, (const float*)lreg_of(c), have_halo ? (const float*)c->thalo.p : nullptr, c->leaf_first,
-            c->loop_r2, npackets, nblocks, (int32_t*)c->nn_idx.p, want, (const float*)c->trec.p, d, partial, (uint32_t*)c->ticket.p, sys);
+#define MI_FUSED_ARGS (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns, (const float*)c->nodes.p, \
+            (const float*)c->tblk.p, (const float*)lreg_of(c), have_halo ? (const float*)c->thalo.p : nullptr, c->leaf_first, \
+            c->loop_r2, npackets, nblocks, (int32_t*)c->nn_idx.p, want, (const float*)c->trec.p, d, partial, (uint32_t*)c->ticket.p, sys
+    if (c->loop_est == kEstP2P) icp_small_iteration_kernel<kEstP2P><<<grid, kReduceThreads, 0, c->stream>>>(MI_FUSED_ARGS);
+    else icp_small_iteration_kernel<kEstPt2Pl><<<grid, kReduceThreads, 0, c->stream>>>(MI_FUSED_ARGS);
+#undef MI_FUSED_ARGS
     KCHK(c);
     c->last_search_kind = 1;
     return MI_ICP_OK;

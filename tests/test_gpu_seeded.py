@@ -200,26 +200,31 @@ def test_first_pass_from_its_own_seeds_equals_the_walk_from_the_root(kind):
         assert got["root"][1] == pytest.approx(got[name][1], abs=1e-7) and got["root"][2] == pytest.approx(got[name][2], rel=1e-5)
 
 
-def _run_small_loop(path):
-    """(child process) a 40k-point point-to-plane registration, results to `path`"""
+def _run_small_loop(path, est="pt2pl"):
+    """(child process) a 40k-point point-to-plane (or point-to-point: no normals) registration, results to `path`"""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from cupoch_amd.engine import Engine
     from conftest import make_pair
     d = make_pair(40_000, seed=77, noise=0.05)
     e = Engine(0)
-    e.set_target(d["tgt"], d["tgt_nrm"])
+    if est == "p2p":
+        e.set_target(d["tgt"])
+    else:
+        e.set_target(d["tgt"], d["tgt_nrm"])
     e.set_source(d["src"])
-    res = e.registration_icp(PT2PL, d["max_dist"], None, 1e-6, 1e-6, 25, -1.0)
+    res = e.registration_icp(P2P if est == "p2p" else PT2PL, d["max_dist"], None, 1e-6, 1e-6, 25, -1.0)
     corr = e.get_correspondences()
     np.savez(path, T=np.array(res.transformation, np.float32), stat=np.array([res.fitness, res.inlier_rmse, res.iterations]),
              corr=corr)
     e.close()
 
 
-def test_one_launch_iteration_equals_the_two_kernel_form(tmp_path):
-    """Sources of up to ~110k points run search + system rows + reduction + step as ONE kernel per
-    iteration (fused_small.h).  Same loop with MI_ICP_NO_FUSED_ITERATION=1 in a child process (the switch
+@pytest.mark.parametrize("est", ["pt2pl", "p2p"])
+def test_one_launch_iteration_equals_the_two_kernel_form(tmp_path, est):
+    """Sources of up to ~170k points run search + system rows + reduction + step as ONE kernel per
+    iteration (fused_small.h; point-to-plane and -- late in round 5 -- point-to-point, whose rows are the Kabsch
+    sums).  Same loop with MI_ICP_NO_FUSED_ITERATION=1 in a child process (the switch
     is read once per process): same iteration count, same correspondence set, transformation and statistics
     equal to the rounding of the sums' order."""
     import subprocess
@@ -228,8 +233,8 @@ def test_one_launch_iteration_equals_the_two_kernel_form(tmp_path):
     outs = {}
     for name, extra in (("fused", {}), ("split", {"MI_ICP_NO_FUSED_ITERATION": "1"})):
         path = str(tmp_path / (name + ".npz"))
-        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_seeded as t; t._run_small_loop(%r)"
-                % (os.path.dirname(here), os.path.dirname(os.path.dirname(here)), path))
+        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_seeded as t; t._run_small_loop(%r, %r)"
+                % (os.path.dirname(here), os.path.dirname(os.path.dirname(here)), path, est))
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[name] = np.load(path)
