@@ -662,11 +662,17 @@ static int loop_pull(mi_icp_ctx* c) {  // device state -> pinned mirror, synchro
 // 307k 1.18 / 0.91 -- past ~170k points the per-packet totals (one set of 30 sums per 64 points instead of
 // one per 4096) cost more than the second launch; MI_ICP_FUSED_MAX moves the limit.
 constexpr int64_t kFusedMax = 170000;
+// (point-to-point: its rows are cheaper to form than to total -- on converged clean clouds the one launch wins by 10 % at
+// 50k points, 5 % at 114k and loses 6 % at 170k, 20 % at 250k against search + reduction + step:
+// profiles/r05_p2p_one_launch_by_size.txt)
+constexpr int64_t kFusedMaxP2P = 135000;
 static bool fused_iteration_applies(const mi_icp_ctx* c, bool seed) {
     static const bool off = std::getenv("MI_ICP_NO_FUSED_ITERATION") != nullptr;  // A/B switch
-    static const int64_t limit = [] { const char* e = std::getenv("MI_ICP_FUSED_MAX"); return e ? std::atoll(e) : kFusedMax; }();
+    static const int64_t forced = [] { const char* e = std::getenv("MI_ICP_FUSED_MAX"); return e ? std::atoll(e) : (int64_t)-1; }();
     const bool pt2pl = c->loop_est == kEstPt2Pl && estimator_ready(c, kEstPt2Pl) && c->t_has_rec && c->trec.p != nullptr;
-    return !off && seed && c->nn_valid && (pt2pl || c->loop_est == kEstP2P) && !c->comm && !c->mail_dev &&
+    const bool p2p = c->loop_est == kEstP2P;
+    const int64_t limit = forced >= 0 ? forced : (p2p ? kFusedMaxP2P : kFusedMax);
+    return !off && seed && c->nn_valid && (pt2pl || p2p) && !c->comm && !c->mail_dev &&
            c->n_user_pairs < 0 && c->ns > 0 && c->ns <= limit && c->nt > 0;
 }
 
