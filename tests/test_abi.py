@@ -125,3 +125,25 @@ def test_host_kabsch_matches_oracle_and_golden(golden):
     np.testing.assert_allclose(T, orc.kabsch_from_sums(sys, 20), atol=1e-6)
     # the reference divides by model.size(), not by the number of pairs (kabsch.cu:76,107)
     np.testing.assert_allclose(engine.kabsch_from_sums(sys, 40), orc.kabsch_from_sums(sys, 40), atol=1e-6)
+
+
+def test_every_environment_switch_is_in_the_design_table():
+    """DESIGN.md section 7 lists every MI_ICP_* environment variable the library, the Python loader and bench.py read
+    (A/B measurements and tests only: none changes results) -- a switch that is not there is clutter nobody can find."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    seen = set()
+    for base, _, files in os.walk(os.path.join(root, "cupoch_amd")):
+        if os.sep + "lib" in base:
+            continue
+        for f in files:
+            if f.endswith((".h", ".hip", ".cpp", ".py")):
+                src = open(os.path.join(base, f), errors="replace").read()
+                seen |= set(re.findall(r'getenv\(\s*"(MI_ICP_[A-Z0-9_]+)"', src))
+                seen |= set(re.findall(r'environ(?:\.get)?\(?\[?\s*"(MI_ICP_[A-Z0-9_]+)"', src))
+    src = open(os.path.join(root, "bench.py")).read()
+    seen |= set(re.findall(r'environ(?:\.get|\.setdefault)?\(?\[?\s*"(MI_ICP_[A-Z0-9_]+)"', src))
+    assert len(seen) >= 20, sorted(seen)
+    missing = sorted(v for v in seen if v not in design)
+    assert not missing, missing
