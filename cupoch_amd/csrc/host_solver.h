@@ -290,11 +290,15 @@ MI_HD void svd3(const D3& A, D3& U, double* S, D3& V) {
     for (int i = 0; i < 2; ++i)
         for (int j = i + 1; j < 3; ++j)
             if (sv[order[j]] > sv[order[i]]) swap_(order[i], order[j]);
+    // (a singular value that is zero up to rounding -- an exactly planar or collinear source: ~1e-17 of the largest --
+    // has no column of U: a / sv would be noise inside the others' span, U singular, det(U V) = 0 and the "rotation" of
+    // rank 2; Eigen's two-sided JacobiSVD returns full orthogonal factors, so such a column is completed below)
+    const double sv_floor = 1e-10 * sv[order[0]];
     bool ok[3];
     for (int k = 0; k < 3; ++k) {
         const int c = order[k];
         S[k] = sv[c];
-        ok[k] = sv[c] > 1e-300;
+        ok[k] = sv[c] > 1e-300 && sv[c] > sv_floor;
         for (int r = 0; r < 3; ++r) {
             V.m[r][k] = v.m[r][c];
             U.m[r][k] = ok[k] ? a.m[r][c] / sv[c] : 0.0;

@@ -636,13 +636,19 @@ static void svd3(const double A[9], double U[9], double S[3], double V[9]) {
                 order[i] = order[j];
                 order[j] = t;
             }
+    /* A singular value that is ZERO up to rounding (an exactly planar or collinear source: a row of the cross-covariance
+     * is zero and its third value comes out ~1e-17 of the largest) has no column of U: a / sv would be a unit vector of
+     * noise inside the span of the others, U singular, det(U*V) = 0 and the "rotation" of rank 2.  Eigen's two-sided
+     * JacobiSVD (kabsch.cu:108, ComputeFullU | ComputeFullV) builds U and V from rotations and always returns full
+     * orthogonal factors, hence a proper rotation; so such a column is completed below instead. */
+    const double sv_floor = 1e-10 * sv[order[0]];
     double u[3][3];
     for (int k = 0; k < 3; ++k) {
         const int c = order[k];
         S[k] = sv[c];
         for (int r = 0; r < 3; ++r) {
             V[r * 3 + k] = v[r][c];
-            u[r][k] = (sv[c] > 1e-300) ? a[r][c] / sv[c] : 0.0;
+            u[r][k] = (sv[c] > 1e-300 && sv[c] > sv_floor) ? a[r][c] / sv[c] : 0.0;
         }
     }
     /* complete U to an orthonormal basis when rank deficient */

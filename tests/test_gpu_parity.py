@@ -356,6 +356,34 @@ def test_icp_final_transform_matches_oracle(eng, est, n):
         assert abs(da - db) <= 1e-5 * max(da, db), "source %d: %s vs %s is not a near-tie" % (i, ja, jb)
 
 
+def test_point_to_point_on_an_exactly_planar_cloud_returns_a_rotation(eng):
+    """A source whose points all share one coordinate: the Kabsch cross-covariance has a zero row and its smallest
+    singular value is rounding noise.  Eigen's JacobiSVD (kabsch.cu:108, full U and V) still yields a proper rotation;
+    so must the loop's step (host_solver.h svd3: the column of a vanishing singular value is completed, not divided out)
+    -- and the transform equals the oracle's, whose Kabsch is pinned against numpy's fp64 SVD on such clouds."""
+    rng = np.random.default_rng(5)
+    n = 30000
+    tgt = rng.random((n, 3), dtype=np.float32)
+    tgt[:, 2] = np.float32(0.25)
+    a = 0.01
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    src = ((tgt.astype(np.float64) - [0.5, 0.5, 0.25]) @ Rz.T + [0.5, 0.5, 0.25] + [0.004, -0.003, 0.0]).astype(np.float32)
+    src[:, 2] = np.float32(0.25)
+    src = np.ascontiguousarray(src[rng.permutation(n)])
+    r = 0.02
+    eng.set_target(tgt)
+    eng.set_source(src)
+    res = eng.registration_icp(P2P, r, None, 0.0, 0.0, 12, -1.0)
+    T = np.array(res.transformation, np.float32).reshape(4, 4).T
+    ref = orc.registration_icp(src, tgt, r, est=P2P, det_thresh=-1.0, relative_fitness=0.0, relative_rmse=0.0, max_iteration=12)
+    R = T[:3, :3].astype(np.float64)
+    assert abs(np.linalg.det(R) - 1.0) <= 1e-5 and np.abs(R @ R.T - np.eye(3)).max() <= 1e-5
+    assert np.linalg.norm(T - ref.transformation) <= 1e-5
+    assert res.fitness == pytest.approx(ref.fitness, abs=2e-5) and res.fitness > 0.99
+    moved = src.astype(np.float64) @ R.T + T[:3, 3]
+    assert np.abs(moved[:, 2] - 0.25).max() <= 1e-5          # (the plane stays the plane)
+
+
 def test_icp_default_criteria_init_and_convergence(eng):
     d = make_pair(50000, seed=77)
     init = rigid(0.01, [0, 0, 1], [0.001, 0.0, -0.001])

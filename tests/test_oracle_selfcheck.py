@@ -291,3 +291,50 @@ def test_weighted_odometry_and_twist_conversion():
     ok, T2, _, _ = orc.compute_weighted_rgbd_odometry(cb, db, ca, da, K, max_depth=6.0, prev_twist=np.zeros(6),
                                                       inv_sigma_mat_diag=[1e7] * 6)
     assert np.linalg.norm(T2 - np.eye(4)) < np.linalg.norm(T - np.eye(4))
+
+
+def _kabsch_numpy_fp64(src32, tgt32):
+    """registration/kabsch.cu:74-118 in fp64 with numpy's SVD: R = V diag(1, 1, det(U V)) U^T, t = ct - R cs"""
+    S, G = src32.astype(np.float64), tgt32.astype(np.float64)
+    cs, ct = S.mean(0), G.mean(0)
+    H = (S - cs).T @ (G - ct) / len(S)
+    U, s, Vt = np.linalg.svd(H)
+    R = Vt.T @ np.diag([1.0, 1.0, np.linalg.det(U @ Vt.T)]) @ U.T
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = ct - R @ cs
+    return T, s
+
+
+def test_kabsch_matches_numpy_fp64_svd_also_on_planar_sources():
+    """The oracle's and the engine's Kabsch (their own restatements of a 3x3 SVD: third_party/eigen is not vendored)
+    against numpy's fp64 SVD on 200 random clouds -- general, nearly planar, and EXACTLY planar, where a row of the
+    cross-covariance is zero: Eigen's two-sided JacobiSVD returns full orthogonal factors there, i.e. a proper
+    rotation (until late in round 5 both restatements divided a column of noise by a singular value of ~1e-17 and
+    returned a 'rotation' of rank 2)."""
+    from cupoch_amd import engine
+    rng = np.random.default_rng(11)
+    for case in range(200):
+        n = int(rng.integers(3, 300))
+        scale = 10 ** rng.uniform(-2, 1)
+        src = rng.standard_normal((n, 3)) * scale
+        if case % 4 == 1:
+            src[:, 2] *= 1e-3
+        if case % 4 == 2:
+            src[:, 2] = 0.25 * scale                       # exactly planar
+        a = rng.standard_normal(3)
+        a /= np.linalg.norm(a)
+        th = rng.uniform(0, np.pi)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+        tgt = src @ R.T + rng.standard_normal(3) * scale + rng.standard_normal((n, 3)) * scale * 1e-3
+        s32, t32 = src.astype(np.float32), tgt.astype(np.float32)
+        cor = np.stack([np.arange(n), np.arange(n)], 1).astype(np.int32)
+        sys = orc.compute_system(orc.EST_P2P, s32, t32, cor)
+        ref, sv = _kabsch_numpy_fp64(s32, t32)
+        if sv[1] < 1e-6 * sv[0]:
+            continue                                        # (collinear: the rotation about the line is free)
+        unit = max(1.0, float(np.abs(ref[:3, 3]).max()))
+        for name, T in (("oracle", orc.kabsch_from_sums(sys, n)), ("engine", engine.kabsch_from_sums(sys, n))):
+            assert abs(np.linalg.det(T[:3, :3].astype(np.float64)) - 1.0) <= 1e-5, (name, case)
+            assert np.abs(T - ref).max() <= 2e-6 * unit, (name, case, float(np.abs(T - ref).max()))
