@@ -47,7 +47,10 @@ def build(force=False, verbose=False, variant=None, defines=()):
     """hipcc --offload-arch=gfx950 -c csrc/<unit>.hip for every unit (in parallel; a unit whose object is newer than
     every source is kept), then hipcc -shared ... -o cupoch_amd/lib/libmi_icp.so
     variant / defines: a second build for same-box A/B runs (MI_ICP_LIB_PATH), e.g. variant="h4",
-    defines=("-DMI_HALO_STORED=4",) -> cupoch_amd/lib/libmi_icp_h4.so"""
+    defines=("-DMI_HALO_STORED=4",) -> cupoch_amd/lib/libmi_icp_h4.so
+    Safe against several processes building at once (every rank of a multi-process test imports the package): one
+    file lock around the whole build, objects and the library written under a temporary name and renamed; objects
+    compiled with other flags / defines are never reused (a stamp in the object directory holds their hash)."""
     lib_path = LIB_PATH if not variant else os.path.join(LIB_DIR, "libmi_icp_%s.so" % variant)
     obj_dir = OBJ_DIR if not variant else OBJ_DIR + "_" + variant
     if not force and not variant and not needs_build():
@@ -56,27 +59,50 @@ def build(force=False, verbose=False, variant=None, defines=()):
     if not os.path.exists(hipcc):
         raise MiIcpError("hipcc not found; cannot build libmi_icp.so")
     os.makedirs(obj_dir, exist_ok=True)
+    import fcntl
+    import hashlib
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not variant and not needs_build():
+                return LIB_PATH          # (another process built it while this one waited)
+            return _build_locked(hipcc, lib_path, obj_dir, force, verbose, tuple(defines), hashlib)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(hipcc, lib_path, obj_dir, force, verbose, defines, hashlib):
     headers = [s for s in _sources() if s.endswith(".h")]
     newest_header = max(os.path.getmtime(h) for h in headers)
+    flags_hash = hashlib.sha1(" ".join(HIPCC_FLAGS + list(defines)).encode()).hexdigest()
+    stamp = os.path.join(obj_dir, "flags.stamp")
+    if not (os.path.exists(stamp) and open(stamp).read().strip() == flags_hash):
+        force = True                     # objects of another flag set: none may be reused
 
     def compile_unit(u):
         src, obj = os.path.join(CSRC, u + ".hip"), os.path.join(obj_dir, u + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(newest_header, os.path.getmtime(src)):
             return obj
-        cmd = [hipcc] + HIPCC_FLAGS + list(defines) + ["-c", src, "-o", obj]
+        tmp = "%s.tmp.%d" % (obj, os.getpid())
+        cmd = [hipcc] + HIPCC_FLAGS + list(defines) + ["-c", src, "-o", tmp]
         if verbose:
-            print(" ".join(cmd), flush=True)
+            print(" ".join(cmd[:-1] + [obj]), flush=True)
         subprocess.check_call(cmd)
+        os.replace(tmp, obj)
         return obj
 
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=len(UNITS)) as pool:
         objs = list(pool.map(compile_unit, UNITS))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_path + ".tmp"]
+    with open(stamp + ".tmp", "w") as f:
+        f.write(flags_hash + "\n")
+    os.replace(stamp + ".tmp", stamp)
+    tmp = "%s.tmp.%d" % (lib_path, os.getpid())
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    os.replace(lib_path + ".tmp", lib_path)
+    os.replace(tmp, lib_path)
     return lib_path
 
 
@@ -171,6 +197,7 @@ SIGNATURES = {
     "mi_icp_debug_solve_both": (_I, [_I, _P, _I, C.c_float, _P, _P, _P, _P]),
     "mi_icp_debug_get_leaf_regions": (_I, [_P, _P]),
     "mi_icp_debug_get_leaf_halos": (_I, [_P, _P]),
+    "mi_icp_debug_eigen3": (_I, [_I, _P, _L, _P, _P, _P]),
 }
 
 _lib = None

@@ -1,6 +1,8 @@
 // eigen3.h -- closed-form symmetric 3x3 eigen-solver and friends (fp32),
 // restating utility/eigenvalue.inl:26-177 with the same operation order as the
 // CPU oracle.  Used by the GICP reduction and by EstimateNormals.
+// (__host__ __device__: mi_icp_debug_eigen3 evaluates the very same code on the host or in a kernel, so that the
+// tests can hold it against LAPACK -- tests/test_outside_checks.py.)
 #pragma once
 #include "device_utils.h"
 
@@ -10,20 +12,20 @@ struct M3 {
     float m[3][3];
 };
 
-__device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
+__host__ __device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
     o[0] = a[1] * b[2] - a[2] * b[1];
     o[1] = a[2] * b[0] - a[0] * b[2];
     o[2] = a[0] * b[1] - a[1] * b[0];
 }
-__device__ __forceinline__ float dot3(const float* a, const float* b) {
+__host__ __device__ __forceinline__ float dot3(const float* a, const float* b) {
     return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
 }
 // utility/eigenvalue.inl:28 signf(x) = x/fabs(x); sign(0) := +1 instead of NaN
 // (deliberate deviation, DESIGN.md "GICP degenerate eigenvalues")
-__device__ __forceinline__ float sign1(float x) { return copysignf(1.0f, x); }
+__host__ __device__ __forceinline__ float sign1(float x) { return copysignf(1.0f, x); }
 
 // utility/eigenvalue.inl:30-49
-__device__ __forceinline__ void eigvec0(const M3& A, float eval0, float* out) {
+__host__ __device__ __forceinline__ void eigvec0(const M3& A, float eval0, float* out) {
     const float row0[3] = {A.m[0][0] - eval0, A.m[0][1], A.m[0][2]};
     const float row1[3] = {A.m[0][1], A.m[1][1] - eval0, A.m[1][2]};
     const float row2[3] = {A.m[0][2], A.m[1][2], A.m[2][2] - eval0};
@@ -53,7 +55,7 @@ __device__ __forceinline__ void eigvec0(const M3& A, float eval0, float* out) {
 }
 
 // utility/eigenvalue.inl:51-91
-__device__ __forceinline__ void eigvec1(const M3& A, const float* e0, float eval1, float* out) {
+__host__ __device__ __forceinline__ void eigvec1(const M3& A, const float* e0, float eval1, float* out) {
     const float mx = fmaxf(fabsf(e0[0]), fabsf(e0[1]));
     const float inv_length = 1.0f / sqrtf(mx * mx + e0[2] * e0[2]);
     float U[3], V[3];
@@ -102,7 +104,7 @@ __device__ __forceinline__ void eigvec1(const M3& A, const float* e0, float eval
 // FastEigen3x3 (utility/eigenvalue.inl:93-154).  Eigenvector k is (e[k][0..2]).
 // As in the reference, the general branch returns the eigenvalues of
 // A / A.maxCoeff() (signed max), the diagonal branch those of A itself.
-__device__ __forceinline__ void fast_eigen3x3(const M3& A, float* eval, float e[3][3]) {
+__host__ __device__ __forceinline__ void fast_eigen3x3(const M3& A, float* eval, float e[3][3]) {
     float max_coeff = A.m[0][0];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -155,7 +157,7 @@ __device__ __forceinline__ void fast_eigen3x3(const M3& A, float* eval, float e[
 }
 
 // SqrtMatrix3x3 (utility/eigenvalue.inl:172-177): V diag(sqrt(eval)) V^T
-__device__ __forceinline__ void sqrt_matrix3x3(const M3& A, M3& W) {
+__host__ __device__ __forceinline__ void sqrt_matrix3x3(const M3& A, M3& W) {
     float eval[3], e[3][3];
     fast_eigen3x3(A, eval, e);
     const float s0 = sqrtf(eval[0]), s1 = sqrtf(eval[1]), s2 = sqrtf(eval[2]);
@@ -170,7 +172,7 @@ __device__ __forceinline__ void sqrt_matrix3x3(const M3& A, M3& W) {
 // its input by its largest coefficient (signed maximum, starting from A[0][0]), returns the eigenvalues of THAT
 // matrix -- they are never scaled back -- and reads the upper triangle only; an input without off-diagonal entries
 // gets eval = its diagonal, unscaled, and the identity as eigenvectors; an all-non-positive one (max_coeff == 0) zeros.
-__device__ __forceinline__ void gicp_weight(const M3& A, float (&S)[3][3]) {
+__host__ __device__ __forceinline__ void gicp_weight(const M3& A, float (&S)[3][3]) {
     float mx = A.m[0][0];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -189,7 +191,7 @@ __device__ __forceinline__ void gicp_weight(const M3& A, float (&S)[3][3]) {
 }
 
 // Eigen 3x3 inverse by cofactors (generalized_icp.cu:91)
-__device__ __forceinline__ void inverse3(const M3& M, M3& I) {
+__host__ __device__ __forceinline__ void inverse3(const M3& M, M3& I) {
     const float c00 = M.m[1][1] * M.m[2][2] - M.m[1][2] * M.m[2][1];
     const float c10 = M.m[1][2] * M.m[2][0] - M.m[1][0] * M.m[2][2];
     const float c20 = M.m[1][0] * M.m[2][1] - M.m[1][1] * M.m[2][0];

@@ -6,6 +6,7 @@
 #include "halo_format.h"
 #include "traverse.h"
 #include "wave_solver.h"
+#include "eigen3.h"
 
 using namespace mi;
 using namespace mi::eng;
@@ -27,6 +28,25 @@ __global__ __launch_bounds__(64) void solve_both_kernel(const double* systems, f
         ok_serial[n] = host::solve_system(s_sys, det_thresh, S) ? 1 : 0;
         for (int e = 0; e < 16; ++e) out_serial[(int64_t)n * 16 + e] = S.m[e];
     }
+}
+__host__ __device__ inline void eigen3_one(const float* A9, float* eval, float* evec, float* S) {
+    M3 A;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) A.m[r][c] = A9[r * 3 + c];
+    float ev[3], e[3][3], s[3][3];
+    fast_eigen3x3(A, ev, e);
+    gicp_weight(A, s);
+    for (int k = 0; k < 3; ++k) {
+        if (eval) eval[k] = ev[k];
+        for (int d = 0; d < 3; ++d) {
+            if (evec) evec[d * 3 + k] = e[k][d];  // column k = eigenvector k
+            if (S) S[k * 3 + d] = s[k][d];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void eigen3_kernel(const float* A, int64_t n, float* eval, float* evec, float* S) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) eigen3_one(A + 9 * i, eval ? eval + 3 * i : nullptr, evec ? evec + 9 * i : nullptr, S ? S + 9 * i : nullptr);
 }
 }  // namespace mi
 
@@ -220,6 +240,34 @@ int mi_icp_debug_get_tree(mi_icp_ctx* c, int64_t* info5, float* records_out, flo
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MI_ICP_OK;
+}
+
+int mi_icp_debug_eigen3(int device, const float* A, int64_t n, float* eval, float* evec, float* S) {
+    if (n < 0 || (n > 0 && !A)) return MI_ICP_ERR_INVALID;
+    if (n == 0) return MI_ICP_OK;
+    if (device < 0) {
+        for (int64_t i = 0; i < n; ++i)
+            eigen3_one(A + 9 * i, eval ? eval + 3 * i : nullptr, evec ? evec + 9 * i : nullptr, S ? S + 9 * i : nullptr);
+        return MI_ICP_OK;
+    }
+    if (hipSetDevice(device) != hipSuccess) return MI_ICP_ERR_NO_DEVICE;
+    float *dA = nullptr, *de = nullptr, *dv = nullptr, *dS = nullptr;
+    int rc = MI_ICP_ERR_HIP;
+    if (hipMalloc(&dA, (size_t)n * 36) == hipSuccess && hipMalloc(&de, (size_t)n * 12) == hipSuccess &&
+        hipMalloc(&dv, (size_t)n * 36) == hipSuccess && hipMalloc(&dS, (size_t)n * 36) == hipSuccess &&
+        hipMemcpy(dA, A, (size_t)n * 36, hipMemcpyHostToDevice) == hipSuccess) {
+        hipLaunchKernelGGL(eigen3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dA, n, de, dv, dS);
+        bool ok = hipDeviceSynchronize() == hipSuccess;
+        if (ok && eval) ok = hipMemcpy(eval, de, (size_t)n * 12, hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok && evec) ok = hipMemcpy(evec, dv, (size_t)n * 36, hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok && S) ok = hipMemcpy(S, dS, (size_t)n * 36, hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok) rc = MI_ICP_OK;
+    }
+    (void)hipFree(dA);
+    (void)hipFree(de);
+    (void)hipFree(dv);
+    (void)hipFree(dS);
+    return rc;
 }
 
 }  // extern "C"

@@ -69,6 +69,12 @@ MI_ICP_API int mi_icp_debug_get_step_stamps(mi_icp_ctx* ctx, uint64_t* out32, do
  * (0 = the determinant check failed, result identity).  The two must agree bit for bit. */
 MI_ICP_API int mi_icp_debug_solve_both(int device, const double* systems, int n, float det_thresh,
                                        float* out_serial, float* out_wave, int32_t* ok_serial, int32_t* ok_wave);
+/* csrc/eigen3.h one matrix at a time, so that an outside implementation (LAPACK through numpy, in fp64) can be held
+ * against it: n symmetric 3x3 matrices A (row-major, host memory) -> eval (n * 3), evec (n * 9 row-major, COLUMN k =
+ * eigenvector k), S (n * 9: what the GICP reduction adds for W = SqrtMatrix3x3(A), S = W W) as FastEigen3x3 /
+ * gicp_weight compute them -- on the host (device < 0: the __host__ half of the same functions, no GPU needed) or in
+ * a kernel on that device (the GPU's own acosf / cosf / sqrtf / divisions).  Any output may be NULL. */
+MI_ICP_API int mi_icp_debug_eigen3(int device, const float* A, int64_t n, float* eval, float* evec, float* S);
 /* The target's tree as built by mi_icp_set_target, for invariant tests.  info5 = {slots
  * (padded sorted positions), leaves, leaf_first (id of the first leaf-level node), records,
  * points}.  records_out (records * 64 floats: 8 child boxes as 4 sibling pairs of 12,

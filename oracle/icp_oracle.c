@@ -24,7 +24,13 @@
  *     point-cloud factories, KinFu pose estimation
  *                                : PARITY UNPINNED by the reference's own
  *                                  tests (none exist); checked by
- *                                  self-consistency (recover a known T_gt).
+ *                                  self-consistency (recover a known T_gt)
+ *                                  and, since round 6, against outside
+ *                                  implementations: LAPACK through numpy for
+ *                                  the eigen-solver / GICP weight / det /
+ *                                  LDLT / colour-gradient fit, and a second
+ *                                  loop on scipy's cKDTree (icp_numpy.py;
+ *                                  tests/test_outside_checks.py).
  *
  * Arithmetic conventions (the reference is compiled with --use_fast_math, so
  * it defines no bit-exact order itself):
@@ -914,6 +920,25 @@ ORACLE_API void oracle_gicp_weight(const float *Cs, const float *Ct, float *W_ro
     gicp_weight(Cs, Ct, W);
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) W_rowmajor[r * 3 + c] = W[r][c];
+}
+
+/* Entry points for tests/test_outside_checks.py: the pieces above one at a time, so that
+ * numpy's / scipy's own routines (LAPACK in fp64) can be held against them. */
+ORACLE_API void oracle_fast_eigen3x3(const float *A_rowmajor, int64_t n, float *eval, float *evec_rowmajor) {
+    for (int64_t i = 0; i < n; ++i) {
+        float A[3][3], ev[3][3];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) A[r][c] = A_rowmajor[9 * i + r * 3 + c];
+        fast_eigen3x3(A, eval + 3 * i, ev);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) evec_rowmajor[9 * i + r * 3 + c] = ev[r][c]; /* column c = eigenvector c */
+    }
+}
+
+ORACLE_API float oracle_det6(const float *A_colmajor) { return det6f(A_colmajor); }
+
+ORACLE_API void oracle_ldlt6_solve(const float *A_colmajor, const float *b, float *x) {
+    ldlt6_solve(A_colmajor, b, x);
 }
 
 /* ------------------------------------------------------------------ */
