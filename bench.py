@@ -349,6 +349,22 @@ def rccl_beside(D, Engine, local, rank, world, timeout_s=180.0):
             "note": "ncclCommInitRank + known-answer self-test + timed ncclAllReduce of the 32 sums, in-library, on a scratch context"}
 
 
+def self_launch(n_ranks):
+    """Re-run this command under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on a free local port
+    (one rank per GPU; MI_ICP_BENCH_ONE_DEVICE=1: all on cuda:0).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_ranks)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -371,9 +387,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own (the shape of the driver's N = 1 command): launch the N ranks here --
+        # the same command the driver uses for N > 1 -- pass rank 0's single JSON line through, leave with their rc
+        sys.exit(self_launch(args.gpus))
     # MI_ICP_BENCH_ONE_DEVICE=1: a rehearsal of the N > 1 path on a one-GPU box -- every rank on cuda:0, gloo for
     # the host-side collectives (RCCL cannot put two ranks on one device); the numbers mean nothing, the control flow does
     one_device = os.environ.get("MI_ICP_BENCH_ONE_DEVICE") == "1"

@@ -450,3 +450,24 @@ def test_autotune_on_a_one_rank_rccl_communicator_reports_the_collective():
     np.testing.assert_array_equal(np.array(got.transformation), np.array(ref.transformation))
     eng.comm_destroy()
     eng.close()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run (the shape of the driver's N = 1 command): the bench
+    re-launches itself with one rank per GPU, rank 0 prints the one JSON line, the exit code is the ranks'.
+    MI_ICP_BENCH_ONE_DEVICE=1: both ranks on cuda:0 (the control flow of the N > 1 path on a one-GPU box)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MI_ICP_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--points", "200000", "--steps", "5",
+                        "--warmup", "2", "--repeats", "3", "--no-secondary", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["steps"] == 5

@@ -1,0 +1,159 @@
+"""GPU: the GROUP-STATIONARY search (csrc/group_search.h) -- what a pass without usable previous matches runs on large
+clouds: queries binned by the kd cell they fall into, every group searched from LDS through its own split planes, the
+queries near a cell's faces finished by the packet search.  Every answer must be the oracle's: d2 bit-exact, an index
+may differ only between two target points at exactly the same fp32 distance.
+
+The cases aim at what is particular to this path: the planes' quantisation sliver (targets on a coarse grid, where
+many points share a coordinate and a split's halves overlap), cells that needed several groups (exact duplicates),
+queries far outside every cell, groups that get many times their share of the queries (several work items per group),
+sources much denser / much sparser than the target, radii from tiny to larger than a group."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from test_gpu_seeded import cloud, compare, cuda, rigid
+
+pytestmark = pytest.mark.gpu
+GROUP_SEARCH = 3
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from cupoch_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def first_pass(eng, tgt, src, radius, T=None, tree=None, expect_kind=GROUP_SEARCH):
+    own = tree is None
+    tree = tree or orc.Tree(tgt)
+    eng.drop_seeds()
+    idx, d2, st = eng.search_radius_1nn(radius, T)
+    assert eng.last_search_kind() == expect_kind
+    q = src if T is None else orc.transform_points(T, src)
+    hits = compare(idx, d2, q, tgt, tree, radius)
+    assert st[0] == hits
+    if own:
+        tree.close()
+    return hits
+
+
+@pytest.mark.parametrize("kind", ["uniform", "clustered", "surface"])
+def test_first_pass_equals_oracle(eng, kind):
+    n = 400_000
+    rng = np.random.default_rng({"uniform": 1, "clustered": 2, "surface": 3}[kind])
+    tgt = cloud(kind, n, rng)
+    spacing = n ** (-1.0 / 3.0) if kind != "surface" else n ** (-0.5)
+    T0 = rigid(0.02, [1, 2, 3], [0.004, -0.003, 0.002])
+    take = rng.permutation(n)[: int(0.7 * n)]
+    src = orc.transform_points(np.linalg.inv(T0).astype(np.float32), tgt[take])
+    src = (src + rng.standard_normal(src.shape).astype(np.float32) * np.float32(0.15 * spacing)).astype(np.float32)
+    eng.set_target(cuda(tgt))
+    eng.set_source(cuda(src))
+    tree = orc.Tree(tgt)
+    for radius in (0.05 * spacing, 2.0 * spacing, 40.0 * spacing):        # nothing near / the usual / larger than a group
+        for T in (None, T0, rigid(0.3, [0, 0, 1], [0.2, -0.1, 0.05])):     # displaced / aligned / mostly outside
+            first_pass(eng, tgt, src, radius, T, tree)
+    tree.close()
+
+
+def test_targets_on_a_grid_and_with_duplicates(eng):
+    """coordinates on a 1/256 grid (every split plane passes through many equal coordinates: the halves of a split
+    overlap by the quantisation sliver) and a quarter of the points repeated exactly (cells of several groups)"""
+    rng = np.random.default_rng(7)
+    n = 300_000
+    base = (np.floor(rng.random((n, 3)) * 256) / 256).astype(np.float32)
+    tgt = np.concatenate([base, base[: n // 4], base[: n // 8]])
+    rng.shuffle(tgt)
+    src = (rng.random((200_000, 3)) * 1.1 - 0.05).astype(np.float32)
+    eng.set_target(cuda(tgt))
+    eng.set_source(cuda(src))
+    tree = orc.Tree(tgt)
+    for radius in (1.0 / 512, 1.0 / 200, 0.05):
+        first_pass(eng, tgt, src, radius, None, tree)
+    # queries exactly ON grid points and exactly between two of them (equal distances: the lowest slot wins)
+    on = np.concatenate([base[:100_000], base[:100_000] + np.float32(1.0 / 512)]).astype(np.float32)
+    eng.set_source(cuda(on))
+    first_pass(eng, tgt, on, 1.0 / 128, None, tree)
+    tree.close()
+
+
+def test_one_huge_cell_of_copies(eng):
+    """100k copies of one point among 300k others: its cell needs 25 groups, none of which has a region"""
+    rng = np.random.default_rng(8)
+    tgt = rng.random((400_000, 3), dtype=np.float32)
+    tgt[:100_000] = tgt[0]
+    rng.shuffle(tgt)
+    src = rng.random((150_000, 3), dtype=np.float32)
+    src[:20_000] = tgt[:20_000] + rng.standard_normal((20_000, 3)).astype(np.float32) * np.float32(1e-4)
+    eng.set_target(cuda(tgt))
+    eng.set_source(cuda(src))
+    first_pass(eng, tgt, src, 0.02)
+
+
+def test_unbalanced_queries(eng):
+    """all queries inside two groups' worth of space (tens of work items per group), then a source forty times denser
+    than the target, then one forty times sparser"""
+    rng = np.random.default_rng(9)
+    tgt = rng.random((500_000, 3), dtype=np.float32)
+    eng.set_target(cuda(tgt))
+    tree = orc.Tree(tgt)
+    src = (0.5 + 0.02 * rng.standard_normal((300_000, 3))).astype(np.float32)
+    eng.set_source(cuda(src))
+    first_pass(eng, tgt, src, 0.02, None, tree)
+    tree.close()
+    small = rng.random((70_000, 3), dtype=np.float32)[:, :] * np.float32(0.3)
+    many = (rng.random((2_000_000, 3)) * 0.3).astype(np.float32)
+    eng.set_target(cuda(np.ascontiguousarray(tgt[:300_000] * np.float32(0.3))))
+    eng.set_source(cuda(many))
+    first_pass(eng, np.ascontiguousarray(tgt[:300_000] * np.float32(0.3)), many, 0.01)
+    eng.set_source(cuda(small))
+    first_pass(eng, np.ascontiguousarray(tgt[:300_000] * np.float32(0.3)), small, 0.01)
+
+
+def test_outliers_nan_and_far_queries(eng):
+    rng = np.random.default_rng(10)
+    tgt = rng.random((300_000, 3), dtype=np.float32)
+    src = rng.random((100_000, 3), dtype=np.float32)
+    src[:500] = src[:500] * 50 - 25                   # far outside every cell, radius reaches the cloud for some
+    src[500:520] = np.nan
+    src[520:540] = np.inf
+    eng.set_target(cuda(tgt))
+    eng.set_source(cuda(src))
+    tree = orc.Tree(tgt)
+    eng.drop_seeds()
+    idx, d2, st = eng.search_radius_1nn(3.0)
+    assert eng.last_search_kind() == GROUP_SEARCH
+    ok = np.isfinite(src).all(1)
+    assert (idx[~ok] == -1).all() and np.isinf(d2[~ok]).all()
+    compare(idx[ok], d2[ok], src[ok], tgt, tree, 3.0)
+    tree.close()
+
+
+def test_small_clouds_keep_the_packet_search(eng):
+    rng = np.random.default_rng(11)
+    tgt = rng.random((100_000, 3), dtype=np.float32)
+    src = rng.random((30_000, 3), dtype=np.float32)
+    eng.set_target(cuda(tgt))
+    eng.set_source(cuda(src))
+    eng.drop_seeds()
+    eng.search_radius_1nn(0.05)
+    assert eng.last_search_kind() in (0, 2)
+
+
+@pytest.mark.parametrize("est", [1, 2])
+def test_registration_through_the_group_search_matches_the_oracle(eng, est):
+    """a whole registration whose first pass (and, on noisy data, whose iterations) go through the group search"""
+    from conftest import make_pair
+    d = make_pair(300_000, seed=31 + est, noise=0.15)
+    eng.set_target(d["tgt"], d["tgt_nrm"] if est == 2 else None)
+    eng.set_source(d["src"])
+    res = eng.registration_icp(est, d["max_dist"], None, 0.0, 0.0, 12, -1.0)
+    T = np.array(res.transformation, np.float32).reshape(4, 4).T
+    ref = orc.registration_icp(d["src"], d["tgt"], d["max_dist"], est=est, det_thresh=-1.0, relative_fitness=0.0,
+                               relative_rmse=0.0, max_iteration=12, tgt_nrm=d["tgt_nrm"], composed=True)
+    assert res.iterations == 12 and ref.iterations == 12
+    assert np.linalg.norm(T - ref.transformation) <= 1e-6
+    assert abs(res.fitness - ref.fitness) <= 2e-6
