@@ -85,11 +85,6 @@ struct mi_icp_ctx {
     bool nn_valid = false;  // nn_idx holds a search result (usable as seed / correspondences)
     mi::eng::DevBuf src_bounds;    // min[3], max[3] of the staged source (the loop's step sizes the displacement of its corners: loop.h)
     bool relocate_armed = false;   // this loop's next chunk of iterations carries the gated re-location launches (loop_run)
-    // ---- group-stationary search (group_search.h): the passes without good previous matches
-    mi::eng::DevBuf gs_qgroup, gs_qlist, gs_left, gs_tab, gs_misc;  // per query: group, grouped list, leftover list; per group: tables; a few words
-    bool gs_mode = false;          // this loop's seeded iterations go through the group search too (loop_run decides per chunk)
-    int64_t gs_hard_seen = 0;      // (loop_run) queries of the last group searches their own leaf did not finish
-    int64_t gs_passes_seen = 0;
 
     // ---- explicit correspondence set ----
     mi::eng::DevBuf user_pairs;
@@ -331,7 +326,6 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
 int occupancy_loop(int which);
 bool planes_available(const mi_icp_ctx* c);
 int launch_locate_by_planes(mi_icp_ctx* c, const Xform& X, const DevLoop* loop, int gated);
-bool group_search_available(const mi_icp_ctx* c);
 // ---- mi_geometry.hip
 int occupancy_geometry(int which);
 // ---- mi_comm.hip

@@ -7,7 +7,6 @@
 // allocated inside the loop.  (The other translation units: csrc/ctx.h.)
 #include "ctx.h"
 #include "fused_small.h"
-#include "group_search.h"
 #include "loop_step_kernel.h"
 #include "lzf.h"
 #include "nn_search.h"
@@ -40,71 +39,6 @@ int launch_locate_by_planes(mi_icp_ctx* c, const Xform& X, const DevLoop* loop, 
     locate_by_planes<<<grid, 256, 0, c->stream>>>((const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns,
                                                  (const float2*)c->cell_planes.p, c->cell_levels, (const uint32_t*)c->cell_gstart.p,
                                                  (const float2*)c->gplanes.p, (uint32_t)c->nleaf, X, loop, gated, (int32_t*)c->nn_idx.p);
-    KCHK(c);
-    return MI_ICP_OK;
-}
-
-// THE GROUP-STATIONARY SEARCH (group_search.h) applies to targets with kd cells and group planes, large enough to fill
-// the chip with one workgroup per group, and sources large enough to pay for five launches.
-// MI_ICP_NO_GROUP_SEARCH: A/B switch; MI_ICP_GROUP_SEARCH_MIN: the smallest source (default 2^16 points).
-static int64_t group_search_min() {
-    static const int64_t v = [] { const char* s = std::getenv("MI_ICP_GROUP_SEARCH_MIN"); return s ? std::atoll(s) : (int64_t)1 << 16; }();
-    return v;
-}
-bool group_search_available(const mi_icp_ctx* c) {
-    static const bool off = std::getenv("MI_ICP_NO_GROUP_SEARCH") != nullptr;
-    return !off && planes_available(c) && c->nleaf >= 64 * 512 && (c->nleaf & 511) == 0 && c->ns >= group_search_min() &&
-           c->nts == (int64_t)c->nleaf * kLeaf;
-}
-
-// One exact pass over all source points without using previous matches: count / scan / scatter the queries by group,
-// search every group from LDS, finish the leftover list with the packet search (seeded with what the groups found).
-static int launch_group_search(mi_icp_ctx* c, const Xform& X, float r2, const DevLoop* loop, float* d2, const float* links,
-                               uint32_t* want) {
-    const uint32_t ngroups = (uint32_t)(c->nleaf / 512);
-    GsArgs a;
-    uint32_t* tab;
-    TRY(ensure(c, c->gs_qgroup, (size_t)c->ns, &a.qgroup));
-    TRY(ensure(c, c->gs_qlist, (size_t)c->ns, &a.qlist));
-    TRY(ensure(c, c->gs_left, (size_t)c->ns, &a.left_list));
-    const size_t tab_words = (size_t)4 * (ngroups + 1u) + kGsStatSlots;
-    const bool fresh = c->gs_tab.bytes < tab_words * sizeof(uint32_t);
-    TRY(ensure(c, c->gs_tab, tab_words, &tab));
-    TRY(ensure(c, c->gs_misc, 1, &a.misc));
-    if (fresh) HIPCHK(c, hipMemsetAsync(tab, 0, tab_words * sizeof(uint32_t), c->stream));  // (count[] is zero between passes)
-    a.count = tab;
-    a.start = tab + (ngroups + 1u);
-    a.cursor = tab + 2u * (ngroups + 1u);
-    a.wstart = tab + 3u * (ngroups + 1u);
-    a.stat = tab + 4u * (ngroups + 1u);
-    a.sx = (const float*)c->sx.p;
-    a.sy = (const float*)c->sy.p;
-    a.sz = (const float*)c->sz.p;
-    a.ns = (int)c->ns;
-    a.cell_planes = (const float2*)c->cell_planes.p;
-    a.cell_levels = c->cell_levels;
-    a.gstart = (const uint32_t*)c->cell_gstart.p;
-    a.ngroups = ngroups;
-    a.tblk = (const float*)c->tblk.p;
-    a.gplanes = (const float2*)c->gplanes.p;
-    a.records = (const float*)c->nodes.p;
-    a.leaf_first = c->leaf_first;
-    a.T = X;
-    a.loop = loop;
-    a.r2 = r2;
-    a.nn_idx = (int32_t*)c->nn_idx.p;
-    a.nn_d2 = d2;
-    const int grid = (int)std::min<int64_t>(blocks_for(c->ns), 8192);
-    gs_count<<<grid, 256, 0, c->stream>>>(a);
-    gs_scan<<<1, 1024, 0, c->stream>>>(a);
-    gs_scatter<<<grid, 256, 0, c->stream>>>(a);
-    const uint32_t work_max = ngroups + (uint32_t)((c->ns + kGsChunk - 1) / kGsChunk);
-    gs_search<<<work_max, kGsThreads, 0, c->stream>>>(a);
-    KCHK(c);
-    // the leftover list: 8 waves per SIMD's worth of packets in flight, each wave taking packets until the list ends
-    nn_list_kernel<false><<<8192, kNNThreads, 0, c->stream>>>(
-            a.sx, a.sy, a.sz, a.ns, a.records, a.tblk, (const float*)lreg_of(c), links, c->leaf_first, X, loop, r2, a.nn_idx, d2,
-            nullptr, want, a.left_list, &a.misc->left_count);
     KCHK(c);
     return MI_ICP_OK;
 }
@@ -157,15 +91,6 @@ int launch_nn(mi_icp_ctx* c, const Mat4& T, float r2, bool seed, unsigned long l
         }
 #undef MI_NN_ARGS
     };
-    // No previous matches (or, inside a loop whose matches keep changing, none worth starting from: gs_mode): the
-    // group-stationary search.
-    if ((!use_seed || (loop && c->gs_mode)) && !stats && group_search_available(c)) {
-        TRY(launch_group_search(c, X, r2, loop, loop ? nullptr : d2, links, want));
-        c->last_search_kind = 3;
-        c->nn_valid = true;
-        c->n_user_pairs = -1;
-        return MI_ICP_OK;
-    }
     // No previous matches, but the target's halos are there: every query takes the leaf a greedy descent lands in
     // as its seed (nn_search.h: locate_leaves) and the seeded search does the rest.  (Without halos every lane
     // whose seed leaf's region does not finish it walks up from there -- under the displacement a registration
@@ -432,8 +357,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
                      &c->dense_idx, &c->flags, &c->pairs_out, &c->seg_start, &c->loop_dev, &c->ticket, &c->mail_state, &c->alt[0],
                      &c->alt[1], &c->alt[2], &c->alt[3], &c->alt[4], &c->alt[5], &c->alt[6], &c->alt[7], &c->alt[8], &c->stage[0],
                      &c->stage[1], &c->stage[2], &c->stage[3], &c->stage[4], &c->stage[5], &c->knn_idx, &c->tscale, &c->vpay[0], &c->vpay[1],
-                     &c->vpay[2], &c->vpay[3], &c->vpay[4], &c->vpay[5], &c->stamps, &c->knn_flags, &c->gplanes, &c->src_bounds, &c->cell_boxes, &c->cell_hist,
-                     &c->gs_qgroup, &c->gs_qlist, &c->gs_left, &c->gs_tab, &c->gs_misc};
+                     &c->vpay[2], &c->vpay[3], &c->vpay[4], &c->vpay[5], &c->stamps, &c->knn_flags, &c->gplanes, &c->src_bounds, &c->cell_boxes, &c->cell_hist};
     for (DevBuf* b : all) release(*b);
     if (c->sys_host) (void)hipHostFree(c->sys_host);
     if (c->cell_total_host) (void)hipHostFree(c->cell_total_host);

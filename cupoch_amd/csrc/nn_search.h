@@ -174,20 +174,16 @@ struct PacketResult {
 // index; wave-uniform).  `loop` != nullptr: the transform comes from the device-resident loop state and
 // nothing is done once that loop is finished (returns false, wave-uniformly); otherwise Tv (by value) is
 // used.  Stores the matches (and distances / statistics when asked) itself.
-// LIST: the packet's 64 points are entries packet * 64 .. + 63 of `list` (positions in the staged source; `nlist` of
-// them) instead of 64 consecutive ones -- the queries a group search (group_search.h) could not finish inside their group.
-template <bool SEED, bool STATS, bool LIST = false>
+template <bool SEED, bool STATS>
 __device__ __forceinline__ bool nn_packet_body(
         PacketShared& sh, uint32_t packet,
         const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
         int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
         const float* __restrict__ lreg_g, const float* __restrict__ halo_g, uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2, int32_t* __restrict__ nn_idx,
-        float* __restrict__ nn_d2, unsigned long long* __restrict__ stats, uint32_t* __restrict__ want, PacketResult& out,
-        const int32_t* __restrict__ list = nullptr, int nlist = 0) {
+        float* __restrict__ nn_d2, unsigned long long* __restrict__ stats, uint32_t* __restrict__ want, PacketResult& out) {
     const int lane = lane_id();
-    const int li = (int)(packet * 64u) + lane;  // (ns < 2^31)
-    const bool valid = LIST ? li < nlist : li < ns;
-    const int i = LIST ? list[valid ? li : 0] : li;
+    const int i = (int)(packet * 64u) + lane;  // (ns < 2^31)
+    const bool valid = i < ns;
     // Everything this lane needs from global memory that does not depend on anything else is
     // requested FIRST, branch-free (lanes past the end re-read element 0), so that these loads,
     // the scalar loads of the loop state below and -- seeded -- the previous match travel together:
@@ -548,27 +544,6 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(SEED
     (void)nn_packet_body<SEED, STATS>(s_pk[0], logical, sx, sy, sz, ns, records_g, tblk_g, lreg_g, halo_g, leaf_first, Tv, loop,
                                       r2, nn_idx, nn_d2, stats, want, unused);
     if (STAMP && stamps && threadIdx.x == 0 && blockIdx.x + 256u >= gridDim.x) atomicMax(stamps + 1, stamp_now());
-}
-
-// The packet search on a LIST of queries (group_search.h: those its group could not finish; their seed is what the
-// group search found).  The list's length is known on the device only: a fixed grid of waves, each taking packets
-// blockIdx.x, + gridDim.x, ... until the list ends.
-template <bool STATS = false>
-__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void nn_list_kernel(
-        const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
-        int ns, const float* __restrict__ records_g, const float* __restrict__ tblk_g,
-        const float* __restrict__ lreg_g, const float* __restrict__ halo_g, uint32_t leaf_first, Xform Tv, const DevLoop* __restrict__ loop, float r2,
-        int32_t* __restrict__ nn_idx, float* __restrict__ nn_d2, unsigned long long* __restrict__ stats, uint32_t* __restrict__ want,
-        const int32_t* __restrict__ list, const uint32_t* __restrict__ nlist_p) {
-    __shared__ PacketShared s_pk[1];
-    const uint32_t nlist = *nlist_p;
-    PacketResult unused;
-    for (uint32_t packet = blockIdx.x; packet * 64u < nlist; packet += gridDim.x) {
-        if (!nn_packet_body<true, STATS, true>(s_pk[0], packet, sx, sy, sz, ns, records_g, tblk_g, lreg_g, halo_g, leaf_first, Tv, loop,
-                                               r2, nn_idx, nn_d2, stats, want, unused, list, (int)nlist))
-            return;
-        __builtin_amdgcn_wave_barrier();
-    }
 }
 
 // ---------------------------------------------------------------------------

@@ -471,7 +471,10 @@ __device__ __forceinline__ void solo_walk(const float* __restrict__ records_g, u
     uint32_t id = 1u;
     int32_t off = -1;
     uint64_t pend = 0ull;
-    bool on = solo;
+    // (a query with a NaN coordinate has no neighbours and must not walk: fmaxf drops the NaN, every gap below comes out
+    // 0, every slot -- the empty ones with their inverted boxes too -- counts as hit, and the lane descends into records
+    // that do not exist: a memory fault until round 6, found by a source with NaN points under a radius beyond the cap)
+    bool on = solo && qx == qx && qy == qy && qz == qz;
     while (__ballot(on) != 0ull) {
         uint32_t hit = 0u, nearest = 0u;
         float dnear = INFINITY;

@@ -4,7 +4,7 @@
 O=gpurun_out/r06c
 mkdir -p $O
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_group_search.py -x -q --timeout=600 > $O/t_gs.log 2>&1; echo "gs tests rc=$?"; tail -15 $O/t_gs.log | grep -v "^E  "
+timeout 900 python -m pytest tests/test_gpu_first_pass.py -x -q --timeout=600 > $O/t_gs.log 2>&1; echo "gs tests rc=$?"; tail -15 $O/t_gs.log | grep -v "^E  "
 timeout 900 python bench.py --no-cpu-baseline --big-points 0 2>&1 | grep '^{"metric' | tee $O/bench_10m.json | python scripts/benchline.py
 python - <<'PY'
 import json

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 6: where the group search's first pass spends its time (kernel trace), and which inputs abort the search
+# Round 6: where the group search's first pass spent its time (kernel trace of scripts/dev/gs_first_pass.py, both removed with
+# the experiment: git show 5f03866), and which inputs abort the search
 O=gpurun_out/r06d
 mkdir -p $O
 export TMPDIR=/tmp

@@ -1,12 +1,11 @@
-"""GPU: the GROUP-STATIONARY search (csrc/group_search.h) -- what a pass without usable previous matches runs on large
-clouds: queries binned by the kd cell they fall into, every group searched from LDS through its own split planes, the
-queries near a cell's faces finished by the packet search.  Every answer must be the oracle's: d2 bit-exact, an index
-may differ only between two target points at exactly the same fp32 distance.
-
-The cases aim at what is particular to this path: the planes' quantisation sliver (targets on a coarse grid, where
-many points share a coordinate and a split's halves overlap), cells that needed several groups (exact duplicates),
-queries far outside every cell, groups that get many times their share of the queries (several work items per group),
-sources much denser / much sparser than the target, radii from tiny to larger than a group."""
+"""GPU: a search WITHOUT previous matches on large clouds, on inputs chosen to stress what sits between a query and its
+answer in the kd-cell tree: targets on a coarse grid (many points share a coordinate: the halves of a split overlap by the
+quantisation sliver, kd_refine.h), cells that needed several groups (exact duplicates, one point copied 100k times),
+queries far outside every cell, queries crowded into two groups' worth of space, sources forty times denser / sparser than
+the target, radii from a twentieth of a spacing to larger than a group.  Every answer must be the oracle's: d2 bit-exact,
+an index may differ only between two target points at exactly the same fp32 distance.
+(Written in round 6 for the group-stationary search experiment -- EXPERIMENTS.md -- which passed all of it and was not
+adopted for its speed; the cases stay, for the packet search's passes from the root and from located seeds.)"""
 import numpy as np
 import pytest
 import torch
@@ -15,7 +14,7 @@ from oracle import oracle as orc
 from test_gpu_seeded import cloud, compare, cuda, rigid
 
 pytestmark = pytest.mark.gpu
-GROUP_SEARCH = 3
+FIRST_PASS = (0, 2)     # mi_icp_debug_last_search_kind: from the root / from seeds the queries made themselves
 
 
 @pytest.fixture(scope="module")
@@ -26,12 +25,12 @@ def eng():
     e.close()
 
 
-def first_pass(eng, tgt, src, radius, T=None, tree=None, expect_kind=GROUP_SEARCH):
+def first_pass(eng, tgt, src, radius, T=None, tree=None):
     own = tree is None
     tree = tree or orc.Tree(tgt)
     eng.drop_seeds()
     idx, d2, st = eng.search_radius_1nn(radius, T)
-    assert eng.last_search_kind() == expect_kind
+    assert eng.last_search_kind() in FIRST_PASS
     q = src if T is None else orc.transform_points(T, src)
     hits = compare(idx, d2, q, tgt, tree, radius)
     assert st[0] == hits
@@ -113,39 +112,19 @@ def test_unbalanced_queries(eng):
     first_pass(eng, np.ascontiguousarray(tgt[:300_000] * np.float32(0.3)), small, 0.01)
 
 
-def test_outliers_nan_and_far_queries(eng):
+def test_far_queries_under_a_generous_radius(eng):
     rng = np.random.default_rng(10)
     tgt = rng.random((300_000, 3), dtype=np.float32)
     src = rng.random((100_000, 3), dtype=np.float32)
-    src[:500] = src[:500] * 50 - 25                   # far outside every cell, radius reaches the cloud for some
-    src[500:520] = np.nan
-    src[520:540] = np.inf
+    src[:500] = src[:500] * 50 - 25                   # far outside every cell; the radius reaches the cloud for some
     eng.set_target(cuda(tgt))
     eng.set_source(cuda(src))
-    tree = orc.Tree(tgt)
-    eng.drop_seeds()
-    idx, d2, st = eng.search_radius_1nn(3.0)
-    assert eng.last_search_kind() == GROUP_SEARCH
-    ok = np.isfinite(src).all(1)
-    assert (idx[~ok] == -1).all() and np.isinf(d2[~ok]).all()
-    compare(idx[ok], d2[ok], src[ok], tgt, tree, 3.0)
-    tree.close()
-
-
-def test_small_clouds_keep_the_packet_search(eng):
-    rng = np.random.default_rng(11)
-    tgt = rng.random((100_000, 3), dtype=np.float32)
-    src = rng.random((30_000, 3), dtype=np.float32)
-    eng.set_target(cuda(tgt))
-    eng.set_source(cuda(src))
-    eng.drop_seeds()
-    eng.search_radius_1nn(0.05)
-    assert eng.last_search_kind() in (0, 2)
+    first_pass(eng, tgt, src, 3.0)
 
 
 @pytest.mark.parametrize("est", [1, 2])
-def test_registration_through_the_group_search_matches_the_oracle(eng, est):
-    """a whole registration whose first pass (and, on noisy data, whose iterations) go through the group search"""
+def test_noisy_registration_matches_the_oracle(eng, est):
+    """a whole registration on noisy data (every cube pokes out of its leaf: halo lines and walks in every iteration)"""
     from conftest import make_pair
     d = make_pair(300_000, seed=31 + est, noise=0.15)
     eng.set_target(d["tgt"], d["tgt_nrm"] if est == 2 else None)
@@ -157,3 +136,30 @@ def test_registration_through_the_group_search_matches_the_oracle(eng, est):
     assert res.iterations == 12 and ref.iterations == 12
     assert np.linalg.norm(T - ref.transformation) <= 1e-6
     assert abs(res.fitness - ref.fitness) <= 2e-6
+
+
+def test_non_finite_source_points(eng):
+    """NaN / inf coordinates in the SOURCE: no match for them (-1, +inf), everybody else as the oracle says -- also under a
+    radius beyond the walk's cap, where an unmatched query goes on alone (traverse.h solo_walk): until round 6 a NaN
+    query there hit every slot of every record, the empty ones too, and the process died of a memory fault."""
+    rng = np.random.default_rng(12)
+    tgt = rng.random((300_000, 3), dtype=np.float32)
+    src = rng.random((100_000, 3), dtype=np.float32)
+    src[500:520] = np.nan
+    src[520:530, 1] = np.nan
+    src[530:540] = np.inf
+    src[540:550, 2] = -np.inf
+    ok = np.isfinite(src).all(1)
+    eng.set_target(cuda(tgt))
+    eng.set_source(cuda(src))
+    tree = orc.Tree(tgt)
+    for radius in (0.01, 3.0):
+        for seeded in (False, True):
+            if not seeded:
+                eng.drop_seeds()
+            idx, d2, st = eng.search_radius_1nn(radius)
+            assert (idx[~ok] == -1).all() and np.isinf(d2[~ok]).all()
+            compare(idx[ok], d2[ok], src[ok], tgt, tree, radius)
+    tree.close()
+    res = eng.registration_icp(1, 0.02, None, 1e-6, 1e-6, 5, -1.0)
+    assert np.isfinite(np.array(res.transformation)).all() and res.fitness > 0.9
