@@ -519,6 +519,7 @@ def main():
         eng.icp_begin(_lib.EST_POINT_TO_PLANE, max_dist, None, -1.0)
         eng.icp_iterate(args.warmup)
     windows = []
+    halo_builds_before = eng.get_profile()["halo_builds_by_loops"]
     for _ in range(max(1, args.repeats)):
         if world > 1:
             dist.barrier()
@@ -535,6 +536,8 @@ def main():
             w = float(t.item())
         windows.append(w)
     elapsed = float(np.median(windows))
+    # did the loop start a build of the target's halos (2 ms of GPU time at 10M points) inside the timed windows?
+    halo_builds_in_windows = eng.get_profile()["halo_builds_by_loops"] - halo_builds_before
     eng.set_profiling(True)
     prof0 = eng.get_profile()
     torch.cuda.synchronize()
@@ -598,6 +601,7 @@ def main():
                        if world > 1 else "single GPU",
                        "exchange": exchange,
                        "accumulate": "f64", "build_ms": round(build_ms, 2),
+                       "halo_builds_inside_the_timed_windows": int(halo_builds_in_windows),
                        "final_fitness": round(float(res.fitness), 6),
                        "final_rmse": float(res.inlier_rmse),
                        "T_error_fro_vs_ground_truth": err},

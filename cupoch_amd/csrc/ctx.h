@@ -70,6 +70,7 @@ struct mi_icp_ctx {
     bool halo_declined = false;  // this loop's searches have been looked at and did not ask
     int64_t halo_iters = 0;      // seeded iterations against this target since it was set ...
     int64_t halo_asked = 0;      // ... and the lanes that asked for a halo in them
+    int64_t halo_lanes = 0;      // ... out of this many lanes (source points x iterations looked at)
     int64_t halo_want_seen = 0;  // the counter's value at the last look (it is zeroed when a loop begins)
     int halo_looks = 0;          // looks of this loop while undecided
     bool halo_use = false;       // the loop's launches take the halos (looked up once per chunk: an event query costs microseconds)

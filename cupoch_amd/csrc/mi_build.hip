@@ -472,7 +472,7 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
         KCHK(c);
     }
     c->links_ready = false;  // (the leaves' halos: started below, or by the registration loop / the first seeded search)
-    c->halo_iters = c->halo_asked = 0;
+    c->halo_iters = c->halo_asked = c->halo_lanes = 0;
     c->links_allowed = !no_cells && (uint32_t)nleaf <= kLinkIdMask;
     c->nt = n;
     c->nts = nts;

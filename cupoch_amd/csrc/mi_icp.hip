@@ -19,6 +19,10 @@ using host::Mat4;
 namespace mi {
 namespace eng {
 
+// elements per thread that travel together in reduce_pt2pl_kernel: 2 since round 6 (4 before: profiles/r06_reduce_shape_sweep.txt --
+// the step 1-3 % shorter at 10M, 5M and 2.5M source points, unchanged at 1.25M)
+constexpr int kPt2PlInFlight = 2;
+
 // sources of at least this many points make their own seeds for a first pass (tuning knob MI_ICP_COARSE_MIN)
 static int64_t coarse_first_min() {
     static const int64_t v = [] { const char* s = std::getenv("MI_ICP_COARSE_MIN"); return s ? std::atoll(s) : (int64_t)1 << 16; }();
@@ -121,7 +125,7 @@ int occupancy_loop(int which) {
     hipError_t e = hipErrorInvalidValue;
     if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, nn_packet_kernel<true, false>, kNNThreads, 0);
     else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, nn_packet_kernel<false, false>, kNNThreads, 0);
-    else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reduce_pt2pl_kernel<4, 1>, kReduceThreads, 0);
+    else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reduce_pt2pl_kernel<kPt2PlInFlight, 1>, kReduceThreads, 0);
     else return -1;
     return e == hipSuccess ? blocks : -2;
 }
@@ -186,7 +190,7 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, DevLoop* loop
     if (stepped) *stepped = false;
     double *partial, *sys;
     uint32_t* ticket;
-    TRY(ensure(c, c->partial, (size_t)kReduceBlocks * kSysSize, &partial));
+    TRY(ensure(c, c->partial, (size_t)4 * kReduceBlocks * kSysSize, &partial));
     TRY(ensure(c, c->sys_dev, kSysSize, &sys));
     if (!c->ticket.p) {
         TRY(ensure(c, c->ticket, 64, &ticket));
@@ -237,20 +241,37 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, DevLoop* loop
         // four elements in flight per thread; at most 512 blocks (2 per CU): measured best on the 10M bench
         // (256 / 512 / 1024 / 2048 blocks: 0.090 / 0.079 / 0.080 / 0.091 ms; 6 or 8 elements in flight on 512,
         // 768 or 1024 blocks: 0.078 - 0.084 ms -- the kernel sits at ~5.1 TB/s of the ~6.3 a pure stream reaches)
-        const int g2 = std::min(grid, 512);
+        int g2 = std::min(grid, 512);
         EvTimer t(c, 1, loop != nullptr);
         const MailArgs no_mail = {nullptr, nullptr, 0, 1, 0u, nullptr, nullptr};
         const bool mail = mail_on(c);
+#ifdef MI_AB_REDUCE_SWEEP
+        {   // (dev: scripts/dev/reduce_shape_sweep.py)
+            const char* eg = std::getenv("MI_ICP_AB_REDUCE_GRID");
+            const char* eu = std::getenv("MI_ICP_AB_REDUCE_U");
+            if (eg) g2 = std::atoi(eg);
+            const int u = eu ? std::atoi(eu) : 4;
+            if (fuse_step && loop && !c->comm && !c->mail_dev && (eg || eu)) {
+                if (u == 1) reduce_pt2pl_kernel<1, 1><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
+                else if (u == 2) reduce_pt2pl_kernel<2, 1><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
+                else if (u == 8) reduce_pt2pl_kernel<8, 1><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
+                else reduce_pt2pl_kernel<4, 1><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
+                if (stepped) *stepped = true;
+                KCHK(c);
+                return MI_ICP_OK;
+            }
+        }
+#endif
         if (fuse_step && loop && mail) {  // N ranks on one node: exchange + step in the finishing block
-            if (c->stamps_on) reduce_pt2pl_kernel<4, 2, true><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, mail_args(c));
-            else reduce_pt2pl_kernel<4, 2><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, mail_args(c));
+            if (c->stamps_on) reduce_pt2pl_kernel<kPt2PlInFlight, 2, true><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, mail_args(c));
+            else reduce_pt2pl_kernel<kPt2PlInFlight, 2><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, mail_args(c));
             if (stepped) *stepped = true;
         } else if (fuse_step && loop && !c->comm && !c->mail_dev) {
-            if (c->stamps_on) reduce_pt2pl_kernel<4, 1, true><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
-            else reduce_pt2pl_kernel<4, 1><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
+            if (c->stamps_on) reduce_pt2pl_kernel<kPt2PlInFlight, 1, true><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
+            else reduce_pt2pl_kernel<kPt2PlInFlight, 1><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
             if (stepped) *stepped = true;
         } else {
-            reduce_pt2pl_kernel<4, 0><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
+            reduce_pt2pl_kernel<kPt2PlInFlight, 0><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
         }
         KCHK(c);
         return MI_ICP_OK;
@@ -746,6 +767,13 @@ static int loop_enqueue_evaluation(mi_icp_ctx* c, bool seed) {
 // match's region): their packets' one-record walks are ~4 % of a search -- not worth a build to one registration,
 // worth it to a target that keeps being registered against: after kHaloLongRun iterations on the same target the
 // build is started in the background and taken up whenever it is done.
+// twice what the halos and their build's scratch take (~128 + ~56 bytes per slot) must be free on the device
+static bool halo_memory_free(const mi_icp_ctx* c) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    return free_b >= (size_t)c->nts * 368u;
+}
+
 static int loop_run(mi_icp_ctx* c, int budget) {
     constexpr int kChunk = 8;
     constexpr int64_t kLarge = 500000, kHaloLongRun = 40;
@@ -783,6 +811,7 @@ static int loop_run(mi_icp_ctx* c, int budget) {
             const int64_t asked = (int64_t)(uint32_t)(counted - (uint32_t)c->halo_want_seen);  // by this chunk's iterations
             c->halo_want_seen = (int64_t)counted;
             c->halo_asked += asked;
+            c->halo_lanes += c->ns * (int64_t)std::max(executed, 0);
             if (undecided) {
                 ++c->halo_looks;
                 const int64_t per = std::max(executed, 1);
@@ -791,10 +820,16 @@ static int loop_run(mi_icp_ctx* c, int budget) {
                     c->halo_declined = true;
                 } else if (most || c->halo_looks >= 2 || c->ns < kLarge) {
                     c->halo_sticky = true;
+                    ++c->prof[6];
                     TRY(start_links_async(c));
                 }
-            } else if (c->halo_iters >= kHaloLongRun && c->halo_asked > 0) {
-                TRY(start_links_async(c));  // (in the background: halo_declined stays, nothing waits)
+            } else if (c->halo_iters >= kHaloLongRun && c->halo_asked * 100 >= c->halo_lanes && halo_memory_free(c)) {
+                // (in the background: halo_declined stays, nothing waits.  Until round 6 ANY lane that had ever asked
+                // started this build -- 2.2 ms of GPU time and 1.6 GB at 10M points inside the loop of a caller whose
+                // data never reads a halo: one window in seven of the headline bench 70 % slow.  Now: at least 1 % of
+                // the lanes per iteration, and twice the build's memory free.)
+                ++c->prof[6];
+                TRY(start_links_async(c));
             }
         }
         if (c->loop_host->done) break;

@@ -583,7 +583,8 @@ class Engine:
         out = np.zeros(8, np.float64)
         self._chk(self._L.mi_icp_get_profile(self._ctx, out.ctypes.data_as(C.c_void_p)))
         return dict(nn_ms=out[0], nn_launches=int(out[1]), reduce_ms=out[2],
-                    reduce_launches=int(out[3]), build_target_ms=out[4], build_source_ms=out[5])
+                    reduce_launches=int(out[3]), build_target_ms=out[4], build_source_ms=out[5],
+                    halo_builds_by_loops=int(out[6]))
 
 
 def comm_unique_id():

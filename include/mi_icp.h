@@ -453,7 +453,8 @@ MI_ICP_API int mi_icp_set_iteration_callback(mi_icp_ctx* ctx, mi_icp_iteration_f
 /* ---- instrumentation ----------------------------------------------------
  * enable != 0: every nearest-neighbour and reduction launch is bracketed by
  * hipEvents on the context's stream.  out[8] = {nn_ms_total, nn_launches,
- * reduce_ms_total, reduce_launches, build_ms_target, build_ms_source, 0, 0}. */
+ * reduce_ms_total, reduce_launches, build_ms_target, build_ms_source, halo builds
+ * started by registration loops on this context (always counted), 0}. */
 MI_ICP_API int mi_icp_set_profiling(mi_icp_ctx* ctx, int enable);
 MI_ICP_API int mi_icp_get_profile(mi_icp_ctx* ctx, double* out8);
 
