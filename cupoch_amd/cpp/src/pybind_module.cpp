@@ -223,6 +223,9 @@ py::capsule to_dlpack_capsule(const utility::device_vector<Eigen::Vector3f>& src
     e->handle = src.share();  // no copy: the tensor and the cloud hold the same block
     int dev = 0;
     (void)hipGetDevice(&dev);
+    // (the legacy capsule has no stream handshake: everything enqueued that writes the block has finished before a
+    // consumer on any stream sees the pointer -- ADVICE r5; INTEGRATION.md section 2 lists what aliasing means otherwise)
+    (void)hipDeviceSynchronize();
     e->shape[0] = (int64_t)src.size();
     e->shape[1] = 3;
     MiDLTensor& t = e->tensor.dl_tensor;

@@ -86,6 +86,7 @@ struct mi_icp_ctx {
     bool nn_valid = false;  // nn_idx holds a search result (usable as seed / correspondences)
     mi::eng::DevBuf src_bounds;    // min[3], max[3] of the staged source (the loop's step sizes the displacement of its corners: loop.h)
     bool relocate_armed = false;   // this loop's next chunk of iterations carries the gated re-location launches (loop_run)
+    bool relocate_possible = false;  // ... this loop's step sizes its displacement (loop_begin): the launches may be armed again
 
     // ---- explicit correspondence set ----
     mi::eng::DevBuf user_pairs;

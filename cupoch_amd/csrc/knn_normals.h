@@ -67,7 +67,18 @@ __device__ __forceinline__ uint32_t knn_row_claim(const KnnSlab& sl, uint32_t se
         xcc &= 7u;
         uint32_t* f = sl.flags + xcc * sl.per_xcc;
         uint32_t r = (seed * 2654435761u) % sl.per_xcc;
-        while (atomicCAS(f + r, 0u, 1u) != 0u) r = (r + 1u == sl.per_xcc) ? 0u : r + 1u;  // (holders never wait: one frees up)
+        // (holders never wait: a row frees up.  A pool is sized for an eighth of the device's CUs; in a partitioned mode
+        // or under a CU mask all resident waves may sit on one or two XCDs -- a wave that has probed its whole pool
+        // once moves on to the next XCD's, so that the slab as a whole serves whatever is resident: ADVICE r5)
+        uint32_t probes = 0u;
+        while (atomicCAS(f + r, 0u, 1u) != 0u) {
+            r = (r + 1u == sl.per_xcc) ? 0u : r + 1u;
+            if (++probes == sl.per_xcc) {
+                probes = 0u;
+                xcc = (xcc + 1u) & 7u;
+                f = sl.flags + xcc * sl.per_xcc;
+            }
+        }
         row = xcc * sl.per_xcc + r;
     }
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)row);

@@ -135,12 +135,19 @@ bool inbox_open(mi_icp_ctx* c, MailBox* box, int nranks, int rank, const std::fu
     __atomic_store_n(&box->inbox_state[rank], 2u, __ATOMIC_RELEASE);
     if (!wait_all(2u)) give_up();
     ok = __atomic_load_n(&box->device_failed, __ATOMIC_ACQUIRE) == 0u;
+    // The table of everybody's inboxes goes up BEFORE the mode is final: a rank whose upload fails -- or that ran out of
+    // time in the wait above while a peer had already passed it -- says so, and nobody decides before every rank has
+    // reached state 3 (table uploaded or given up).  Until round 6 the decision was read after state 2 and a late failure
+    // left the ranks posting into different media, every exchange running into its 10-s timeout.
     unsigned long long** table = nullptr;
     if (ok && (ensure(c, c->inbox_table, kMailRanks, &table) != MI_ICP_OK ||
                hipMemcpy(table, c->inbox_peer, sizeof(c->inbox_peer), hipMemcpyHostToDevice) != hipSuccess)) {
-        // (too late to tell the others: they will wait for this rank's posts in vain and time out; cannot happen short of an out-of-memory)
-        ok = false;
+        (void)hipGetLastError();
+        give_up();
     }
+    __atomic_store_n(&box->inbox_state[rank], 3u, __ATOMIC_RELEASE);
+    if (!wait_all(3u)) give_up();  // (a peer that never arrives: this rank falls back; so do the others, once they see the flag or run out of time themselves)
+    ok = __atomic_load_n(&box->device_failed, __ATOMIC_ACQUIRE) == 0u;
     if (!ok) {
         for (int r = 0; r < nranks; ++r)
             if (r != rank && c->inbox_peer[r]) (void)hipIpcCloseMemHandle(c->inbox_peer[r]);

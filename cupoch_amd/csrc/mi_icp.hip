@@ -801,6 +801,9 @@ static int loop_run(mi_icp_ctx* c, int budget) {
         collect_pooled(c, executed);
         // (a chunk that carried the launches and never needed one: the steps have become small, and they only shrink)
         if (carried && c->loop_host->relocations == relocations_before) c->relocate_armed = false;
+        // ... and they may grow again (point-to-plane sliding, an escape from a plateau): the step keeps sizing itself on
+        // the device whether or not the launches ride along, so a chunk without them that took a large step arms the next
+        else if (!c->relocate_armed && c->relocate_possible && c->loop_host->relocations != relocations_before) c->relocate_armed = true;
         budget -= n;
         c->halo_iters += executed;
         if (no_halo) {
@@ -860,7 +863,7 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
     const bool can_locate = planes_available(c) && c->ns >= coarse_first_min() && c->src_bounds.p != nullptr && c->nt > 0;
     L.near2_ptr = can_locate ? (uint64_t)(uintptr_t)((const float*)c->nodes.p + kRecordNear2) : 0ull;
     L.src_bounds_ptr = can_locate ? (uint64_t)(uintptr_t)c->src_bounds.p : 0ull;
-    c->relocate_armed = can_locate;
+    c->relocate_armed = c->relocate_possible = can_locate;
     if (c->stamps_on) {  // (mi_icp_debug_set_step_stamps: armed -- minima at all ones -- before the loop's first launch)
         unsigned long long* st;
         TRY(ensure(c, c->stamps, kStampWords, &st));
