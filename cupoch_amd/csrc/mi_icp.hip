@@ -190,7 +190,7 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, DevLoop* loop
     if (stepped) *stepped = false;
     double *partial, *sys;
     uint32_t* ticket;
-    TRY(ensure(c, c->partial, (size_t)4 * kReduceBlocks * kSysSize, &partial));
+    TRY(ensure(c, c->partial, (size_t)kReduceBlocks * kSysSize, &partial));
     TRY(ensure(c, c->sys_dev, kSysSize, &sys));
     if (!c->ticket.p) {
         TRY(ensure(c, c->ticket, 64, &ticket));
@@ -241,27 +241,10 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, DevLoop* loop
         // four elements in flight per thread; at most 512 blocks (2 per CU): measured best on the 10M bench
         // (256 / 512 / 1024 / 2048 blocks: 0.090 / 0.079 / 0.080 / 0.091 ms; 6 or 8 elements in flight on 512,
         // 768 or 1024 blocks: 0.078 - 0.084 ms -- the kernel sits at ~5.1 TB/s of the ~6.3 a pure stream reaches)
-        int g2 = std::min(grid, 512);
+        const int g2 = std::min(grid, 512);
         EvTimer t(c, 1, loop != nullptr);
         const MailArgs no_mail = {nullptr, nullptr, 0, 1, 0u, nullptr, nullptr};
         const bool mail = mail_on(c);
-#ifdef MI_AB_REDUCE_SWEEP
-        {   // (dev: scripts/dev/reduce_shape_sweep.py)
-            const char* eg = std::getenv("MI_ICP_AB_REDUCE_GRID");
-            const char* eu = std::getenv("MI_ICP_AB_REDUCE_U");
-            if (eg) g2 = std::atoi(eg);
-            const int u = eu ? std::atoi(eu) : 4;
-            if (fuse_step && loop && !c->comm && !c->mail_dev && (eg || eu)) {
-                if (u == 1) reduce_pt2pl_kernel<1, 1><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
-                else if (u == 2) reduce_pt2pl_kernel<2, 1><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
-                else if (u == 8) reduce_pt2pl_kernel<8, 1><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
-                else reduce_pt2pl_kernel<4, 1><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
-                if (stepped) *stepped = true;
-                KCHK(c);
-                return MI_ICP_OK;
-            }
-        }
-#endif
         if (fuse_step && loop && mail) {  // N ranks on one node: exchange + step in the finishing block
             if (c->stamps_on) reduce_pt2pl_kernel<kPt2PlInFlight, 2, true><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, mail_args(c));
             else reduce_pt2pl_kernel<kPt2PlInFlight, 2><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, mail_args(c));

@@ -1,5 +1,6 @@
 """The point-to-plane reduction's launch shape by shard size: grid x elements in flight, on 1/N Morton shards of the
-bench's 10M source (needs a library built with -DMI_AB_REDUCE_SWEEP: MI_ICP_LIB_PATH).  Prints reduce_ms (HIP events)
+bench's 10M source (needs the MI_ICP_AB_REDUCE_GRID / _U knobs of commit e056bb3..: a -DMI_AB_REDUCE_SWEEP build, taken out
+again once profiles/r06_reduce_shape_sweep.txt was measured).  Prints reduce_ms (HIP events)
 and the step (wall clock / iterations, no events)."""
 import json, os, sys, time
 import numpy as np, torch
