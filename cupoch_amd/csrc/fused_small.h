@@ -31,7 +31,7 @@ __device__ __forceinline__ bool icp_small_iteration_body(
         const float* __restrict__ records_g, const float* __restrict__ tblk_g, const float* __restrict__ lreg_g,
         const float* __restrict__ halo_g, uint32_t leaf_first, float r2, uint32_t npackets, uint32_t nblocks,
         int32_t* __restrict__ nn_idx, uint32_t* __restrict__ want, const float* __restrict__ trec, DevLoop* __restrict__ loop,
-        double* __restrict__ partial, uint32_t* __restrict__ ticket, double* __restrict__ out32, const Xform* tforce = nullptr) {
+        double* __restrict__ partial, uint32_t* __restrict__ ticket, double* __restrict__ out32) {
     __shared__ PacketShared s_pk[kFusedPackets];
     const int wid = (int)(threadIdx.x >> 6);
     uint32_t logical;
@@ -44,10 +44,9 @@ __device__ __forceinline__ bool icp_small_iteration_body(
     r.best = 0.0f;
     r.qx = r.qy = r.qz = 0.0f;
     if (in_range && packet < npackets) {
-        // (tforce: the caller has read the loop's transform itself -- the several-iterations kernel below, past its epoch)
         const Xform none = {};
         (void)nn_packet_body<true, false>(s_pk[wid], packet, sx, sy, sz, ns, records_g, tblk_g, lreg_g, halo_g, leaf_first,
-                                          tforce ? *tforce : none, tforce ? nullptr : loop, r2, nn_idx, nullptr, nullptr, want, r);
+                                          none, loop, r2, nn_idx, nullptr, nullptr, want, r);
     }
     // ---- this lane's row of the system (reduce_pt2pl_kernel's arithmetic): J[6], residual, d2 into LDS
     // ([component][lane], component stride 65 floats: the sums below read one column per lane group without
@@ -163,65 +162,6 @@ __global__ __launch_bounds__(kReduceThreads) void icp_small_iteration_kernel(
     (void)icp_small_iteration_body<EST>(MI_SMALL_ARGS);
 }
 
-// SEVERAL ITERATIONS IN ONE LAUNCH (round 6; kinfu.cpp:105-135's loops of a few thousand to a few ten thousand points,
-// where an iteration is ~9 us of kernel behind ~6 us of launch gap).  The same body, `n_iter` times, the grid's
-// workgroups all resident (a cooperative launch: <= one per CU) and held together by an epoch word: the workgroup that
-// took the last ticket totals the rows, steps the loop (loop.h), publishes the state (release) and bumps the epoch; the
-// others poll it and read the new transform and the done flag past their caches (agent-scope loads: an acquire fence here
-// would empty every XCD's L2 of the target it is searching, iteration after iteration -- measured: 19 us per iteration
-// instead of 15) -- or leave, once the state says done.  Results are those of `n_iter` launches of icp_small_iteration_kernel bit for bit: same blocks, same
-// packets, same rows, same fixed-order totals.  A wait that does not end (it cannot, with every workgroup resident)
-// gives up after ~0.2 s, flags the loop (error 2) and ends it.
-constexpr uint32_t kSmallLoopSpinLimit = 4000000u;
-constexpr int kSmallLoopEpochWord = 16;  // of the ticket buffer (a cache line of its own)
-template <int EST>
-__global__ __launch_bounds__(kReduceThreads) void icp_small_loop_kernel(
-        const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int ns,
-        const float* __restrict__ records_g, const float* __restrict__ tblk_g, const float* __restrict__ lreg_g,
-        const float* __restrict__ halo_g, uint32_t leaf_first, float r2, uint32_t npackets, uint32_t nblocks,
-        int32_t* __restrict__ nn_idx, uint32_t* __restrict__ want, const float* __restrict__ trec, DevLoop* loop,
-        double* __restrict__ partial, uint32_t* __restrict__ ticket, double* __restrict__ out32, int n_iter) {
-    uint32_t* epoch = ticket + kSmallLoopEpochWord;
-    // (read before this block's first ticket: nobody bumps it before every block has taken that one)
-    const uint32_t epoch0 = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __shared__ uint32_t s_go;
-    for (int it = 0; it < n_iter; ++it) {
-        if (__hip_atomic_load(&loop->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;  // (uniform)
-        Xform T;
-        {
-            const float* xs = reinterpret_cast<const float*>(&loop->X);
-            float* xd = reinterpret_cast<float*>(&T);
-#pragma unroll
-            for (int e = 0; e < 12; ++e) xd[e] = __hip_atomic_load(xs + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const bool last = icp_small_iteration_body<EST>(MI_SMALL_ARGS, &T);
-        if (it + 1 == n_iter) return;
-        const uint32_t want_epoch = epoch0 + (uint32_t)it + 1u;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t ok = 1u;
-            if (last) {
-                // the stepped state (plain stores of this block) reaches memory before the epoch says so
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __hip_atomic_store(epoch, want_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                uint32_t spins = 0u;
-                while (__hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want_epoch) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > kSmallLoopSpinLimit) {
-                        __hip_atomic_store(&loop->error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&loop->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = 0u;
-                        break;
-                    }
-                }
-            }
-            s_go = ok;
-        }
-        __syncthreads();
-        if (s_go == 0u) return;
-    }
-}
 #undef MI_SMALL_ARGS
 
 }  // namespace mi

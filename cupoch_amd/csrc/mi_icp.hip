@@ -644,7 +644,6 @@ static void fill_result(const mi_icp_ctx* c, mi_icp_result* out) {
 static int loop_pull(mi_icp_ctx* c) {  // device state -> pinned mirror, synchronises
     HIPCHK(c, hipMemcpyAsync(c->loop_host, c->loop_dev.p, sizeof(DevLoop), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->loop_host->error == 2) return fail(c, MI_ICP_ERR_HIP, "the small-cloud loop's workgroups lost each other (epoch wait timed out): the registration is void");
     if (c->loop_host->error) return comm_failed(c, "the ranks' exchange timed out (mailbox): a peer did not post its sums");
     if (c->iter_fn && c->loop_host->history != 0ull && c->loop_host->iterations > c->iter_reported) {
         // the iterations started since the last look, in order (a ring: at most kLoopHistory of them per look)
@@ -681,8 +680,7 @@ static bool fused_iteration_applies(const mi_icp_ctx* c, bool seed) {
            c->n_user_pairs < 0 && c->ns > 0 && c->ns <= limit && c->nt > 0;
 }
 
-// n_iter > 1: that many iterations in ONE cooperative launch (fused_small.h icp_small_loop_kernel)
-static int launch_fused_iteration(mi_icp_ctx* c, DevLoop* d, int n_iter = 1) {
+static int launch_fused_iteration(mi_icp_ctx* c, DevLoop* d) {
     static const bool always_wait = std::getenv("MI_ICP_WAIT_LINKS") != nullptr;  // A/B switch (soak tests)
     if (always_wait) {
         TRY(start_links_async(c));
@@ -703,23 +701,6 @@ static int launch_fused_iteration(mi_icp_ctx* c, DevLoop* d, int n_iter = 1) {
         HIPCHK(c, hipMemsetAsync(ticket, 0, 256, c->stream));
     }
     EvTimer t(c, 0, true);
-    if (n_iter > 1) {
-        const float *a_sx = (const float*)c->sx.p, *a_sy = (const float*)c->sy.p, *a_sz = (const float*)c->sz.p;
-        int a_ns = (int)c->ns;
-        const float *a_rec = (const float*)c->nodes.p, *a_tblk = (const float*)c->tblk.p, *a_lreg = (const float*)lreg_of(c);
-        const float* a_halo = have_halo ? (const float*)c->thalo.p : nullptr;
-        uint32_t a_lf = c->leaf_first, a_np = npackets, a_nb = nblocks;
-        float a_r2 = c->loop_r2;
-        int32_t* a_idx = (int32_t*)c->nn_idx.p;
-        const float* a_trec = (const float*)c->trec.p;
-        uint32_t* a_ticket = (uint32_t*)c->ticket.p;
-        void* args[] = {&a_sx, &a_sy, &a_sz, &a_ns, &a_rec, &a_tblk, &a_lreg, &a_halo, &a_lf, &a_r2, &a_np, &a_nb, &a_idx, &want,
-                        &a_trec, &d, &partial, &a_ticket, &sys, &n_iter};
-        const void* fn = (c->loop_est == kEstP2P) ? (const void*)icp_small_loop_kernel<kEstP2P> : (const void*)icp_small_loop_kernel<kEstPt2Pl>;
-        HIPCHK(c, hipLaunchCooperativeKernel(fn, dim3(grid), dim3(kReduceThreads), args, 0, c->stream));
-        c->last_search_kind = 1;
-        return MI_ICP_OK;
-    }
 #define MI_FUSED_ARGS (const float*)c->sx.p, (const float*)c->sy.p, (const float*)c->sz.p, (int)c->ns, (const float*)c->nodes.p, \
             (const float*)c->tblk.p, (const float*)lreg_of(c), have_halo ? (const float*)c->thalo.p : nullptr, c->leaf_first, \
             c->loop_r2, npackets, nblocks, (int32_t*)c->nn_idx.p, want, (const float*)c->trec.p, d, partial, (uint32_t*)c->ticket.p, sys
@@ -729,24 +710,6 @@ static int launch_fused_iteration(mi_icp_ctx* c, DevLoop* d, int n_iter = 1) {
     KCHK(c);
     c->last_search_kind = 1;
     return MI_ICP_OK;
-}
-
-// SEVERAL ITERATIONS PER LAUNCH (fused_small.h icp_small_loop_kernel) where the one-launch iteration applies, the grid fits
-// the device one workgroup per CU (a cooperative launch: every workgroup resident), nothing asks for per-launch events
-// and no re-location launch has to ride between iterations (sources below the size that makes its own seeds never arm
-// one).  MI_ICP_NO_SMALL_LOOP: A/B switch.
-static bool small_loop_applies(const mi_icp_ctx* c) {
-    static const bool off = std::getenv("MI_ICP_NO_SMALL_LOOP") != nullptr;
-    static const int coop_cus = [] {
-        int dev = 0, coop = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop) return 0;
-        return (hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 0;
-    }();
-    if (off || coop_cus <= 0 || c->profiling || c->stamps_on || c->relocate_armed || c->iter_fn) return false;
-    if (!fused_iteration_applies(c, true)) return false;
-    const int64_t nblocks = ((c->ns + 63) / 64 + kFusedPackets - 1) / kFusedPackets;
-    return ((nblocks + 7) / 8) * 8 <= coop_cus;
 }
 
 // one evaluation: search under the loop's transform, reduction, all-reduce, step kernel
@@ -814,8 +777,7 @@ static int loop_run(mi_icp_ctx* c, int budget) {
         c->halo_use = halo_poll(c);
         const bool carried = c->relocate_armed && c->halo_use;  // this chunk's iterations carry the gated re-location launches
         const int relocations_before = c->loop_host->relocations;
-        if (n > 1 && small_loop_applies(c)) TRY(launch_fused_iteration(c, (DevLoop*)c->loop_dev.p, n));
-        else for (int i = 0; i < n; ++i) TRY(loop_enqueue_evaluation(c, true));
+        for (int i = 0; i < n; ++i) TRY(loop_enqueue_evaluation(c, true));
         if (no_halo) HIPCHK(c, hipMemcpyAsync(c->u_host + 16, c->halo_want.p, kWantSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         TRY(loop_pull(c));
         const int executed = c->loop_host->passes - passes_before;

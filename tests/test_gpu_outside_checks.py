@@ -108,3 +108,60 @@ def test_colour_gradient_kernel_against_lstsq(eng):
         worst = max(worst, np.abs(g[i] - ref).max() / tol)
         checked += 1
     assert checked > 500 and worst <= 1.0, worst
+
+
+def test_symmetric_and_colored_systems_of_the_engine_against_numpy_rows(eng):
+    """the two estimators the second loop does not run: the engine's 6x6 systems against rows written out in numpy fp64
+    (transformation_estimation.cu:58-90; colored_icp.cu:150-216), correspondences from the engine's own search"""
+    d = make_pair(30000, seed=8, noise=0.05)
+    eng.set_target(d["tgt"], d["tgt_nrm"])
+    eng.set_source(d["src"], d["src_nrm"])
+    eng.search_radius_1nn(d["max_dist"])
+    cor = eng.get_correspondences()
+    got = eng.compute_system(3)
+    J, r = inp.rows_symmetric(d["src"][cor[:, 0]], d["src_nrm"][cor[:, 0]], d["tgt"][cor[:, 1]], d["tgt_nrm"][cor[:, 1]])
+    ref = inp.system_of_rows(J, r)
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    assert rel(got[:21], ref[:21]) <= 1e-6 and rel(got[21:27], ref[21:27]) <= 1e-5 and abs(got[27] - ref[27]) <= 1e-5 * ref[27]
+    assert got[29] == len(cor)
+    # colored: the engine's own gradients (held against lstsq above), intensities as colored_icp.cu:91 forms them
+    tgt, col, T = make_colored(12000, seed=6, planar=False)
+    nrm = np.asarray(eng.estimate_normals_knn(tgt, 20), F32)
+    src = (tgt.astype(np.float64) @ np.linalg.inv(T.astype(np.float64))[:3, :3].T + np.linalg.inv(T.astype(np.float64))[:3, 3]).astype(F32)
+    eng.set_target(tgt, nrm)
+    eng.set_source(src)
+    eng.set_target_colors(col)
+    eng.set_source_colors(col)
+    grad = np.asarray(eng.compute_color_gradients(6.0, 30), F32)
+    eng.search_radius_1nn(3.0)
+    cor = eng.get_correspondences()
+    got = eng.compute_system(4)
+    c = col.astype(F32)
+    inten = (((c[:, 0] + c[:, 1]) + c[:, 2]).astype(np.float64) / 3.0).astype(F32)
+    J, r = inp.rows_colored(src[cor[:, 0]], tgt[cor[:, 1]], nrm[cor[:, 1]], inten[cor[:, 0]], inten[cor[:, 1]], grad[cor[:, 1]], 0.968)
+    ref = inp.system_of_rows(J, r)
+    assert rel(got[:21], ref[:21]) <= 2e-6 and rel(got[21:27], ref[21:27]) <= 2e-5 and abs(got[27] - ref[27]) <= 2e-5 * ref[27]
+
+
+def test_non_finite_target_points_are_never_matched(eng):
+    """NaN / inf points in the TARGET: the tree is built, nobody matches them, EstimateNormals and VoxelDownSample survive
+    (a grid whose extent overflows: no voxels, down_sample.cu:186-189)"""
+    rng = np.random.default_rng(10)
+    for kind in ("nan", "inf", "one coordinate"):
+        tgt = rng.random((200_000, 3), dtype=np.float32)
+        if kind == "nan":
+            tgt[1000:1020] = np.nan
+        elif kind == "inf":
+            tgt[1000:1020] = np.inf
+        else:
+            tgt[1000:1020, 1] = np.nan
+        src = rng.random((50_000, 3), dtype=np.float32)
+        eng.set_target(tgt)
+        eng.set_source(src)
+        for radius in (0.03, 3.0):
+            idx, d2, st = eng.search_radius_1nn(radius)
+            assert not np.isin(idx, np.arange(1000, 1020)).any() and np.isfinite(d2[idx >= 0]).all(), kind
+        nrm = np.asarray(eng.estimate_normals_knn(tgt, 30))
+        assert np.isfinite(nrm[np.isfinite(tgt).all(1)]).all(), kind
+        p, _, _ = eng.voxel_downsample(tgt, 0.02)
+        assert (len(p) == 0) if kind == "inf" else (len(p) > 1000), kind

@@ -245,27 +245,6 @@ def test_one_launch_iteration_equals_the_two_kernel_form(tmp_path, est):
     assert np.array_equal(a["corr"], b["corr"])
 
 
-@pytest.mark.parametrize("est", ["pt2pl", "p2p"])
-def test_several_iterations_per_launch_equal_one_launch_each_bit_for_bit(tmp_path, est):
-    """Round 6: sources whose one-launch iteration fits the device one workgroup per CU (<= 64k points) run a whole chunk of
-    iterations in ONE cooperative launch (fused_small.h icp_small_loop_kernel: the workgroups wait for the stepping one at
-    an epoch word).  Same blocks, packets, rows and fixed-order totals as a launch per iteration
-    (MI_ICP_NO_SMALL_LOOP=1 in a child process): every number identical."""
-    import subprocess
-    import sys
-    here = os.path.abspath(__file__)
-    outs = {}
-    for name, extra in (("loop", {}), ("launches", {"MI_ICP_NO_SMALL_LOOP": "1"})):
-        path = str(tmp_path / (name + ".npz"))
-        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_seeded as t; t._run_small_loop(%r, %r)"
-                % (os.path.dirname(here), os.path.dirname(os.path.dirname(here)), path, est))
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs[name] = np.load(path)
-    a, b = outs["loop"], outs["launches"]
-    assert np.array_equal(a["stat"], b["stat"]) and np.array_equal(a["T"], b["T"]) and np.array_equal(a["corr"], b["corr"])
-
-
 def _loop_counters(e):
     import ctypes as C
     out = (C.c_int32 * 4)()
