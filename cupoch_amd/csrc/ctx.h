@@ -71,6 +71,8 @@ struct mi_icp_ctx {
     int64_t halo_iters = 0;      // seeded iterations against this target since it was set ...
     int64_t halo_asked = 0;      // ... and the lanes that asked for a halo in them
     int64_t halo_lanes = 0;      // ... out of this many lanes (source points x iterations looked at)
+    int64_t halo_iters_unseen = 0;  // iterations since the counter was last looked at
+    uint32_t halo_chunks = 0;    // chunks of a declined loop (it looks at the counter every eighth)
     int64_t halo_want_seen = 0;  // the counter's value at the last look (it is zeroed when a loop begins)
     int halo_looks = 0;          // looks of this loop while undecided
     bool halo_use = false;       // the loop's launches take the halos (looked up once per chunk: an event query costs microseconds)

@@ -19,9 +19,10 @@ using host::Mat4;
 namespace mi {
 namespace eng {
 
-// elements per thread that travel together in reduce_pt2pl_kernel: 2 since round 6 (4 before: profiles/r06_reduce_shape_sweep.txt --
-// the step 1-3 % shorter at 10M, 5M and 2.5M source points, unchanged at 1.25M)
-constexpr int kPt2PlInFlight = 2;
+// elements per thread that travel together in reduce_pt2pl_kernel: 2 from kPt2PlTwoFrom source points up (round 6:
+// profiles/r06_reduce_shape_sweep.txt -- the step 2 % shorter at 10M and 5M points on 512 blocks), 4 below (an eighth of the
+// bench's source takes 16 elements per thread on ~300 blocks: in pairs that is eight dependent round trips instead of four)
+constexpr int64_t kPt2PlTwoFrom = (int64_t)4 << 20;
 
 // sources of at least this many points make their own seeds for a first pass (tuning knob MI_ICP_COARSE_MIN)
 static int64_t coarse_first_min() {
@@ -125,7 +126,7 @@ int occupancy_loop(int which) {
     hipError_t e = hipErrorInvalidValue;
     if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, nn_packet_kernel<true, false>, kNNThreads, 0);
     else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, nn_packet_kernel<false, false>, kNNThreads, 0);
-    else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reduce_pt2pl_kernel<kPt2PlInFlight, 1>, kReduceThreads, 0);
+    else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reduce_pt2pl_kernel<2, 1>, kReduceThreads, 0);
     else return -1;
     return e == hipSuccess ? blocks : -2;
 }
@@ -245,17 +246,24 @@ int launch_reduce(mi_icp_ctx* c, int est, int mode, const Mat4& T, DevLoop* loop
         EvTimer t(c, 1, loop != nullptr);
         const MailArgs no_mail = {nullptr, nullptr, 0, 1, 0u, nullptr, nullptr};
         const bool mail = mail_on(c);
+        const bool two = a.count >= kPt2PlTwoFrom;
+#define MI_PT2PL(STEP, STAMP, MAILARGS)                                                                                       \
+    do {                                                                                                                     \
+        if (two) reduce_pt2pl_kernel<2, STEP, STAMP><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, MAILARGS); \
+        else reduce_pt2pl_kernel<4, STEP, STAMP><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, MAILARGS);     \
+    } while (0)
         if (fuse_step && loop && mail) {  // N ranks on one node: exchange + step in the finishing block
-            if (c->stamps_on) reduce_pt2pl_kernel<kPt2PlInFlight, 2, true><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, mail_args(c));
-            else reduce_pt2pl_kernel<kPt2PlInFlight, 2><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, mail_args(c));
+            if (c->stamps_on) MI_PT2PL(2, true, mail_args(c));
+            else MI_PT2PL(2, false, mail_args(c));
             if (stepped) *stepped = true;
         } else if (fuse_step && loop && !c->comm && !c->mail_dev) {
-            if (c->stamps_on) reduce_pt2pl_kernel<kPt2PlInFlight, 1, true><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
-            else reduce_pt2pl_kernel<kPt2PlInFlight, 1><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
+            if (c->stamps_on) MI_PT2PL(1, true, no_mail);
+            else MI_PT2PL(1, false, no_mail);
             if (stepped) *stepped = true;
         } else {
-            reduce_pt2pl_kernel<kPt2PlInFlight, 0><<<g2, kReduceThreads, 0, c->stream>>>(a, X, loop, partial, ticket, sys, no_mail);
+            MI_PT2PL(0, false, no_mail);
         }
+#undef MI_PT2PL
         KCHK(c);
         return MI_ICP_OK;
     }
@@ -759,7 +767,7 @@ static bool halo_memory_free(const mi_icp_ctx* c) {
 
 static int loop_run(mi_icp_ctx* c, int budget) {
     constexpr int kChunk = 8;
-    constexpr int64_t kLarge = 500000, kHaloLongRun = 40;
+    constexpr int64_t kLarge = 500000, kHaloLongRun = 40, kHaloVeryLongRun = 1000;
     while (budget > 0) {
         const bool no_halo = !c->links_ready && !c->links_inflight && c->links_allowed && c->nt > 0;
         const bool undecided = no_halo && !c->halo_declined;
@@ -778,7 +786,10 @@ static int loop_run(mi_icp_ctx* c, int budget) {
         const bool carried = c->relocate_armed && c->halo_use;  // this chunk's iterations carry the gated re-location launches
         const int relocations_before = c->loop_host->relocations;
         for (int i = 0; i < n; ++i) TRY(loop_enqueue_evaluation(c, true));
-        if (no_halo) HIPCHK(c, hipMemcpyAsync(c->u_host + 16, c->halo_want.p, kWantSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        // (a loop that has declined keeps counting -- a target registered against for long may still earn its halos -- but
+        // looks at the 4-KB counter only every eighth chunk: the copy is ~1 us per iteration of an 8-way shard's 36-us step)
+        const bool look = no_halo && (!c->halo_declined || (++c->halo_chunks & 7) == 0);
+        if (look) HIPCHK(c, hipMemcpyAsync(c->u_host + 16, c->halo_want.p, kWantSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         TRY(loop_pull(c));
         const int executed = c->loop_host->passes - passes_before;
         collect_pooled(c, executed);
@@ -789,7 +800,10 @@ static int loop_run(mi_icp_ctx* c, int budget) {
         else if (!c->relocate_armed && c->relocate_possible && c->loop_host->relocations != relocations_before) c->relocate_armed = true;
         budget -= n;
         c->halo_iters += executed;
-        if (no_halo) {
+        c->halo_iters_unseen += executed;
+        if (look) {
+            const int64_t seen_iters = c->halo_iters_unseen;
+            c->halo_iters_unseen = 0;
             // (a 32-bit device counter that keeps counting through a long stepping loop: the difference is taken
             // modulo 2^32, so a wrap between two looks costs nothing)
             uint32_t counted = 0u;  // (nn_search.h kWantSlots: the counter's words, summed modulo 2^32)
@@ -797,7 +811,7 @@ static int loop_run(mi_icp_ctx* c, int budget) {
             const int64_t asked = (int64_t)(uint32_t)(counted - (uint32_t)c->halo_want_seen);  // by this chunk's iterations
             c->halo_want_seen = (int64_t)counted;
             c->halo_asked += asked;
-            c->halo_lanes += c->ns * (int64_t)std::max(executed, 0);
+            c->halo_lanes += c->ns * std::max<int64_t>(seen_iters, 0);
             if (undecided) {
                 ++c->halo_looks;
                 const int64_t per = std::max(executed, 1);
@@ -809,11 +823,15 @@ static int loop_run(mi_icp_ctx* c, int budget) {
                     ++c->prof[6];
                     TRY(start_links_async(c));
                 }
-            } else if (c->halo_iters >= kHaloLongRun && c->halo_asked * 100 >= c->halo_lanes && halo_memory_free(c)) {
+            } else if (((c->halo_iters >= kHaloLongRun && c->halo_asked * 100 >= c->halo_lanes) ||
+                        (c->halo_iters >= kHaloVeryLongRun && c->halo_asked > 0)) && halo_memory_free(c)) {
                 // (in the background: halo_declined stays, nothing waits.  Until round 6 ANY lane that had ever asked
-                // started this build -- 2.2 ms of GPU time and 1.6 GB at 10M points inside the loop of a caller whose
-                // data never reads a halo: one window in seven of the headline bench 70 % slow.  Now: at least 1 % of
-                // the lanes per iteration, and twice the build's memory free.)
+                // started this build after 40 iterations -- 2.2 ms of GPU time and 1.6 GB at 10M points inside the loop
+                // of a caller whose data hardly reads a halo: one window in seven of the headline bench 70 % slow.  What
+                // the halos save such a loop is the tail of its searches -- the few packets that take a one-record walk:
+                // 2-3 us per iteration, 2 % of a 10M-point step, 7 % of an eighth's -- which pays for the build after
+                // ~1000 iterations.  So: at least 1 % of the lanes asking per iteration after 40, or anybody asking
+                // after 1000 (a map that keeps being registered against), and twice the build's memory free.)
                 ++c->prof[6];
                 TRY(start_links_async(c));
             }
@@ -884,6 +902,8 @@ static int loop_begin(mi_icp_ctx* c, int est, float max_distance, const float* i
     c->halo_declined = false;
     c->halo_want_seen = 0;
     c->halo_looks = 0;
+    c->halo_iters_unseen = 0;
+    c->halo_chunks = 0;
     c->ran_loop = true;
     {
         uint32_t* want;
