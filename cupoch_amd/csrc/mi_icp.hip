@@ -797,7 +797,10 @@ static int loop_run(mi_icp_ctx* c, int budget) {
         if (carried && c->loop_host->relocations == relocations_before) c->relocate_armed = false;
         // ... and they may grow again (point-to-plane sliding, an escape from a plateau): the step keeps sizing itself on
         // the device whether or not the launches ride along, so a chunk without them that took a large step arms the next
-        else if (!c->relocate_armed && c->relocate_possible && c->loop_host->relocations != relocations_before) c->relocate_armed = true;
+        // (large sources only: a stale seed's climb costs a 10M-point search milliseconds, a 100k-point one less than the
+        // eight 5-us launches an armed chunk carries -- the reference's own benchmark call, 113k points sliding along
+        // themselves, 1.66 -> 1.71 ms with the re-arming at every size)
+        else if (!c->relocate_armed && c->relocate_possible && c->ns >= kLarge && c->loop_host->relocations != relocations_before) c->relocate_armed = true;
         budget -= n;
         c->halo_iters += executed;
         c->halo_iters_unseen += executed;
