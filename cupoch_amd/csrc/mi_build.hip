@@ -480,11 +480,13 @@ int mi_icp_set_target(mi_icp_ctx* c, const float* xyz, const float* normals, con
     c->leaf_first = leaf_first;
     c->nrecords = nrecords;
     c->cell_levels = no_cells ? -1 : lay.levels;
-    // A context that has run a registration loop will run another.  For a small target (frame-to-frame callers:
-    // KinFu, odometry) the halos are started right away, on the private stream, next to the staging of the source:
-    // they cost that little, and the loop's first seeded iterations find them ready.  For a large one the build
-    // would fight the staging for the memory system; there the loop's own searches say whether it is wanted.
-    if (c->ran_loop && c->links_allowed && n < kHaloAheadMax) TRY(start_links_async(c));
+    // A context whose loops have ASKED for halos will run another such loop.  For a small target (frame-to-frame
+    // callers: KinFu, odometry) the halos are then started right away, on the private stream, next to the staging of the
+    // source: the loop's first seeded iterations find them ready.  For a large one the build would fight the staging
+    // for the memory system; there the loop's own searches say whether it is wanted.  (Until round 6 ANY earlier loop on
+    // the context was enough: on clean frames the 0.18-ms build per pyramid level cost a KinFu step 2-5 % and a
+    // 100k-300k-point call 4 %, same box, for halos nothing read.)
+    if (c->ran_loop && c->halo_sticky && c->links_allowed && n < kHaloAheadMax) TRY(start_links_async(c));
     if (c->profiling) {
         (void)hipEventRecord(e1, c->stream);
         (void)hipStreamSynchronize(c->stream);

@@ -66,7 +66,7 @@ if key:
            "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb, "calibration_reported_over_known": factor,
            "fetch_correction": fsum, "hbm_bytes_per_launch": int(fetch_bytes + write_bytes),
            "note": "FETCH_SIZE x %.3f (byte-weighted over the kernel's access shapes, calibrated on 1 GiB of known "
-                   "bytes each: profiles/r05_fetch_calibration.txt) + WRITE_SIZE / %.3f" % (fsum, factor.get("calib_write4", 1.0))}
+                   "bytes each: profiles/r06_fetch_calibration.txt) + WRITE_SIZE / %.3f" % (fsum, factor.get("calib_write4", 1.0))}
     json.dump(out, open("gpurun_out/nn_traffic.json", "w"), indent=1)
 else:
     print("no nn_packet_kernel<true,false> rows found")
