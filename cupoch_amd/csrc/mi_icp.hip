@@ -768,14 +768,19 @@ static bool halo_memory_free(const mi_icp_ctx* c) {
 static int loop_run(mi_icp_ctx* c, int budget) {
     constexpr int kChunk = 8;
     constexpr int64_t kLarge = 500000, kHaloLongRun = 40, kHaloVeryLongRun = 1000;
+    int chunk = kChunk;
     while (budget > 0) {
         const bool no_halo = !c->links_ready && !c->links_inflight && c->links_allowed && c->nt > 0;
         const bool undecided = no_halo && !c->halo_declined;
         // (a build the loop's decision started -- or one started with the loop on a context that has asked
         // before, or behind a small target's tree: the stream waits for what is left of it rather than walk)
         if (c->links_inflight && !c->halo_declined) TRY(ensure_links(c));
-        // (a short remainder rides along: one host synchronisation less than it would cost)
-        int n = (budget <= kChunk + kChunk / 2) ? budget : kChunk;
+        // (a short remainder rides along: one host synchronisation less than it would cost.  The chunks of one call grow
+        // -- 8, 16, 32, 32 ...: a look at the loop is ~30 us of copies, synchronisation and relaunch, two iterations of a
+        // 100k-point loop; a loop that has not converged within its first chunks is unlikely to in the next few, and an
+        // iteration enqueued past the end costs ~3 us.  The sizes depend on the budget alone: every rank enqueues alike.)
+        int n = (budget <= chunk + chunk / 2) ? budget : chunk;
+        const bool grown = n == chunk;
         // (with several ranks the chunking must not depend on anything a rank sees alone: every rank has to
         // enqueue the same number of evaluations -- an in-library RCCL all-reduce is a host-side call per
         // evaluation, and a rank that stops at `done` after fewer of them would leave its peers' calls unmatched)
@@ -840,6 +845,7 @@ static int loop_run(mi_icp_ctx* c, int budget) {
             }
         }
         if (c->loop_host->done) break;
+        if (grown && n == chunk) chunk = std::min(chunk * 2, 32);
     }
     return MI_ICP_OK;
 }

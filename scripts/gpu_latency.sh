@@ -21,11 +21,11 @@ seq=rows[b0:]
 def span(s): return (int(s[-1]['End_Timestamp'])-int(s[0]['Start_Timestamp']))/1e3
 def ksum(s): return sum(int(r['End_Timestamp'])-int(r['Start_Timestamp']) for r in s)/1e3
 print('last call: %d kernels, span %.1f us, kernel time %.1f us' % (len(seq), span(seq), ksum(seq)))
-nn=[i for i,r in enumerate(seq) if 'nn_packet_kernel<true' in r['Kernel_Name']]
+nn=[i for i,r in enumerate(seq) if 'nn_packet_kernel<true' in r['Kernel_Name'] or 'icp_small_iteration' in r['Kernel_Name']]
 it=seq[nn[1]:]           # from the second seeded pass on: the steady iterations
-n_it=sum(1 for r in it if 'nn_packet_kernel<true' in r['Kernel_Name'])
+n_it=sum(1 for r in it if 'nn_packet_kernel<true' in r['Kernel_Name'] or 'icp_small_iteration' in r['Kernel_Name'])
 print('steady iterations: %d, span %.1f us (%.1f per iteration), kernel time %.1f us (%.1f per iteration)' % (n_it, span(it), span(it)/n_it, ksum(it), ksum(it)/n_it))
 t0=int(seq[0]['Start_Timestamp'])
-for r in seq[:40]:
+for r in seq[:70]:
     print('%9.1f %8.1f  %s' % ((int(r['Start_Timestamp'])-t0)/1e3,(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3, r['Kernel_Name'].split('(')[0][:50]))
 PY
