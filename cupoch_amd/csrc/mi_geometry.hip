@@ -7,6 +7,7 @@
 #include "lbvh.h"
 #include "odometry.h"
 #include "reduce.h"
+#include "voxel_dense.h"
 
 using namespace mi;
 using namespace mi::eng;
@@ -19,6 +20,8 @@ int occupancy_geometry(int which) {
     hipError_t e = hipErrorInvalidValue;
     if (which == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, rs_scatter_pay<8>, kSortThreads, 0);
     else if (which == 6) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, voxel_means_wave, 64, 0);
+    else if (which == 7) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vx_scatter, kVxThreads, 0);
+    else if (which == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vx_finish, kVxFinThreads, 0);
     else return -1;
     return e == hipSuccess ? blocks : -2;
 }
@@ -26,6 +29,13 @@ int occupancy_geometry(int which) {
 }  // namespace mi
 
 extern "C" {
+
+#ifdef MI_VX_CLOCKS
+// measurements only (scripts/dev/voxel_dense_clocks.py): the phase clocks of the last vx_scatter / vx_finish launches
+int mi_vx_clocks_dump(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vx_clk), sizeof(unsigned long long) * 2 * 4096 * kVxClkSlots) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // ---------------------------------------------------------------------------
 int mi_icp_transform(mi_icp_ctx* c, const float* T, float* xyz, float* normals, float* covs,
@@ -132,6 +142,100 @@ int mi_icp_covariances_from_normals(mi_icp_ctx* c, const float* normals, int64_t
     KCHK(c);
     if (mem_kind == MI_ICP_HOST) TRY(from_device(c, (const float*)dc, covs, (size_t)n * 9, mem_kind));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MI_ICP_OK;
+}
+
+// VoxelDownSample of a DENSE grid (voxel_dense.h): every point moves once.  Which clouds: a packed key of 14 ... 21 bits
+// (the finishing kernel gives a thread a voxel of its bucket: L <= 10 low bits; the partition has at most 2048 buckets:
+// hb <= 11 high bits) and enough points to fill the buckets.  hb is chosen for ~6k points per bucket (one LDS chunk).
+static bool vx_plan(int64_t n, int bits, VxPlan* p) {
+    if (std::getenv("MI_ICP_NO_DENSE_VOXEL")) return false;  // A/B switch, read at every call (tests compare both paths)
+    if (bits < 14 || bits > 21 || n < (1 << 17) || n > 0x7fff0000ll) return false;
+    int hb = 0;
+    while (((int64_t)6144 << hb) < n) ++hb;
+    hb = std::max(hb, bits - 10);
+    hb = std::min(hb, std::min(11, bits - 6));
+    if (hb < bits - 10 || (n >> hb) < 256) return false;
+    p->bits = bits;
+    p->hb = hb;
+    p->L = bits - hb;
+    p->ntiles = (int)((n + kVxTile - 1) / kVxTile);
+    p->nsegs = (p->ntiles + kVxSeg - 1) / kVxSeg;
+    p->max_bucket = (uint32_t)std::max<int64_t>(32768, 4 * (n >> hb));
+    return true;
+}
+
+// the order of LDS adds inside one instruction (voxel_dense.h "Ranks"), checked once per context
+static int vx_order_ok(mi_icp_ctx* c, bool* ok) {
+    if (c->vx_order == 0) {
+        uint32_t* w;
+        TRY(ensure(c, c->vx_tab, (size_t)64, &w));
+        HIPCHK(c, hipMemsetAsync(w, 0, sizeof(uint32_t), c->stream));
+        vx_probe_order<<<64, 256, 0, c->stream>>>(w);
+        KCHK(c);
+        HIPCHK(c, hipMemcpyAsync(c->u_host, w, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->vx_order = (c->u_host[0] == 0u) ? 1 : -1;
+    }
+    *ok = c->vx_order > 0;
+    return MI_ICP_OK;
+}
+
+// returns MI_ICP_OK with *done = false when the cloud turns out to crowd into a few buckets (nothing has been written)
+static int voxel_downsample_dense(mi_icp_ctx* c, const float* dp, const float* dn, const float* dcol, int64_t n,
+                                  const VoxelGrid& grid, const VxPlan& pl, float* out_xyz, float* out_normals, float* out_colors,
+                                  int64_t* m, int mem_kind, bool* done) {
+    *done = false;
+    bool ordered = false;
+    TRY(vx_order_ok(c, &ordered));
+    if (!ordered) return MI_ICP_OK;
+    VxGrid g;
+    g.g = grid;
+    g.inv = 1.0f / grid.voxel;
+    g.key_mask = (1u << pl.bits) - 1u;
+    const int B = 1 << pl.hb;
+    // the tables: status words first (64-bit), then [ntiles][B], [nsegs][B], bucket_start[B + 1], the control words
+    const size_t words = (size_t)2 * B + (size_t)pl.ntiles * B + (size_t)pl.nsegs * B + (size_t)B + 1 + kVxCtlWords;
+    uint32_t* w;
+    TRY(ensure(c, c->vx_tab, words, &w));
+    unsigned long long* status = reinterpret_cast<unsigned long long*>(w);
+    uint32_t* tab = w + 2 * (size_t)B;
+    uint32_t* seg_tot = tab + (size_t)pl.ntiles * B;
+    uint32_t* bucket_start = seg_tot + (size_t)pl.nsegs * B;
+    uint32_t* ctl = bucket_start + B + 1;
+    VxArrays a;
+    const float* in[3] = {dp, dn, dcol};
+    for (int k = 0; k < 3; ++k) {
+        a.in[k] = reinterpret_cast<const Pay3*>(in[k]);
+        a.out[k] = nullptr;
+        if (in[k]) TRY(ensure(c, c->vpay[k], (size_t)n, &a.out[k]));
+    }
+    const int64_t vmax = std::min<int64_t>(n, (int64_t)1 << pl.bits);
+    float *op = out_xyz, *on = out_normals, *oc = out_colors;
+    if (mem_kind == MI_ICP_HOST) {
+        TRY(ensure(c, c->stage[3], (size_t)vmax * 3, &op));
+        if (dn) TRY(ensure(c, c->stage[4], (size_t)vmax * 3, &on));
+        if (dcol) TRY(ensure(c, c->stage[5], (size_t)vmax * 3, &oc));
+    }
+    vx_hist<<<pl.ntiles, kVxThreads, 0, c->stream>>>(a.in[0], (int)n, g, pl.bits, pl.L, tab);
+    vx_colsum<<<dim3((unsigned)pl.nsegs, (unsigned)((B + 255) / 256)), 256, 0, c->stream>>>(tab, pl.ntiles, B, seg_tot);
+    vx_colscan<<<1, 1024, 0, c->stream>>>(seg_tot, pl.nsegs, B, (int)n, pl.max_bucket, bucket_start, ctl, status);
+    vx_scatter<<<pl.ntiles, kVxThreads, 0, c->stream>>>(a, (int)n, g, pl.bits, pl.L, tab, seg_tot, bucket_start, ctl);
+    vx_finish<<<B, kVxFinThreads, 0, c->stream>>>(a.out[0], a.out[1], a.out[2], g, pl.bits, pl.L, bucket_start, ctl, status, op,
+                                                   dn ? on : nullptr, dcol ? oc : nullptr);
+    KCHK(c);
+    HIPCHK(c, hipMemcpyAsync(c->u_host, ctl, kVxCtlWords * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->u_host[0] != 0u) return MI_ICP_OK;  // skewed: the general path
+    const int64_t nvox = (int64_t)c->u_host[2];
+    if (mem_kind == MI_ICP_HOST) {
+        TRY(from_device(c, (const float*)op, out_xyz, (size_t)nvox * 3, mem_kind));
+        if (dn) TRY(from_device(c, (const float*)on, out_normals, (size_t)nvox * 3, mem_kind));
+        if (dcol) TRY(from_device(c, (const float*)oc, out_colors, (size_t)nvox * 3, mem_kind));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    *m = nvox;
+    *done = true;
     return MI_ICP_OK;
 }
 
@@ -255,6 +359,15 @@ int mi_icp_voxel_downsample(mi_icp_ctx* c, const float* xyz, const float* normal
         g.bits_z = bits[2];
     }
 
+    // a dense grid: one move of every point (voxel_dense.h); a cloud that crowds into a few buckets comes back undone
+    {
+        VxPlan pl;
+        if (vx_plan(n, bits[0] + bits[1] + bits[2], &pl)) {
+            bool done = false;
+            TRY(voxel_downsample_dense(c, dp, dn, dcol, n, g, pl, out_xyz, out_normals, out_colors, m, mem_kind, &done));
+            if (done) return MI_ICP_OK;
+        }
+    }
     // (grids whose packed key needs more than 32 bits keep the first form below: 64-bit keys + indices, one gather)
     if (bits[0] + bits[1] + bits[2] <= 32)
         return voxel_downsample_keys32(c, dp, dn, dcol, n, g, bits[0] + bits[1] + bits[2], out_xyz, out_normals, out_colors, m,

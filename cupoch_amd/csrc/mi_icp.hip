@@ -369,7 +369,7 @@ void mi_icp_destroy(mi_icp_ctx* c) {
                      &c->dense_idx, &c->flags, &c->pairs_out, &c->seg_start, &c->loop_dev, &c->ticket, &c->mail_state, &c->alt[0],
                      &c->alt[1], &c->alt[2], &c->alt[3], &c->alt[4], &c->alt[5], &c->alt[6], &c->alt[7], &c->alt[8], &c->stage[0],
                      &c->stage[1], &c->stage[2], &c->stage[3], &c->stage[4], &c->stage[5], &c->knn_idx, &c->tscale, &c->vpay[0], &c->vpay[1],
-                     &c->vpay[2], &c->vpay[3], &c->vpay[4], &c->vpay[5], &c->stamps, &c->knn_flags, &c->gplanes, &c->src_bounds, &c->cell_boxes, &c->cell_hist};
+                     &c->vpay[2], &c->vpay[3], &c->vpay[4], &c->vpay[5], &c->stamps, &c->knn_flags, &c->gplanes, &c->src_bounds, &c->cell_boxes, &c->cell_hist, &c->vx_tab};
     for (DevBuf* b : all) release(*b);
     if (c->sys_host) (void)hipHostFree(c->sys_host);
     if (c->cell_total_host) (void)hipHostFree(c->cell_total_host);
