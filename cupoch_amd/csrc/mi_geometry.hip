@@ -20,8 +20,8 @@ int occupancy_geometry(int which) {
     hipError_t e = hipErrorInvalidValue;
     if (which == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, rs_scatter_pay<8>, kSortThreads, 0);
     else if (which == 6) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, voxel_means_wave, 64, 0);
-    else if (which == 7) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vx_scatter, kVxThreads, 0);
-    else if (which == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vx_finish, kVxFinThreads, 0);
+    else if (which == 7) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vx_scatter<1>, kVxThreads, 0);
+    else if (which == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vx_finish<false, false>, kVxFinThreads, 0);
     else return -1;
     return e == hipSuccess ? blocks : -2;
 }
@@ -145,26 +145,6 @@ int mi_icp_covariances_from_normals(mi_icp_ctx* c, const float* normals, int64_t
     return MI_ICP_OK;
 }
 
-// VoxelDownSample of a DENSE grid (voxel_dense.h): every point moves once.  Which clouds: a packed key of 14 ... 21 bits
-// (the finishing kernel gives a thread a voxel of its bucket: L <= 10 low bits; the partition has at most 2048 buckets:
-// hb <= 11 high bits) and enough points to fill the buckets.  hb is chosen for ~6k points per bucket (one LDS chunk).
-static bool vx_plan(int64_t n, int bits, VxPlan* p) {
-    if (std::getenv("MI_ICP_NO_DENSE_VOXEL")) return false;  // A/B switch, read at every call (tests compare both paths)
-    if (bits < 14 || bits > 21 || n < (1 << 17) || n > 0x7fff0000ll) return false;
-    int hb = 0;
-    while (((int64_t)6144 << hb) < n) ++hb;
-    hb = std::max(hb, bits - 10);
-    hb = std::min(hb, std::min(11, bits - 6));
-    if (hb < bits - 10 || (n >> hb) < 256) return false;
-    p->bits = bits;
-    p->hb = hb;
-    p->L = bits - hb;
-    p->ntiles = (int)((n + kVxTile - 1) / kVxTile);
-    p->nsegs = (p->ntiles + kVxSeg - 1) / kVxSeg;
-    p->max_bucket = (uint32_t)std::max<int64_t>(32768, 4 * (n >> hb));
-    return true;
-}
-
 // the order of LDS adds inside one instruction (voxel_dense.h "Ranks"), checked once per context
 static int vx_order_ok(mi_icp_ctx* c, bool* ok) {
     if (c->vx_order == 0) {
@@ -181,61 +161,86 @@ static int vx_order_ok(mi_icp_ctx* c, bool* ok) {
     return MI_ICP_OK;
 }
 
-// returns MI_ICP_OK with *done = false when the cloud turns out to crowd into a few buckets (nothing has been written)
-static int voxel_downsample_dense(mi_icp_ctx* c, const float* dp, const float* dn, const float* dcol, int64_t n,
-                                  const VoxelGrid& grid, const VxPlan& pl, float* out_xyz, float* out_normals, float* out_colors,
-                                  int64_t* m, int mem_kind, bool* done) {
-    *done = false;
+// VoxelDownSample of a DENSE grid (voxel_dense.h): every point moves once.  Launched BEHIND the bounds kernels without
+// waiting for them: the plan is made on the device (vx_plan_kernel: a packed key of 14 ... 21 bits and enough points per
+// bucket), every kernel reads it there and does nothing when the grid is not one for this path.  The caller then waits
+// ONCE, for the bounds and this path's control words together.  *launched = false: nothing was started.
+static int voxel_dense_launch(mi_icp_ctx* c, const float* dp, const float* dn, const float* dcol, int64_t n, float voxel,
+                              const float* bounds_dev, float* out_xyz, float* out_normals, float* out_colors, int mem_kind,
+                              bool* launched, float** op_, float** on_, float** oc_) {
+    *launched = false;
+    if (std::getenv("MI_ICP_NO_DENSE_VOXEL")) return MI_ICP_OK;  // A/B switch, read at every call (tests compare both paths)
+    if (n < (1 << 17) || n > ((int64_t)1 << 26)) return MI_ICP_OK;
     bool ordered = false;
     TRY(vx_order_ok(c, &ordered));
     if (!ordered) return MI_ICP_OK;
-    VxGrid g;
-    g.g = grid;
-    g.inv = 1.0f / grid.voxel;
-    g.key_mask = (1u << pl.bits) - 1u;
-    const int B = 1 << pl.hb;
-    // the tables: status words first (64-bit), then [ntiles][B], [nsegs][B], bucket_start[B + 1], the control words
-    const size_t words = (size_t)2 * B + (size_t)pl.ntiles * B + (size_t)pl.nsegs * B + (size_t)B + 1 + kVxCtlWords;
+    static const int ncu = [] { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); return (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }();
+    const int ntiles = (int)((n + kVxTile - 1) / kVxTile);
+    const int nsegs = (ntiles + kVxSeg - 1) / kVxSeg;
+    // the tables, sized for 2048 buckets: the buckets' occupied-voxel counts, the plan, [ntiles][2048], [nsegs][2048],
+    // bucket_start[2049], the control words
+    const size_t plan_words = (sizeof(VxDev) + 7) / 8 * 2;
+    const size_t words = (size_t)kVxMaxBins + plan_words + ((size_t)ntiles + nsegs) * kVxMaxBins + kVxMaxBins + 1 + kVxCtlWords;
     uint32_t* w;
     TRY(ensure(c, c->vx_tab, words, &w));
-    unsigned long long* status = reinterpret_cast<unsigned long long*>(w);
-    uint32_t* tab = w + 2 * (size_t)B;
-    uint32_t* seg_tot = tab + (size_t)pl.ntiles * B;
-    uint32_t* bucket_start = seg_tot + (size_t)pl.nsegs * B;
-    uint32_t* ctl = bucket_start + B + 1;
+    uint32_t* occ = w;
+    VxDev* plan = reinterpret_cast<VxDev*>(w + (size_t)kVxMaxBins);
+    uint32_t* tab = w + (size_t)kVxMaxBins + plan_words;
+    uint32_t* seg_tot = tab + (size_t)ntiles * kVxMaxBins;
+    uint32_t* bucket_start = seg_tot + (size_t)nsegs * kVxMaxBins;
+    uint32_t* ctl = bucket_start + kVxMaxBins + 1;
     VxArrays a;
     const float* in[3] = {dp, dn, dcol};
+    const int64_t vmax = std::min<int64_t>(n, (int64_t)1 << 21);
+    Pay3* tmp[3] = {nullptr, nullptr, nullptr};  // the buckets' means before they are moved together: a slot per cell of the grid
     for (int k = 0; k < 3; ++k) {
         a.in[k] = reinterpret_cast<const Pay3*>(in[k]);
         a.out[k] = nullptr;
-        if (in[k]) TRY(ensure(c, c->vpay[k], (size_t)n, &a.out[k]));
+        if (in[k]) {
+            TRY(ensure(c, c->vpay[k], (size_t)n, &a.out[k]));
+            TRY(ensure(c, c->vpay[3 + k], (size_t)1 << 21, &tmp[k]));
+        }
     }
-    const int64_t vmax = std::min<int64_t>(n, (int64_t)1 << pl.bits);
     float *op = out_xyz, *on = out_normals, *oc = out_colors;
     if (mem_kind == MI_ICP_HOST) {
         TRY(ensure(c, c->stage[3], (size_t)vmax * 3, &op));
         if (dn) TRY(ensure(c, c->stage[4], (size_t)vmax * 3, &on));
         if (dcol) TRY(ensure(c, c->stage[5], (size_t)vmax * 3, &oc));
     }
-    vx_hist<<<pl.ntiles, kVxThreads, 0, c->stream>>>(a.in[0], (int)n, g, pl.bits, pl.L, tab);
-    vx_colsum<<<dim3((unsigned)pl.nsegs, (unsigned)((B + 255) / 256)), 256, 0, c->stream>>>(tab, pl.ntiles, B, seg_tot);
-    vx_colscan<<<1, 1024, 0, c->stream>>>(seg_tot, pl.nsegs, B, (int)n, pl.max_bucket, bucket_start, ctl, status);
-    vx_scatter<<<pl.ntiles, kVxThreads, 0, c->stream>>>(a, (int)n, g, pl.bits, pl.L, tab, seg_tot, bucket_start, ctl);
-    vx_finish<<<B, kVxFinThreads, 0, c->stream>>>(a.out[0], a.out[1], a.out[2], g, pl.bits, pl.L, bucket_start, ctl, status, op,
-                                                   dn ? on : nullptr, dcol ? oc : nullptr);
+    vx_plan_kernel<<<1, 64, 0, c->stream>>>(bounds_dev, voxel, (long long)n, 1, plan, ctl);
+    vx_hist<<<ntiles, kVxThreads, 0, c->stream>>>(a.in[0], (int)n, plan, tab);
+    vx_colsum<<<dim3((unsigned)nsegs, (unsigned)(kVxMaxBins / 256)), 256, 0, c->stream>>>(tab, ntiles, plan, seg_tot);
+    vx_colscan<<<1, 1024, 0, c->stream>>>(seg_tot, nsegs, (int)n, plan, bucket_start, ctl);
+    {   // the arrays that are there, packed to the front (vx_scatter<kArrays>)
+        VxArrays pk = a;
+        int na = 1;
+        for (int k = 1; k < 3; ++k)
+            if (a.in[k]) {
+                pk.in[na] = a.in[k];
+                pk.out[na] = a.out[k];
+                ++na;
+            }
+        const int grid = std::min(ntiles, ncu);
+        if (na == 1) vx_scatter<1><<<grid, kVxThreads, 0, c->stream>>>(pk, (int)n, ntiles, plan, tab, seg_tot, bucket_start, ctl);
+        else if (na == 2) vx_scatter<2><<<grid, kVxThreads, 0, c->stream>>>(pk, (int)n, ntiles, plan, tab, seg_tot, bucket_start, ctl);
+        else vx_scatter<3><<<grid, kVxThreads, 0, c->stream>>>(pk, (int)n, ntiles, plan, tab, seg_tot, bucket_start, ctl);
+    }
+#define MI_VX_FINISH(N, C)                                                                                                     \
+    vx_finish<N, C><<<std::min(kVxMaxBins, ncu), kVxFinThreads, 0, c->stream>>>(a.out[0], a.out[1], a.out[2], plan, bucket_start, ctl, \
+                                                                               occ, tmp[0], tmp[1], tmp[2])
+    if (dn && dcol) MI_VX_FINISH(true, true);
+    else if (dn) MI_VX_FINISH(true, false);
+    else if (dcol) MI_VX_FINISH(false, true);
+    else MI_VX_FINISH(false, false);
+#undef MI_VX_FINISH
+    vx_compact<<<kVxMaxBins, 256, 0, c->stream>>>(plan, ctl, occ, tmp[0], tmp[1], tmp[2], reinterpret_cast<Pay3*>(op),
+                                                   reinterpret_cast<Pay3*>(dn ? on : nullptr), reinterpret_cast<Pay3*>(dcol ? oc : nullptr));
     KCHK(c);
     HIPCHK(c, hipMemcpyAsync(c->u_host, ctl, kVxCtlWords * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->u_host[0] != 0u) return MI_ICP_OK;  // skewed: the general path
-    const int64_t nvox = (int64_t)c->u_host[2];
-    if (mem_kind == MI_ICP_HOST) {
-        TRY(from_device(c, (const float*)op, out_xyz, (size_t)nvox * 3, mem_kind));
-        if (dn) TRY(from_device(c, (const float*)on, out_normals, (size_t)nvox * 3, mem_kind));
-        if (dcol) TRY(from_device(c, (const float*)oc, out_colors, (size_t)nvox * 3, mem_kind));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    *m = nvox;
-    *done = true;
+    *launched = true;
+    *op_ = op;
+    *on_ = on;
+    *oc_ = oc;
     return MI_ICP_OK;
 }
 
@@ -335,8 +340,23 @@ int mi_icp_voxel_downsample(mi_icp_ctx* c, const float* xyz, const float* normal
 
     float* bnd;
     TRY(compute_bounds(c, dp, n, &bnd));
+    // a dense grid: one move of every point (voxel_dense.h), started behind the bounds without waiting for them
+    bool dense = false;
+    float *dop = nullptr, *don = nullptr, *doc = nullptr;
+    TRY(voxel_dense_launch(c, dp, dn, dcol, n, voxel, bnd, out_xyz, out_normals, out_colors, mem_kind, &dense, &dop, &don, &doc));
     HIPCHK(c, hipMemcpyAsync(c->f_host, bnd, 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (dense && c->u_host[0] == 0u) {  // (1: the cloud crowds into a few buckets, 2: not a grid for that path -- nothing was written)
+        const int64_t nvox = (int64_t)c->u_host[2];
+        if (mem_kind == MI_ICP_HOST) {
+            TRY(from_device(c, (const float*)dop, out_xyz, (size_t)nvox * 3, mem_kind));
+            if (dn) TRY(from_device(c, (const float*)don, out_normals, (size_t)nvox * 3, mem_kind));
+            if (dcol) TRY(from_device(c, (const float*)doc, out_colors, (size_t)nvox * 3, mem_kind));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        *m = nvox;
+        return MI_ICP_OK;
+    }
     VoxelGrid g;
     float ext = 0.0f;
     int bits[3];
@@ -359,15 +379,6 @@ int mi_icp_voxel_downsample(mi_icp_ctx* c, const float* xyz, const float* normal
         g.bits_z = bits[2];
     }
 
-    // a dense grid: one move of every point (voxel_dense.h); a cloud that crowds into a few buckets comes back undone
-    {
-        VxPlan pl;
-        if (vx_plan(n, bits[0] + bits[1] + bits[2], &pl)) {
-            bool done = false;
-            TRY(voxel_downsample_dense(c, dp, dn, dcol, n, g, pl, out_xyz, out_normals, out_colors, m, mem_kind, &done));
-            if (done) return MI_ICP_OK;
-        }
-    }
     // (grids whose packed key needs more than 32 bits keep the first form below: 64-bit keys + indices, one gather)
     if (bits[0] + bits[1] + bits[2] <= 32)
         return voxel_downsample_keys32(c, dp, dn, dcol, n, g, bits[0] + bits[1] + bits[2], out_xyz, out_normals, out_colors, m,

@@ -14,10 +14,8 @@
 //   vx_finish   one workgroup per bucket: the bucket's points 8192 at a time, ordered in LDS by the key's low L <= 10
 //               bits (the voxel inside the bucket; the same stable counting sort), then thread v adds up voxel v's run
 //               IN INPUT ORDER in fp64 -- the order the CPU oracle adds in, so the means are the oracle's bit for bit
-//               and the same from run to run.  The occupied voxels of a bucket are counted, the buckets' counts chained
-//               through a decoupled look-back (one 64-bit status word per bucket, workgroups numbered by a ticket so
-//               that every predecessor is running; a wave reads 64 predecessors at a time), and the means written at
-//               their place in lexicographic order.
+//               and the same from run to run.  The bucket's means go to the bucket's own stretch of a scratch array;
+//   vx_compact  moves every bucket's stretch behind its predecessors': lexicographic order, no gaps.
 //
 // Ranks.  Both counting sorts need, for every point, its rank among the EARLIER points of its bin.  A wave owns a
 // contiguous stretch of the tile and private counters, two 16-bit counters to a word, and takes the rank from ONE
@@ -64,6 +62,18 @@ struct VxGrid {
     uint32_t key_mask;
 };
 
+// The plan, made ON THE DEVICE from the bounds (vx_plan_kernel) so that the host does not have to wait for them before it
+// launches: every kernel below reads it, and does nothing when `ok` is 0 (the grid is not one for this path; the host
+// learns that with the result and takes the general path).
+struct VxDev {
+    VxGrid g;
+    int bits, hb, L, B;
+    int ok;               // 1: this path runs
+    uint32_t max_bucket;  // a larger bucket sets the skew flag
+    int empty;            // 1: the grid overflows int32 (down_sample.cu:186-189): no voxels at all
+    int pad;
+};
+
 // control words (device): [0] skew flag, [1] ticket of vx_finish, [2] voxel count, [3] largest bucket
 constexpr int kVxCtlWords = 4;
 
@@ -99,6 +109,16 @@ __device__ __forceinline__ uint32_t vx_key(const VxGrid& g, const Pay3& p) {
     return ((kx << (g.g.bits_y + g.g.bits_z)) | (ky << g.g.bits_z) | kz) & g.key_mask;
 }
 
+// A workgroup barrier for data shared through LDS only: __syncthreads() also makes the workgroup's GLOBAL stores
+// visible, i.e. waits until every store (and, the counter being one, every load asked for since) has come back --
+// which is exactly what the kernels below must not do: their loads for the NEXT piece of work are in flight across
+// the barriers of the present one.  Waves of a workgroup share nothing through global memory here.
+__device__ __forceinline__ void vx_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // exclusive prefix over the threads of a workgroup of NW waves (wtot: NW words of LDS); *total = the sum
 template <int NW>
 __device__ __forceinline__ uint32_t vx_block_scan(uint32_t v, uint32_t* total, uint32_t* wtot) {
@@ -111,7 +131,7 @@ __device__ __forceinline__ uint32_t vx_block_scan(uint32_t v, uint32_t* total, u
         if (lane >= o) x += y;
     }
     if (lane == 63) wtot[wid] = x;
-    __syncthreads();
+    vx_barrier();
     uint32_t woff = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -119,15 +139,18 @@ __device__ __forceinline__ uint32_t vx_block_scan(uint32_t v, uint32_t* total, u
         if (w < wid) woff += s;
         tot += s;
     }
-    __syncthreads();
+    vx_barrier();
     *total = tot;
     return woff + x - v;
 }
 
 // rank of this lane's element among the wave's earlier elements of bin `bin`: one add on the wave's packed counters
 // (row: the wave's counters as words, two 16-bit counters each; a wave adds at most 1024 to a counter)
-__device__ __forceinline__ uint32_t vx_rank(uint32_t* row, uint32_t bin) {
-    const uint32_t v = atomicAdd(&row[bin >> 1], (bin & 1u) ? 0x10000u : 1u);
+// (a lane without an element adds nothing -- no branch around the add: a guarded ds_add_rtn is followed by its own wait,
+// and sixteen guarded ones by sixteen waits)
+__device__ __forceinline__ uint32_t vx_rank(uint32_t* row, uint32_t bin, bool valid = true) {
+    const uint32_t inc = (bin & 1u) ? 0x10000u : 1u;
+    const uint32_t v = atomicAdd(&row[bin >> 1], valid ? inc : 0u);
     return (bin & 1u) ? (v >> 16) : (v & 0xffffu);
 }
 
@@ -161,55 +184,112 @@ static __global__ __launch_bounds__(256) void vx_probe_order(uint32_t* __restric
     if (bad) atomicAdd(out, bad);
 }
 
+// ---- 0b: the plan ----------------------------------------------------------------------------------------------------
+// bounds: min[3], max[3] (lbvh.h bounds_final).  The host evaluates the same expressions (mi_geometry.hip) when it needs
+// the grid itself; hb is chosen for ~6k points per bucket (one LDS chunk of vx_finish).
+static __global__ void vx_plan_kernel(const float* __restrict__ bounds, float voxel, long long n, int allowed, VxDev* __restrict__ d,
+                                      uint32_t* __restrict__ ctl) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    VxDev v;
+    float origin[3], ext = 0.0f;
+    int nb[3];
+    for (int k = 0; k < 3; ++k) {
+        origin[k] = bounds[k] - voxel * 0.5f;
+        ext = fmaxf(ext, (bounds[3 + k] + voxel * 0.5f) - origin[k]);
+        const double cells = floor(((double)bounds[3 + k] - (double)origin[k]) / (double)voxel) + 2.0;
+        int b = 1;
+        while (b < 32 && (double)(1ull << b) < cells) ++b;
+        nb[k] = b;
+    }
+    v.empty = (voxel * (float)INT32_MAX < ext) ? 1 : 0;
+    v.g.g.ox = origin[0];
+    v.g.g.oy = origin[1];
+    v.g.g.oz = origin[2];
+    v.g.g.voxel = voxel;
+    v.g.g.bits_y = nb[1];
+    v.g.g.bits_z = nb[2];
+    v.g.inv = 1.0f / voxel;
+    const int bits = nb[0] + nb[1] + nb[2];
+    v.bits = bits;
+    v.g.key_mask = (bits >= 32) ? 0xffffffffu : ((1u << bits) - 1u);
+    int hb = 0;
+    while (((long long)6144 << hb) < n) ++hb;
+    hb = max(hb, bits - 10);
+    hb = min(hb, min(11, bits - 6));
+    v.ok = (allowed && !v.empty && bits >= 14 && bits <= 21 && hb >= bits - 10 && hb >= 0 && (n >> max(hb, 0)) >= 256) ? 1 : 0;
+    if (!v.ok) hb = 0;
+    v.hb = hb;
+    v.L = v.ok ? bits - hb : 0;
+    v.B = 1 << hb;
+    const long long four = 4 * (n >> hb);
+    v.max_bucket = (uint32_t)(four > 32768 ? four : 32768);
+    v.pad = 0;
+    *d = v;
+    ctl[0] = v.ok ? 0u : 2u;  // (2: not planned; vx_colscan sets 1 for a crowded cloud)
+    ctl[1] = 0u;
+    ctl[2] = 0u;
+    ctl[3] = 0u;
+}
+
 // ---- 1: the [tile][bucket] table ------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(kVxThreads) void vx_hist(const Pay3* __restrict__ pts, int n, VxGrid g, int bits, int L,
-                                                        uint32_t* __restrict__ tab /*[ntiles][B]*/) {
+// (the table's rows are kVxMaxBins words apart whatever B is: the host sizes it before the plan exists)
+static __global__ __launch_bounds__(kVxThreads) void vx_hist(const Pay3* __restrict__ pts, int n, const VxDev* __restrict__ d,
+                                                        uint32_t* __restrict__ tab /*[ntiles][kVxMaxBins]*/) {
     __shared__ uint32_t cnt[kVxMaxBins];
-    const int B = 1 << (bits - L);
+    if (!d->ok) return;
+    const VxGrid g = d->g;
+    const int L = d->L, B = d->B;
     const int tid = (int)threadIdx.x;
     for (int b = tid; b < B; b += kVxThreads) cnt[b] = 0u;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kVxTile;
     Pay3 p[kVxItems];
+    // (every lane loads -- past the end: the last point again -- so that the sixteen loads are in flight together; a load
+    // under a condition is followed by its own wait)
 #pragma unroll
     for (int c = 0; c < kVxItems; ++c) {
         const int64_t i = base + c * kVxThreads + tid;
-        if (i < n) p[c] = pts[i];
+        p[c] = pts[min(i, (int64_t)n - 1)];
     }
 #pragma unroll
     for (int c = 0; c < kVxItems; ++c) {
         const int64_t i = base + c * kVxThreads + tid;
-        if (i < n) atomicAdd(&cnt[vx_key(g, p[c]) >> L], 1u);
+        const uint32_t bin = vx_key(g, p[c]) >> L;
+        if (i < n) atomicAdd(&cnt[bin], 1u);
     }
     __syncthreads();
-    uint32_t* row = tab + (int64_t)blockIdx.x * B;
+    uint32_t* row = tab + (int64_t)blockIdx.x * kVxMaxBins;
     for (int b = tid; b < B; b += kVxThreads) row[b] = cnt[b];
 }
 
 // ---- 2: column sums ---------------------------------------------------------------------------------------------------
 // tab[t][b] -> the count of bucket b in the tiles of t's segment before t; seg_tot[s][b] = the segment's total
-static __global__ __launch_bounds__(256) void vx_colsum(uint32_t* __restrict__ tab, int ntiles, int B, uint32_t* __restrict__ seg_tot) {
+static __global__ __launch_bounds__(256) void vx_colsum(uint32_t* __restrict__ tab, int ntiles, const VxDev* __restrict__ d,
+                                                  uint32_t* __restrict__ seg_tot) {
+    if (!d->ok) return;
+    const int B = d->B;
     const int b = (int)blockIdx.y * 256 + (int)threadIdx.x;
     if (b >= B) return;
     const int t0 = (int)blockIdx.x * kVxSeg, t1 = min(ntiles, t0 + kVxSeg);
     uint32_t v[kVxSeg];
 #pragma unroll
-    for (int k = 0; k < kVxSeg; ++k) v[k] = (t0 + k < t1) ? tab[(int64_t)(t0 + k) * B + b] : 0u;
+    for (int k = 0; k < kVxSeg; ++k) v[k] = (t0 + k < t1) ? tab[(int64_t)(t0 + k) * kVxMaxBins + b] : 0u;
     uint32_t run = 0;
 #pragma unroll
     for (int k = 0; k < kVxSeg; ++k) {
-        if (t0 + k < t1) tab[(int64_t)(t0 + k) * B + b] = run;
+        if (t0 + k < t1) tab[(int64_t)(t0 + k) * kVxMaxBins + b] = run;
         run += v[k];
     }
-    seg_tot[(int64_t)blockIdx.x * B + b] = run;
+    seg_tot[(int64_t)blockIdx.x * kVxMaxBins + b] = run;
 }
 
 // one workgroup: seg_tot[s][b] -> the count of bucket b in the segments before s; bucket_start[0..B]; the control words
-static __global__ __launch_bounds__(1024) void vx_colscan(uint32_t* __restrict__ seg_tot, int nsegs, int B, int n, uint32_t max_bucket,
-                                                    uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ ctl,
-                                                    unsigned long long* __restrict__ status) {
+static __global__ __launch_bounds__(1024) void vx_colscan(uint32_t* __restrict__ seg_tot, int nsegs, int n, const VxDev* __restrict__ d,
+                                                    uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ ctl) {
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t wmax[16];
+    if (!d->ok) return;
+    const int B = d->B;
     const int tid = (int)threadIdx.x;
     // thread t: buckets t and t + 1024 (coalesced rows); their totals first, 16 segments in flight
     uint32_t tot[2] = {0u, 0u};
@@ -220,15 +300,14 @@ static __global__ __launch_bounds__(1024) void vx_colscan(uint32_t* __restrict__
         for (int s0 = 0; s0 < nsegs; s0 += 16) {
             uint32_t v[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = (s0 + k < nsegs) ? seg_tot[(int64_t)(s0 + k) * B + b] : 0u;
+            for (int k = 0; k < 16; ++k) v[k] = (s0 + k < nsegs) ? seg_tot[(int64_t)(s0 + k) * kVxMaxBins + b] : 0u;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                if (s0 + k < nsegs) seg_tot[(int64_t)(s0 + k) * B + b] = run;
+                if (s0 + k < nsegs) seg_tot[(int64_t)(s0 + k) * kVxMaxBins + b] = run;
                 run += v[k];
             }
         }
         tot[j] = run;
-        status[b] = 0ull;
     }
     // bucket order is b = tid (first half), then tid + 1024: two scans
     uint32_t all0, all1;
@@ -245,9 +324,7 @@ static __global__ __launch_bounds__(1024) void vx_colscan(uint32_t* __restrict__
         uint32_t m = 0;
         for (int w = 0; w < 16; ++w) m = max(m, wmax[w]);
         bucket_start[B] = (uint32_t)n;
-        ctl[0] = (m > max_bucket) ? 1u : 0u;
-        ctl[1] = 0u;
-        ctl[2] = 0u;
+        ctl[0] = (m > d->max_bucket) ? 1u : 0u;
         ctl[3] = m;
     }
 }
@@ -258,7 +335,36 @@ struct VxArrays {
     Pay3* out[3];
 };
 
-static __global__ __launch_bounds__(kVxThreads) void vx_scatter(VxArrays a, int n, VxGrid g, int bits, int L,
+// Workgroup i takes tiles i, i + gridDim.x, ...: the next tile's points are asked for as soon as this tile's last array
+// has gone into the stage, and arrive while it is written out.  kArrays: 1 points, 2 points + one of normals / colours
+// (a.in[1]), 3 all three.
+#define MI_VX_LOAD(r, in, t)                                                               \
+    do {                                                                                   \
+        const int64_t tb_ = (int64_t)(t) * kVxTile;                                        \
+        const int tn_ = (int)min((int64_t)kVxTile, (int64_t)n - tb_);                      \
+        _Pragma("unroll") for (int c = 0; c < kVxItems; ++c) {                             \
+            const int e_ = wid * kVxWaveSeg + c * 64 + lane;                               \
+            const Pay3 v_ = (in)[tb_ + min(e_, tn_ - 1)]; /* (unconditional: see vx_hist) */ \
+            r##x[c] = v_.x;                                                                \
+            r##y[c] = v_.y;                                                                \
+            r##z[c] = v_.z;                                                                \
+        }                                                                                  \
+    } while (0)
+#define MI_VX_RESTAGE(r)                                                                   \
+    do {                                                                                   \
+        _Pragma("unroll") for (int c = 0; c < kVxItems; ++c) {                             \
+            const int e_ = wid * kVxWaveSeg + c * 64 + lane;                               \
+            if (e_ < tile_n) stage[packed[c]] = Pay3{r##x[c], r##y[c], r##z[c]};           \
+        }                                                                                  \
+    } while (0)
+#define MI_VX_WRITE_OUT(out)                                                               \
+    do {                                                                                   \
+        Pay3* __restrict__ o_ = (out);                                                     \
+        for (int q_ = tid; q_ < tile_n; q_ += kVxThreads) o_[(uint32_t)(gdelta[sbin[q_]] + (int32_t)q_)] = stage[q_]; \
+    } while (0)
+
+template <int kArrays>
+static __global__ __launch_bounds__(kVxThreads) void vx_scatter(VxArrays a, int n, int ntiles, const VxDev* __restrict__ d,
                                                            const uint32_t* __restrict__ tab, const uint32_t* __restrict__ seg_tot,
                                                            const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ ctl) {
     __shared__ __attribute__((aligned(16))) uint16_t wcnt[kVxWaves][kVxMaxBins];  // a wave's count per bucket, then its first local position there
@@ -266,362 +372,335 @@ static __global__ __launch_bounds__(kVxThreads) void vx_scatter(VxArrays a, int 
     __shared__ uint16_t sbin[kVxTile];               // the bucket at every local position
     __shared__ int32_t gdelta[kVxMaxBins];           // global position - local position, per bucket
     __shared__ uint32_t wtot[kVxWaves];
-    if (ctl[0] != 0u) return;  // skewed: the general path takes the call
-    const int B = 1 << (bits - L);
+    if (ctl[0] != 0u) return;  // not planned, or crowded: the general path takes the call
+    const VxGrid g = d->g;
+    const int L = d->L, B = d->B;
     const int tid = (int)threadIdx.x;
     const int lane = lane_id();
     const int wid = tid >> 6;
-    const int tile = (int)blockIdx.x;
-    const int64_t tbase = (int64_t)tile * kVxTile;
-    const int tile_n = (int)min((int64_t)kVxTile, (int64_t)n - tbase);
-    VX_CLK(0, tile, 0);
     uint32_t* const row = reinterpret_cast<uint32_t*>(&wcnt[wid][0]);
-    for (int k = lane; k < kVxMaxBins / 2; k += 64) row[k] = 0u;
-    __builtin_amdgcn_wave_barrier();
-    Pay3 p[kVxItems];
+    const int per = (B + kVxThreads - 1) / kVxThreads;  // consecutive buckets per thread: 1, 2 or 4
+    // (coordinates in arrays of their own: an array of the packed 12-byte struct that is loaded in one place of the loop
+    // and read in another stayed in scratch memory)
+    float px[kVxItems], py[kVxItems], pz[kVxItems];  // the points; then the third array; then the next tile's points
+    float qx[kVxItems], qy[kVxItems], qz[kVxItems];  // the second array: asked for at the top of a tile, used when the points are out
+    int tile = (int)blockIdx.x;
+    if (tile < ntiles) MI_VX_LOAD(p, a.in[0], tile);
+    for (; tile < ntiles; tile += (int)gridDim.x) {
+        const int64_t tbase = (int64_t)tile * kVxTile;
+        const int tile_n = (int)min((int64_t)kVxTile, (int64_t)n - tbase);
+        const int next = tile + (int)gridDim.x;
+        VX_CLK(0, tile, 0);
+        if (kArrays >= 2) MI_VX_LOAD(q, a.in[1], tile);
+        for (int k = lane; k < kVxMaxBins / 2; k += 64) row[k] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        // where the tile's bucket runs go: fetched now, used after the ranks
+        uint32_t goff[4] = {0u, 0u, 0u, 0u};
+        {
+            const uint32_t* trow = tab + (int64_t)tile * kVxMaxBins;
+            const uint32_t* srow = seg_tot + (int64_t)(tile / kVxSeg) * kVxMaxBins;
 #pragma unroll
-    for (int c = 0; c < kVxItems; ++c) {
-        const int e = wid * kVxWaveSeg + c * 64 + lane;
-        if (e < tile_n) p[c] = a.in[0][tbase + e];
-    }
-    // where the tile's bucket runs go: fetched now, used after the ranks (consecutive buckets per thread: 1, 2 or 4)
-    const int per = (B + kVxThreads - 1) / kVxThreads;
-    uint32_t goff[4] = {0u, 0u, 0u, 0u};
-    {
-        const uint32_t* trow = tab + (int64_t)tile * B;
-        const uint32_t* srow = seg_tot + (int64_t)(tile / kVxSeg) * B;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int b = tid * per + j;
-            if (j < per && b < B) goff[j] = bucket_start[b] + srow[b] + trow[b];
-        }
-    }
-    VX_DRAIN();
-    VX_CLK(0, tile, 1);
-    uint32_t packed[kVxItems];  // bucket << 16 | rank among the wave's earlier elements of that bucket; later the local position
-#pragma unroll
-    for (int c = 0; c < kVxItems; ++c) {
-        const int e = wid * kVxWaveSeg + c * 64 + lane;
-        packed[c] = 0u;
-        if (e < tile_n) {
-            const uint32_t bin = vx_key(g, p[c]) >> L;
-            packed[c] = (bin << 16) | vx_rank(row, bin);
-        }
-    }
-    __syncthreads();
-    VX_CLK(0, tile, 2);
-    // the tile's bucket runs: every wave's first position in every bucket, and where the run goes
-    {
-        uint32_t k[4][kVxWaves];
-        uint32_t tot[4] = {0u, 0u, 0u, 0u};
-        uint32_t sum = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int b = tid * per + j;
-            if (j < per && b < B) {
-#pragma unroll
-                for (int w = 0; w < kVxWaves; ++w) {
-                    k[j][w] = wcnt[w][b];
-                    tot[j] += k[j][w];
-                }
-                sum += tot[j];
+            for (int j = 0; j < 4; ++j) {
+                const int b = tid * per + j;
+                if (j < per && b < B) goff[j] = bucket_start[b] + srow[b] + trow[b];
             }
         }
-        uint32_t all;
-        uint32_t start = vx_block_scan<kVxWaves>(sum, &all, wtot);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int b = tid * per + j;
-            if (j < per && b < B) {
-                uint32_t run = start;
-#pragma unroll
-                for (int w = 0; w < kVxWaves; ++w) {
-                    wcnt[w][b] = (uint16_t)run;
-                    run += k[j][w];
-                }
-                gdelta[b] = (int32_t)(goff[j] - start);
-                start += tot[j];
-            }
-        }
-    }
-    __syncthreads();
-    VX_CLK(0, tile, 3);
-#pragma unroll
-    for (int c = 0; c < kVxItems; ++c) {
-        const int e = wid * kVxWaveSeg + c * 64 + lane;
-        if (e < tile_n) {
-            const uint32_t bin = packed[c] >> 16;
-            const uint32_t pos = (uint32_t)wcnt[wid][bin] + (packed[c] & 0xffffu);
-            packed[c] = pos;
-            stage[pos] = p[c];
-            sbin[pos] = (uint16_t)bin;
-        }
-    }
-    // array after array through the stage; the next one's elements are on their way while this one is written out
-    const Pay3* const in1 = a.in[1] ? a.in[1] : a.in[2];   // the first array after the points, if any
-    Pay3* const out1 = a.in[1] ? a.out[1] : a.out[2];
-    const Pay3* const in2 = (a.in[1] && a.in[2]) ? a.in[2] : nullptr;
-    auto load_next = [&](const Pay3* __restrict__ in) {
+        VX_DRAIN();
+        VX_CLK(0, tile, 1);
+        uint32_t packed[kVxItems];  // bucket << 16 | rank among the wave's earlier elements of that bucket; later the local position
 #pragma unroll
         for (int c = 0; c < kVxItems; ++c) {
             const int e = wid * kVxWaveSeg + c * 64 + lane;
-            if (e < tile_n) p[c] = in[tbase + e];
+            const uint32_t bin = vx_key(g, Pay3{px[c], py[c], pz[c]}) >> L;
+            packed[c] = (bin << 16) | vx_rank(row, bin, e < tile_n);
         }
-    };
-    auto restage = [&]() {
+        vx_barrier();  // (also: every thread has finished writing the previous tile out of the stage)
+        VX_CLK(0, tile, 2);
+        // the tile's bucket runs: every wave's first position in every bucket, and where the run goes
+        {
+            uint32_t k[4][kVxWaves];
+            uint32_t tot[4] = {0u, 0u, 0u, 0u};
+            uint32_t sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int b = tid * per + j;
+                if (j < per && b < B) {
+#pragma unroll
+                    for (int w = 0; w < kVxWaves; ++w) {
+                        k[j][w] = wcnt[w][b];
+                        tot[j] += k[j][w];
+                    }
+                    sum += tot[j];
+                }
+            }
+            uint32_t all;
+            uint32_t start = vx_block_scan<kVxWaves>(sum, &all, wtot);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int b = tid * per + j;
+                if (j < per && b < B) {
+                    uint32_t run = start;
+#pragma unroll
+                    for (int w = 0; w < kVxWaves; ++w) {
+                        wcnt[w][b] = (uint16_t)run;
+                        run += k[j][w];
+                    }
+                    gdelta[b] = (int32_t)(goff[j] - start);
+                    start += tot[j];
+                }
+            }
+        }
+        vx_barrier();
+        VX_CLK(0, tile, 3);
 #pragma unroll
         for (int c = 0; c < kVxItems; ++c) {
             const int e = wid * kVxWaveSeg + c * 64 + lane;
-            if (e < tile_n) stage[packed[c]] = p[c];
+            if (e < tile_n) {
+                const uint32_t bin = packed[c] >> 16;
+                const uint32_t pos = (uint32_t)wcnt[wid][bin] + (packed[c] & 0xffffu);
+                packed[c] = pos;
+                stage[pos] = Pay3{px[c], py[c], pz[c]};
+                sbin[pos] = (uint16_t)bin;
+            }
         }
-    };
-    auto write_out = [&](Pay3* __restrict__ out) {
-        for (int q = tid; q < tile_n; q += kVxThreads) out[(uint32_t)(gdelta[sbin[q]] + (int32_t)q)] = stage[q];
-    };
-    if (in1) load_next(in1);
-    __syncthreads();
-    VX_CLK(0, tile, 4);
-    write_out(a.out[0]);
-    VX_CLK(0, tile, 5);
-    if (in1) {
-        __syncthreads();
-        restage();
-        if (in2) load_next(in2);
-        __syncthreads();
-        write_out(out1);
-        if (in2) {
-            __syncthreads();
-            restage();
-            __syncthreads();
-            write_out(a.out[2]);
+        // array after array through the stage; what is needed next is on its way while this one is written out
+        if (kArrays == 3) MI_VX_LOAD(p, a.in[2], tile);
+        else if (next < ntiles) MI_VX_LOAD(p, a.in[0], next);
+        vx_barrier();
+        VX_CLK(0, tile, 4);
+        MI_VX_WRITE_OUT(a.out[0]);
+        VX_CLK(0, tile, 5);
+        if (kArrays >= 2) {
+            vx_barrier();
+            MI_VX_RESTAGE(q);
+            vx_barrier();
+            MI_VX_WRITE_OUT(a.out[1]);
         }
+        if (kArrays == 3) {
+            vx_barrier();
+            MI_VX_RESTAGE(p);
+            if (next < ntiles) MI_VX_LOAD(p, a.in[0], next);
+            vx_barrier();
+            MI_VX_WRITE_OUT(a.out[2]);
+        }
+#ifdef MI_VX_CLOCKS
+        VX_CLK(0, tile, 6);
+#endif
     }
-    VX_DRAIN();
-    VX_CLK(0, tile, 6);
 }
+#undef MI_VX_LOAD
+#undef MI_VX_RESTAGE
+#undef MI_VX_WRITE_OUT
 
 // ---- 4: a workgroup per bucket ---------------------------------------------------------------------------------------------
-constexpr unsigned long long kVxAggregate = 1ull << 62, kVxInclusive = 2ull << 62, kVxValue = (1ull << 62) - 1ull;
-
-// the voxels before this bucket's: wave 0 reads the status words of 64 predecessors at a time (nearest in lane 0), adds
-// the aggregates up to and including the nearest inclusive prefix, and waits where a needed word is not there yet
-__device__ __forceinline__ unsigned long long vx_look_back(const unsigned long long* status, int bucket) {
-    const int lane = lane_id();
-    unsigned long long base = 0ull;
-    for (int j0 = bucket - 1; j0 >= 0;) {
-        const int idx = j0 - lane;
-        unsigned long long v = kVxInclusive;  // before bucket 0: an inclusive prefix of zero
-        if (idx >= 0) v = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned f = (unsigned)(v >> 62);
-        const uint64_t missing = __ballot(f == 0u);
-        const uint64_t incl = __ballot(f == 2u);
-        const int first = incl ? (int)__builtin_ctzll(incl) : 64;
-        const uint64_t needed = (first >= 63) ? ~0ull : ((2ull << first) - 1ull);  // lanes 0 .. first
-        if (missing & needed) {
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-        }
-        unsigned long long part = (lane <= first) ? (v & kVxValue) : 0ull;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-        base += part;
-        if (first < 64) break;
-        j0 -= 64;
-    }
-    return base;
-}
-
+// A workgroup takes bucket after bucket (a ticket each).  A bucket's means go to the bucket's OWN stretch of a scratch
+// array (slot bucket * 2^L + rank among the bucket's occupied voxels) and its number of occupied voxels to occ[bucket]:
+// where they belong among all voxels is vx_compact's business.  (A decoupled look-back that placed them at once -- status
+// words, 64 then 1024 predecessors read per round trip, deferred behind the next bucket's loads -- cost 4 ... 10 of a
+// bucket's 13 ... 19 us in every form tried: the workgroups of a chip-wide wave of buckets finish together, and a wave's
+// loads come back in the order they were asked for, the status words behind 60 KB of points.)
+template <bool kNrm, bool kCol>
 static __global__ __launch_bounds__(kVxFinThreads) void vx_finish(const Pay3* __restrict__ pts, const Pay3* __restrict__ nrm,
-                                                            const Pay3* __restrict__ col, VxGrid g, int bits, int L,
+                                                            const Pay3* __restrict__ col, const VxDev* __restrict__ d,
                                                             const uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ ctl,
-                                                            unsigned long long* __restrict__ status, float* __restrict__ out_pts,
-                                                            float* __restrict__ out_nrm, float* __restrict__ out_col) {
+                                                            uint32_t* __restrict__ occ, Pay3* __restrict__ tmp_pts,
+                                                            Pay3* __restrict__ tmp_nrm, Pay3* __restrict__ tmp_col) {
     __shared__ __attribute__((aligned(16))) uint16_t wcnt[kVxFinWaves][kVxMaxSub];  // a wave's count per voxel of the bucket, then its offset inside the voxel's run
     __shared__ Pay3 stage[kVxChunk];                   // one array at a time, in voxel order
     __shared__ uint16_t vstart[kVxMaxSub];             // first position of every voxel's run
     __shared__ uint32_t wtot[kVxFinWaves];
     __shared__ uint32_t s_bucket;
-    __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_start[kVxMaxBins + 1];       // bucket_start, here once: a bucket's extent is then an LDS read away from its ticket
     if (ctl[0] != 0u) return;
+    const VxGrid g = d->g;
+    const int L = d->L, B = d->B;
     const int tid = (int)threadIdx.x;
     const int lane = lane_id();
     const int wid = tid >> 6;
-    const int B = 1 << (bits - L);
     const int V = 1 << L;
     const uint32_t sub_mask = (uint32_t)V - 1u;
-#ifdef MI_VX_CLOCKS
-    const unsigned long long clk0 = (unsigned long long)wall_clock64();
-#endif
-    if (tid == 0) s_bucket = __hip_atomic_fetch_add(&ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int bucket = (int)s_bucket;  // (the grid has B workgroups: every ticket is a bucket)
-#ifdef MI_VX_CLOCKS
-    if (tid == 0) g_vx_clk[1][bucket][0] = clk0;
-#endif
-    VX_CLK(1, bucket, 1);
-    const uint32_t s = bucket_start[bucket], e = bucket_start[bucket + 1];
-    double ap[3] = {0.0, 0.0, 0.0}, an[3] = {0.0, 0.0, 0.0}, ac[3] = {0.0, 0.0, 0.0};
-    uint32_t count = 0;
-    uint32_t orank = 0, occupied = 0;
     uint32_t* const row = reinterpret_cast<uint32_t*>(&wcnt[wid][0]);
     constexpr int kItems = kVxChunk / kVxFinThreads;  // 8
-    if (s == e && tid == 0)  // an empty bucket: nothing of its own (bucket 0: an inclusive prefix of zero)
-        __hip_atomic_store(&status[bucket], bucket == 0 ? kVxInclusive : kVxAggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (uint32_t cbase = s; cbase < e; cbase += (uint32_t)kVxChunk) {
-        const int cn = (int)min((uint32_t)kVxChunk, e - cbase);
-        const bool last = cbase + (uint32_t)kVxChunk >= e;
-        for (int k = lane; k < kVxMaxSub / 2; k += 64) row[k] = 0u;
-        __builtin_amdgcn_wave_barrier();
-        Pay3 p[kItems];
+    float px[kItems], py[kItems], pz[kItems];  // (coordinates apart: see vx_scatter)
+    auto load = [&](const Pay3* __restrict__ in, uint32_t cbase, int cn) {
+        if (cn <= 0) return;  // (uniform)
 #pragma unroll
         for (int k = 0; k < kItems; ++k) {
             const int i = wid * kVxFinWaveSeg + k * 64 + lane;
-            if (i < cn) p[k] = pts[cbase + (uint32_t)i];
+            const Pay3 v = in[cbase + (uint32_t)min(i, cn - 1)];  // (unconditional: see vx_hist)
+            px[k] = v.x;
+            py[k] = v.y;
+            pz[k] = v.z;
         }
-        VX_DRAIN();
-        VX_CLK(1, bucket, 2);
-        uint32_t packed[kItems];  // voxel << 16 | rank among the wave's earlier points of that voxel; later the position
+    };
+    if (tid == 0) s_bucket = __hip_atomic_fetch_add(&ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int b = tid; b <= B; b += kVxFinThreads) s_start[b] = bucket_start[b];
+    vx_barrier();
+    int bucket = (int)s_bucket;
+    uint32_t s = 0, e = 0;
+    if (bucket < B) {
+        s = s_start[bucket];
+        e = s_start[bucket + 1];
+        load(pts, s, (int)min((uint32_t)kVxChunk, e - s));
+    }
+    while (bucket < B) {
+        VX_CLK(1, bucket, 1);
+        // the next ticket: asked for now, kept in a register until the bucket's end (stored to LDS at once it would be waited for at once)
+        uint32_t ticket = 0;
+        if (tid == 0) ticket = __hip_atomic_fetch_add(&ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double ap[3] = {0.0, 0.0, 0.0}, an[3] = {0.0, 0.0, 0.0}, ac[3] = {0.0, 0.0, 0.0};
+        uint32_t count = 0;
+        uint32_t orank = 0, occupied = 0;
+        for (uint32_t cbase = s; cbase < e; cbase += (uint32_t)kVxChunk) {
+            const int cn = (int)min((uint32_t)kVxChunk, e - cbase);
+            const bool last = cbase + (uint32_t)kVxChunk >= e;
+            if (cbase != s) load(pts, cbase, cn);  // (the first chunk was asked for ahead)
+            for (int k = lane; k < kVxMaxSub / 2; k += 64) row[k] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            VX_DRAIN();
+            VX_CLK(1, bucket, 2);
+            uint32_t packed[kItems];  // voxel << 16 | rank among the wave's earlier points of that voxel; later the position
 #pragma unroll
-        for (int k = 0; k < kItems; ++k) {
-            const int i = wid * kVxFinWaveSeg + k * 64 + lane;
-            packed[k] = 0u;
-            if (i < cn) {
-                const uint32_t sub = vx_key(g, p[k]) & sub_mask;
-                packed[k] = (sub << 16) | vx_rank(row, sub);
+            for (int k = 0; k < kItems; ++k) {
+                const int i = wid * kVxFinWaveSeg + k * 64 + lane;
+                const uint32_t sub = vx_key(g, Pay3{px[k], py[k], pz[k]}) & sub_mask;
+                packed[k] = (sub << 16) | vx_rank(row, sub, i < cn);
             }
-        }
-        __syncthreads();
-        VX_CLK(1, bucket, 3);
-        uint32_t mine = 0;  // points of voxel `tid` in this chunk
-        if (tid < V) {
+            vx_barrier();
+            VX_CLK(1, bucket, 3);
+            uint32_t mine = 0;  // points of voxel `tid` in this chunk
+            if (tid < V) {
 #pragma unroll
-            for (int h = 0; h < kVxFinWaves; h += 8) {
-                uint32_t k[8];
+                for (int h = 0; h < kVxFinWaves; h += 8) {
+                    uint32_t k[8];
 #pragma unroll
-                for (int w = 0; w < 8; ++w) k[w] = wcnt[h + w][tid];
+                    for (int w = 0; w < 8; ++w) k[w] = wcnt[h + w][tid];
 #pragma unroll
-                for (int w = 0; w < 8; ++w) {
-                    wcnt[h + w][tid] = (uint16_t)mine;
-                    mine += k[w];
+                    for (int w = 0; w < 8; ++w) {
+                        wcnt[h + w][tid] = (uint16_t)mine;
+                        mine += k[w];
+                    }
                 }
             }
-        }
-        uint32_t all;
-        const uint32_t first = vx_block_scan<kVxFinWaves>(mine, &all, wtot);
-        if (tid < V) vstart[tid] = (uint16_t)first;
-        if (last) {  // the bucket's occupied voxels are known: the aggregate goes out before the sums are made
-            orank = vx_block_scan<kVxFinWaves>((count + mine) > 0u ? 1u : 0u, &occupied, wtot);
-            if (tid == 0)
-                __hip_atomic_store(&status[bucket], (bucket == 0 ? kVxInclusive : kVxAggregate) | (unsigned long long)occupied,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            __syncthreads();
-        }
-        VX_CLK(1, bucket, 4);
-#pragma unroll
-        for (int k = 0; k < kItems; ++k) {
-            const int i = wid * kVxFinWaveSeg + k * 64 + lane;
-            if (i < cn) {
-                const uint32_t sub = packed[k] >> 16;
-                const uint32_t pos = (uint32_t)vstart[sub] + (uint32_t)wcnt[wid][sub] + (packed[k] & 0xffffu);
-                packed[k] = pos;
-                stage[pos] = p[k];
-            }
-        }
-        if (nrm) {  // on their way while the points are added up
+            uint32_t all;
+            const uint32_t first = vx_block_scan<kVxFinWaves>(mine, &all, wtot);
+            if (tid < V) vstart[tid] = (uint16_t)first;
+            if (last) orank = vx_block_scan<kVxFinWaves>((count + mine) > 0u ? 1u : 0u, &occupied, wtot);  // the bucket's occupied voxels, in key order
+            else vx_barrier();
+            VX_CLK(1, bucket, 4);
 #pragma unroll
             for (int k = 0; k < kItems; ++k) {
                 const int i = wid * kVxFinWaveSeg + k * 64 + lane;
-                if (i < cn) p[k] = nrm[cbase + (uint32_t)i];
+                if (i < cn) {
+                    const uint32_t sub = packed[k] >> 16;
+                    const uint32_t pos = (uint32_t)vstart[sub] + (uint32_t)wcnt[wid][sub] + (packed[k] & 0xffffu);
+                    packed[k] = pos;
+                    stage[pos] = Pay3{px[k], py[k], pz[k]};
+                }
             }
-        } else if (col) {
-#pragma unroll
-            for (int k = 0; k < kItems; ++k) {
-                const int i = wid * kVxFinWaveSeg + k * 64 + lane;
-                if (i < cn) p[k] = col[cbase + (uint32_t)i];
+            if (kNrm) load(nrm, cbase, cn);  // on their way while the points are added up
+            else if (kCol) load(col, cbase, cn);
+            vx_barrier();
+            VX_CLK(1, bucket, 5);
+            for (uint32_t q = first; q < first + mine; ++q) {
+                const Pay3 v = stage[q];
+                ap[0] += (double)v.x;
+                ap[1] += (double)v.y;
+                ap[2] += (double)v.z;
             }
-        }
-        __syncthreads();
-        VX_CLK(1, bucket, 5);
-        for (uint32_t q = first; q < first + mine; ++q) {
-            const Pay3 v = stage[q];
-            ap[0] += (double)v.x;
-            ap[1] += (double)v.y;
-            ap[2] += (double)v.z;
-        }
-        count += mine;
-        if (nrm) {
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < kItems; ++k) {
-                const int i = wid * kVxFinWaveSeg + k * 64 + lane;
-                if (i < cn) stage[packed[k]] = p[k];
-            }
-            if (col) {
+            count += mine;
+            auto restage = [&]() {
 #pragma unroll
                 for (int k = 0; k < kItems; ++k) {
                     const int i = wid * kVxFinWaveSeg + k * 64 + lane;
-                    if (i < cn) p[k] = col[cbase + (uint32_t)i];
+                    if (i < cn) stage[packed[k]] = Pay3{px[k], py[k], pz[k]};
+                }
+            };
+            if (kNrm) {
+                vx_barrier();
+                restage();
+                if (kCol) load(col, cbase, cn);
+                vx_barrier();
+                for (uint32_t q = first; q < first + mine; ++q) {
+                    const Pay3 v = stage[q];
+                    an[0] += (double)v.x;
+                    an[1] += (double)v.y;
+                    an[2] += (double)v.z;
                 }
             }
-            __syncthreads();
-            for (uint32_t q = first; q < first + mine; ++q) {
-                const Pay3 v = stage[q];
-                an[0] += (double)v.x;
-                an[1] += (double)v.y;
-                an[2] += (double)v.z;
+            if (kCol) {
+                vx_barrier();
+                restage();
+                vx_barrier();
+                for (uint32_t q = first; q < first + mine; ++q) {
+                    const Pay3 v = stage[q];
+                    ac[0] += (double)v.x;
+                    ac[1] += (double)v.y;
+                    ac[2] += (double)v.z;
+                }
             }
+            if (!last) vx_barrier();  // the stage and the counters are reused
+            VX_CLK(1, bucket, 6);
         }
-        if (col) {
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < kItems; ++k) {
-                const int i = wid * kVxFinWaveSeg + k * 64 + lane;
-                if (i < cn) stage[packed[k]] = p[k];
+        VX_CLK(1, bucket, 7);
+        if (tid == 0) {
+            s_bucket = ticket;
+            occ[bucket] = occupied;
+        }
+        vx_barrier();  // (also: the stage and the counters are free)
+        const int done = bucket;
+        bucket = (int)s_bucket;
+        if (bucket < B) {  // the next bucket's first chunk: asked for before this one's means are worked out and stored
+            s = s_start[bucket];
+            e = s_start[bucket + 1];
+            load(pts, s, (int)min((uint32_t)kVxChunk, e - s));
+        }
+        // the means (normals normalised after averaging, down_sample.cu:77-90), at the bucket's own stretch
+        if (count > 0u) {
+            const size_t slot = ((size_t)done << L) + orank;
+            const double cnt = (double)count;
+            tmp_pts[slot] = Pay3{(float)(ap[0] / cnt), (float)(ap[1] / cnt), (float)(ap[2] / cnt)};
+            if (kNrm) {
+                const float w[3] = {(float)(an[0] / cnt), (float)(an[1] / cnt), (float)(an[2] / cnt)};
+                const float l = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+                tmp_nrm[slot] = Pay3{w[0] / l, w[1] / l, w[2] / l};
             }
-            __syncthreads();
-            for (uint32_t q = first; q < first + mine; ++q) {
-                const Pay3 v = stage[q];
-                ac[0] += (double)v.x;
-                ac[1] += (double)v.y;
-                ac[2] += (double)v.z;
-            }
+            if (kCol) tmp_col[slot] = Pay3{(float)(ac[0] / cnt), (float)(ac[1] / cnt), (float)(ac[2] / cnt)};
         }
-        __syncthreads();  // the stage and the counters are reused
-        VX_CLK(1, bucket, 6);
+        VX_CLK(1, done, 8);
+        vx_barrier();  // (s_bucket is read by all before the next bucket's end rewrites it -- an empty bucket has no other barrier)
     }
-    VX_CLK(1, bucket, 7);
-    // the bucket's place among all buckets' voxels
-    if (wid == 0) {
-        const unsigned long long base = vx_look_back(status, bucket);
-        if (lane == 0) {
-            if (bucket > 0)
-                __hip_atomic_store(&status[bucket], kVxInclusive | (base + (unsigned long long)occupied), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            s_base = base;
-            if (bucket == B - 1) ctl[2] = (uint32_t)(base + (unsigned long long)occupied);
+}
+
+// ---- 5: the buckets' means to their places ----------------------------------------------------------------------------------
+// workgroup b: the occupied voxels of the buckets before b (every workgroup adds them up for itself: 8 KB), then its own
+// stretch copied there; the last bucket's workgroup leaves the total
+static __global__ __launch_bounds__(256) void vx_compact(const VxDev* __restrict__ d, uint32_t* __restrict__ ctl, const uint32_t* __restrict__ occ,
+                                                   const Pay3* __restrict__ tmp_pts, const Pay3* __restrict__ tmp_nrm,
+                                                   const Pay3* __restrict__ tmp_col, Pay3* __restrict__ out_pts, Pay3* __restrict__ out_nrm,
+                                                   Pay3* __restrict__ out_col) {
+    __shared__ uint32_t wsum[4];
+    if (ctl[0] != 0u) return;
+    const int B = d->B, L = d->L;
+    const int tid = (int)threadIdx.x;
+    for (int b = (int)blockIdx.x; b < B; b += (int)gridDim.x) {
+        uint32_t part = 0;
+        for (int j = tid; j < b; j += 256) part += occ[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += (uint32_t)__shfl_xor((int)part, o, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) wsum[tid >> 6] = part;
+        __syncthreads();
+        const uint32_t base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        const uint32_t mine = occ[b];
+        const size_t from = (size_t)b << L;
+        for (uint32_t r = (uint32_t)tid; r < mine; r += 256u) {
+            out_pts[base + r] = tmp_pts[from + r];
+            if (tmp_nrm) out_nrm[base + r] = tmp_nrm[from + r];
+            if (tmp_col) out_col[base + r] = tmp_col[from + r];
         }
+        if (b == B - 1 && tid == 0) ctl[2] = base + mine;
     }
-    __syncthreads();
-    VX_CLK(1, bucket, 8);
-    if (count > 0u) {
-        const int64_t v = (int64_t)s_base + (int64_t)orank;
-        const double cnt = (double)count;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) out_pts[v * 3 + d] = (float)(ap[d] / cnt);
-        if (nrm) {
-            const float w[3] = {(float)(an[0] / cnt), (float)(an[1] / cnt), (float)(an[2] / cnt)};
-            const float l = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) out_nrm[v * 3 + d] = w[d] / l;
-        }
-        if (col) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) out_col[v * 3 + d] = (float)(ac[d] / cnt);
-        }
-    }
-    VX_DRAIN();
-    VX_CLK(1, bucket, 9);
 }
 
 }  // namespace mi

@@ -17,17 +17,16 @@ torch.cuda.synchronize()
 L = C.CDLL(os.environ["MI_ICP_LIB_PATH"])
 buf = np.zeros((2, 4096, 12), np.uint64)
 assert L.mi_vx_clocks_dump(buf.ctypes.data_as(C.c_void_p)) == 0
-names = (("start", "loaded", "ranked", "bin scan", "staged", "written", "end"),
-         ("start", "ticket", "loaded", "ranked", "scanned", "staged", "chunk end", "occupancy", "look-back", "end"))
+names = ((0, ("start", "loaded", "ranked", "bin scan", "staged", "written", "end")),
+         (1, ("start", "loaded", "ranked", "scanned", "staged", "chunk end", "means", "stored")))
 for k, label in ((0, "vx_scatter"), (1, "vx_finish")):
-    t = buf[k].astype(np.int64)
-    live = t[:, 0] > 0
-    t = t[live]
-    nm = names[k]
+    first, nm = names[k]
+    t = buf[k].astype(np.int64)[:, first:first + len(nm)]
+    t = t[(t > 0).all(axis=1)]
     t0 = t[:, 0].min()
-    print("%s: %d workgroups, kernel span %.1f us" % (label, len(t), (t[:, len(nm) - 1].max() - t0) / 100.0))
-    d = np.diff(t[:, :len(nm)], axis=1) / 100.0
+    print("%s: %d work items, span %.1f us" % (label, len(t), (t[:, -1].max() - t0) / 100.0))
+    d = np.diff(t, axis=1) / 100.0
     for j in range(len(nm) - 1):
         print("   %-10s -> %-10s mean %7.2f us  median %7.2f  max %7.2f" % (nm[j], nm[j + 1], d[:, j].mean(), np.median(d[:, j]), d[:, j].max()))
-    tot = (t[:, len(nm) - 1] - t[:, 0]) / 100.0
-    print("   whole workgroup: mean %.2f us, median %.2f, max %.2f; start times: first %.1f, median %.1f, last %.1f us" % (tot.mean(), np.median(tot), tot.max(), 0.0, np.median(t[:, 0] - t0) / 100.0, (t[:, 0].max() - t0) / 100.0))
+    tot = (t[:, -1] - t[:, 0]) / 100.0
+    print("   whole item: mean %.2f us, median %.2f, max %.2f; start times: median %.1f, last %.1f us" % (tot.mean(), np.median(tot), tot.max(), np.median(t[:, 0] - t0) / 100.0, (t[:, 0].max() - t0) / 100.0))
