@@ -189,6 +189,7 @@ SIGNATURES = {
     "mi_icp_debug_get_tree": (_I, [_P, C.POINTER(_L), _P, _P]),
     "mi_icp_debug_drop_seeds": (_I, [_P]),
     "mi_icp_debug_last_search_kind": (_I, [_P]),
+    "mi_icp_debug_last_voxel_path": (_I, [_P]),
     "mi_icp_debug_occupancy": (_I, [_I]),
     "mi_icp_debug_loop_counters": (_I, [_P, _P]),
     "mi_icp_debug_locate": (_I, [_P, _P, _P]),

@@ -63,6 +63,7 @@ struct mi_icp_ctx {
     hipEvent_t ev_fork = nullptr, ev_links = nullptr;
     bool links_inflight = false;
     int last_search_kind = -1;  // mi_icp_debug.h
+    int last_voxel_path = -1;   // mi_icp_debug.h
     // Halos are built when a registration loop's searches ask for them (nn_search.h counts the lanes one would
     // serve): clean data never does.  A context whose loops have asked before starts the build with the loop.
     bool halo_sticky = false;

@@ -134,11 +134,12 @@ int mi_icp_debug_get_leaf_halos(mi_icp_ctx* c, float* halos_out) {
 }
 
 int mi_icp_debug_last_search_kind(const mi_icp_ctx* c) { return c ? c->last_search_kind : -1; }
+int mi_icp_debug_last_voxel_path(const mi_icp_ctx* c) { return c ? c->last_voxel_path : -1; }
 
 int mi_icp_debug_occupancy(int which) {
     if (which == 0 || which == 4) return occupancy_build(which);
     if (which >= 1 && which <= 3) return occupancy_loop(which);
-    if (which == 5 || which == 6) return occupancy_geometry(which);
+    if (which >= 5 && which <= 8) return occupancy_geometry(which);
     return -1;
 }
 

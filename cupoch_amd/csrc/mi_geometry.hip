@@ -166,7 +166,7 @@ static int vx_order_ok(mi_icp_ctx* c, bool* ok) {
 // bucket), every kernel reads it there and does nothing when the grid is not one for this path.  The caller then waits
 // ONCE, for the bounds and this path's control words together.  *launched = false: nothing was started.
 static int voxel_dense_launch(mi_icp_ctx* c, const float* dp, const float* dn, const float* dcol, int64_t n, float voxel,
-                              const float* bounds_dev, float* out_xyz, float* out_normals, float* out_colors, int mem_kind,
+                              float* out_xyz, float* out_normals, float* out_colors, int mem_kind,
                               bool* launched, float** op_, float** on_, float** oc_) {
     *launched = false;
     if (std::getenv("MI_ICP_NO_DENSE_VOXEL")) return MI_ICP_OK;  // A/B switch, read at every call (tests compare both paths)
@@ -207,7 +207,13 @@ static int voxel_dense_launch(mi_icp_ctx* c, const float* dp, const float* dn, c
         if (dn) TRY(ensure(c, c->stage[4], (size_t)vmax * 3, &on));
         if (dcol) TRY(ensure(c, c->stage[5], (size_t)vmax * 3, &oc));
     }
-    vx_plan_kernel<<<1, 64, 0, c->stream>>>(bounds_dev, voxel, (long long)n, 1, plan, ctl);
+    {   // the bounds (compute_bounds' two launches, the second one making the plan as well)
+        float* part;
+        TRY(ensure(c, c->bounds_part, (size_t)kBoundsBlocks * 6, &part));
+        const int nb = (int)std::min<int64_t>(kBoundsBlocks, blocks_for(n));
+        bounds_partial<<<nb, 256, 0, c->stream>>>(dp, (int)n, part);
+        vx_bounds_plan<<<1, 64, 0, c->stream>>>(part, nb, voxel, (long long)n, plan, ctl);
+    }
     vx_hist<<<ntiles, kVxThreads, 0, c->stream>>>(a.in[0], (int)n, plan, tab);
     vx_colsum<<<dim3((unsigned)nsegs, (unsigned)(kVxMaxBins / 256)), 256, 0, c->stream>>>(tab, ntiles, plan, seg_tot);
     vx_colscan<<<1, 1024, 0, c->stream>>>(seg_tot, nsegs, (int)n, plan, bucket_start, ctl);
@@ -236,7 +242,7 @@ static int voxel_dense_launch(mi_icp_ctx* c, const float* dp, const float* dn, c
     vx_compact<<<kVxMaxBins, 256, 0, c->stream>>>(plan, ctl, occ, tmp[0], tmp[1], tmp[2], reinterpret_cast<Pay3*>(op),
                                                    reinterpret_cast<Pay3*>(dn ? on : nullptr), reinterpret_cast<Pay3*>(dcol ? oc : nullptr));
     KCHK(c);
-    HIPCHK(c, hipMemcpyAsync(c->u_host, ctl, kVxCtlWords * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->u_host, ctl, kVxCtlWords * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));  // (with the bounds)
     *launched = true;
     *op_ = op;
     *on_ = on;
@@ -328,6 +334,7 @@ int mi_icp_voxel_downsample(mi_icp_ctx* c, const float* xyz, const float* normal
     TRY(check_ctx(c));
     if (!m) return fail(c, MI_ICP_ERR_INVALID, "voxel_downsample: m is null");
     *m = 0;
+    c->last_voxel_path = -1;
     if (n < 0 || n > 0x7fffff00ll) return fail(c, MI_ICP_ERR_INVALID, "voxel_downsample: bad size");
     if (n == 0 || !(voxel > 0.0f)) return MI_ICP_OK;  // down_sample.cu:173-176
     if (!xyz || !out_xyz || (normals && !out_normals) || (colors && !out_colors))
@@ -338,14 +345,18 @@ int mi_icp_voxel_downsample(mi_icp_ctx* c, const float* xyz, const float* normal
     TRY(to_device(c, normals, (size_t)n * 3, mem_kind, c->stage[1], &dn));
     TRY(to_device(c, colors, (size_t)n * 3, mem_kind, c->stage[2], &dcol));
 
-    float* bnd;
-    TRY(compute_bounds(c, dp, n, &bnd));
-    // a dense grid: one move of every point (voxel_dense.h), started behind the bounds without waiting for them
+    // a dense grid: one move of every point (voxel_dense.h), started behind the bounds without waiting for them; the
+    // bounds come back with its control words
     bool dense = false;
     float *dop = nullptr, *don = nullptr, *doc = nullptr;
-    TRY(voxel_dense_launch(c, dp, dn, dcol, n, voxel, bnd, out_xyz, out_normals, out_colors, mem_kind, &dense, &dop, &don, &doc));
-    HIPCHK(c, hipMemcpyAsync(c->f_host, bnd, 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    TRY(voxel_dense_launch(c, dp, dn, dcol, n, voxel, out_xyz, out_normals, out_colors, mem_kind, &dense, &dop, &don, &doc));
+    if (!dense) {
+        float* bnd;
+        TRY(compute_bounds(c, dp, n, &bnd));
+        HIPCHK(c, hipMemcpyAsync(c->f_host, bnd, 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (dense) std::memcpy(c->f_host, c->u_host + kVxCtlBounds, 6 * sizeof(float));
     if (dense && c->u_host[0] == 0u) {  // (1: the cloud crowds into a few buckets, 2: not a grid for that path -- nothing was written)
         const int64_t nvox = (int64_t)c->u_host[2];
         if (mem_kind == MI_ICP_HOST) {
@@ -355,6 +366,7 @@ int mi_icp_voxel_downsample(mi_icp_ctx* c, const float* xyz, const float* normal
             HIPCHK(c, hipStreamSynchronize(c->stream));
         }
         *m = nvox;
+        c->last_voxel_path = 1;
         return MI_ICP_OK;
     }
     VoxelGrid g;
@@ -365,6 +377,7 @@ int mi_icp_voxel_downsample(mi_icp_ctx* c, const float* xyz, const float* normal
         const float origin[3] = {b[0] - voxel * 0.5f, b[1] - voxel * 0.5f, b[2] - voxel * 0.5f};
         for (int d = 0; d < 3; ++d) ext = std::fmax(ext, (b[3 + d] + voxel * 0.5f) - origin[d]);
         if (voxel * (float)INT32_MAX < ext) return MI_ICP_OK;  // down_sample.cu:186-189
+        c->last_voxel_path = 0;
         g.ox = origin[0];
         g.oy = origin[1];
         g.oz = origin[2];

@@ -74,8 +74,11 @@ struct VxDev {
     int pad;
 };
 
-// control words (device): [0] skew flag, [1] ticket of vx_finish, [2] voxel count, [3] largest bucket
-constexpr int kVxCtlWords = 4;
+// control words (device): [0] 0: done by this path, 1: crowded, 2: not planned; [1] ticket of vx_finish; [2] voxel count;
+// [3] largest bucket; [4..11] the bounds (min[3], max[3], extent, 0) as floats -- ONE copy brings the host everything it
+// waits for
+constexpr int kVxCtlWords = 12;
+constexpr int kVxCtlBounds = 4;
 
 // -DMI_VX_CLOCKS (measurements only): thread 0 of every workgroup of vx_scatter / vx_finish notes the 100-MHz clock at its
 // phase boundaries; mi_vx_clocks_dump (mi_geometry.hip) copies the table out
@@ -187,9 +190,7 @@ static __global__ __launch_bounds__(256) void vx_probe_order(uint32_t* __restric
 // ---- 0b: the plan ----------------------------------------------------------------------------------------------------
 // bounds: min[3], max[3] (lbvh.h bounds_final).  The host evaluates the same expressions (mi_geometry.hip) when it needs
 // the grid itself; hb is chosen for ~6k points per bucket (one LDS chunk of vx_finish).
-static __global__ void vx_plan_kernel(const float* __restrict__ bounds, float voxel, long long n, int allowed, VxDev* __restrict__ d,
-                                      uint32_t* __restrict__ ctl) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void vx_make_plan(const float* bounds, float voxel, long long n, VxDev* __restrict__ d, uint32_t* __restrict__ ctl) {
     VxDev v;
     float origin[3], ext = 0.0f;
     int nb[3];
@@ -216,7 +217,7 @@ static __global__ void vx_plan_kernel(const float* __restrict__ bounds, float vo
     while (((long long)6144 << hb) < n) ++hb;
     hb = max(hb, bits - 10);
     hb = min(hb, min(11, bits - 6));
-    v.ok = (allowed && !v.empty && bits >= 14 && bits <= 21 && hb >= bits - 10 && hb >= 0 && (n >> max(hb, 0)) >= 256) ? 1 : 0;
+    v.ok = (!v.empty && bits >= 14 && bits <= 21 && hb >= bits - 10 && hb >= 0 && (n >> max(hb, 0)) >= 256) ? 1 : 0;
     if (!v.ok) hb = 0;
     v.hb = hb;
     v.L = v.ok ? bits - hb : 0;
@@ -225,10 +226,35 @@ static __global__ void vx_plan_kernel(const float* __restrict__ bounds, float vo
     v.max_bucket = (uint32_t)(four > 32768 ? four : 32768);
     v.pad = 0;
     *d = v;
-    ctl[0] = v.ok ? 0u : 2u;  // (2: not planned; vx_colscan sets 1 for a crowded cloud)
+    ctl[0] = v.ok ? 0u : 2u;  // (2: not planned; the column scan sets 1 for a crowded cloud)
     ctl[1] = 0u;
     ctl[2] = 0u;
     ctl[3] = 0u;
+    for (int k = 0; k < 6; ++k) ctl[kVxCtlBounds + k] = __float_as_uint(bounds[k]);
+    ctl[kVxCtlBounds + 6] = 0u;
+    ctl[kVxCtlBounds + 7] = 0u;
+}
+
+// one wave behind bounds_partial (lbvh.h): the bounds of the cloud -- bounds_final's reduction -- and, in the same launch, the plan
+static __global__ __launch_bounds__(64) void vx_bounds_plan(const float* __restrict__ partial, int nblocks, float voxel, long long n,
+                                                      VxDev* __restrict__ d, uint32_t* __restrict__ ctl) {
+    const int lane = lane_id();
+    float mn[3] = {INFINITY, INFINITY, INFINITY};
+    float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int b = lane; b < nblocks; b += 64) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = fminf(mn[k], partial[b * 6 + k]);
+            mx[k] = fmaxf(mx[k], partial[b * 6 + 3 + k]);
+        }
+    }
+    float b6[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        b6[k] = wave_min(mn[k]);      // (lane 0 holds the result)
+        b6[3 + k] = wave_max(mx[k]);
+    }
+    if (lane == 0) vx_make_plan(b6, voxel, n, d, ctl);
 }
 
 // ---- 1: the [tile][bucket] table ------------------------------------------------------------------------------------
@@ -263,6 +289,8 @@ static __global__ __launch_bounds__(kVxThreads) void vx_hist(const Pay3* __restr
 }
 
 // ---- 2: column sums ---------------------------------------------------------------------------------------------------
+// (two launches.  One, with the workgroup that finishes last going on alone to add the segments up, was measured: 35.9 us
+// against 5.8 + 10.6 -- 256 threads with eight buckets each behind loads that go past the caches)
 // tab[t][b] -> the count of bucket b in the tiles of t's segment before t; seg_tot[s][b] = the segment's total
 static __global__ __launch_bounds__(256) void vx_colsum(uint32_t* __restrict__ tab, int ntiles, const VxDev* __restrict__ d,
                                                   uint32_t* __restrict__ seg_tot) {
@@ -291,18 +319,18 @@ static __global__ __launch_bounds__(1024) void vx_colscan(uint32_t* __restrict__
     if (!d->ok) return;
     const int B = d->B;
     const int tid = (int)threadIdx.x;
-    // thread t: buckets t and t + 1024 (coalesced rows); their totals first, 16 segments in flight
+    // thread t: buckets t and t + 1024 (coalesced rows); their totals first, 32 segments in flight
     uint32_t tot[2] = {0u, 0u};
     for (int j = 0; j < 2; ++j) {
         const int b = tid + j * 1024;
         if (b >= B) break;
         uint32_t run = 0;
-        for (int s0 = 0; s0 < nsegs; s0 += 16) {
-            uint32_t v[16];
+        for (int s0 = 0; s0 < nsegs; s0 += 32) {
+            uint32_t v[32];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = (s0 + k < nsegs) ? seg_tot[(int64_t)(s0 + k) * kVxMaxBins + b] : 0u;
+            for (int k = 0; k < 32; ++k) v[k] = (s0 + k < nsegs) ? seg_tot[(int64_t)(s0 + k) * kVxMaxBins + b] : 0u;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
+            for (int k = 0; k < 32; ++k) {
                 if (s0 + k < nsegs) seg_tot[(int64_t)(s0 + k) * kVxMaxBins + b] = run;
                 run += v[k];
             }

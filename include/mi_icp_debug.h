@@ -39,9 +39,15 @@ MI_ICP_API int mi_icp_debug_drop_seeds(mi_icp_ctx* ctx);
  * previous pass's matches, 2 = from seeds it made itself (a greedy descent per query; what a registration
  * loop's first pass does when the target's halos exist already), -1 = no pass yet. */
 MI_ICP_API int mi_icp_debug_last_search_kind(const mi_icp_ctx* ctx);
+/* Which path the last mi_icp_voxel_downsample call took: 1 = the dense-grid path (csrc/voxel_dense.h: one partition,
+ * a workgroup per bucket), 0 = the general path (radix passes with the payload), -1 = no call yet (or one that returned
+ * early: an empty cloud, a voxel size <= 0, a grid beyond int32).  Both are exact; tests run each on purpose
+ * (the switch MI_ICP_NO_DENSE_VOXEL is read at every call). */
+MI_ICP_API int mi_icp_debug_last_voxel_path(const mi_icp_ctx* ctx);
 /* Resident workgroups per CU the runtime grants a kernel at its launch shape (hipOccupancyMaxActiveBlocksPerMultiprocessor):
  * which = 0 kd_build_groups, 1 nn_packet_kernel<seeded>, 2 nn_packet_kernel<from the root>, 3 reduce_pt2pl_kernel<4,1>,
- * 4 leaf_halo_build, 5 rs_scatter_pay<8>, 6 voxel_means_wave.  Returns the count, < 0 on error. */
+ * 4 leaf_halo_build, 5 rs_scatter_pay<8>, 6 voxel_means_wave, 7 vx_scatter<1>, 8 vx_finish<points only>.  Returns the
+ * count, < 0 on error. */
 MI_ICP_API int mi_icp_debug_occupancy(int which);
 /* Where an iteration's time goes (csrc/loop.h): with stamps enabled the NEXT registration loop on the context runs the
  * same search / point-to-plane reduction kernels instantiated with device-clock stamps (s_memrealtime, one clock for the
