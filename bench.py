@@ -139,6 +139,21 @@ def secondary(eng, src, tgt, nrm, d_tgt, d_nrm, d_src, max_dist, n, torch, _lib)
             fp.append(p1["nn_ms"] - p0["nn_ms"])
         return round(med(fp), 4), kinds.get(eng.last_search_kind(), "?")
 
+    # -- VoxelDownSample of the target (voxel = 2.154 mean spacings: ~10 points per occupied
+    # voxel, 0.01 at 10M points in the unit cube, the shape profiles/r06_voxel.txt is quoted on), clouds on the device,
+    # host-visible wall time of the whole call (its one synchronisation included)
+    vox = 2.154 * float(n) ** (-1.0 / 3.0)
+    for key, nn_ in (("voxel_downsample_ms", None), ("voxel_downsample_with_normals_ms", d_nrm)):
+        tv = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            v = eng.voxel_downsample(d_tgt, vox, nn_)
+            torch.cuda.synchronize()
+            tv.append(time.perf_counter() - t0)
+        out[key] = round(med(tv[1:]) * 1e3, 4)
+    out["voxel_downsample"] = "%d points, voxel %.4g -> %d voxels, %s path" % (
+        n, vox, len(v[0]), {1: "dense-grid (voxel_dense.h)", 0: "general (radix passes)"}.get(eng._L.mi_icp_debug_last_voxel_path(eng._ctx), "?"))
     eng.set_profiling(True)
     out["first_pass_ms"], out["first_pass_kind"] = first_pass()
     # -- the same loop on data that looks like a sensor's: a random 60 % of the target as the source,

@@ -81,22 +81,38 @@ static __global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_
     __syncthreads();
     const uint32_t src0 = s_src[0];
     const int count = (int)s_src[1];
-    for (int i = tid; i < kKdGroup; i += kKdThreads) {
-        float x = INFINITY, y = INFINITY, z = INFINITY;  // padding sorts to the end on every axis
-        if (i < count) {
+    {   // the group's points into LDS.  All of a thread's loads are asked for together -- the four indices, then the
+        // twelve coordinates: under `if (i < count)` each load was followed by its own wait, eight dependent round trips
+        // per thread (a slot past the group's end reads the group's last point and is overwritten with the padding)
+        constexpr int kPer = kKdGroup / kKdThreads;
+        int64_t o[kPer];
+        float c[kPer][3];
+        if (count > 0) {  // (uniform)
+#pragma unroll
+            for (int t = 0; t < kPer; ++t) {
+                const int i = min(tid + t * kKdThreads, count - 1);
 #ifdef MI_AB_COHERENT
-            const int64_t o = src0 + i;
+                o[t] = (int64_t)src0 + i;
 #else
-            const int64_t o = a.vals[src0 + i];
+                o[t] = a.vals[src0 + i];
 #endif
-            x = a.pts[o * 3];
-            y = a.pts[o * 3 + 1];
-            z = a.pts[o * 3 + 2];
+            }
+#pragma unroll
+            for (int t = 0; t < kPer; ++t) {
+                c[t][0] = a.pts[o[t] * 3];
+                c[t][1] = a.pts[o[t] * 3 + 1];
+                c[t][2] = a.pts[o[t] * 3 + 2];
+            }
         }
-        s.cx[i] = x;
-        s.cy[i] = y;
-        s.cz[i] = z;
-        s.key[i] = (uint32_t)i;
+#pragma unroll
+        for (int t = 0; t < kPer; ++t) {
+            const int i = tid + t * kKdThreads;
+            const bool real = i < count;
+            s.cx[i] = real ? c[t][0] : INFINITY;  // padding sorts to the end on every axis
+            s.cy[i] = real ? c[t][1] : INFINITY;
+            s.cz[i] = real ? c[t][2] : INFINITY;
+            s.key[i] = (uint32_t)i;
+        }
     }
     __syncthreads();
 #ifndef MI_AB_NO_SORT
@@ -105,39 +121,65 @@ static __global__ __launch_bounds__(kKdThreads) __attribute__((amdgpu_waves_per_
 
     // ---- leaf lines + sorted attributes: position p of the group = slot g*4096 + p
     const int64_t slot0 = (int64_t)g * kKdGroup;
-    for (int p = tid; p < kKdGroup; p += kKdThreads) {
-        const int li = (int)(s.key[p] & 4095u);
-        const bool real = li < count;
+    {   // (as above: a thread's four indices are asked for together, then its four normals -- each was a dependent round
+        // trip of its own inside the loop over p)
+        constexpr int kPer = kKdGroup / kKdThreads;
+        int li[kPer];
+        int64_t o[kPer];
+        float nv[kPer][3];
+#pragma unroll
+        for (int t = 0; t < kPer; ++t) {
+            li[t] = (int)(s.key[tid + t * kKdThreads] & 4095u);
+            o[t] = -1;
+        }
+        if (count > 0) {  // (uniform)
+#pragma unroll
+            for (int t = 0; t < kPer; ++t) {
 #ifdef MI_AB_COHERENT
-        const int64_t o = real ? (int64_t)(src0 + li) : -1;
+                o[t] = (int64_t)src0 + min(li[t], count - 1);
 #else
-        const int64_t o = real ? (int64_t)a.vals[src0 + li] : -1;
+                o[t] = (int64_t)a.vals[src0 + min(li[t], count - 1)];
 #endif
-#ifdef MI_AB_NO_WRITE
-        if (a.link_delta != 12345.0f) continue;
-#endif
-        float* line = a.tblk + (slot0 + p) / kLeaf * kLeafFloats + (p & 7);
-        line[0] = s.cx[li];
-        line[8] = s.cy[li];
-        line[16] = s.cz[li];
-        a.tidx[slot0 + p] = (int32_t)o;
-        if (a.tnrm) {
-            const float4 n4 = real ? make_float4(a.nrm[o * 3], a.nrm[o * 3 + 1], a.nrm[o * 3 + 2], 0.0f)
-                                   : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            a.tnrm[slot0 + p] = n4;
-            if (a.trec) {
-                float* r = a.trec + (slot0 + p) * 6;
-                r[0] = s.cx[li];
-                r[1] = s.cy[li];
-                r[2] = s.cz[li];
-                r[3] = n4.x;
-                r[4] = n4.y;
-                r[5] = n4.z;
+            }
+            if (a.tnrm) {
+#pragma unroll
+                for (int t = 0; t < kPer; ++t) {
+                    nv[t][0] = a.nrm[o[t] * 3];
+                    nv[t][1] = a.nrm[o[t] * 3 + 1];
+                    nv[t][2] = a.nrm[o[t] * 3 + 2];
+                }
             }
         }
-        if (a.tcov) {
 #pragma unroll
-            for (int e = 0; e < 9; ++e) a.tcov[(slot0 + p) * 9 + e] = real ? a.cov[o * 9 + e] : 0.0f;
+        for (int t = 0; t < kPer; ++t) {
+            const int p = tid + t * kKdThreads;
+            const bool real = li[t] < count;
+            if (!real) o[t] = -1;
+#ifdef MI_AB_NO_WRITE
+            if (a.link_delta != 12345.0f) continue;
+#endif
+            float* line = a.tblk + (slot0 + p) / kLeaf * kLeafFloats + (p & 7);
+            line[0] = s.cx[li[t]];
+            line[8] = s.cy[li[t]];
+            line[16] = s.cz[li[t]];
+            a.tidx[slot0 + p] = (int32_t)o[t];
+            if (a.tnrm) {
+                const float4 n4 = real ? make_float4(nv[t][0], nv[t][1], nv[t][2], 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                a.tnrm[slot0 + p] = n4;
+                if (a.trec) {
+                    float* r = a.trec + (slot0 + p) * 6;
+                    r[0] = s.cx[li[t]];
+                    r[1] = s.cy[li[t]];
+                    r[2] = s.cz[li[t]];
+                    r[3] = n4.x;
+                    r[4] = n4.y;
+                    r[5] = n4.z;
+                }
+            }
+            if (a.tcov) {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) a.tcov[(slot0 + p) * 9 + e] = real ? a.cov[o[t] * 9 + e] : 0.0f;
+            }
         }
     }
     // ---- boxes: 512 leaves (= the 8-position chunks), then unions of 8, 64, 512

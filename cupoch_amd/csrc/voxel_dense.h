@@ -419,7 +419,9 @@ static __global__ __launch_bounds__(kVxThreads) void vx_scatter(VxArrays a, int 
         const int tile_n = (int)min((int64_t)kVxTile, (int64_t)n - tbase);
         const int next = tile + (int)gridDim.x;
         VX_CLK(0, tile, 0);
+#ifdef MI_VX_Q_EARLY
         if (kArrays >= 2) MI_VX_LOAD(q, a.in[1], tile);
+#endif
         for (int k = lane; k < kVxMaxBins / 2; k += 64) row[k] = 0u;
         __builtin_amdgcn_wave_barrier();
         // where the tile's bucket runs go: fetched now, used after the ranks
@@ -442,6 +444,9 @@ static __global__ __launch_bounds__(kVxThreads) void vx_scatter(VxArrays a, int 
             const uint32_t bin = vx_key(g, Pay3{px[c], py[c], pz[c]}) >> L;
             packed[c] = (bin << 16) | vx_rank(row, bin, e < tile_n);
         }
+#ifndef MI_VX_Q_EARLY
+        if (kArrays >= 2) MI_VX_LOAD(q, a.in[1], tile);  // (behind the ranks: at the top of the tile it delayed the points it queued behind)
+#endif
         vx_barrier();  // (also: every thread has finished writing the previous tile out of the stage)
         VX_CLK(0, tile, 2);
         // the tile's bucket runs: every wave's first position in every bucket, and where the run goes
