@@ -346,12 +346,17 @@ static __global__ __launch_bounds__(256) void permute_source(const uint32_t* __r
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= ns) return;
     const int64_t o = ord[p];
-    out.sx[p] = in.sx[o];
-    out.sy[p] = in.sy[o];
-    out.sz[p] = in.sz[o];
-    out.sperm[p] = in.sperm[o];
-    out.nn_idx[p] = in.nn_idx[o];
-    out.nn_d2[p] = in.nn_d2[o];
+    // (all six gathers asked for before the first store: the arrays come in structs, the compiler cannot know that `out`
+    // does not alias `in`, and every load behind a store waited for its own round trip)
+    const float x = in.sx[o], y = in.sy[o], z = in.sz[o];
+    const int32_t perm = in.sperm[o], idx = in.nn_idx[o];
+    const float d2 = in.nn_d2[o];
+    out.sx[p] = x;
+    out.sy[p] = y;
+    out.sz[p] = z;
+    out.sperm[p] = perm;
+    out.nn_idx[p] = idx;
+    out.nn_d2[p] = d2;
     if (in.snrm) out.snrm[p] = in.snrm[o];
     if (in.sint) out.sint[p] = in.sint[o];
     if (in.scov) {

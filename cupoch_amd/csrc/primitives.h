@@ -155,10 +155,18 @@ __global__ __launch_bounds__(kSortThreads) void rs_histogram(const K* __restrict
     if (tid < 256) cnt[tid] = 0;
     __syncthreads();
     const int64_t base = (int64_t)seg * kSortSeg;
-#pragma unroll 4
-    for (int c = 0; c < kSortSeg / kSortThreads; ++c) {
-        const int64_t i = base + c * kSortThreads + tid;
-        if (i < n) atomicAdd(&cnt[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    // (the loads are unconditional -- past the end: the last key again -- and only the count is guarded: a load under
+    // `if (i < n)` is followed by its own wait, and a thread's sixteen keys came in one after the other)
+    constexpr int kPer = kSortSeg / kSortThreads;
+#pragma unroll
+    for (int c0 = 0; c0 < kPer; c0 += 8) {
+        K k[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c0 + c < kPer) k[c] = keys[min(base + (int64_t)(c0 + c) * kSortThreads + tid, (int64_t)n - 1)];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c0 + c < kPer && base + (int64_t)(c0 + c) * kSortThreads + tid < n) atomicAdd(&cnt[(uint32_t)(k[c] >> shift) & 255u], 1u);
     }
     __syncthreads();
     if (tid < 256) hist[(int64_t)tid * nseg + seg] = cnt[tid];
@@ -316,9 +324,9 @@ __global__ __launch_bounds__(kSortThreads) void rs_scatter_pay(const uint32_t* _
     for (int c = 0; c < kSortChunks; ++c) {
         const int e = wid * kSortWaveSeg + c * 64 + lane;
         const bool valid = e < tile_n;
-        const uint32_t key = valid ? keys_in[tbase + e] : 0u;
-        mykey[c] = key;
-        const uint32_t digit = (key >> shift) & 255u;
+        const uint32_t key = keys_in[tbase + min(e, tile_n - 1)];  // (unconditional: guarded loads are waited for one by one)
+        mykey[c] = valid ? key : 0u;
+        const uint32_t digit = (mykey[c] >> shift) & 255u;
         uint64_t peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -383,10 +391,13 @@ __global__ __launch_bounds__(kSortThreads) void rs_scatter_pay(const uint32_t* _
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         if (!pay.in[a]) continue;  // (uniform)
+        Pay3 v[kSortChunks];
+#pragma unroll
+        for (int c = 0; c < kSortChunks; ++c) v[c] = pay.in[a][tbase + min(wid * kSortWaveSeg + c * 64 + lane, tile_n - 1)];
 #pragma unroll
         for (int c = 0; c < kSortChunks; ++c) {
             const int e = wid * kSortWaveSeg + c * 64 + lane;
-            if (e < tile_n) stage[packed[c]] = pay.in[a][tbase + e];
+            if (e < tile_n) stage[packed[c]] = v[c];
         }
         __syncthreads();
         for (int p = tid; p < tile_n; p += kSortThreads)
