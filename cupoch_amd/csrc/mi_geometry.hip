@@ -21,7 +21,7 @@ int occupancy_geometry(int which) {
     if (which == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, rs_scatter_pay<8>, kSortThreads, 0);
     else if (which == 6) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, voxel_means_wave, 64, 0);
     else if (which == 7) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vx_scatter<1>, kVxThreads, 0);
-    else if (which == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vx_finish<false, false>, kVxFinThreads, 0);
+    else if (which == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vx_finish<false, false, 1>, kVxFinThreads, 0);
     else return -1;
     return e == hipSuccess ? blocks : -2;
 }
@@ -191,14 +191,14 @@ static int voxel_dense_launch(mi_icp_ctx* c, const float* dp, const float* dn, c
     uint32_t* ctl = bucket_start + kVxMaxBins + 1;
     VxArrays a;
     const float* in[3] = {dp, dn, dcol};
-    const int64_t vmax = std::min<int64_t>(n, (int64_t)1 << 21);
+    const int64_t vmax = std::min<int64_t>(n, (int64_t)1 << 22);
     Pay3* tmp[3] = {nullptr, nullptr, nullptr};  // the buckets' means before they are moved together: a slot per cell of the grid
     for (int k = 0; k < 3; ++k) {
         a.in[k] = reinterpret_cast<const Pay3*>(in[k]);
         a.out[k] = nullptr;
         if (in[k]) {
             TRY(ensure(c, c->vpay[k], (size_t)n, &a.out[k]));
-            TRY(ensure(c, c->vpay[3 + k], (size_t)1 << 21, &tmp[k]));
+            TRY(ensure(c, c->vpay[3 + k], (size_t)1 << 22, &tmp[k]));
         }
     }
     float *op = out_xyz, *on = out_normals, *oc = out_colors;
@@ -212,7 +212,8 @@ static int voxel_dense_launch(mi_icp_ctx* c, const float* dp, const float* dn, c
         TRY(ensure(c, c->bounds_part, (size_t)kBoundsBlocks * 6, &part));
         const int nb = (int)std::min<int64_t>(kBoundsBlocks, blocks_for(n));
         bounds_partial<<<nb, 256, 0, c->stream>>>(dp, (int)n, part);
-        vx_bounds_plan<<<1, 64, 0, c->stream>>>(part, nb, voxel, (long long)n, plan, ctl);
+        static const int hb_force = [] { const char* e = std::getenv("MI_ICP_VOXEL_HB"); return e ? std::atoi(e) : 0; }();  // measurements
+        vx_bounds_plan<<<1, 64, 0, c->stream>>>(part, nb, voxel, (long long)n, hb_force, plan, ctl);
     }
     vx_hist<<<ntiles, kVxThreads, 0, c->stream>>>(a.in[0], (int)n, plan, tab);
     vx_colsum<<<dim3((unsigned)nsegs, (unsigned)(kVxMaxBins / 256)), 256, 0, c->stream>>>(tab, ntiles, plan, seg_tot);
@@ -231,9 +232,15 @@ static int voxel_dense_launch(mi_icp_ctx* c, const float* dp, const float* dn, c
         else if (na == 2) vx_scatter<2><<<grid, kVxThreads, 0, c->stream>>>(pk, (int)n, ntiles, plan, tab, seg_tot, bucket_start, ctl);
         else vx_scatter<3><<<grid, kVxThreads, 0, c->stream>>>(pk, (int)n, ntiles, plan, tab, seg_tot, bucket_start, ctl);
     }
+    // (both cuts of a bucket are launched: the plan, which the host does not know yet, says which one runs -- the other
+    // returns at its first test)
 #define MI_VX_FINISH(N, C)                                                                                                     \
-    vx_finish<N, C><<<std::min(kVxMaxBins, ncu), kVxFinThreads, 0, c->stream>>>(a.out[0], a.out[1], a.out[2], plan, bucket_start, ctl, \
-                                                                               occ, tmp[0], tmp[1], tmp[2])
+    do {                                                                                                                       \
+        vx_finish<N, C, 1><<<std::min(kVxMaxBins, ncu), kVxFinThreads, 0, c->stream>>>(a.out[0], a.out[1], a.out[2], plan, bucket_start, \
+                                                                                      ctl, occ, tmp[0], tmp[1], tmp[2]);        \
+        vx_finish<N, C, 2><<<std::min(kVxMaxBins, ncu), kVxFinThreads, 0, c->stream>>>(a.out[0], a.out[1], a.out[2], plan, bucket_start, \
+                                                                                      ctl, occ, tmp[0], tmp[1], tmp[2]);        \
+    } while (0)
     if (dn && dcol) MI_VX_FINISH(true, true);
     else if (dn) MI_VX_FINISH(true, false);
     else if (dcol) MI_VX_FINISH(false, true);

@@ -190,7 +190,7 @@ static __global__ __launch_bounds__(256) void vx_probe_order(uint32_t* __restric
 // ---- 0b: the plan ----------------------------------------------------------------------------------------------------
 // bounds: min[3], max[3] (lbvh.h bounds_final).  The host evaluates the same expressions (mi_geometry.hip) when it needs
 // the grid itself; hb is chosen for ~6k points per bucket (one LDS chunk of vx_finish).
-__device__ __forceinline__ void vx_make_plan(const float* bounds, float voxel, long long n, VxDev* __restrict__ d, uint32_t* __restrict__ ctl) {
+__device__ __forceinline__ void vx_make_plan(const float* bounds, float voxel, long long n, int hb_force, VxDev* __restrict__ d, uint32_t* __restrict__ ctl) {
     VxDev v;
     float origin[3], ext = 0.0f;
     int nb[3];
@@ -214,10 +214,13 @@ __device__ __forceinline__ void vx_make_plan(const float* bounds, float voxel, l
     v.bits = bits;
     v.g.key_mask = (bits >= 32) ? 0xffffffffu : ((1u << bits) - 1u);
     int hb = 0;
-    while (((long long)6144 << hb) < n) ++hb;
-    hb = max(hb, bits - 10);
+    const long long per_bucket = max(12288ll, n >> 10);  // ~12k points per bucket, and no more than 1024 buckets, the grid permitting ...
+    while ((per_bucket << hb) < n) ++hb;         // (30M points, 21-bit key: 1024 buckets 0.645 ms, 2048: 0.685)
+    if (hb < 8 && (n >> 8) >= 1024) hb = 8;      // ... but a bucket per CU at least (1M points: 128 buckets 0.125 ms, 256: 0.087)
+    hb = max(hb, bits - 11);                     // (a bucket has at most 2048 voxels)
     hb = min(hb, min(11, bits - 6));
-    v.ok = (!v.empty && bits >= 14 && bits <= 21 && hb >= bits - 10 && hb >= 0 && (n >> max(hb, 0)) >= 256) ? 1 : 0;
+    if (hb_force > 0 && hb_force >= bits - 11 && hb_force <= min(11, bits - 6)) hb = hb_force;  // (measurements: MI_ICP_VOXEL_HB)
+    v.ok = (!v.empty && bits >= 14 && bits <= 22 && hb >= bits - 11 && hb >= 0 && (n >> max(hb, 0)) >= 256) ? 1 : 0;
     if (!v.ok) hb = 0;
     v.hb = hb;
     v.L = v.ok ? bits - hb : 0;
@@ -236,7 +239,7 @@ __device__ __forceinline__ void vx_make_plan(const float* bounds, float voxel, l
 }
 
 // one wave behind bounds_partial (lbvh.h): the bounds of the cloud -- bounds_final's reduction -- and, in the same launch, the plan
-static __global__ __launch_bounds__(64) void vx_bounds_plan(const float* __restrict__ partial, int nblocks, float voxel, long long n,
+static __global__ __launch_bounds__(64) void vx_bounds_plan(const float* __restrict__ partial, int nblocks, float voxel, long long n, int hb_force,
                                                       VxDev* __restrict__ d, uint32_t* __restrict__ ctl) {
     const int lane = lane_id();
     float mn[3] = {INFINITY, INFINITY, INFINITY};
@@ -254,7 +257,7 @@ static __global__ __launch_bounds__(64) void vx_bounds_plan(const float* __restr
         b6[k] = wave_min(mn[k]);      // (lane 0 holds the result)
         b6[3 + k] = wave_max(mx[k]);
     }
-    if (lane == 0) vx_make_plan(b6, voxel, n, d, ctl);
+    if (lane == 0) vx_make_plan(b6, voxel, n, hb_force, d, ctl);
 }
 
 // ---- 1: the [tile][bucket] table ------------------------------------------------------------------------------------
@@ -532,34 +535,42 @@ static __global__ __launch_bounds__(kVxThreads) void vx_scatter(VxArrays a, int 
 // words, 64 then 1024 predecessors read per round trip, deferred behind the next bucket's loads -- cost 4 ... 10 of a
 // bucket's 13 ... 19 us in every form tried: the workgroups of a chip-wide wave of buckets finish together, and a wave's
 // loads come back in the order they were asked for, the status words behind 60 KB of points.)
-template <bool kNrm, bool kCol>
+// kVpt voxels per thread: 1 for buckets of up to 1024 voxels (L <= 10; chunks of 8192 points), 2 for up to 2048 (L = 11;
+// the counters take 64 KB then and a chunk is 6144 points).  Fewer, larger buckets are the better cut where the grid
+// allows both (a 20-bit key at 10M points: 1024 buckets against 2048: partition 85 -> 74 us, runs of 8 points per tile
+// instead of 4; finish 74 -> 65), and L = 11 is what lets a 21-bit key -- the 10M bench -- have 1024 of them.
+template <bool kNrm, bool kCol, int kVpt>
 static __global__ __launch_bounds__(kVxFinThreads) void vx_finish(const Pay3* __restrict__ pts, const Pay3* __restrict__ nrm,
                                                             const Pay3* __restrict__ col, const VxDev* __restrict__ d,
                                                             const uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ ctl,
                                                             uint32_t* __restrict__ occ, Pay3* __restrict__ tmp_pts,
                                                             Pay3* __restrict__ tmp_nrm, Pay3* __restrict__ tmp_col) {
-    __shared__ __attribute__((aligned(16))) uint16_t wcnt[kVxFinWaves][kVxMaxSub];  // a wave's count per voxel of the bucket, then its offset inside the voxel's run
-    __shared__ Pay3 stage[kVxChunk];                   // one array at a time, in voxel order
-    __shared__ uint16_t vstart[kVxMaxSub];             // first position of every voxel's run
+    constexpr int kSub = kVxMaxSub * kVpt;               // voxels of a bucket
+    constexpr int kChunk = (kVpt == 1) ? kVxChunk : 6144;  // points of a bucket in LDS at a time
+    constexpr int kWaveSeg = kChunk / kVxFinWaves;
+    constexpr int kItems = kChunk / kVxFinThreads;       // 8 / 6
+    __shared__ __attribute__((aligned(16))) uint16_t wcnt[kVxFinWaves][kSub];  // a wave's count per voxel of the bucket, then its offset inside the voxel's run
+    __shared__ Pay3 stage[kChunk];                     // one array at a time, in voxel order
+    __shared__ __attribute__((aligned(16))) uint16_t vstart[kSub];  // first position of every voxel's run
     __shared__ uint32_t wtot[kVxFinWaves];
     __shared__ uint32_t s_bucket;
     __shared__ uint32_t s_start[kVxMaxBins + 1];       // bucket_start, here once: a bucket's extent is then an LDS read away from its ticket
     if (ctl[0] != 0u) return;
     const VxGrid g = d->g;
     const int L = d->L, B = d->B;
+    if ((L > 10) != (kVpt == 2)) return;  // (both instantiations are launched; the plan says which one runs)
     const int tid = (int)threadIdx.x;
     const int lane = lane_id();
     const int wid = tid >> 6;
     const int V = 1 << L;
     const uint32_t sub_mask = (uint32_t)V - 1u;
     uint32_t* const row = reinterpret_cast<uint32_t*>(&wcnt[wid][0]);
-    constexpr int kItems = kVxChunk / kVxFinThreads;  // 8
     float px[kItems], py[kItems], pz[kItems];  // (coordinates apart: see vx_scatter)
     auto load = [&](const Pay3* __restrict__ in, uint32_t cbase, int cn) {
         if (cn <= 0) return;  // (uniform)
 #pragma unroll
         for (int k = 0; k < kItems; ++k) {
-            const int i = wid * kVxFinWaveSeg + k * 64 + lane;
+            const int i = wid * kWaveSeg + k * 64 + lane;
             const Pay3 v = in[cbase + (uint32_t)min(i, cn - 1)];  // (unconditional: see vx_hist)
             px[k] = v.x;
             py[k] = v.y;
@@ -574,56 +585,91 @@ static __global__ __launch_bounds__(kVxFinThreads) void vx_finish(const Pay3* __
     if (bucket < B) {
         s = s_start[bucket];
         e = s_start[bucket + 1];
-        load(pts, s, (int)min((uint32_t)kVxChunk, e - s));
+        load(pts, s, (int)min((uint32_t)kChunk, e - s));
     }
+    const int v0 = tid * kVpt;  // this thread's voxels: v0 ... v0 + kVpt - 1
     while (bucket < B) {
         VX_CLK(1, bucket, 1);
         // the next ticket: asked for now, kept in a register until the bucket's end (stored to LDS at once it would be waited for at once)
         uint32_t ticket = 0;
         if (tid == 0) ticket = __hip_atomic_fetch_add(&ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        double ap[3] = {0.0, 0.0, 0.0}, an[3] = {0.0, 0.0, 0.0}, ac[3] = {0.0, 0.0, 0.0};
-        uint32_t count = 0;
+        double ap[kVpt][3], an[kVpt][3], ac[kVpt][3];
+        uint32_t count[kVpt];
+#pragma unroll
+        for (int h = 0; h < kVpt; ++h) {
+            count[h] = 0u;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ap[h][c] = an[h][c] = ac[h][c] = 0.0;
+        }
         uint32_t orank = 0, occupied = 0;
-        for (uint32_t cbase = s; cbase < e; cbase += (uint32_t)kVxChunk) {
-            const int cn = (int)min((uint32_t)kVxChunk, e - cbase);
-            const bool last = cbase + (uint32_t)kVxChunk >= e;
+        for (uint32_t cbase = s; cbase < e; cbase += (uint32_t)kChunk) {
+            const int cn = (int)min((uint32_t)kChunk, e - cbase);
+            const bool last = cbase + (uint32_t)kChunk >= e;
             if (cbase != s) load(pts, cbase, cn);  // (the first chunk was asked for ahead)
-            for (int k = lane; k < kVxMaxSub / 2; k += 64) row[k] = 0u;
+            for (int k = lane; k < kSub / 2; k += 64) row[k] = 0u;
             __builtin_amdgcn_wave_barrier();
             VX_DRAIN();
             VX_CLK(1, bucket, 2);
             uint32_t packed[kItems];  // voxel << 16 | rank among the wave's earlier points of that voxel; later the position
 #pragma unroll
             for (int k = 0; k < kItems; ++k) {
-                const int i = wid * kVxFinWaveSeg + k * 64 + lane;
+                const int i = wid * kWaveSeg + k * 64 + lane;
                 const uint32_t sub = vx_key(g, Pay3{px[k], py[k], pz[k]}) & sub_mask;
                 packed[k] = (sub << 16) | vx_rank(row, sub, i < cn);
             }
             vx_barrier();
             VX_CLK(1, bucket, 3);
-            uint32_t mine = 0;  // points of voxel `tid` in this chunk
-            if (tid < V) {
+            uint32_t mine[kVpt];  // points of this thread's voxels in this chunk
 #pragma unroll
-                for (int h = 0; h < kVxFinWaves; h += 8) {
-                    uint32_t k[8];
+            for (int h = 0; h < kVpt; ++h) mine[h] = 0u;
+            if (v0 < V) {
 #pragma unroll
-                    for (int w = 0; w < 8; ++w) k[w] = wcnt[h + w][tid];
+                for (int w0 = 0; w0 < kVxFinWaves; w0 += 8) {
+                    if (kVpt == 1) {
+                        uint32_t k[8];
 #pragma unroll
-                    for (int w = 0; w < 8; ++w) {
-                        wcnt[h + w][tid] = (uint16_t)mine;
-                        mine += k[w];
+                        for (int w = 0; w < 8; ++w) k[w] = wcnt[w0 + w][tid];
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) {
+                            wcnt[w0 + w][tid] = (uint16_t)mine[0];
+                            mine[0] += k[w];
+                        }
+                    } else {  // both counters of the thread in one word
+                        uint32_t k[8];
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) k[w] = reinterpret_cast<const uint32_t*>(&wcnt[w0 + w][0])[tid];
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) {
+                            reinterpret_cast<uint32_t*>(&wcnt[w0 + w][0])[tid] = mine[0] | (mine[kVpt - 1] << 16);
+                            mine[0] += k[w] & 0xffffu;
+                            mine[kVpt - 1] += k[w] >> 16;
+                        }
                     }
                 }
             }
-            uint32_t all;
-            const uint32_t first = vx_block_scan<kVxFinWaves>(mine, &all, wtot);
-            if (tid < V) vstart[tid] = (uint16_t)first;
-            if (last) orank = vx_block_scan<kVxFinWaves>((count + mine) > 0u ? 1u : 0u, &occupied, wtot);  // the bucket's occupied voxels, in key order
-            else vx_barrier();
+            uint32_t all, msum = 0;
+#pragma unroll
+            for (int h = 0; h < kVpt; ++h) msum += mine[h];
+            uint32_t first[kVpt];
+            first[0] = vx_block_scan<kVxFinWaves>(msum, &all, wtot);
+#pragma unroll
+            for (int h = 1; h < kVpt; ++h) first[h] = first[h - 1] + mine[h - 1];
+            if (v0 < V) {
+                if (kVpt == 1) vstart[tid] = (uint16_t)first[0];
+                else reinterpret_cast<uint32_t*>(vstart)[tid] = first[0] | (first[kVpt - 1] << 16);
+            }
+            if (last) {  // the bucket's occupied voxels, in key order
+                uint32_t f = 0;
+#pragma unroll
+                for (int h = 0; h < kVpt; ++h) f += (count[h] + mine[h]) > 0u ? 1u : 0u;
+                orank = vx_block_scan<kVxFinWaves>(f, &occupied, wtot);
+            } else {
+                vx_barrier();
+            }
             VX_CLK(1, bucket, 4);
 #pragma unroll
             for (int k = 0; k < kItems; ++k) {
-                const int i = wid * kVxFinWaveSeg + k * 64 + lane;
+                const int i = wid * kWaveSeg + k * 64 + lane;
                 if (i < cn) {
                     const uint32_t sub = packed[k] >> 16;
                     const uint32_t pos = (uint32_t)vstart[sub] + (uint32_t)wcnt[wid][sub] + (packed[k] & 0xffffu);
@@ -635,17 +681,23 @@ static __global__ __launch_bounds__(kVxFinThreads) void vx_finish(const Pay3* __
             else if (kCol) load(col, cbase, cn);
             vx_barrier();
             VX_CLK(1, bucket, 5);
-            for (uint32_t q = first; q < first + mine; ++q) {
-                const Pay3 v = stage[q];
-                ap[0] += (double)v.x;
-                ap[1] += (double)v.y;
-                ap[2] += (double)v.z;
-            }
-            count += mine;
+            auto add_runs = [&](double (&acc)[kVpt][3]) {
+#pragma unroll
+                for (int h = 0; h < kVpt; ++h)
+                    for (uint32_t q = first[h]; q < first[h] + mine[h]; ++q) {
+                        const Pay3 v = stage[q];
+                        acc[h][0] += (double)v.x;
+                        acc[h][1] += (double)v.y;
+                        acc[h][2] += (double)v.z;
+                    }
+            };
+            add_runs(ap);
+#pragma unroll
+            for (int h = 0; h < kVpt; ++h) count[h] += mine[h];
             auto restage = [&]() {
 #pragma unroll
                 for (int k = 0; k < kItems; ++k) {
-                    const int i = wid * kVxFinWaveSeg + k * 64 + lane;
+                    const int i = wid * kWaveSeg + k * 64 + lane;
                     if (i < cn) stage[packed[k]] = Pay3{px[k], py[k], pz[k]};
                 }
             };
@@ -654,23 +706,13 @@ static __global__ __launch_bounds__(kVxFinThreads) void vx_finish(const Pay3* __
                 restage();
                 if (kCol) load(col, cbase, cn);
                 vx_barrier();
-                for (uint32_t q = first; q < first + mine; ++q) {
-                    const Pay3 v = stage[q];
-                    an[0] += (double)v.x;
-                    an[1] += (double)v.y;
-                    an[2] += (double)v.z;
-                }
+                add_runs(an);
             }
             if (kCol) {
                 vx_barrier();
                 restage();
                 vx_barrier();
-                for (uint32_t q = first; q < first + mine; ++q) {
-                    const Pay3 v = stage[q];
-                    ac[0] += (double)v.x;
-                    ac[1] += (double)v.y;
-                    ac[2] += (double)v.z;
-                }
+                add_runs(ac);
             }
             if (!last) vx_barrier();  // the stage and the counters are reused
             VX_CLK(1, bucket, 6);
@@ -686,19 +728,24 @@ static __global__ __launch_bounds__(kVxFinThreads) void vx_finish(const Pay3* __
         if (bucket < B) {  // the next bucket's first chunk: asked for before this one's means are worked out and stored
             s = s_start[bucket];
             e = s_start[bucket + 1];
-            load(pts, s, (int)min((uint32_t)kVxChunk, e - s));
+            load(pts, s, (int)min((uint32_t)kChunk, e - s));
         }
         // the means (normals normalised after averaging, down_sample.cu:77-90), at the bucket's own stretch
-        if (count > 0u) {
-            const size_t slot = ((size_t)done << L) + orank;
-            const double cnt = (double)count;
-            tmp_pts[slot] = Pay3{(float)(ap[0] / cnt), (float)(ap[1] / cnt), (float)(ap[2] / cnt)};
-            if (kNrm) {
-                const float w[3] = {(float)(an[0] / cnt), (float)(an[1] / cnt), (float)(an[2] / cnt)};
-                const float l = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-                tmp_nrm[slot] = Pay3{w[0] / l, w[1] / l, w[2] / l};
+        uint32_t r = orank;
+#pragma unroll
+        for (int h = 0; h < kVpt; ++h) {
+            if (count[h] > 0u) {
+                const size_t slot = ((size_t)done << L) + r;
+                ++r;
+                const double cnt = (double)count[h];
+                tmp_pts[slot] = Pay3{(float)(ap[h][0] / cnt), (float)(ap[h][1] / cnt), (float)(ap[h][2] / cnt)};
+                if (kNrm) {
+                    const float w[3] = {(float)(an[h][0] / cnt), (float)(an[h][1] / cnt), (float)(an[h][2] / cnt)};
+                    const float l = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+                    tmp_nrm[slot] = Pay3{w[0] / l, w[1] / l, w[2] / l};
+                }
+                if (kCol) tmp_col[slot] = Pay3{(float)(ac[h][0] / cnt), (float)(ac[h][1] / cnt), (float)(ac[h][2] / cnt)};
             }
-            if (kCol) tmp_col[slot] = Pay3{(float)(ac[0] / cnt), (float)(ac[1] / cnt), (float)(ac[2] / cnt)};
         }
         VX_CLK(1, done, 8);
         vx_barrier();  // (s_bucket is read by all before the next bucket's end rewrites it -- an empty bucket has no other barrier)
