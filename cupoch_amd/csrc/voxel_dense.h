@@ -1,5 +1,5 @@
 // voxel_dense.h -- VoxelDownSample (geometry/down_sample.cu:64-90,170-273) for DENSE grids: clouds whose voxel grid has
-// at most 2^21 cells and many points per cell block (the 10M-point bench: 102^3 cells, ten points per occupied voxel).
+// at most 2^22 cells and many points per cell block (the 10M-point bench: 102^3 cells, ten points per occupied voxel).
 //
 // The general path (geometry_kernels.h) sorts the cloud on its packed voxel key with 8-bit radix passes that carry the
 // payload -- two moves of every point (and of every normal and colour), each behind a histogram and a scan, then run
@@ -11,8 +11,8 @@
 //               inside every bucket, the buckets' starts, and the largest bucket (a cloud that crowds into a few buckets
 //               is left to the general path: the finishing kernel gives a bucket to ONE workgroup);
 //   vx_scatter  the stable partition: a tile is ordered by bucket in LDS and written out bucket run by bucket run;
-//   vx_finish   one workgroup per bucket: the bucket's points 8192 at a time, ordered in LDS by the key's low L <= 10
-//               bits (the voxel inside the bucket; the same stable counting sort), then thread v adds up voxel v's run
+//   vx_finish   one workgroup per bucket: the bucket's points 8192 (6144) at a time, ordered in LDS by the key's low
+//               L <= 10 (11) bits (the voxel inside the bucket; the same stable counting sort), then a thread adds up its voxel's (two voxels') run
 //               IN INPUT ORDER in fp64 -- the order the CPU oracle adds in, so the means are the oracle's bit for bit
 //               and the same from run to run.  The bucket's means go to the bucket's own stretch of a scratch array;
 //   vx_compact  moves every bucket's stretch behind its predecessors': lexicographic order, no gaps.
@@ -42,7 +42,7 @@ constexpr int kVxTile = kVxThreads * kVxItems;  // 8192 points
 constexpr int kVxWaveSeg = kVxTile / kVxWaves;  // a wave's contiguous share of a tile
 constexpr int kVxMaxBins = 2048;              // buckets (hb <= 11)
 constexpr int kVxSeg = 32;                    // tiles per segment of the column sums
-constexpr int kVxFinThreads = 1024;           // vx_finish: thread v <-> voxel v of the bucket (L <= 10)
+constexpr int kVxFinThreads = 1024;           // vx_finish: thread v <-> voxel v of the bucket (L <= 10), or voxels 2v and 2v + 1 (L = 11)
 constexpr int kVxFinWaves = kVxFinThreads / 64;
 constexpr int kVxChunk = 8192;                // points of a bucket in LDS at a time
 constexpr int kVxFinWaveSeg = kVxChunk / kVxFinWaves;  // 512

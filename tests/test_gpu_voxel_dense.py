@@ -45,10 +45,10 @@ def took_dense_path(eng):
     return eng._L.mi_icp_debug_last_voxel_path(eng._ctx) == 1
 
 
-# (n, voxel, extent per axis, offset): the plan (voxel_dense.h vx_make_plan) takes keys of 14 ... 21 bits with at least 256
-# points per bucket; these cover 2048 / 512 / 256 / 16 buckets, 1024 ... 64 voxels per bucket, a bucket of several LDS
-# chunks (6M points in 512 buckets), a slab (the key's bits all in x and y), a cloud far from the origin and one that
-# straddles it
+# (n, voxel, extent per axis, offset): the plan (voxel_dense.h vx_make_plan) takes keys of 14 ... 22 bits with at least 256
+# points per bucket; these cover 2048 ... 16 buckets, 2048 ... 64 voxels per bucket (one or two per thread of the
+# finishing kernel), buckets of several LDS chunks (6M points in 512 buckets), a slab (the key's bits all in x and y),
+# a cloud far from the origin and one that straddles it
 CASES = [
     (800_000, 0.01, (1.0, 1.0, 1.0), 0.0),
     (200_000, 0.02, (1.0, 1.0, 1.0), 0.0),
@@ -60,6 +60,7 @@ CASES = [
     (700_000, 0.011, (1.0, 1.0, 1.0), 0.0),
     (300_000, 0.02, (4.0, 4.0, 0.03), 0.0),
     (131_072, 0.04, (1.0, 1.0, 1.0), 0.0),
+    (2_500_000, 0.01, (1.3, 1.0, 1.0), 0.0),                     # a 22-bit key: 2048 buckets of 2048 voxels
 ]
 
 
