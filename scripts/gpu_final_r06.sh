@@ -97,7 +97,7 @@ if has pmcrows; then
     [ $i -le 2 ] && { prof --kernel-trace --pmc $set --output-format csv -d $R/$O/pmc_knn$i -o p -- python $R/scripts/measure_knn.py 30,0.0 100,0.0 > $O/pmc_knn$i.log 2>&1; echo "pmc knn $i rc=$?"; }
   done
   { echo "# rocprofv3 --pmc passes of scripts/measure_configs.py (config 2, config 5 = GICP 5M, builds and one-time costs at 10M, VoxelDownSample, EstimateNormals 2M) and scripts/measure_knn.py 30,0.0 100,0.0; averages per launch"
-    python scripts/pmc_kernels.py "$O/pmc_rows*/p_counter_collection.csv" reduce_kernel kd_build_groups cells_ voxel vox_ rs_scatter knn_normals transform_cloud cov_from tree_scale
+    python scripts/pmc_kernels.py "$O/pmc_rows*/p_counter_collection.csv" reduce_kernel kd_build_groups cells_ voxel vox_ vx_ rs_scatter knn_normals transform_cloud cov_from tree_scale
     python scripts/pmc_kernels.py "$O/pmc_knn*/p_counter_collection.csv" knn_search; } | tee $O/pmc_rows_summary.txt
 fi
 # keep the merge small: rocprofv3's databases are not needed
