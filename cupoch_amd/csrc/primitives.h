@@ -172,7 +172,13 @@ __global__ __launch_bounds__(kSortThreads) void rs_histogram(const K* __restrict
     if (tid < 256) hist[(int64_t)tid * nseg + seg] = cnt[tid];
 }
 
-template <typename K, int kSortChunks>
+// kWhole: a pass in ONE launch for short arrays (n <= kSortWholeMax).  Every workgroup goes through ALL the keys itself
+// -- the digits' counts in the whole array and in the tiles before its own (256 KB of keys at most, from the L2) --
+// instead of reading offsets that a histogram kernel and a three-launch scan left for it: a launch is ~5 us on the
+// timeline whatever it does, and a 20k-element pass was five of them for ~2 us of work (`offs` / `nseg` are not read).
+constexpr int kSortWholeMax = 1 << 16;
+
+template <typename K, int kSortChunks, bool kWhole = false>
 __global__ __launch_bounds__(kSortThreads) void rs_scatter(const K* __restrict__ keys_in,
                                                            const uint32_t* __restrict__ vals_in,
                                                            K* __restrict__ keys_out,
@@ -186,6 +192,7 @@ __global__ __launch_bounds__(kSortThreads) void rs_scatter(const K* __restrict__
     __shared__ int32_t gdelta[256];             // global position - local position, per digit (mod 2^32)
     __shared__ uint32_t wtot[kSortThreads / 64];
     __shared__ uint16_t perm[kSortSeg];         // local sorted position -> element of the tile
+    __shared__ uint32_t whole[kWhole ? 512 : 1];  // kWhole: [digit] count in the whole array | [256 + digit] in the tiles before this one
     const int tid = (int)threadIdx.x;
     const int lane = lane_id();
     const int wid = tid >> 6;
@@ -195,6 +202,25 @@ __global__ __launch_bounds__(kSortThreads) void rs_scatter(const K* __restrict__
 #pragma unroll
     for (int k = 0; k < 4; ++k) wcnt[wid][lane + 64 * k] = 0;
     __builtin_amdgcn_wave_barrier();
+    if (kWhole) {
+        whole[tid] = 0u;  // (512 threads)
+        __syncthreads();
+        for (int64_t i0 = 0; i0 < n; i0 += 8 * kSortThreads) {  // eight keys in flight per thread
+            K k8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) k8[u] = keys_in[min(i0 + (int64_t)u * kSortThreads + tid, (int64_t)n - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = i0 + (int64_t)u * kSortThreads + tid;
+                if (i < n) {
+                    const uint32_t d = (uint32_t)(k8[u] >> shift) & 255u;
+                    atomicAdd(&whole[d], 1u);
+                    if (i < tbase) atomicAdd(&whole[256 + d], 1u);
+                }
+            }
+        }
+        __syncthreads();
+    }
 
     // ---- 1: rank of every element among the same-digit elements of its wave
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -249,7 +275,24 @@ __global__ __launch_bounds__(kSortThreads) void rs_scatter(const K* __restrict__
             for (int w = 0; w < wid; ++w) woff += wtot[w];
             const uint32_t start = woff + x - total;
             tile_start[tid] = start;
-            gdelta[tid] = (int32_t)(offs[(int64_t)tid * nseg + seg] - start);
+            if (!kWhole) gdelta[tid] = (int32_t)(offs[(int64_t)tid * nseg + seg] - start);
+        }
+        if (kWhole) {  // the digit's first position in the whole array (a second scan, of the whole array's counts) + what the tiles before hold of it
+            __syncthreads();
+            const uint32_t cnt = (tid < 256) ? whole[tid] : 0u;
+            uint32_t y = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t z = __shfl_up(y, o, 64);
+                if (lane >= o) y += z;
+            }
+            if (lane == 63) wtot[wid] = y;
+            __syncthreads();
+            if (tid < 256) {
+                uint32_t woff = 0;
+                for (int w = 0; w < wid; ++w) woff += wtot[w];
+                gdelta[tid] = (int32_t)((woff + y - cnt) + whole[256 + tid] - tile_start[tid]);
+            }
         }
     }
     __syncthreads();
@@ -426,6 +469,14 @@ static inline int radix_sort_pairs_t(hipStream_t st, K* const keys[2], uint32_t*
     const int chunks = sort_chunks_for(n);
     const int passes = (key_bits + 7) / 8;
     int cur = 0;
+    if (n <= kSortWholeMax) {  // short arrays: a pass is one launch (tiles of 2048 elements)
+        const int nblk_w = (int)((n + 2047) / 2048);
+        for (int p = 0; p < passes; ++p) {
+            rs_scatter<K, 4, true><<<nblk_w, kSortThreads, 0, st>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], hist, (int)n, nblk_w, p * 8);
+            cur ^= 1;
+        }
+        return cur;
+    }
     for (int p = 0; p < passes; ++p) {
         const int shift = p * 8;
         switch (chunks) {
