@@ -101,6 +101,8 @@ struct mi_icp_ctx {
     mi::eng::DevBuf stage[6];
     mi::eng::DevBuf tscale;   // scratch of kd_build.h tree_scale
     mi::eng::DevBuf knn_idx, knn_flags;  // the k-NN lists' index rows, [XCD][row][slot][lane], and the rows' claim flags (knn_normals.h KnnSlab)
+    float vx_refused_voxel = 0.0f;  // the last voxel size / cloud size the dense path's plan turned away (mi_icp_voxel_downsample)
+    int64_t vx_refused_n = 0;
     int vx_order = 0;         // LDS adds of one instruction served in lane order (voxel_dense.h)?  0: not checked yet, 1: yes, -1: no
     mi::eng::DevBuf vx_tab;   // VoxelDownSample of a dense grid (voxel_dense.h): the [tile][bucket] table, bucket starts, status and control words
     mi::eng::DevBuf vpay[6];  // VoxelDownSample: two sets of payload arrays (points, normals, colours) the radix passes alternate between
