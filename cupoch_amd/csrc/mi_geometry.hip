@@ -21,7 +21,7 @@ int occupancy_geometry(int which) {
     if (which == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, rs_scatter_pay<8>, kSortThreads, 0);
     else if (which == 6) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, voxel_means_wave, 64, 0);
     else if (which == 7) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vx_scatter<1>, kVxThreads, 0);
-    else if (which == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vx_finish<false, false, 1>, kVxFinThreads, 0);
+    else if (which == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, vx_finish<false, false>, kVxFinThreads, 0);
     else return -1;
     return e == hipSuccess ? blocks : -2;
 }
@@ -232,15 +232,9 @@ static int voxel_dense_launch(mi_icp_ctx* c, const float* dp, const float* dn, c
         else if (na == 2) vx_scatter<2><<<grid, kVxThreads, 0, c->stream>>>(pk, (int)n, ntiles, plan, tab, seg_tot, bucket_start, ctl);
         else vx_scatter<3><<<grid, kVxThreads, 0, c->stream>>>(pk, (int)n, ntiles, plan, tab, seg_tot, bucket_start, ctl);
     }
-    // (both cuts of a bucket are launched: the plan, which the host does not know yet, says which one runs -- the other
-    // returns at its first test)
 #define MI_VX_FINISH(N, C)                                                                                                     \
-    do {                                                                                                                       \
-        vx_finish<N, C, 1><<<std::min(kVxMaxBins, ncu), kVxFinThreads, 0, c->stream>>>(a.out[0], a.out[1], a.out[2], plan, bucket_start, \
-                                                                                      ctl, occ, tmp[0], tmp[1], tmp[2]);        \
-        vx_finish<N, C, 2><<<std::min(kVxMaxBins, ncu), kVxFinThreads, 0, c->stream>>>(a.out[0], a.out[1], a.out[2], plan, bucket_start, \
-                                                                                      ctl, occ, tmp[0], tmp[1], tmp[2]);        \
-    } while (0)
+    vx_finish<N, C><<<std::min(kVxMaxBins, ncu), kVxFinThreads, 0, c->stream>>>(a.out[0], a.out[1], a.out[2], plan, bucket_start, ctl, \
+                                                                               occ, tmp[0], tmp[1], tmp[2])
     if (dn && dcol) MI_VX_FINISH(true, true);
     else if (dn) MI_VX_FINISH(true, false);
     else if (dcol) MI_VX_FINISH(false, true);

@@ -539,26 +539,24 @@ static __global__ __launch_bounds__(kVxThreads) void vx_scatter(VxArrays a, int 
 // the counters take 64 KB then and a chunk is 6144 points).  Fewer, larger buckets are the better cut where the grid
 // allows both (a 20-bit key at 10M points: 1024 buckets against 2048: partition 85 -> 74 us, runs of 8 points per tile
 // instead of 4; finish 74 -> 65), and L = 11 is what lets a 21-bit key -- the 10M bench -- have 1024 of them.
+// (one launch for both cuts: the kernel below looks at the plan and calls the body it asks for on the same piece of LDS --
+// two launches of which one returned at once were ~5 us on the timeline for nothing)
+constexpr int kVxFinLdsBytes = 2 * kVxFinWaves * kVxMaxSub * 2 + 6144 * 12 + 2 * kVxMaxSub * 2;  // kVpt = 2: counters, stage, run starts (kVpt = 1: 32 + 96 + 2 KB)
+static_assert(kVxFinLdsBytes >= kVxFinWaves * kVxMaxSub * 2 + kVxChunk * 12 + kVxMaxSub * 2, "the LDS piece serves both cuts");
+
 template <bool kNrm, bool kCol, int kVpt>
-static __global__ __launch_bounds__(kVxFinThreads) void vx_finish(const Pay3* __restrict__ pts, const Pay3* __restrict__ nrm,
-                                                            const Pay3* __restrict__ col, const VxDev* __restrict__ d,
-                                                            const uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ ctl,
-                                                            uint32_t* __restrict__ occ, Pay3* __restrict__ tmp_pts,
-                                                            Pay3* __restrict__ tmp_nrm, Pay3* __restrict__ tmp_col) {
+__device__ __forceinline__ void vx_finish_body(unsigned char* __restrict__ lds, uint32_t* __restrict__ wtot, uint32_t& s_bucket,
+                                               const uint32_t* __restrict__ s_start, const Pay3* __restrict__ pts,
+                                               const Pay3* __restrict__ nrm, const Pay3* __restrict__ col, const VxGrid g, const int L,
+                                               const int B, uint32_t* __restrict__ ctl, uint32_t* __restrict__ occ,
+                                               Pay3* __restrict__ tmp_pts, Pay3* __restrict__ tmp_nrm, Pay3* __restrict__ tmp_col) {
     constexpr int kSub = kVxMaxSub * kVpt;               // voxels of a bucket
     constexpr int kChunk = (kVpt == 1) ? kVxChunk : 6144;  // points of a bucket in LDS at a time
     constexpr int kWaveSeg = kChunk / kVxFinWaves;
     constexpr int kItems = kChunk / kVxFinThreads;       // 8 / 6
-    __shared__ __attribute__((aligned(16))) uint16_t wcnt[kVxFinWaves][kSub];  // a wave's count per voxel of the bucket, then its offset inside the voxel's run
-    __shared__ Pay3 stage[kChunk];                     // one array at a time, in voxel order
-    __shared__ __attribute__((aligned(16))) uint16_t vstart[kSub];  // first position of every voxel's run
-    __shared__ uint32_t wtot[kVxFinWaves];
-    __shared__ uint32_t s_bucket;
-    __shared__ uint32_t s_start[kVxMaxBins + 1];       // bucket_start, here once: a bucket's extent is then an LDS read away from its ticket
-    if (ctl[0] != 0u) return;
-    const VxGrid g = d->g;
-    const int L = d->L, B = d->B;
-    if ((L > 10) != (kVpt == 2)) return;  // (both instantiations are launched; the plan says which one runs)
+    uint16_t (*wcnt)[kSub] = reinterpret_cast<uint16_t (*)[kSub]>(lds);  // [waves][kSub]: a wave's count per voxel of the bucket, then its offset inside the voxel's run
+    Pay3* const stage = reinterpret_cast<Pay3*>(lds + kVxFinWaves * kSub * 2);  // [kChunk]: one array at a time, in voxel order
+    uint16_t* const vstart = reinterpret_cast<uint16_t*>(lds + kVxFinWaves * kSub * 2 + kChunk * 12);  // [kSub]: first position of every voxel's run
     const int tid = (int)threadIdx.x;
     const int lane = lane_id();
     const int wid = tid >> 6;
@@ -577,9 +575,6 @@ static __global__ __launch_bounds__(kVxFinThreads) void vx_finish(const Pay3* __
             pz[k] = v.z;
         }
     };
-    if (tid == 0) s_bucket = __hip_atomic_fetch_add(&ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int b = tid; b <= B; b += kVxFinThreads) s_start[b] = bucket_start[b];
-    vx_barrier();
     int bucket = (int)s_bucket;
     uint32_t s = 0, e = 0;
     if (bucket < B) {
@@ -750,6 +745,26 @@ static __global__ __launch_bounds__(kVxFinThreads) void vx_finish(const Pay3* __
         VX_CLK(1, done, 8);
         vx_barrier();  // (s_bucket is read by all before the next bucket's end rewrites it -- an empty bucket has no other barrier)
     }
+}
+
+template <bool kNrm, bool kCol>
+static __global__ __launch_bounds__(kVxFinThreads) void vx_finish(const Pay3* __restrict__ pts, const Pay3* __restrict__ nrm,
+                                                            const Pay3* __restrict__ col, const VxDev* __restrict__ d,
+                                                            const uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ ctl,
+                                                            uint32_t* __restrict__ occ, Pay3* __restrict__ tmp_pts,
+                                                            Pay3* __restrict__ tmp_nrm, Pay3* __restrict__ tmp_col) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kVxFinLdsBytes];
+    __shared__ uint32_t wtot[kVxFinWaves];
+    __shared__ uint32_t s_bucket;
+    __shared__ uint32_t s_start[kVxMaxBins + 1];       // bucket_start, here once: a bucket's extent is then an LDS read away from its ticket
+    if (ctl[0] != 0u) return;
+    const VxGrid g = d->g;
+    const int L = d->L, B = d->B;
+    if (threadIdx.x == 0) s_bucket = __hip_atomic_fetch_add(&ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int b = (int)threadIdx.x; b <= B; b += kVxFinThreads) s_start[b] = bucket_start[b];
+    vx_barrier();
+    if (L > 10) vx_finish_body<kNrm, kCol, 2>(lds, wtot, s_bucket, s_start, pts, nrm, col, g, L, B, ctl, occ, tmp_pts, tmp_nrm, tmp_col);
+    else vx_finish_body<kNrm, kCol, 1>(lds, wtot, s_bucket, s_start, pts, nrm, col, g, L, B, ctl, occ, tmp_pts, tmp_nrm, tmp_col);
 }
 
 // ---- 5: the buckets' means to their places ----------------------------------------------------------------------------------
