@@ -314,6 +314,9 @@ static int voxel_downsample_keys32(mi_icp_ctx* c, const float* dp, const float* 
         const int64_t rmax = (bits - L >= 31) ? n : std::min<int64_t>(n, (int64_t)1 << (bits - L));
         voxel_means_wave<<<(unsigned)rmax, 64, 0, c->stream>>>(skeys, pay[0], pay[1], pay[2], run_start, voff, mask, nruns, rmax, L,
                                                                       op, dn ? on : nullptr, dcol ? oc : nullptr);
+    } else if (n <= 16 * nvox) {  // a run is a voxel, and a short one: a thread each
+        voxel_means_thread<<<blocks_for(nvox), 256, 0, c->stream>>>(pay[0], pay[1], pay[2], run_start, nvox, op, dn ? on : nullptr,
+                                                                    dcol ? oc : nullptr);
     } else {      // a run is a voxel: 8 lanes each
         voxel_means_runs<<<blocks_for(nvox * 8), 256, 0, c->stream>>>(skeys, pay[0], pay[1], pay[2], run_start, voff, mask, nruns, L,
                                                                      nvox, op, dn ? on : nullptr, dcol ? oc : nullptr);
