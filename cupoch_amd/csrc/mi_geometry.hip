@@ -145,6 +145,11 @@ int mi_icp_covariances_from_normals(mi_icp_ctx* c, const float* normals, int64_t
     return MI_ICP_OK;
 }
 
+static int vx_cu_count() {
+    static const int ncu = [] { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); return (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }();
+    return ncu;
+}
+
 // the order of LDS adds inside one instruction (voxel_dense.h "Ranks"), checked once per context
 static int vx_order_ok(mi_icp_ctx* c, bool* ok) {
     if (c->vx_order == 0) {
@@ -174,7 +179,7 @@ static int voxel_dense_launch(mi_icp_ctx* c, const float* dp, const float* dn, c
     bool ordered = false;
     TRY(vx_order_ok(c, &ordered));
     if (!ordered) return MI_ICP_OK;
-    static const int ncu = [] { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); return (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }();
+    const int ncu = vx_cu_count();
     const int ntiles = (int)((n + kVxTile - 1) / kVxTile);
     const int nsegs = (ntiles + kVxSeg - 1) / kVxSeg;
     // the tables, sized for 2048 buckets: the buckets' occupied-voxel counts, the plan, [ntiles][2048], [nsegs][2048],
@@ -251,6 +256,77 @@ static int voxel_dense_launch(mi_icp_ctx* c, const float* dp, const float* dn, c
     return MI_ICP_OK;
 }
 
+// The general path's sort for LARGE clouds on fine grids (the key sorted whole, L = 0): the dense path's partition
+// kernels as a radix sort of 11-bit digits -- two or three stable passes for a key of up to 32 bits where 8-bit digits
+// take three or four, keys recomputed from the points in every pass instead of carried and stored, four launches a pass
+// instead of five.  The plans of the passes (digit = (key >> L) & (B - 1)) are written by the host, which knows the grid
+// here.  pay[]: the arrays that hold the sorted cloud.
+static int voxel_wide_sort(mi_icp_ctx* c, const Pay3* const first[3], int64_t n, const VoxelGrid& grid, int bits, const Pay3* pay[3]) {
+    const int npass = (bits + 10) / 11, width = (bits + npass - 1) / npass;
+    const int ntiles = (int)((n + kVxTile - 1) / kVxTile);
+    const int nsegs = (ntiles + kVxSeg - 1) / kVxSeg;
+    static_assert(sizeof(VxDev) == 64, "three plans in 192 bytes of the pinned block");
+    const size_t plan_words = 3 * sizeof(VxDev) / 4;
+    const size_t words = plan_words + ((size_t)ntiles + nsegs) * kVxMaxBins + kVxMaxBins + 1 + kVxCtlWords;
+    uint32_t* w;
+    TRY(ensure(c, c->vx_tab, words, &w));
+    VxDev* plans = reinterpret_cast<VxDev*>(w);
+    uint32_t* tab = w + plan_words;
+    uint32_t* seg_tot = tab + (size_t)ntiles * kVxMaxBins;
+    uint32_t* bucket_start = seg_tot + (size_t)nsegs * kVxMaxBins;
+    uint32_t* ctl = bucket_start + kVxMaxBins + 1;
+    VxDev* hp = reinterpret_cast<VxDev*>(c->f_host + 16);  // (pinned; [0..7] hold the bounds)
+    for (int p = 0; p < npass; ++p) {
+        VxDev v;
+        v.g.g = grid;
+        v.g.inv = 1.0f / grid.voxel;
+        v.g.key_mask = (bits >= 32) ? 0xffffffffu : ((1u << bits) - 1u);
+        v.bits = bits;
+        v.L = p * width;
+        v.hb = std::min(width, bits - p * width);
+        v.B = 1 << v.hb;
+        v.ok = 1;
+        v.max_bucket = 0xffffffffu;
+        v.empty = 0;
+        v.pad = 0;
+        hp[p] = v;
+    }
+    HIPCHK(c, hipMemcpyAsync(plans, hp, (size_t)npass * sizeof(VxDev), hipMemcpyHostToDevice, c->stream));
+    Pay3* buf[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    for (int set = 0; set < std::min(npass, 2); ++set)
+        for (int a = 0; a < 3; ++a)
+            if (first[a]) TRY(ensure(c, c->vpay[set * 3 + a], (size_t)n, &buf[set][a]));
+    for (int a = 0; a < 3; ++a) pay[a] = first[a];
+    int na = 0;
+    for (int a = 0; a < 3; ++a) na += first[a] ? 1 : 0;
+    const int grid_sc = std::min(ntiles, vx_cu_count());
+    for (int p = 0; p < npass; ++p) {
+        VxArrays pk;
+        int k = 0;
+        for (int a = 0; a < 3; ++a) {
+            pk.in[a] = nullptr;
+            pk.out[a] = nullptr;
+        }
+        for (int a = 0; a < 3; ++a)
+            if (first[a]) {
+                pk.in[k] = pay[a];
+                pk.out[k] = buf[p & 1][a];
+                ++k;
+            }
+        const VxDev* d = plans + p;
+        vx_hist<<<ntiles, kVxThreads, 0, c->stream>>>(pk.in[0], (int)n, d, tab);
+        vx_colsum<<<dim3((unsigned)nsegs, (unsigned)(kVxMaxBins / 256)), 256, 0, c->stream>>>(tab, ntiles, d, seg_tot);
+        vx_colscan<<<1, 1024, 0, c->stream>>>(seg_tot, nsegs, (int)n, d, bucket_start, ctl);
+        if (na == 1) vx_scatter<1><<<grid_sc, kVxThreads, 0, c->stream>>>(pk, (int)n, ntiles, d, tab, seg_tot, bucket_start, ctl);
+        else if (na == 2) vx_scatter<2><<<grid_sc, kVxThreads, 0, c->stream>>>(pk, (int)n, ntiles, d, tab, seg_tot, bucket_start, ctl);
+        else vx_scatter<3><<<grid_sc, kVxThreads, 0, c->stream>>>(pk, (int)n, ntiles, d, tab, seg_tot, bucket_start, ctl);
+        for (int a = 0; a < 3; ++a)
+            if (first[a]) pay[a] = buf[p & 1][a];
+    }
+    KCHK(c);
+    return MI_ICP_OK;
+}
+
 // VoxelDownSample for grids whose packed (x, y, z) key fits 32 bits (geometry_kernels.h, "the path for grids ..."):
 // keys -> radix passes on the bits above the lowest L that carry the payload -> runs of equal key >> L -> which voxels
 // occur in each run -> their output positions -> means.  Two host synchronisations in the whole call (the bounds that
@@ -261,8 +337,6 @@ static int voxel_downsample_keys32(mi_icp_ctx* c, const float* dp, const float* 
     SortBuffers sb;
     TRY(sort_buffers(c, n, &sb));
     uint32_t* const keys[2] = {reinterpret_cast<uint32_t*>(sb.keys[0]), reinterpret_cast<uint32_t*>(sb.keys[1])};
-    voxel_keys32<<<blocks_for(n), 256, 0, c->stream>>>(dp, n, g, keys[0]);
-    KCHK(c);
     // the lowest L <= 5 key bits stay unsorted where that saves a pass (21 bits: 2 passes, L = 5; 24 bits: 3, L = 0)
     int passes = std::max(0, (bits - 5 + 7) / 8);
     int L = std::min(5, std::max(0, bits - 8 * passes));
@@ -273,14 +347,26 @@ static int voxel_downsample_keys32(mi_icp_ctx* c, const float* dp, const float* 
         passes = (bits + 7) / 8;
     }
     const Pay3* first[3] = {reinterpret_cast<const Pay3*>(dp), reinterpret_cast<const Pay3*>(dn), reinterpret_cast<const Pay3*>(dcol)};
-    Pay3* scratch[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-    for (int set = 0; set < std::min(passes, 2); ++set)
-        for (int a = 0; a < 3; ++a)
-            if (first[a]) TRY(ensure(c, c->vpay[set * 3 + a], (size_t)n, &scratch[set][a]));
     const Pay3* pay[3];
-    const int cur = radix_sort_payload32(c->stream, keys, first, scratch, sb.hist, sb.scan_tmp, n, L, bits, pay);
-    KCHK(c);
-    const uint32_t* skeys = keys[cur];
+    const uint32_t* skeys;
+    static const bool no_wide = std::getenv("MI_ICP_NO_WIDE_VOXEL_SORT") != nullptr;  // A/B switch
+    if (L == 0 && n >= (1 << 17) && n <= ((int64_t)1 << 26) && bits >= 12 && !no_wide) {
+        // a large cloud, the key sorted whole: 11-bit digits, the keys made once, from the sorted points
+        TRY(voxel_wide_sort(c, first, n, g, bits, pay));
+        voxel_keys32<<<blocks_for(n), 256, 0, c->stream>>>(reinterpret_cast<const float*>(pay[0]), n, g, keys[0]);
+        KCHK(c);
+        skeys = keys[0];
+    } else {
+        voxel_keys32<<<blocks_for(n), 256, 0, c->stream>>>(dp, n, g, keys[0]);
+        KCHK(c);
+        Pay3* scratch[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+        for (int set = 0; set < std::min(passes, 2); ++set)
+            for (int a = 0; a < 3; ++a)
+                if (first[a]) TRY(ensure(c, c->vpay[set * 3 + a], (size_t)n, &scratch[set][a]));
+        const int cur = radix_sort_payload32(c->stream, keys, first, scratch, sb.hist, sb.scan_tmp, n, L, bits, pay);
+        KCHK(c);
+        skeys = keys[cur];
+    }
     // runs of equal key >> L
     const int ntiles = scan_num_tiles(n);
     uint32_t *run_start, *mask = nullptr, *voff = nullptr, *tmp = sb.scan_tmp;

@@ -268,6 +268,7 @@ static __global__ __launch_bounds__(kVxThreads) void vx_hist(const Pay3* __restr
     if (!d->ok) return;
     const VxGrid g = d->g;
     const int L = d->L, B = d->B;
+    const uint32_t bin_mask = (uint32_t)B - 1u;  // (the dense path's bucket is the key's top: the mask changes nothing there; a wide radix pass takes a middle digit)
     const int tid = (int)threadIdx.x;
     for (int b = tid; b < B; b += kVxThreads) cnt[b] = 0u;
     __syncthreads();
@@ -283,7 +284,7 @@ static __global__ __launch_bounds__(kVxThreads) void vx_hist(const Pay3* __restr
 #pragma unroll
     for (int c = 0; c < kVxItems; ++c) {
         const int64_t i = base + c * kVxThreads + tid;
-        const uint32_t bin = vx_key(g, p[c]) >> L;
+        const uint32_t bin = (vx_key(g, p[c]) >> L) & bin_mask;
         if (i < n) atomicAdd(&cnt[bin], 1u);
     }
     __syncthreads();
@@ -444,7 +445,7 @@ static __global__ __launch_bounds__(kVxThreads) void vx_scatter(VxArrays a, int 
 #pragma unroll
         for (int c = 0; c < kVxItems; ++c) {
             const int e = wid * kVxWaveSeg + c * 64 + lane;
-            const uint32_t bin = vx_key(g, Pay3{px[c], py[c], pz[c]}) >> L;
+            const uint32_t bin = (vx_key(g, Pay3{px[c], py[c], pz[c]}) >> L) & (uint32_t)(B - 1);
             packed[c] = (bin << 16) | vx_rank(row, bin, e < tile_n);
         }
 #ifndef MI_VX_Q_EARLY

@@ -183,3 +183,27 @@ def test_points_exactly_on_cell_faces_and_non_finite_coordinates(eng):
     pn, _, _ = dense(eng, cuda(bad), float(voxel))
     assert took_dense_path(eng)
     assert abs(len(pn) - len(rp)) <= 1
+
+
+@pytest.mark.parametrize("n,voxel,off", [(600_000, 0.004, 0.0), (500_000, 0.0012, -3.0), (250_000, 0.002, 40.0), (1_500_000, 0.0031, 0.0)])
+def test_large_clouds_on_fine_grids_take_the_wide_sort(eng, n, voxel, off):
+    """Beyond the dense path's 22 key bits a cloud of >= 2^17 points is sorted whole by 11-bit digits with the dense path's
+    partition kernels (mi_geometry.hip voxel_wide_sort: 24, 30, 27 and 27 key bits here -- three passes), the keys made
+    once from the sorted points, and a thread per voxel walks its run in input order: the oracle's sums, bit for bit."""
+    rng = np.random.default_rng(n)
+    pts = (rng.random((n, 3), dtype=np.float32) + np.float32(off)).astype(np.float32)
+    nrm = rng.standard_normal((n, 3)).astype(np.float32)
+    col = rng.random((n, 3), dtype=np.float32)
+    p, nn, c = dense(eng, cuda(pts), voxel, cuda(nrm), cuda(col))
+    assert not took_dense_path(eng)
+    rp, rn, rc = orc.voxel_downsample(pts, voxel, nrm, col)
+    assert len(p) == len(rp) and len(rp) > n // 3                # (a fine grid: short runs)
+    np.testing.assert_array_equal(p.cpu().numpy(), rp)
+    np.testing.assert_array_equal(c.cpu().numpy(), rc)
+    np.testing.assert_array_equal(nn.cpu().numpy(), rn)
+    p1, _, _ = dense(eng, cuda(pts), voxel)
+    np.testing.assert_array_equal(p1.cpu().numpy(), rp)
+    p2, _, c2 = dense(eng, pts, voxel, None, col)                # host arrays
+    np.testing.assert_array_equal(np.asarray(p2), rp)
+    np.testing.assert_array_equal(np.asarray(c2), rc)
+
