@@ -235,7 +235,12 @@ MI_ICP_API int mi_icp_affine(mi_icp_ctx* ctx, const float* R9, float scale, int 
 /* PointCloud::VoxelDownSample (geometry/down_sample.cu:170-273): outputs in
  * lexicographic voxel order; out arrays must hold n entries; *m receives the
  * voxel count (0 for voxel_size <= 0 or a too-small voxel, as the reference
- * returns an empty cloud).  normals / colors and their outputs may be NULL. */
+ * returns an empty cloud).  normals / colors and their outputs may be NULL.
+ * A voxel's values are added in fp64 in a fixed order -- the same result on
+ * every run; in the input's order on dense grids (csrc/voxel_dense.h) and on
+ * fine ones (a point or two per voxel), where the means equal the CPU oracle's
+ * bit for bit (the reference's thrust::reduce_by_key adds in fp32 in an order
+ * of its own choosing).  The entry point synchronises the context's stream. */
 MI_ICP_API int mi_icp_voxel_downsample(mi_icp_ctx* ctx, const float* xyz, const float* normals,
                                        const float* colors, int64_t n, float voxel_size,
                                        float* out_xyz, float* out_normals, float* out_colors,
