@@ -29,6 +29,9 @@
 // otherwise the division is done (one point in ~10^4).
 //
 // Algorithmic bytes: 12 (N + M) per array; moved: 12 N read three times, written once, per array.
+//
+// The same vx_hist / vx_colsum / vx_colscan / vx_scatter, with plans the host writes, are the general path's radix passes
+// for large clouds on fine grids (mi_geometry.hip voxel_wide_sort: digits of 11 bits, a digit = (key >> L) & (B - 1)).
 #pragma once
 #include "geometry_kernels.h"
 #include "primitives.h"
@@ -48,13 +51,6 @@ constexpr int kVxChunk = 8192;                // points of a bucket in LDS at a 
 constexpr int kVxFinWaveSeg = kVxChunk / kVxFinWaves;  // 512
 constexpr int kVxMaxSub = 1024;
 
-struct VxPlan {
-    int bits;    // of the packed key
-    int hb, L;   // bucket = key >> L (hb bits), voxel inside the bucket = key & (2^L - 1)
-    int ntiles, nsegs;
-    uint32_t max_bucket;  // a larger bucket sets the skew flag
-};
-
 // the grid with the reciprocal of the voxel size
 struct VxGrid {
     VoxelGrid g;
@@ -62,7 +58,7 @@ struct VxGrid {
     uint32_t key_mask;
 };
 
-// The plan, made ON THE DEVICE from the bounds (vx_plan_kernel) so that the host does not have to wait for them before it
+// The plan, made ON THE DEVICE from the bounds (vx_bounds_plan) so that the host does not have to wait for them before it
 // launches: every kernel below reads it, and does nothing when `ok` is 0 (the grid is not one for this path; the host
 // learns that with the result and takes the general path).
 struct VxDev {
