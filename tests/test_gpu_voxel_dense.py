@@ -61,6 +61,7 @@ CASES = [
     (300_000, 0.02, (4.0, 4.0, 0.03), 0.0),
     (131_072, 0.04, (1.0, 1.0, 1.0), 0.0),
     (2_500_000, 0.01, (1.3, 1.0, 1.0), 0.0),                     # a 22-bit key: 2048 buckets of 2048 voxels
+    (10_000_000, 0.01, (1.0, 1.0, 1.0), 0.0),                    # the bench's shape: 1024 buckets of ~9.8k points, two LDS chunks each, two voxels per thread
 ]
 
 
